@@ -1,0 +1,141 @@
+"""CPU ORACLE (test infrastructure, NOT product code) - numpy restatement of the
+pseudo-label uncertainty filter and weight arithmetic of FPL+.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+Pinned by tests/test_oracle_golden.py against fixtures produced by running the reference
+(tests/golden/fpl_filter.npz, pixel_weight.npz) and against the reference's own
+known-answer data pair (tests/golden/image_weight_kat.json).
+Reference paths are relative to /root/reference.
+"""
+import numpy as np
+
+
+def softmax(x, axis):
+    """scipy.special.softmax as the reference calls it (PyMIC/pymic/net_run_dsbn/agent_seg.py:911,
+    1049): exp(x - max) / sum, in the input dtype (float32)."""
+    m = np.amax(x, axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / np.sum(e, axis=axis, keepdims=True)
+
+
+def fpl_filter(logits_stack):
+    """FPL branch of SegmentationAgent.infer (agent_seg.py:897-931) for ONE volume.
+
+    logits_stack: float32 [T, C, D, H, W] - the T (=6 in the reference, line 898) MC/TTA
+    predictions, each one the [1, C, D, H, W] array `pred` of line 905-909.
+    Returns dict with maps [T,C,D,H,W] f32, hards [T,D,H,W] u8, vars, means, uncertainty,
+    boundary (int) and uncer_one."""
+    maps, hards = None, None
+    for i in range(logits_stack.shape[0]):
+        pred = logits_stack[i:i + 1]
+        prob = softmax(pred, axis=1)                                   # line 911
+        hard = np.asarray(np.argmax(prob, axis=1), np.uint8)           # line 914
+        if i == 0:
+            maps, hards = prob, hard
+        else:
+            maps = np.concatenate((maps, prob), axis=0)                # lines 919-920
+            hards = np.concatenate((hards, hard), axis=0)
+    vars_ = maps.var(axis=0).sum()                                     # line 921
+    means = np.mean(maps[:, 1], axis=0)                                # line 922
+    uncertainty = -1.0 * (means * np.log(means + 1e-6))                # line 923
+    boundary = np.where(uncertainty > 0.01, 1, 0).sum()                # line 924
+    uncer_one = 1 if boundary < 50 else vars_ / boundary               # lines 926-929
+    return dict(maps=maps, hards=hards, vars=vars_, means=means, uncertainty=uncertainty,
+                boundary=int(boundary), uncer_one=uncer_one)
+
+
+def sort_uncertainty(uncer_by_name):
+    """agent_seg.py:957-959: ascending sort of ([uncer], name) tuples."""
+    pairs = list(zip([[v] for v in uncer_by_name.values()], uncer_by_name.keys()))
+    return sorted(pairs, reverse=False)
+
+
+def hard_label(logits):
+    """save_outputs (agent_seg.py:1049-1050): softmax -> argmax -> uint8, [N,C,...] -> [N,...]."""
+    return np.asarray(np.argmax(softmax(logits, axis=1), axis=1), np.uint8)
+
+
+def pixel_weight_from_masks(a, b):
+    """data/get_pixel_weight.py:21-26 (= merge_pixelw.py:21-27): union, intersection, xor ->
+    weight 1 where the two masks agree, 0.5 where they differ (float64)."""
+    both = a + b
+    both[both > 1] = 1
+    and_arr = b * a
+    sub = both - and_arr
+    return np.ones_like(sub) - sub * 0.5
+
+
+def set_weight(img_weight, pixel_weight):
+    """NiftyDataset.set_weight_ (PyMIC/pymic/io/nifty_dataset.py:165-168): disagreeing voxels
+    (w < 1) are zeroed, the rest scaled by the image weight.  Modifies its argument like the
+    reference does."""
+    pixel_weight[pixel_weight < 1] = 0
+    return pixel_weight * img_weight
+
+
+def image_weights(rows):
+    """`data/get image_weight.py`:10-28.  rows: [(uncertainty, path)] in file order.
+    Returns the image_weight column (python floats), same order."""
+    allw = [u for u, _ in rows if u != 1]
+    mx, mn = max(allw), min(allw)
+    out = []
+    for u, _ in rows:
+        if u > mx:
+            u = mx
+        out.append(abs((mx - u) / (mx - mn)) + 0.01)
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# Philox4x32-10 keep-mask: the counter-based dropout stream of the HIP path
+# (fpl-plus_amd/csrc/philox.h).  The reference draws dropout from torch's global RNG; no other
+# implementation can replay that, so the GPU path defines its own stream and this function
+# reproduces it bit-for-bit for the parity tests.
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = [np.asarray(c, np.uint32).copy() for c in (c0, c1, c2, c3)]
+    k0, k1 = np.uint32(k0), np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = c0.astype(np.uint64) * _M0
+            p1 = c2.astype(np.uint64) * _M1
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0, k1 = np.uint32(k0 + _W0), np.uint32(k1 + _W1)
+    return c0, c1, c2, c3
+
+
+def philox_keep_mask(seed, stream, n_elems, p):
+    """keep[i] for the flat NDHWC element index i: word (i & 3) of
+    philox(counter=(i>>2, 0, stream, 0), key=(seed_lo, seed_hi)) >= floor(p * 2^32)."""
+    n4 = (n_elems + 3) // 4
+    idx = np.arange(n4, dtype=np.uint32)
+    z = np.zeros(n4, np.uint32)
+    r = philox4x32_10(idx, z, np.full(n4, stream, np.uint32), z,
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = np.stack(r, axis=1).reshape(-1)[:n_elems]
+    thr = np.uint32(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    return words >= thr
+
+
+def dropout_masks_ncdhw(seed, step, net_params, in_shape, ps):
+    """Keep-masks (NCDHW bool tensors) for the 9 ConvBlockND dropout sites of one forward,
+    matching fplx's stream numbering: stream = step * 16 + block_index."""
+    n, _, D, H, W = in_shape
+    ft = net_params["feature_chns"]
+    lv = [0, 1, 2, 3, 4, 3, 2, 1, 0]
+    out = []
+    for b in range(9):
+        p = ps[b]
+        if p <= 0:
+            out.append(None)
+            continue
+        L = lv[b]
+        d, h, w, c = D >> L, H >> L, W >> L, ft[L]
+        keep = philox_keep_mask(seed, step * 16 + b, n * d * h * w * c, p)
+        out.append(np.ascontiguousarray(keep.reshape(n, d, h, w, c).transpose(0, 4, 1, 2, 3)))
+    return out

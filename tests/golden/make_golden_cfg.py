@@ -1,0 +1,32 @@
+"""Network configs / shapes / labels shared by the fixture generator and the tests."""
+import numpy as np
+import detdata
+
+NETS = {
+    "tiny": dict(in_chns=1, feature_chns=[8, 16, 32, 64, 128], dropout=[0, 0, 0, 0, 0],
+                 conv_dims=[3, 3, 3, 3, 3], class_num=2, bilinear=False, num_domains=2,
+                 net_type="UNet2D5_dsbn"),
+    "cfg1": dict(in_chns=1, feature_chns=[16, 32, 64, 128, 256], dropout=[0, 0, 0, 0, 0],
+                 conv_dims=[3, 3, 3, 3, 3], class_num=2, bilinear=False, num_domains=2,
+                 net_type="UNet2D5_dsbn"),
+    "c4": dict(in_chns=4, feature_chns=[8, 16, 32, 64, 128], dropout=[0, 0, 0, 0, 0],
+               conv_dims=[3, 3, 3, 3, 3], class_num=3, bilinear=False, num_domains=2,
+               net_type="UNet2D5_dsbn"),
+}
+SHAPES = {"tiny": (2, 1, 16, 32, 32), "cfg1": (1, 1, 32, 64, 64), "c4": (2, 4, 16, 32, 32)}
+
+
+def label_for(name):
+    n, _, D, H, W = SHAPES[name]
+    cls = NETS[name]["class_num"]
+    lab = detdata.ball_label((D, H, W), radius=min(D, H, W) / 4.0, n=n, class_num=2,
+                             offsets=[(0, 1, -2), (1, -3, 2)][:n])
+    if cls == 3:  # split the ball into two classes by x
+        out = np.zeros((n, 3, D, H, W), np.float32)
+        out[:, 0] = lab[:, 0]
+        half = np.zeros((D, H, W), bool)
+        half[:, :, W // 2:] = True
+        out[:, 1] = lab[:, 1] * half
+        out[:, 2] = lab[:, 1] * (~half)
+        lab = out
+    return lab
