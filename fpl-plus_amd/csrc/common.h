@@ -1,0 +1,75 @@
+// Shared helpers for the fplx HIP kernels (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include "../../include/fplx.h"
+
+typedef __bf16 bf16_t;
+
+#define FPLX_WAVE 64
+
+// ---- error reporting (thread-local last message, no global mutable state shared across threads)
+inline char* fplx_err_buf() {
+  static thread_local char buf[512];
+  return buf;
+}
+inline int fplx_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(fplx_err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+inline int fplx_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fplx_fail(FPLX_E_HIP, "%s: %s", what, hipGetErrorString(e));
+  return FPLX_OK;
+}
+#define FPLX_REQUIRE(cond, code, ...) \
+  do {                                 \
+    if (!(cond)) return fplx_fail(code, __VA_ARGS__); \
+  } while (0)
+
+// ---- dtype traits
+template <typename T> struct Act;
+template <> struct Act<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Act<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// load/store of a generic element by dtype enum (slow paths only)
+__device__ __forceinline__ float ld_dt(const void* p, int64_t i, int dt) {
+  return dt == FPLX_F32 ? ((const float*)p)[i] : (float)((const bf16_t*)p)[i];
+}
+__device__ __forceinline__ void st_dt(void* p, int64_t i, int dt, float v) {
+  if (dt == FPLX_F32) ((float*)p)[i] = v;
+  else ((bf16_t*)p)[i] = (bf16_t)v;
+}
+
+// ---- wave / block reductions (fixed order => deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// number of partial rows used by the streaming reductions: a fixed function of the voxel count
+// so that producer and consumer agree without extra plumbing.
+static inline int fplx_rows_for(int64_t voxels) {
+  int64_t r = (voxels + 2047) / 2048;
+  if (r > 2048) r = 2048;
+  if (r < 1) r = 1;
+  return (int)r;
+}

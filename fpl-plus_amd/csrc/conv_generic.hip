@@ -1,0 +1,540 @@
+// Generic (any shape, any stride, fp32 or bf16) convolution kernels: plain FMA, fp32 accumulate.
+// They serve (a) the fp32 parity mode, (b) layers the MFMA kernels do not cover (odd channel
+// counts), (c) the in-GPU cross-check of the MFMA kernels.  The bf16 hot path of the 3x3x3
+// convolutions is in conv_mfma.hip.
+#include "common.h"
+
+namespace {
+
+struct Strides { int64_t n, d, h, w, c; };
+
+constexpr int CO_T = 8;     // output channels per thread (forward / dgrad)
+constexpr int FWD_THREADS = 256;
+constexpr int MAX_ROWS = 2048;
+
+// ------------------------------------------------------------------------------------------
+// forward: thread = one output voxel x CO_T output channels
+template <typename TX, typename TW, typename TY>
+__global__ void __launch_bounds__(FWD_THREADS)
+conv_fwd_generic(const TX* __restrict__ x, Strides xs, const TW* __restrict__ wp, const float* __restrict__ bias,
+                 TY* __restrict__ y, Strides ys, int N, int D, int H, int W, int Cin, int Cout,
+                 int KD, int KH, int KW, float* __restrict__ stats, int64_t tiles) {
+  const int co0 = blockIdx.y * CO_T;
+  const int64_t V = (int64_t)N * D * H * W;
+  float s[CO_T], q[CO_T];
+#pragma unroll
+  for (int j = 0; j < CO_T; ++j) s[j] = q[j] = 0.f;
+  const int pd = KD / 2, ph = KH / 2, pw = KW / 2;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t v = tile * FWD_THREADS + threadIdx.x;
+    const bool valid = v < V;
+    int64_t r = valid ? v : 0;
+    const int w0 = r % W; r /= W;
+    const int h0 = r % H; r /= H;
+    const int d0 = r % D; r /= D;
+    const int n0 = (int)r;
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.f;
+    if (valid) {
+      for (int kd = 0; kd < KD; ++kd) {
+        const int dd = d0 + kd - pd;
+        if (dd < 0 || dd >= D) continue;
+        for (int kh = 0; kh < KH; ++kh) {
+          const int hh = h0 + kh - ph;
+          if (hh < 0 || hh >= H) continue;
+          for (int kw = 0; kw < KW; ++kw) {
+            const int ww = w0 + kw - pw;
+            if (ww < 0 || ww >= W) continue;
+            const TX* xp = x + n0 * xs.n + dd * xs.d + hh * xs.h + ww * xs.w;
+            const TW* wt = wp + ((int64_t)((kd * KH + kh) * KW + kw) * Cout + co0) * Cin;
+            for (int ci = 0; ci < Cin; ++ci) {
+              const float xv = Act<TX>::ld(xp + ci * xs.c);
+#pragma unroll
+              for (int j = 0; j < CO_T; ++j)
+                if (co0 + j < Cout) acc[j] = fmaf(xv, Act<TW>::ld(wt + (int64_t)j * Cin + ci), acc[j]);
+            }
+          }
+        }
+      }
+      TY* yp = y + n0 * ys.n + d0 * ys.d + h0 * ys.h + w0 * ys.w;
+#pragma unroll
+      for (int j = 0; j < CO_T; ++j)
+        if (co0 + j < Cout) {
+          Act<TY>::st(yp + (co0 + j) * ys.c, acc[j]);
+          s[j] += acc[j];
+          q[j] += acc[j] * acc[j];
+        }
+    }
+  }
+  if (stats) {
+    __shared__ float red[FWD_THREADS / 64][2 * CO_T];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < CO_T; ++j) {
+      const float a = wave_sum(s[j]), b = wave_sum(q[j]);
+      if (lane == 0) { red[wv][j] = a; red[wv][CO_T + j] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CO_T) {
+      float t = 0.f;
+      for (int k = 0; k < FWD_THREADS / 64; ++k) t += red[k][threadIdx.x];
+      const int j = threadIdx.x % CO_T, which = threadIdx.x / CO_T;
+      if (co0 + j < Cout) stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + j] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient: block = (voxel chunk, 8x8 (co,ci) tile, tap); thread = voxel lane with an
+// 8x8 register tile; partial tiles [chunk][taps][Cout][Cin] are summed by wgrad_reduce.
+constexpr int WG_T = 8;
+constexpr int WG_THREADS = 256;
+
+template <typename TX, typename TY, bool DECONV>
+__global__ void __launch_bounds__(WG_THREADS)
+wgrad_generic(const TX* __restrict__ x, Strides xs, const TY* __restrict__ dy, Strides ys, float* __restrict__ part,
+              int N, int D, int H, int W, int Cin, int Cout, int KD, int KH, int KW, int chunks) {
+  // D,H,W: for conv the (shared) spatial size; for DECONV the INPUT size (dy is 2x)
+  const int taps = KD * KH * KW;
+  const int tap = blockIdx.z;
+  const int tiles_ci = (Cin + WG_T - 1) / WG_T;
+  const int co0 = (blockIdx.y / tiles_ci) * WG_T, ci0 = (blockIdx.y % tiles_ci) * WG_T;
+  const int kd = tap / (KH * KW), kh = (tap / KW) % KH, kw = tap % KW;
+  const int64_t V = (int64_t)N * D * H * W;
+  float acc[WG_T][WG_T];
+#pragma unroll
+  for (int a = 0; a < WG_T; ++a)
+#pragma unroll
+    for (int b = 0; b < WG_T; ++b) acc[a][b] = 0.f;
+  const int64_t per = (V + chunks - 1) / chunks;
+  const int64_t v0 = (int64_t)blockIdx.x * per, v1 = (v0 + per < V) ? v0 + per : V;
+  for (int64_t v = v0 + threadIdx.x; v < v1; v += WG_THREADS) {
+    int64_t r = v;
+    const int w0 = r % W; r /= W;
+    const int h0 = r % H; r /= H;
+    const int d0 = r % D; r /= D;
+    const int n0 = (int)r;
+    const TX* xp;
+    const TY* gp;
+    if (DECONV) {
+      xp = x + n0 * xs.n + d0 * xs.d + h0 * xs.h + w0 * xs.w;
+      gp = dy + n0 * ys.n + (2 * d0 + kd) * ys.d + (2 * h0 + kh) * ys.h + (2 * w0 + kw) * ys.w;
+    } else {
+      const int dd = d0 + kd - KD / 2, hh = h0 + kh - KH / 2, ww = w0 + kw - KW / 2;
+      if (dd < 0 || dd >= D || hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      xp = x + n0 * xs.n + dd * xs.d + hh * xs.h + ww * xs.w;
+      gp = dy + n0 * ys.n + d0 * ys.d + h0 * ys.h + w0 * ys.w;
+    }
+    float xv[WG_T], gv[WG_T];
+#pragma unroll
+    for (int b = 0; b < WG_T; ++b) xv[b] = (ci0 + b < Cin) ? Act<TX>::ld(xp + (ci0 + b) * xs.c) : 0.f;
+#pragma unroll
+    for (int a = 0; a < WG_T; ++a) gv[a] = (co0 + a < Cout) ? Act<TY>::ld(gp + (co0 + a) * ys.c) : 0.f;
+#pragma unroll
+    for (int a = 0; a < WG_T; ++a)
+#pragma unroll
+      for (int b = 0; b < WG_T; ++b) acc[a][b] = fmaf(gv[a], xv[b], acc[a][b]);
+  }
+  __shared__ float red[WG_THREADS / 64][WG_T * WG_T];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int a = 0; a < WG_T; ++a)
+#pragma unroll
+    for (int b = 0; b < WG_T; ++b) {
+      const float t = wave_sum(acc[a][b]);
+      if (lane == 0) red[wv][a * WG_T + b] = t;
+    }
+  __syncthreads();
+  if (threadIdx.x < WG_T * WG_T) {
+    float t = 0.f;
+    for (int k = 0; k < WG_THREADS / 64; ++k) t += red[k][threadIdx.x];
+    const int a = threadIdx.x / WG_T, b = threadIdx.x % WG_T;
+    if (co0 + a < Cout && ci0 + b < Cin)
+      part[(((int64_t)blockIdx.x * taps + tap) * Cout + co0 + a) * Cin + ci0 + b] = t;
+  }
+}
+
+// part [chunks][taps][Cout][Cin] -> conv: dw[Cout][Cin][taps];  deconv: dw[Cin][Cout][taps]
+__global__ void wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int chunks, int taps, int Cout,
+                             int Cin, int deconv) {
+  const int64_t total = (int64_t)taps * Cout * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += part[(int64_t)c * total + i];
+    const int ci = i % Cin, co = (i / Cin) % Cout, tap = (int)(i / ((int64_t)Cin * Cout));
+    if (deconv) dw[((int64_t)ci * Cout + co) * taps + tap] = t;
+    else dw[((int64_t)co * Cin + ci) * taps + tap] = t;
+  }
+}
+
+// bias gradient: db[c] = sum over voxels of dy[v][c]; two-stage, rows partial blocks
+template <typename TY>
+__global__ void __launch_bounds__(256)
+bias_grad_partial(const TY* __restrict__ dy, Strides ys, int N, int D, int H, int W, int C, float* __restrict__ part) {
+  const int64_t V = (int64_t)N * D * H * W;
+  const int c = blockIdx.y;
+  float t = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < V; v += (int64_t)gridDim.x * 256) {
+    int64_t r = v;
+    const int w0 = r % W; r /= W;
+    const int h0 = r % H; r /= H;
+    const int d0 = r % D; r /= D;
+    t += Act<TY>::ld(dy + r * ys.n + d0 * ys.d + h0 * ys.h + w0 * ys.w + c * ys.c);
+  }
+  __shared__ float red[4];
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(int64_t)blockIdx.x * C + c] = red[0] + red[1] + red[2] + red[3];
+}
+// channels-last variant (ys.c == 1): lanes run over channels, coalesced; grid (rows, ceil(C/64))
+template <typename TY>
+__global__ void __launch_bounds__(256)
+bias_grad_partial_cl(const TY* __restrict__ dy, int64_t ld, int64_t V, int C, float* __restrict__ part) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int vl = threadIdx.x >> 6;
+  float t = 0.f;
+  if (c < C)
+    for (int64_t v = (int64_t)blockIdx.x * 4 + vl; v < V; v += (int64_t)gridDim.x * 4) t += Act<TY>::ld(dy + v * ld + c);
+  __shared__ float red[4][64];
+  red[vl][threadIdx.x & 63] = t;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C)
+    part[(int64_t)blockIdx.x * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void bias_grad_reduce(const float* __restrict__ part, int rows, int C, float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int r = 0; r < rows; ++r) t += part[(int64_t)r * C + c];
+  db[c] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// transposed conv k2 s2: forward (thread = input voxel x CO_T couts, blockIdx.z = tap)
+template <typename T>
+__global__ void __launch_bounds__(FWD_THREADS)
+deconv_fwd_generic(const T* __restrict__ x, int64_t ldx, const T* __restrict__ wf, const float* __restrict__ bias,
+                   T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout) {
+  const int tap = blockIdx.z, co0 = blockIdx.y * CO_T;
+  const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t v = (int64_t)blockIdx.x * FWD_THREADS + threadIdx.x;
+  if (v >= V) return;
+  int64_t r = v;
+  const int w0 = r % W; r /= W;
+  const int h0 = r % H; r /= H;
+  const int d0 = r % D; r /= D;
+  const T* xp = x + v * ldx;
+  const T* wt = wf + ((int64_t)tap * Cout + co0) * Cin;
+  float acc[CO_T];
+#pragma unroll
+  for (int a = 0; a < CO_T; ++a) acc[a] = (co0 + a < Cout) ? bias[co0 + a] : 0.f;
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float xv = Act<T>::ld(xp + ci);
+#pragma unroll
+    for (int a = 0; a < CO_T; ++a)
+      if (co0 + a < Cout) acc[a] = fmaf(xv, Act<T>::ld(wt + (int64_t)a * Cin + ci), acc[a]);
+  }
+  T* yp = y + ((((int64_t)r * 2 * D + 2 * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
+#pragma unroll
+  for (int a = 0; a < CO_T; ++a)
+    if (co0 + a < Cout) Act<T>::st(yp + co0 + a, acc[a]);
+}
+
+// data gradient: dx[v][ci] = sum_tap sum_co dy[out(v,tap)][co] * wb[tap][ci][co]
+template <typename T>
+__global__ void __launch_bounds__(FWD_THREADS)
+deconv_dgrad_generic(const T* __restrict__ dy, int64_t ldy, const T* __restrict__ wb, T* __restrict__ dx, int64_t ldx,
+                     int N, int D, int H, int W, int Cin, int Cout) {
+  const int ci0 = blockIdx.y * CO_T;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t v = (int64_t)blockIdx.x * FWD_THREADS + threadIdx.x;
+  if (v >= V) return;
+  int64_t r = v;
+  const int w0 = r % W; r /= W;
+  const int h0 = r % H; r /= H;
+  const int d0 = r % D; r /= D;
+  float acc[CO_T];
+#pragma unroll
+  for (int a = 0; a < CO_T; ++a) acc[a] = 0.f;
+  for (int tap = 0; tap < 8; ++tap) {
+    const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
+    const T* gp = dy + ((((int64_t)r * 2 * D + 2 * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
+    const T* wt = wb + ((int64_t)tap * Cin + ci0) * Cout;
+    for (int co = 0; co < Cout; ++co) {
+      const float g = Act<T>::ld(gp + co);
+#pragma unroll
+      for (int a = 0; a < CO_T; ++a)
+        if (ci0 + a < Cin) acc[a] = fmaf(g, Act<T>::ld(wt + (int64_t)a * Cout + co), acc[a]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < CO_T; ++a)
+    if (ci0 + a < Cin) Act<T>::st(dx + v * ldx + ci0 + a, acc[a]);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing
+template <typename T>
+__global__ void pack_conv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cout, int Cin,
+                            int taps) {
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = i % taps, ci = (i / taps) % Cin, co = (int)(i / ((int64_t)taps * Cin));
+    const float v = w[i];
+    Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
+    if (wb) Act<T>::st(wb + ((int64_t)(taps - 1 - tap) * Cin + ci) * Cout + co, v);
+  }
+}
+template <typename T>
+__global__ void pack_deconv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin, int Cout) {
+  const int64_t total = (int64_t)Cin * Cout * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = i % 8, co = (i / 8) % Cout, ci = (int)(i / (8 * (int64_t)Cout));
+    const float v = w[i];
+    Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
+    if (wb) Act<T>::st(wb + ((int64_t)tap * Cin + ci) * Cout + co, v);
+  }
+}
+
+template <typename TY>
+void launch_bias_grad(const TY* dy, Strides ys, int n, int d, int h, int w, int c, float* bpart, float* db, hipStream_t st) {
+  const int64_t V = (int64_t)n * d * h * w;
+  const int rows = fplx_rows_for(V);
+  const bool cl = ys.c == 1 && ys.h == ys.w * w && ys.d == ys.h * h && ys.n == ys.d * d;
+  if (cl) {
+    dim3 g(rows, (c + 63) / 64);
+    bias_grad_partial_cl<TY><<<g, 256, 0, st>>>(dy, ys.w, V, c, bpart);
+  } else {
+    dim3 g(rows, c);
+    bias_grad_partial<TY><<<g, 256, 0, st>>>(dy, ys, n, d, h, w, c, bpart);
+  }
+  bias_grad_reduce<<<(c + 63) / 64, 64, 0, st>>>(bpart, rows, c, db);
+}
+
+inline int grid_for(int64_t n, int threads, int cap) {
+  int64_t g = (n + threads - 1) / threads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+inline int wgrad_chunks(int64_t V) {
+  int64_t c = (V + 8191) / 8192;
+  if (c > 64) c = 64;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+}  // namespace
+
+// MFMA fast paths (conv_mfma.hip); return 1 if they handled the call, 0 if not applicable, <0 on error
+extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                    int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
+extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
+
+extern "C" {
+
+int fplx_version(void) { return 1; }
+
+int fplx_last_error(char* buf, size_t n) {
+  const char* e = fplx_err_buf();
+  size_t l = strlen(e);
+  if (buf && n) {
+    size_t c = l < n - 1 ? l : n - 1;
+    memcpy(buf, e, c);
+    buf[c] = 0;
+  }
+  return (int)l;
+}
+
+int fplx_num_partials(int64_t voxels) { return fplx_rows_for(voxels); }
+
+int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin, int kd, int kh, int kw, int dt,
+                          fplx_stream_t stream) {
+  FPLX_REQUIRE(w && wf, FPLX_E_NULL, "pack_conv_weight: null pointer");
+  FPLX_REQUIRE(cout > 0 && cin > 0 && kd > 0 && kh > 0 && kw > 0, FPLX_E_BADSHAPE, "pack_conv_weight: bad shape");
+  const int taps = kd * kh * kw;
+  const int64_t total = (int64_t)cout * cin * taps;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_F32)
+    pack_conv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cout, cin, taps);
+  else if (dt == FPLX_BF16)
+    pack_conv_w<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cout, cin, taps);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "pack_conv_weight: dtype %d", dt);
+  return fplx_check_launch("pack_conv_weight");
+}
+
+int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(w && wf, FPLX_E_NULL, "pack_deconv_weight: null pointer");
+  FPLX_REQUIRE(cout > 0 && cin > 0, FPLX_E_BADSHAPE, "pack_deconv_weight: bad shape");
+  const int64_t total = (int64_t)cout * cin * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_F32)
+    pack_deconv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cin, cout);
+  else if (dt == FPLX_BF16)
+    pack_deconv_w<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cin, cout);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "pack_deconv_weight: dtype %d", dt);
+  return fplx_check_launch("pack_deconv_weight");
+}
+
+int fplx_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt) {
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3) {
+    int r = fplx_mfma_conv3d_stats_rows(n, d, h, w, cin, cout);
+    if (r > 0) return r;
+  }
+  const int64_t V = (int64_t)n * d * h * w;
+  return grid_for(V, FWD_THREADS, MAX_ROWS);
+}
+
+int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                    const void* wp, const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh,
+                    int64_t yw, int64_t yc, int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
+                    float* stats, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && wp && y, FPLX_E_NULL, "conv3d_fwd: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE,
+               "conv3d_fwd: bad shape n=%d d=%d h=%d w=%d cin=%d cout=%d", n, d, h, w, cin, cout);
+  FPLX_REQUIRE((kd & 1) && (kh & 1) && (kw & 1) && kd <= 3 && kh <= 3 && kw <= 3, FPLX_E_BADSHAPE,
+               "conv3d_fwd: kernel %dx%dx%d unsupported (odd sizes <= 3)", kd, kh, kw);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 && sc == 1 && yc == 1 &&
+      sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
+    int r = fplx_mfma_conv3d_fwd(x, sw, wp, bias, y, yw, n, d, h, w, cin, cout, stats, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
+  const int64_t V = (int64_t)n * d * h * w;
+  const int64_t tiles = (V + FWD_THREADS - 1) / FWD_THREADS;
+  dim3 grid(grid_for(V, FWD_THREADS, MAX_ROWS), (cout + CO_T - 1) / CO_T);
+  Strides xs{sn, sd, sh, sw, sc}, ys{yn, yd, yh, yw, yc};
+#define LAUNCH(TX, TW, TY)                                                                                      \
+  conv_fwd_generic<TX, TW, TY><<<grid, FWD_THREADS, 0, st>>>((const TX*)x, xs, (const TW*)wp, bias, (TY*)y, ys, \
+                                                             n, d, h, w, cin, cout, kd, kh, kw, stats, tiles)
+  // packed weight type: that of y when y is an activation tensor in dt, fp32 when y is fp32
+  if (x_dt == FPLX_F32 && y_dt == FPLX_F32) LAUNCH(float, float, float);
+  else if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16) LAUNCH(bf16_t, bf16_t, bf16_t);
+  else if (x_dt == FPLX_F32 && y_dt == FPLX_BF16) LAUNCH(float, bf16_t, bf16_t);
+  else if (x_dt == FPLX_BF16 && y_dt == FPLX_F32) LAUNCH(bf16_t, float, float);
+  else return fplx_fail(FPLX_E_BADDTYPE, "conv3d_fwd: dtypes %d/%d", x_dt, y_dt);
+#undef LAUNCH
+  return fplx_check_launch("conv3d_fwd");
+}
+
+size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw) {
+  const int64_t V = (int64_t)n * d * h * w;
+  const size_t a = (size_t)wgrad_chunks(V) * kd * kh * kw * cout * cin * sizeof(float);
+  const size_t b = (size_t)fplx_rows_for(V) * cout * sizeof(float);
+  return a + b + 256;
+}
+
+int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                      const void* dy, int dy_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
+                      float* dw, float* db, int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
+                      void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && dy && dw && ws, FPLX_E_NULL, "conv3d_wgrad: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "conv3d_wgrad: bad shape");
+  FPLX_REQUIRE(ws_bytes >= fplx_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, kd, kh, kw), FPLX_E_WORKSPACE,
+               "conv3d_wgrad: workspace %zu < %zu", ws_bytes,
+               fplx_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, kd, kh, kw));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t V = (int64_t)n * d * h * w;
+  const int taps = kd * kh * kw, chunks = wgrad_chunks(V);
+  float* part = (float*)ws;
+  float* bpart = part + (size_t)chunks * taps * cout * cin;
+  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), taps);
+  Strides xs{sn, sd, sh, sw, sc}, ys{yn, yd, yh, yw, yc};
+#define LAUNCH(TX, TY)                                                                                         \
+  wgrad_generic<TX, TY, false><<<grid, WG_THREADS, 0, st>>>((const TX*)x, xs, (const TY*)dy, ys, part, n, d, h, w, \
+                                                            cin, cout, kd, kh, kw, chunks)
+  if (x_dt == FPLX_F32 && dy_dt == FPLX_F32) LAUNCH(float, float);
+  else if (x_dt == FPLX_BF16 && dy_dt == FPLX_BF16) LAUNCH(bf16_t, bf16_t);
+  else if (x_dt == FPLX_F32 && dy_dt == FPLX_BF16) LAUNCH(float, bf16_t);
+  else if (x_dt == FPLX_BF16 && dy_dt == FPLX_F32) LAUNCH(bf16_t, float);
+  else return fplx_fail(FPLX_E_BADDTYPE, "conv3d_wgrad: dtypes %d/%d", x_dt, dy_dt);
+#undef LAUNCH
+  wgrad_reduce<<<grid_for((int64_t)taps * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, taps, cout, cin, 0);
+  if (db) {
+    if (dy_dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, ys, n, d, h, w, cout, bpart, db, st);
+    else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, d, h, w, cout, bpart, db, st);
+  }
+  return fplx_check_launch("conv3d_wgrad");
+}
+
+int fplx_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                     int h, int w, int cin, int cout, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && wf && bias && y, FPLX_E_NULL, "deconv2_fwd: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
+               "deconv2_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t V = (int64_t)n * d * h * w;
+  dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cout + CO_T - 1) / CO_T, 8);
+  if (dt == FPLX_F32)
+    deconv_fwd_generic<float><<<grid, FWD_THREADS, 0, st>>>((const float*)x, ldx, (const float*)wf, bias, (float*)y,
+                                                            ldy, n, d, h, w, cin, cout);
+  else if (dt == FPLX_BF16)
+    deconv_fwd_generic<bf16_t><<<grid, FWD_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias,
+                                                             (bf16_t*)y, ldy, n, d, h, w, cin, cout);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "deconv2_fwd: dtype %d", dt);
+  return fplx_check_launch("deconv2_fwd");
+}
+
+int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                       int cin, int cout, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(dy && wb && dx, FPLX_E_NULL, "deconv2_dgrad: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
+               "deconv2_dgrad: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t V = (int64_t)n * d * h * w;
+  dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cin + CO_T - 1) / CO_T);
+  if (dt == FPLX_F32)
+    deconv_dgrad_generic<float><<<grid, FWD_THREADS, 0, st>>>((const float*)dy, ldy, (const float*)wb, (float*)dx, ldx,
+                                                              n, d, h, w, cin, cout);
+  else if (dt == FPLX_BF16)
+    deconv_dgrad_generic<bf16_t><<<grid, FWD_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx,
+                                                               ldx, n, d, h, w, cin, cout);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "deconv2_dgrad: dtype %d", dt);
+  return fplx_check_launch("deconv2_dgrad");
+}
+
+size_t fplx_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  const int64_t V = (int64_t)n * d * h * w;
+  return (size_t)wgrad_chunks(V) * 8 * cout * cin * sizeof(float) + (size_t)fplx_rows_for(V * 8) * cout * sizeof(float) +
+         256;
+}
+
+int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
+                       int h, int w, int cin, int cout, int dt, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && dy && dw && ws, FPLX_E_NULL, "deconv2_wgrad: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "deconv2_wgrad: bad shape");
+  FPLX_REQUIRE(ws_bytes >= fplx_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout), FPLX_E_WORKSPACE,
+               "deconv2_wgrad: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t V = (int64_t)n * d * h * w;
+  const int chunks = wgrad_chunks(V);
+  float* part = (float*)ws;
+  float* bpart = part + (size_t)chunks * 8 * cout * cin;
+  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), 8);
+  Strides xs{(int64_t)d * h * w * ldx, (int64_t)h * w * ldx, (int64_t)w * ldx, ldx, 1};
+  Strides ys{(int64_t)8 * d * h * w * ldy, (int64_t)4 * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};
+  if (dt == FPLX_F32)
+    wgrad_generic<float, float, true><<<grid, WG_THREADS, 0, st>>>((const float*)x, xs, (const float*)dy, ys, part, n,
+                                                                   d, h, w, cin, cout, 2, 2, 2, chunks);
+  else if (dt == FPLX_BF16)
+    wgrad_generic<bf16_t, bf16_t, true><<<grid, WG_THREADS, 0, st>>>((const bf16_t*)x, xs, (const bf16_t*)dy, ys, part,
+                                                                     n, d, h, w, cin, cout, 2, 2, 2, chunks);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "deconv2_wgrad: dtype %d", dt);
+  wgrad_reduce<<<grid_for((int64_t)8 * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, 8, cout, cin, 1);
+  if (db) {
+    if (dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);
+    else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);
+  }
+  return fplx_check_launch("deconv2_wgrad");
+}
+
+}  // extern "C"

@@ -1,0 +1,579 @@
+// HBM-bound passes of the DSBN U-Net: BatchNorm statistics finalisation, the fused
+// BN-apply + PReLU + dropout pass and its three-stage backward, MaxPool3d(2) forward/backward,
+// fused Adam.  One 16-byte vector per lane per access (8 bf16 / 4 fp32 channels of one voxel),
+// fixed-order two-stage reductions (bitwise reproducible).
+#include "common.h"
+#include "philox.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const float4 r = *reinterpret_cast<const float4*>(p);
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec<bf16_t> {
+  static constexpr int N = 8;
+  typedef __attribute__((ext_vector_type(8))) __bf16 raw;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const raw r = *reinterpret_cast<const raw*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    raw r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    *reinterpret_cast<raw*>(p) = r;
+  }
+};
+
+// generic VEC-wide access: VEC == Vec<T>::N uses 16-byte accesses, VEC == 1 scalar
+template <typename T, int VEC>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) v[0] = Act<T>::ld(p);
+  else Vec<T>::load(p, v);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void stv(T* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) Act<T>::st(p, v[0]);
+  else Vec<T>::store(p, v);
+}
+
+// dropout keep flags for VEC consecutive elements starting at flat index e (e % VEC == 0 when VEC>1)
+template <int VEC>
+__device__ __forceinline__ void keep_flags(int64_t e, uint32_t thr, uint32_t k0, uint32_t k1, uint32_t sid,
+                                           bool (&keep)[VEC]) {
+  if constexpr (VEC == 1) {
+    const Philox4 r = philox4x32_10((uint32_t)(e >> 2), 0u, sid, 0u, k0, k1);
+    keep[0] = r.v[e & 3] >= thr;
+  } else {
+#pragma unroll
+    for (int g = 0; g < VEC / 4; ++g) {
+      const Philox4 r = philox4x32_10((uint32_t)((e >> 2) + g), 0u, sid, 0u, k0, k1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) keep[g * 4 + i] = r.v[i] >= thr;
+    }
+  }
+}
+
+struct DropCfg { uint32_t thr, k0, k1, sid; float inv_keep; int on; };
+
+inline DropCfg make_drop(float p, uint64_t seed, uint32_t sid) {
+  DropCfg d;
+  d.on = p > 0.f;
+  d.thr = dropout_threshold(p);
+  d.k0 = (uint32_t)seed;
+  d.k1 = (uint32_t)(seed >> 32);
+  d.sid = sid;
+  d.inv_keep = d.on ? (float)(1.0 / (1.0 - (double)p)) : 1.f;
+  return d;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void bn_train_finalize_k(const float* __restrict__ stats, int rows, int C, double count,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
+                                    float momentum, float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += (double)stats[((int64_t)r * 2 + 0) * C + c];
+    s2 += (double)stats[((int64_t)r * 2 + 1) * C + c];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  const float mf = (float)m;
+  mean[c] = mf;
+  rstd[c] = rs;
+  const float sc = gamma[c] * rs;
+  scale[c] = sc;
+  shift[c] = beta[c] - mf * sc;
+  if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * mf;
+  if (rv) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  }
+}
+
+__global__ void bn_eval_prepare_k(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                  float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rs = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * rs;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t ldo, const float* __restrict__ scale,
+             const float* __restrict__ shift, const float* __restrict__ slope_p, DropCfg dc, int64_t voxels, int C) {
+  const int G = C / VEC;
+  const int64_t total = voxels * G;
+  const float slope = *slope_p;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int64_t v = i / G;
+    const int c0 = (int)(i % G) * VEC;
+    float a[VEC];
+    ldv<T, VEC>(y + v * ldy + c0, a);
+    bool keep[VEC];
+    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z = fmaf(a[j], scale[c0 + j], shift[c0 + j]);
+      z = z > 0.f ? z : z * slope;
+      if (dc.on) z = keep[j] ? z * dc.inv_keep : 0.f;
+      a[j] = z;
+    }
+    stv<T, VEC>(out + v * ldo + c0, a);
+  }
+}
+
+// dz for one element given y, dout
+__device__ __forceinline__ float dz_of(float yv, float dout, float sc, float sh, float slope, bool on, bool keep,
+                                       float inv_keep, float& z_out) {
+  const float z = fmaf(yv, sc, sh);
+  z_out = z;
+  float da = dout;
+  if (on) da = keep ? dout * inv_keep : 0.f;
+  return z > 0.f ? da : da * slope;
+}
+
+// stage 1 of backward: per-channel sums of dz and dz*xhat, and the slope gradient
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dout, int64_t ldd,
+                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const float* __restrict__ slope_p, DropCfg dc, int64_t voxels,
+                    int C, float* __restrict__ part) {
+  const int G = C / VEC;                 // channel groups per voxel (host guarantees G <= EW_THREADS)
+  const int VL = EW_THREADS / G;         // voxel lanes per block
+  const int g = threadIdx.x % G, vl = threadIdx.x / G;
+  const bool active = vl < VL;
+  const int c0 = g * VEC;
+  const float slope = *slope_p;
+  float sdz[VEC], sdx[VEC], sds = 0.f;
+  float m[VEC], rs[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sdz[j] = sdx[j] = 0.f;
+    m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+  }
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < voxels; v += (int64_t)gridDim.x * VL) {
+      float a[VEC], d[VEC];
+      ldv<T, VEC>(y + v * ldy + c0, a);
+      ldv<T, VEC>(dout + v * ldd + c0, d);
+      bool keep[VEC];
+      if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z;
+        const bool kp = dc.on ? keep[j] : true;
+        const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, kp, dc.inv_keep, z);
+        float da = d[j];
+        if (dc.on) da = kp ? d[j] * dc.inv_keep : 0.f;
+        sds += z > 0.f ? 0.f : da * z;
+        sdz[j] += dz;
+        sdx[j] = fmaf(dz, (a[j] - m[j]) * rs[j], sdx[j]);
+      }
+    }
+  }
+  __shared__ float red[EW_THREADS][2 * VEC + 1];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { red[threadIdx.x][j] = sdz[j]; red[threadIdx.x][VEC + j] = sdx[j]; }
+  red[threadIdx.x][2 * VEC] = active ? sds : 0.f;
+  __syncthreads();
+  float* row = part + (int64_t)blockIdx.x * (2 * C + 1);
+  if (threadIdx.x < G) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int k = 0; k < VL; ++k) { t0 += red[k * G + threadIdx.x][j]; t1 += red[k * G + threadIdx.x][VEC + j]; }
+      row[c0 + j] = t0;
+      row[C + c0 + j] = t1;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < VL * G; ++k) t += red[k][2 * VEC];
+    row[2 * C] = t;
+  }
+}
+
+__global__ void bn_act_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double count, int train,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      float* __restrict__ dslope, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      s0 += (double)part[(int64_t)r * (2 * C + 1) + c];
+      s1 += (double)part[(int64_t)r * (2 * C + 1) + C + c];
+    }
+    if (dbeta) dbeta[c] += (float)s0;
+    if (dgamma) dgamma[c] += (float)s1;
+    coef[c] = train ? (float)(s0 / count) : 0.f;
+    coef[C + c] = train ? (float)(s1 / count) : 0.f;
+  }
+  if (c == 0 && dslope) {
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)part[(int64_t)r * (2 * C + 1) + 2 * C];
+    dslope[0] += (float)s;
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dout, int64_t ldd, T* __restrict__ dy,
+                   int64_t ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
+                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ slope_p,
+                   const float* __restrict__ coef, DropCfg dc, int64_t voxels, int C) {
+  const int G = C / VEC;
+  const int64_t total = voxels * G;
+  const float slope = *slope_p;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int64_t v = i / G;
+    const int c0 = (int)(i % G) * VEC;
+    float a[VEC], d[VEC];
+    ldv<T, VEC>(y + v * ldy + c0, a);
+    ldv<T, VEC>(dout + v * ldd + c0, d);
+    bool keep[VEC];
+    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = c0 + j;
+      float z;
+      const float dz = dz_of(a[j], d[j], scale[c], shift[c], slope, dc.on, dc.on ? keep[j] : true, dc.inv_keep, z);
+      const float xh = (a[j] - mean[c]) * rstd[c];
+      d[j] = scale[c] * (dz - coef[c] - xh * coef[C + c]);
+    }
+    stv<T, VEC>(dy + v * ldo + c0, d);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int C) {
+  const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Do * Ho * Wo * G;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int c0 = (int)(i % G) * VEC;
+    int64_t r = i / G;
+    const int64_t vo = r;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho; r /= Ho;
+    const int d_o = r % Do; r /= Do;
+    float best[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t vi = (((int64_t)r * D + 2 * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      float a[VEC];
+      ldv<T, VEC>(x + vi * ldx + c0, a);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) best[j] = a[j] > best[j] ? a[j] : best[j];
+    }
+    stv<T, VEC>(y + vo * ldy + c0, best);
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t ldy, const T* __restrict__ dskip,
+               int64_t lds, T* __restrict__ dx, int64_t ldo, int N, int D, int H, int W, int C) {
+  const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Do * Ho * Wo * G;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int c0 = (int)(i % G) * VEC;
+    int64_t r = i / G;
+    const int64_t vo = r;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho; r /= Ho;
+    const int d_o = r % Do; r /= Do;
+    float g[VEC], best[VEC];
+    int arg[VEC];
+    ldv<T, VEC>(dy + vo * ldy + c0, g);
+    float a[8][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+    int64_t vis[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      vis[t] = (((int64_t)r * D + 2 * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      ldv<T, VEC>(x + vis[t] * ldx + c0, a[t]);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if (a[t][j] > best[j]) { best[j] = a[t][j]; arg[j] = t; }   // first maximum wins (ATen max_pool3d)
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float o[VEC];
+      if (dskip) ldv<T, VEC>(dskip + vis[t] * lds + c0, o);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] += (arg[j] == t) ? g[j] : 0.f;
+      stv<T, VEC>(dx + vis[t] * ldo + c0, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EW_THREADS)
+adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+       float step_size, float b1, float b2, float eps, float wd, float inv_sqrt_bc2, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i] * gscale);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+
+// per-channel sum / sum of squares of an NDHWC tensor: part [rows][2][C] (standalone DSBN layer)
+template <typename T>
+__global__ void __launch_bounds__(EW_THREADS)
+channel_stats_k(const T* __restrict__ x, int64_t ld, int64_t V, int C, float* __restrict__ part) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int vl = threadIdx.x >> 6;
+  float s = 0.f, q = 0.f;
+  if (c < C)
+    for (int64_t v = (int64_t)blockIdx.x * 4 + vl; v < V; v += (int64_t)gridDim.x * 4) {
+      const float a = Act<T>::ld(x + v * ld + c);
+      s += a;
+      q = fmaf(a, a, q);
+    }
+  __shared__ float red[4][2][64];
+  red[vl][0][threadIdx.x & 63] = s;
+  red[vl][1][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int which = threadIdx.x >> 6, cc = blockIdx.y * 64 + (threadIdx.x & 63), l = threadIdx.x & 63;
+    if (cc < C)
+      part[((int64_t)blockIdx.x * 2 + which) * C + cc] = red[0][which][l] + red[1][which][l] + red[2][which][l] + red[3][which][l];
+  }
+}
+
+inline int ew_grid(int64_t total) {
+  int64_t g = (total + EW_THREADS - 1) / EW_THREADS;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+bool vec_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, int C) {
+  constexpr int V = Vec<T>::N;
+  auto ok = [&](const void* p, int64_t ld) { return !p || (((uintptr_t)p % 16 == 0) && (ld % V == 0)); };
+  return (C % V == 0) && ok(a, lda) && ok(b, ldb) && ok(c, ldc);
+}
+
+}  // namespace
+
+#define DISPATCH_VEC(T, OK, KERNEL, ...)                         \
+  do {                                                           \
+    if (OK) KERNEL<T, Vec<T>::N> __VA_ARGS__;                    \
+    else KERNEL<T, 1> __VA_ARGS__;                               \
+  } while (0)
+
+extern "C" {
+
+int fplx_bn_train_finalize(const float* stats, int rows, int c, int64_t count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                           float* mean, float* rstd, float* scale, float* shift, fplx_stream_t stream) {
+  FPLX_REQUIRE(stats && gamma && beta && mean && rstd && scale && shift, FPLX_E_NULL, "bn_train_finalize: null pointer");
+  FPLX_REQUIRE(rows > 0 && c > 0 && count > 0, FPLX_E_BADSHAPE, "bn_train_finalize: bad shape");
+  bn_train_finalize_k<<<(c + 63) / 64, 64, 0, (hipStream_t)stream>>>(stats, rows, c, (double)count, gamma, beta,
+                                                                     running_mean, running_var, nbt, momentum, eps,
+                                                                     mean, rstd, scale, shift);
+  return fplx_check_launch("bn_train_finalize");
+}
+
+int fplx_channel_stats(const void* x, int64_t ldx, int64_t voxels, int c, int dt, float* stats, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && stats, FPLX_E_NULL, "channel_stats: null pointer");
+  FPLX_REQUIRE(voxels > 0 && c > 0 && ldx >= c, FPLX_E_BADSHAPE, "channel_stats: bad shape");
+  dim3 grid(fplx_rows_for(voxels), (c + 63) / 64);
+  if (dt == FPLX_F32) channel_stats_k<float><<<grid, EW_THREADS, 0, (hipStream_t)stream>>>((const float*)x, ldx, voxels, c, stats);
+  else if (dt == FPLX_BF16)
+    channel_stats_k<bf16_t><<<grid, EW_THREADS, 0, (hipStream_t)stream>>>((const bf16_t*)x, ldx, voxels, c, stats);
+  else return fplx_fail(FPLX_E_BADDTYPE, "channel_stats: dtype %d", dt);
+  return fplx_check_launch("channel_stats");
+}
+
+int fplx_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                         float eps, int c, float* scale, float* shift, fplx_stream_t stream) {
+  FPLX_REQUIRE(gamma && beta && running_mean && running_var && scale && shift, FPLX_E_NULL,
+               "bn_eval_prepare: null pointer");
+  FPLX_REQUIRE(c > 0, FPLX_E_BADSHAPE, "bn_eval_prepare: bad shape");
+  bn_eval_prepare_k<<<(c + 63) / 64, 64, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, c, scale,
+                                                                   shift);
+  return fplx_check_launch("bn_eval_prepare");
+}
+
+int fplx_bn_act_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, const float* scale, const float* shift,
+                    const float* slope, float p, uint64_t seed, uint32_t stream_id, int64_t voxels, int c, int dt,
+                    fplx_stream_t stream) {
+  FPLX_REQUIRE(y && out && scale && shift && slope, FPLX_E_NULL, "bn_act_fwd: null pointer");
+  FPLX_REQUIRE(voxels > 0 && c > 0 && ldy >= c && ldo >= c && p >= 0.f && p < 1.f, FPLX_E_BADSHAPE,
+               "bn_act_fwd: bad shape/p");
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg dc = make_drop(p, seed, stream_id);
+  if (dt == FPLX_F32) {
+    const bool ok = vec_ok<float>(y, ldy, out, ldo, nullptr, 0, c);
+    const int g = ew_grid(voxels * (ok ? c / 4 : c));
+    DISPATCH_VEC(float, ok, bn_act_fwd_k, <<<g, EW_THREADS, 0, st>>>((const float*)y, ldy, (float*)out, ldo, scale,
+                                                                     shift, slope, dc, voxels, c));
+  } else if (dt == FPLX_BF16) {
+    const bool ok = vec_ok<bf16_t>(y, ldy, out, ldo, nullptr, 0, c);
+    const int g = ew_grid(voxels * (ok ? c / 8 : c));
+    DISPATCH_VEC(bf16_t, ok, bn_act_fwd_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (bf16_t*)out, ldo, scale,
+                                                                      shift, slope, dc, voxels, c));
+  } else
+    return fplx_fail(FPLX_E_BADDTYPE, "bn_act_fwd: dtype %d", dt);
+  return fplx_check_launch("bn_act_fwd");
+}
+
+int fplx_bn_act_bwd_reduce(const void* y, int64_t ldy, const void* dout, int64_t ldd, const float* mean,
+                           const float* rstd, const float* scale, const float* shift, const float* slope, float p,
+                           uint64_t seed, uint32_t stream_id, int64_t voxels, int c, int dt, float* part,
+                           fplx_stream_t stream) {
+  FPLX_REQUIRE(y && dout && mean && rstd && scale && shift && slope && part, FPLX_E_NULL,
+               "bn_act_bwd_reduce: null pointer");
+  FPLX_REQUIRE(voxels > 0 && c > 0 && ldy >= c && ldd >= c, FPLX_E_BADSHAPE, "bn_act_bwd_reduce: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg dc = make_drop(p, seed, stream_id);
+  const int rows = fplx_rows_for(voxels);
+  if (dt == FPLX_F32) {
+    const bool ok = vec_ok<float>(y, ldy, dout, ldd, nullptr, 0, c) && c / 4 <= EW_THREADS;
+    FPLX_REQUIRE(ok || c <= EW_THREADS, FPLX_E_BADSHAPE, "bn_act_bwd_reduce: C=%d unsupported", c);
+    DISPATCH_VEC(float, ok, bn_act_bwd_reduce_k, <<<rows, EW_THREADS, 0, st>>>((const float*)y, ldy, (const float*)dout,
+                                                                               ldd, mean, rstd, scale, shift, slope,
+                                                                               dc, voxels, c, part));
+  } else if (dt == FPLX_BF16) {
+    const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, nullptr, 0, c) && c / 8 <= EW_THREADS;
+    FPLX_REQUIRE(ok || c <= EW_THREADS, FPLX_E_BADSHAPE, "bn_act_bwd_reduce: C=%d unsupported", c);
+    DISPATCH_VEC(bf16_t, ok, bn_act_bwd_reduce_k, <<<rows, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy,
+                                                                                (const bf16_t*)dout, ldd, mean, rstd,
+                                                                                scale, shift, slope, dc, voxels, c,
+                                                                                part));
+  } else
+    return fplx_fail(FPLX_E_BADDTYPE, "bn_act_bwd_reduce: dtype %d", dt);
+  return fplx_check_launch("bn_act_bwd_reduce");
+}
+
+int fplx_bn_act_bwd_finalize(const float* part, int rows, int c, int64_t count, int train, float* dgamma, float* dbeta,
+                             float* dslope, float* coef, fplx_stream_t stream) {
+  FPLX_REQUIRE(part && coef, FPLX_E_NULL, "bn_act_bwd_finalize: null pointer");
+  FPLX_REQUIRE(rows > 0 && c > 0 && count > 0, FPLX_E_BADSHAPE, "bn_act_bwd_finalize: bad shape");
+  bn_act_bwd_finalize_k<<<(c + 63) / 64, 64, 0, (hipStream_t)stream>>>(part, rows, c, (double)count, train, dgamma,
+                                                                       dbeta, dslope, coef);
+  return fplx_check_launch("bn_act_bwd_finalize");
+}
+
+int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t ldd, void* dy, int64_t ldo,
+                          const float* mean, const float* rstd, const float* scale, const float* shift,
+                          const float* slope, const float* coef, float p, uint64_t seed, uint32_t stream_id,
+                          int64_t voxels, int c, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(y && dout && dy && mean && rstd && scale && shift && slope && coef, FPLX_E_NULL,
+               "bn_act_bwd_apply: null pointer");
+  FPLX_REQUIRE(voxels > 0 && c > 0 && ldy >= c && ldd >= c && ldo >= c, FPLX_E_BADSHAPE, "bn_act_bwd_apply: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const DropCfg dc = make_drop(p, seed, stream_id);
+  if (dt == FPLX_F32) {
+    const bool ok = vec_ok<float>(y, ldy, dout, ldd, dy, ldo, c);
+    const int g = ew_grid(voxels * (ok ? c / 4 : c));
+    DISPATCH_VEC(float, ok, bn_act_bwd_apply_k, <<<g, EW_THREADS, 0, st>>>((const float*)y, ldy, (const float*)dout,
+                                                                           ldd, (float*)dy, ldo, mean, rstd, scale,
+                                                                           shift, slope, coef, dc, voxels, c));
+  } else if (dt == FPLX_BF16) {
+    const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, dy, ldo, c);
+    const int g = ew_grid(voxels * (ok ? c / 8 : c));
+    DISPATCH_VEC(bf16_t, ok, bn_act_bwd_apply_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout,
+                                                                            ldd, (bf16_t*)dy, ldo, mean, rstd, scale,
+                                                                            shift, slope, coef, dc, voxels, c));
+  } else
+    return fplx_fail(FPLX_E_BADDTYPE, "bn_act_bwd_apply: dtype %d", dt);
+  return fplx_check_launch("bn_act_bwd_apply");
+}
+
+int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
+                      fplx_stream_t stream) {
+  FPLX_REQUIRE(x && y, FPLX_E_NULL, "maxpool2_fwd: null pointer");
+  FPLX_REQUIRE(n > 0 && c > 0 && d >= 2 && h >= 2 && w >= 2 && !(d & 1) && !(h & 1) && !(w & 1) && ldx >= c && ldy >= c,
+               FPLX_E_BADSHAPE, "maxpool2_fwd: bad shape (even D,H,W required) %dx%dx%d", d, h, w);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t vo = (int64_t)n * (d / 2) * (h / 2) * (w / 2);
+  if (dt == FPLX_F32) {
+    const bool ok = vec_ok<float>(x, ldx, y, ldy, nullptr, 0, c);
+    DISPATCH_VEC(float, ok, maxpool2_fwd_k, <<<ew_grid(vo * (ok ? c / 4 : c)), EW_THREADS, 0, st>>>(
+                                                (const float*)x, ldx, (float*)y, ldy, n, d, h, w, c));
+  } else if (dt == FPLX_BF16) {
+    const bool ok = vec_ok<bf16_t>(x, ldx, y, ldy, nullptr, 0, c);
+    DISPATCH_VEC(bf16_t, ok, maxpool2_fwd_k, <<<ew_grid(vo * (ok ? c / 8 : c)), EW_THREADS, 0, st>>>(
+                                                 (const bf16_t*)x, ldx, (bf16_t*)y, ldy, n, d, h, w, c));
+  } else
+    return fplx_fail(FPLX_E_BADDTYPE, "maxpool2_fwd: dtype %d", dt);
+  return fplx_check_launch("maxpool2_fwd");
+}
+
+int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds, void* dx,
+                      int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && dy && dx, FPLX_E_NULL, "maxpool2_bwd: null pointer");
+  FPLX_REQUIRE(n > 0 && c > 0 && d >= 2 && h >= 2 && w >= 2 && !(d & 1) && !(h & 1) && !(w & 1), FPLX_E_BADSHAPE,
+               "maxpool2_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t vo = (int64_t)n * (d / 2) * (h / 2) * (w / 2);
+  if (dt == FPLX_F32) {
+    const bool ok = vec_ok<float>(x, ldx, dy, ldy, dx, ldo, c) && vec_ok<float>(dskip, lds, nullptr, 0, nullptr, 0, c);
+    DISPATCH_VEC(float, ok, maxpool2_bwd_k, <<<ew_grid(vo * (ok ? c / 4 : c)), EW_THREADS, 0, st>>>(
+                                                (const float*)x, ldx, (const float*)dy, ldy, (const float*)dskip, lds,
+                                                (float*)dx, ldo, n, d, h, w, c));
+  } else if (dt == FPLX_BF16) {
+    const bool ok = vec_ok<bf16_t>(x, ldx, dy, ldy, dx, ldo, c) && vec_ok<bf16_t>(dskip, lds, nullptr, 0, nullptr, 0, c);
+    DISPATCH_VEC(bf16_t, ok, maxpool2_bwd_k, <<<ew_grid(vo * (ok ? c / 8 : c)), EW_THREADS, 0, st>>>(
+                                                 (const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (const bf16_t*)dskip,
+                                                 lds, (bf16_t*)dx, ldo, n, d, h, w, c));
+  } else
+    return fplx_fail(FPLX_E_BADDTYPE, "maxpool2_bwd: dtype %d", dt);
+  return fplx_check_launch("maxpool2_bwd");
+}
+
+int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, fplx_stream_t stream) {
+  FPLX_REQUIRE(p && g && m && v, FPLX_E_NULL, "adam_step: null pointer");
+  FPLX_REQUIRE(n > 0 && step >= 1, FPLX_E_BADSHAPE, "adam_step: n=%lld step=%d", (long long)n, step);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  adam_k<<<ew_grid(n), EW_THREADS, 0, (hipStream_t)stream>>>(p, g, m, v, n, (float)((double)lr / bc1), beta1, beta2, eps,
+                                                            weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return fplx_check_launch("adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""ctypes binding of libfplx.so (C ABI declared in include/fplx.h).
+
+The prototypes are parsed from the header itself, so the Python side can never drift from
+the C side, and `declared_symbols()` lets the tests check that the library exports exactly
+what the header declares.  There is NO fallback: if the library is missing or a call fails
+the product path raises (RuntimeError / ValueError, mirroring the reference's exception
+style: ValueError for bad names / shapes, e.g. PyMIC/pymic/net_run_dsbn/dsbn.py:61-64).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+HEADER = os.path.join(_ROOT, "include", "fplx.h")
+LIB_PATH = os.path.join(_HERE, "libfplx.so")
+
+F32, BF16 = 0, 1
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+    "uint64_t": ctypes.c_uint64, "uint32_t": ctypes.c_uint32, "fplx_stream_t": ctypes.c_void_p,
+}
+
+
+def _ctype(decl):
+    decl = decl.replace("const", " ").strip()
+    if "*" in decl:
+        return ctypes.c_void_p
+    t = decl.split()[0]
+    return _CT[t]
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(fplx_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                argtypes.append(_ctype(a))
+        out[name] = (_CT[ret], argtypes)
+    return out
+
+
+def declared_symbols():
+    return sorted(parse_header().keys())
+
+
+class FplxError(RuntimeError):
+    pass
+
+
+_lib = None
+_protos = None
+
+
+def lib():
+    """Load libfplx.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "fplx: %s not found - the HIP extension is not built (run __graft_entry__.build() or "
+            "`make -C fpl-plus_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    _lib = ctypes.CDLL(LIB_PATH)
+    _protos = parse_header()
+    for name, (ret, argtypes) in _protos.items():
+        fn = getattr(_lib, name)
+        fn.restype = ret
+        fn.argtypes = argtypes
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().fplx_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc in (-1, -2, -5):
+        raise ValueError("fplx: " + msg)
+    raise FplxError("fplx (%d): %s" % (rc, msg))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))

@@ -1,0 +1,228 @@
+"""SegmentationAgent - host-side mirror of the reference's DSBN agent for the hot path
+(reference: PyMIC/pymic/net_run_dsbn/agent_seg.py:34-1083 and agent_abstract.py:28-357).
+
+Kept: the plugin surface (config dict with sections dataset / network / training / testing;
+set_network / set_net_dict / set_loss_dict / set_optimizer / set_scheduler / set_inferer /
+set_datasets-style loader injection), create_network, create_optimizer, create_loss_calculator,
+get_loss_value, training_all (dual=True), training (dual=False), and infer with its FPL branch.
+Not here (out of the hot-path tier): NIfTI I/O, numpy transforms, tensorboard, validation loop.
+Loaders are any iterables of batch dicts ('image', 'label_prob', optional 'pixel_weight',
+'image_weight', 'names').
+"""
+import logging
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim import lr_scheduler
+
+from . import filter as fpl_filter_mod
+from .infer import Inferer
+from .loss import SegLossDict, make_loss
+from .net import UNet2D5_dsbn
+from .optim import get_optimizer, get_lr_scheduler
+
+SegNetDict = {
+    'UNet2D5_dsbn': UNet2D5_dsbn,      # registry entry of the reference, net/net_dict_seg.py:44
+    'UNet3D_dsbn': UNet2D5_dsbn,       # the all-3D configuration under its descriptive name
+}
+
+
+class SegmentationAgent(object):
+    def __init__(self, config, stage='train'):
+        assert (stage in ['train', 'inference', 'test'])                    # agent_abstract.py:44
+        self.config = config
+        self.stage = 'test' if stage == 'inference' else stage
+        self.net = None
+        self.optimizer = None
+        self.scheduler = None
+        self.net_dict = SegNetDict
+        self.loss_dict = None
+        self.inferer = None
+        self.checkpoint = None
+        self.train_loader_1 = self.train_loader_2 = self.test_loader = None
+        self.tensor_type = config['dataset'].get('tensor_type', 'float')
+        self.fpl_uda = config['training'].get('train_fpl_uda', False) if 'training' in config else False
+        self.device = torch.device("cuda:{0:}".format(self._gpus()[0]))
+        self.transform_list = []
+        seed = config.get('training', {}).get('random_seed', 1)
+        if config.get('training', {}).get('deterministic', True):
+            torch.manual_seed(seed)                                          # agent_abstract.py:61-65
+
+    def _gpus(self):
+        sec = 'training' if self.stage == 'train' else 'testing'
+        return self.config.get(sec, {}).get('gpus', [0])
+
+    # ---- plugin setters (agent_abstract.py:67-134)
+    def set_network(self, net):
+        self.net = net
+
+    def set_net_dict(self, net_dict):
+        self.net_dict = net_dict
+
+    def set_loss_dict(self, loss_dict):
+        self.loss_dict = loss_dict
+
+    def set_optimizer(self, optimizer):
+        self.optimizer = optimizer
+
+    def set_scheduler(self, scheduler):
+        self.scheduler = scheduler
+
+    def set_inferer(self, inferer):
+        self.inferer = inferer
+
+    def set_loaders(self, train_loader_1=None, train_loader_2=None, test_loader=None):
+        self.train_loader_1, self.train_loader_2, self.test_loader = train_loader_1, train_loader_2, test_loader
+
+    # ---- construction (agent_seg.py:82-132, agent_abstract.py:320-337)
+    def create_network(self):
+        if self.net is None:
+            net_name = self.config['network']['net_type']
+            if net_name not in self.net_dict:
+                raise ValueError("Undefined network {0:}".format(net_name))  # agent_seg.py:86-87
+            self.net = self.net_dict[net_name](self.config['network'])
+        if self.tensor_type != 'float':
+            raise ValueError("fplx: tensor_type must be float (fp32 parameters)")
+        self.net.float()
+        self.net.to(self.device)
+        n = sum(p.numel() for p in self.net.parameters() if p.requires_grad)
+        logging.info('parameter number {0:}'.format(n))
+
+    def get_parameters_to_update(self):
+        return self.net.parameters()
+
+    def create_optimizer(self, params=None):
+        opt_params = self.config['training']
+        if self.optimizer is None:
+            self.optimizer = get_optimizer(opt_params['optimizer'], self.net, opt_params)
+        last_iter = -1
+        if self.checkpoint is not None:
+            self.optimizer.load_state_dict(self.checkpoint['optimizer_state_dict'])
+            last_iter = self.checkpoint['iteration'] - 1
+        if self.scheduler is None:
+            opt_params["last_iter"] = last_iter
+            self.scheduler = get_lr_scheduler(self.optimizer, opt_params)
+
+    def create_loss_calculator(self, entropy_weight=0.0):
+        if self.loss_dict is None:
+            self.loss_dict = SegLossDict
+        self.loss_calculator = make_loss(self.config['training'], self.loss_dict, entropy_weight)
+
+    def convert_tensor_type(self, t):
+        return t.float()
+
+    def get_loss_value(self, data, pred, gt, fpl_uda=False):
+        """agent_seg.py:134-142"""
+        d = {'prediction': pred, 'ground_truth': gt}
+        if fpl_uda and data.get('pixel_weight', None) is not None:
+            d['pixel_weight'] = data['pixel_weight'].to(pred.device)
+            if data.get('image_weight', None) is not None:
+                d['image_weight'] = data['image_weight'].to(pred.device)
+        return self.loss_calculator(d)
+
+    # ---- training loops
+    def _next(self, it, loader):
+        try:
+            return next(it), it
+        except StopIteration:
+            it = iter(loader)
+            return next(it), it
+
+    def _train_loop(self, dual):
+        class_num = self.config['network']['class_num']
+        iter_valid = self.config['training']['iter_valid']
+        nd = int(self.config['network']['num_domains'])
+        loaders = [self.train_loader_1, self.train_loader_2][:nd]
+        iters = [iter(l) for l in loaders]
+        self.net.train()
+        train_loss = None
+        dice_lists = [[] for _ in range(nd)]
+        for _ in range(iter_valid):
+            datas = []
+            for k in range(nd):
+                d, iters[k] = self._next(iters[k], loaders[k])
+                datas.append(d)
+            if dual:
+                self.optimizer.zero_grad()
+            loss = None
+            for k in range(nd):
+                x = self.convert_tensor_type(datas[k]['image']).to(self.device)
+                y = self.convert_tensor_type(datas[k]['label_prob']).to(self.device)
+                if not dual:
+                    self.optimizer.zero_grad()
+                out = self.net(x, domain_label=k * torch.ones(x.shape[0], dtype=torch.long))
+                lk = self.get_loss_value(datas[k], out, y, self.fpl_uda)
+                dice_lists[k].append(self.loss_calculator.last_out[4:4 + class_num])   # hard Dice of this pass
+                if dual:
+                    loss = lk if loss is None else (loss + lk) / 2                      # agent_seg.py:468,482
+                else:
+                    lk.backward()
+                    self.optimizer.step()
+                    if self.scheduler is not None and not isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau):
+                        self.scheduler.step()                                           # agent_seg.py:355-357
+                    train_loss = lk.detach() if train_loss is None else train_loss + lk.detach()
+            if dual:
+                loss.backward()                                                         # agent_seg.py:490-494
+                self.optimizer.step()
+                if self.scheduler is not None and not isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau):
+                    self.scheduler.step()
+                train_loss = loss.detach() if train_loss is None else train_loss + loss.detach()
+        # one host sync per round, not per iteration
+        train_avg_loss = float(train_loss.item()) / iter_valid / nd
+        cls = [torch.stack(dl).mean(0).cpu().numpy().astype(np.float64) for dl in dice_lists]
+        train_cls_dice = sum(cls) / nd
+        return {'loss': train_avg_loss, 'avg_dice': float(train_cls_dice.mean()), 'class_dice': train_cls_dice}
+
+    def training_all(self):
+        """agent_seg.py:415-508 (selected by [training] dual = True, 748-749)"""
+        return self._train_loop(True)
+
+    def training(self):
+        """agent_seg.py:291-414 with the backward/step the published loop lacks; the entropy
+        regulariser of lines 352-354 is part of the loss here (create_loss_calculator(1.0))."""
+        return self._train_loop(False)
+
+    # ---- inference (agent_seg.py:834-964)
+    def infer(self, mc_passes=6, return_outputs=False):
+        cfg = self.config['testing']
+        domian_label = cfg['domian_label']
+        self.FPL = cfg.get('fpl', False)
+        self.net.to(self.device)
+        if cfg.get('evaluation_mode', True):
+            self.net.eval()
+            if cfg.get('test_time_dropout', False) or self.FPL:
+                def test_time_dropout(m):
+                    if type(m) == nn.Dropout:
+                        m.train()
+                self.net.apply(test_time_dropout)                            # agent_seg.py:845-852
+        if self.checkpoint is not None:
+            self.net.load_state_dict(self.checkpoint['model_state_dict'])
+        if self.inferer is None:
+            infer_cfg = dict(cfg)
+            infer_cfg['class_num'] = self.config['network']['class_num']
+            self.inferer = Inferer(infer_cfg)
+        uncertainty_list, outputs = {}, {}
+        with torch.no_grad():
+            for data in self.test_loader:
+                images = self.convert_tensor_type(data['image']).to(self.device)
+                names = data['names']
+                dl = domian_label * torch.ones(images.shape[0], dtype=torch.long)
+                if self.FPL:
+                    stack = torch.empty((mc_passes, self.config['network']['class_num']) + tuple(images.shape[2:]),
+                                        dtype=torch.float32, device=self.device)
+                    for i in range(mc_passes):                               # agent_seg.py:898-899 (6 passes)
+                        stack[i] = self.inferer.run(self.net, images, dl)[0]
+                    r = fpl_filter_mod.fpl_uncertainty(stack)
+                    uncertainty_list[names[0]] = r['uncer_one']
+                    if return_outputs:
+                        outputs[names[0]] = r
+                else:
+                    pred = self.inferer.run(self.net, images, dl)
+                    outputs[names[0]] = fpl_filter_mod.hard_label(pred)     # save_outputs, 1049-1050
+        if self.FPL:
+            srt = fpl_filter_mod.sort_uncertainty(uncertainty_list)
+            path = cfg.get('fpl_uncertainty_sorted', None)
+            if path:
+                np.save(path, np.array(srt, dtype=object), allow_pickle=True)
+            return (srt, outputs) if return_outputs else srt
+        return outputs

@@ -1,0 +1,261 @@
+"""Forward / backward schedule of the DSBN 3D U-Net over the fplx C ABI.
+
+This is the host-side "graph": a fixed sequence of kernel launches on the current HIP stream
+(no tracing compiler, no autograd inside).  Activations are NDHWC in `act_dtype`; the skip /
+up-sample concat of every UpBlock is one pre-allocated [voxels, 2*C] buffer that the encoder
+and the transposed convolution write into directly (reference torch.cat,
+PyMIC/pymic/net/net3d/unet2d5_dsbn.py:182, is never executed).
+
+Reference semantics implemented here (paths under /root/reference/PyMIC/pymic):
+  UNet2D5_dsbn.forward            net/net3d/unet2d5_dsbn.py:296-309
+  ConvBlockND.forward (3D branch) net/net3d/unet2d5_dsbn.py:74-81
+  DownBlock / UpBlock             net/net3d/unet2d5_dsbn.py:108-129 / 156-188
+  DomainSpecificBatchNorm3d       net_run_dsbn/dsbn.py:54-57 (bns[domain_label[0]] for the batch)
+"""
+import torch
+from . import ops
+from ._lib import F32, BF16
+
+LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
+
+
+class Saved(object):
+    """what one forward leaves behind for its backward"""
+    __slots__ = ("x", "dims", "domain", "train", "seed", "step", "blocks", "cats", "pooled", "packs",
+                 "drop_on", "deconv_in")
+
+
+class Engine(object):
+    def __init__(self, net):
+        self.net = net                     # fplx.net.UNet2D5_dsbn (parameter container)
+        self.ws = None
+        self._pack_cache = None
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, nbytes, dev):
+        if self.ws is None or self.ws.numel() < nbytes or self.ws.device != dev:
+            self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return self.ws
+
+    def _pack(self, act_dtype):
+        net = self.net
+        packs = {}
+        for name, conv in net.conv_sites():
+            want_wb = name != "block0.conv.conv3d_1"     # no data gradient w.r.t. the network input
+            packs[name] = ops.pack_conv_weight(conv.weight, act_dtype, want_wb)
+        for name, tr in net.deconv_sites():
+            packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
+        oc = net.out_conv
+        wf, _ = ops.pack_conv_weight(oc.weight, torch.float32, False)       # fp32 planar logits
+        _, wb = ops.pack_conv_weight(oc.weight, act_dtype, True)
+        packs["out_conv"] = (wf, wb)
+        return packs
+
+    def invalidate(self):
+        self._pack_cache = None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True):
+        """x: fp32 [N, Cin, D, H, W] contiguous on the GPU -> logits fp32 [N, class_num, D, H, W].
+        train: BatchNorm uses batch statistics (and updates the running ones);
+        drop_on: list of 9 bools - dropout active per ConvBlockND."""
+        net = self.net
+        ops.require_gpu(x)
+        if x.dim() != 5:
+            raise ValueError('expected 5D input (got {}D input)'.format(x.dim()))   # dsbn.py:61-64
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        N, Cin, D, H, W = x.shape
+        if Cin != net.in_chns:
+            raise ValueError("fplx: input has {0:} channels, network expects {1:}".format(Cin, net.in_chns))
+        if (D % 16) or (H % 16) or (W % 16):
+            raise ValueError("fplx: D, H, W must be multiples of 16 (four 2x poolings), got %dx%dx%d" % (D, H, W))
+        if domain < 0 or domain >= net.num_domains:
+            raise IndexError("fplx: domain_label %d out of range" % domain)
+        dev, adt = x.device, net.act_dtype
+        a_dt = ops._DT[adt]
+        ft = net.ft_chns
+        if train or self._pack_cache is None or self._pack_cache[0] != adt:
+            packs = self._pack(adt)
+            self._pack_cache = None if train else (adt, packs)
+        else:
+            packs = self._pack_cache[1]
+        dims = [(N, D >> l, H >> l, W >> l) for l in range(5)]
+        vox = [n * d * h * w for (n, d, h, w) in dims]
+
+        sv = Saved()
+        sv.x, sv.dims, sv.domain, sv.train, sv.seed, sv.step = x, dims, domain, train, seed, step
+        sv.blocks, sv.cats, sv.pooled, sv.packs, sv.drop_on, sv.deconv_in = [], [], [], packs, list(drop_on), []
+
+        def empty(v, c):
+            return torch.empty((v, c), dtype=adt, device=dev)
+
+        # concat buffers of levels 0..3: [skip | up]
+        cats = [empty(vox[l], 2 * ft[l]) for l in range(4)]
+        sv.cats = cats
+
+        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active):
+            """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view"""
+            conv, bn, prelu = site
+            cout = conv.weight.shape[0]
+            y = empty(vox[l], cout)
+            bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
+            bnm = bn.bns[domain]
+            if train:
+                rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt)
+                stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
+            else:
+                rows, stats = 0, None
+            ops.conv3d_fwd(xin, xs, x_dt, packs[key][0], conv.bias, y, ops.cl_strides(*dims[l][1:], cout), a_dt,
+                           dims[l], cin, cout, (3, 3, 3), stats)
+            if train:
+                ops.bn_train_finalize(stats, rows, cout, vox[l], bnm.weight, bnm.bias, bnm.running_mean,
+                                      bnm.running_var, bnm.num_batches_tracked, bnbuf, bnm.momentum, bnm.eps)
+            else:
+                ops.bn_eval_prepare(bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var, bnbuf, bnm.eps)
+            pp = p if dropout_active else 0.0
+            ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
+            return y, bnbuf, pp
+
+        def conv_block(b, xin, xs, x_dt, cin, l, out_view):
+            blk = net.block_modules[b]
+            key = net.block_keys[b]
+            c = ft[l]
+            a1 = empty(vox[l], c)
+            sid = step * 16 + b
+            y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + ".conv3d_1", (blk.conv3d_1, blk.bn3d1, blk.relu_1), l,
+                                    a1, blk.dropout_p, sid, drop_on[b])
+            y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + ".conv3d_2",
+                                   (blk.conv3d_2, blk.bn3d2, blk.relu_2), l, out_view, 0.0, 0, False)
+            sv.blocks.append(dict(xin=xin, xs=xs, x_dt=x_dt, cin=cin, l=l, y1=y1, bn1=bn1, p1=p1, sid=sid, a1=a1,
+                                  y2=y2, bn2=bn2, out=out_view))
+
+        # ---- encoder
+        cur, cur_s, cur_dt, cur_c = x, ops.planar_strides(Cin, D, H, W), F32, Cin
+        for i in range(5):
+            out_view = cats[i][:, :ft[i]] if i < 4 else empty(vox[4], ft[4])
+            conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view)
+            if i < 4:
+                pooled = empty(vox[i + 1], ft[i])
+                ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i])
+                sv.pooled.append(pooled)
+                cur, cur_s, cur_dt, cur_c = pooled, ops.cl_strides(*dims[i + 1][1:], ft[i]), a_dt, ft[i]
+            else:
+                cur = out_view
+        # ---- decoder
+        for j in range(4):
+            l = 3 - j
+            tr = net.up_modules[j].trans3d
+            sv.deconv_in.append(cur)
+            ops.deconv2_fwd(cur, packs["up%d.trans3d" % (j + 1)][0], tr.bias, cats[l][:, ft[l]:], dims[l + 1],
+                            ft[l + 1], ft[l])
+            out = empty(vox[l], ft[l])
+            conv_block(5 + j, cats[l], ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
+            cur = out
+        # ---- out_conv (1x3x3) -> fp32 planar logits
+        ncls = net.n_class
+        logits = torch.empty((N, ncls, D, H, W), dtype=torch.float32, device=dev)
+        ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
+                       ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
+        return logits, (sv if keep else None)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, sv, dlogits, gflat, on_ready=None):
+        """dlogits fp32 [N, class_num, D, H, W]; gflat: fp32 flat gradient buffer laid out like
+        net.flat_params (zeroed first; BN parameters of the other domains stay zero).
+        on_ready(end): optional callback, called whenever the gradients of flat elements [0, end)
+        have been enqueued (flat order = production order) - fplx.ddp launches all-reduce buckets."""
+        net = self.net
+        dims, domain, packs = sv.dims, sv.domain, sv.packs
+        dev, adt = dlogits.device, net.act_dtype
+        a_dt = ops._DT[adt]
+        ft = net.ft_chns
+        N, D, H, W = dims[0]
+        ncls = net.n_class
+        vox = [n * d * h * w for (n, d, h, w) in dims]
+        dlogits = dlogits.contiguous()
+        gflat.zero_()        # BN-affine / PReLU gradients are accumulated by their finalize kernels
+        gv = net.grad_views(gflat)
+
+        def empty(v, c):
+            return torch.empty((v, c), dtype=adt, device=dev)
+
+        # workspace: max over layers
+        need = ops.conv3d_wgrad_ws_bytes(dims[0], ft[0], ncls, (1, 3, 3))
+        for b in range(9):
+            l = LEVEL_OF_BLOCK[b]
+            cin1 = sv.blocks[b]["cin"]
+            need = max(need, ops.conv3d_wgrad_ws_bytes(dims[l], cin1, ft[l], (3, 3, 3)),
+                       ops.conv3d_wgrad_ws_bytes(dims[l], ft[l], ft[l], (3, 3, 3)))
+        for j in range(4):
+            l = 3 - j
+            need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l]))
+        ws = self._workspace(need, dev)
+        maxc = max(ft) * 2
+        part = torch.empty((ops.num_partials(vox[0]), 2 * maxc + 1), dtype=torch.float32, device=dev)
+        coef = torch.empty((2, maxc), dtype=torch.float32, device=dev)
+
+        # ---- out_conv
+        last = sv.blocks[8]["out"]
+        ops.conv3d_wgrad(last, ops.cl_strides(D, H, W, ft[0]), a_dt, dlogits, ops.planar_strides(ncls, D, H, W), F32,
+                         gv["out_conv.weight"], gv["out_conv.bias"], dims[0], ft[0], ncls, (1, 3, 3), ws)
+        def ready(last_name):
+            if on_ready is not None:
+                o, n, _ = net._layout[last_name]
+                on_ready(o + n)
+
+        ready("out_conv.bias")
+        d_cur = empty(vox[0], ft[0])
+        ops.conv3d_fwd(dlogits, ops.planar_strides(ncls, D, H, W), F32, packs["out_conv"][1], None, d_cur,
+                       ops.cl_strides(D, H, W, ft[0]), a_dt, dims[0], ncls, ft[0], (1, 3, 3), None)
+
+        def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view):
+            """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy."""
+            c = ft[l]
+            gkey = "%s.bns.%d" % (bnkey, domain)
+            ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
+                           gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
+            # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
+            db = None if sv.train else gv[key + ".bias"]
+            ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gv[key + ".weight"], db,
+                             dims[l], cin, c, (3, 3, 3), ws)
+            if want_dx:
+                ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
+                               ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None)
+
+        def block_bwd(b, d_out, want_dx):
+            """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""
+            blk = sv.blocks[b]
+            key = net.block_keys[b]
+            l, c, cin = blk["l"], ft[blk["l"]], blk["cin"]
+            d_a1 = empty(vox[l], c)
+            site_bwd(key + ".conv3d_2", key + ".bn3d2", key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0, d_out,
+                     blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1)
+            d_in = empty(vox[l], cin) if want_dx else None
+            site_bwd(key + ".conv3d_1", key + ".bn3d1", key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"], blk["sid"],
+                     d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in)
+            return d_in
+
+        # ---- decoder, up4 .. up1
+        d_skips = [None] * 4
+        for j in range(3, -1, -1):
+            l = 3 - j
+            d_cat = block_bwd(5 + j, d_cur, True)                     # [V_l, 2*ft_l]
+            d_skips[l] = d_cat[:, :ft[l]]
+            d_up = d_cat[:, ft[l]:]
+            name = "up%d.trans3d" % (j + 1)
+            xin = sv.deconv_in[j]
+            ops.deconv2_wgrad(xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws)
+            ready(name + ".bias")
+            d_cur = empty(vox[l + 1], ft[l + 1])
+            ops.deconv2_dgrad(d_up, packs[name][1], d_cur, dims[l + 1], ft[l + 1], ft[l])
+        # ---- encoder, block4 .. block0
+        d_pool = block_bwd(4, d_cur, True)                            # grad w.r.t. pooled3 [V_4, ft_3]
+        ready("block4.conv.relu_1.weight")
+        for i in range(3, -1, -1):
+            d_a2 = empty(vox[i], ft[i])
+            ops.maxpool2_bwd(sv.cats[i][:, :ft[i]], d_pool, d_skips[i], d_a2, dims[i], ft[i])
+            d_pool = block_bwd(i, d_a2, i > 0)
+            ready("block%d.conv.relu_1.weight" % i)
+        return gflat

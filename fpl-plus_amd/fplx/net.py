@@ -1,0 +1,250 @@
+"""UNet2D5_dsbn - drop-in for the reference network class behind PyMIC's SegNetDict
+(reference: PyMIC/pymic/net/net3d/unet2d5_dsbn.py:239-309, registry PyMIC/pymic/net/net_dict_seg.py:44).
+
+Same constructor (`params` dict), same call `net(x, domain_label)`, same state_dict key names
+for the 3D branch (`block{0-4}.conv.conv3d_{1,2}.*`, `*.bn3d{1,2}.bns.{d}.*`, `*.relu_{1,2}.weight`,
+`up{1-4}.trans3d.*`, `up*.conv.*`, `out_conv.*`).  torch.nn modules are used ONLY as parameter
+containers (so init, state_dict and `net.apply(...)` hooks such as the reference's test-time
+dropout switch, net_run_dsbn/agent_seg.py:843-852, behave identically); all arithmetic runs in
+the HIP kernels of libfplx.so through fplx.engine.  There is no CPU path.
+
+Differences, on purpose:
+  * only the configuration the FPL+ hot path uses is built: conv_dims all 3, bilinear False.
+    The reference also instantiates dead 2D twins of every layer (conv2d_*, bn2d*, trans2d,
+    conv2d, conv3d 1x1x1: 8.1 M of 30.7 M parameters at 32 base channels) that never receive a
+    gradient in this configuration; they are not created.  load_state_dict() accepts reference
+    checkpoints and ignores those keys.
+  * params['precision'] = 'fp32' (default, parity mode) | 'bf16' (activations stored as bf16,
+    fp32 master weights, fp32 statistics / reductions).
+"""
+import torch
+import torch.nn as nn
+
+from .dsbn import DomainSpecificBatchNorm3d
+from .engine import Engine
+
+_DEAD_KEY_MARKS = ("conv2d", "bn2d", "trans2d", ".conv3d.")
+
+
+class ConvBlockND(nn.Module):
+    """parameter container of reference ConvBlockND (unet2d5_dsbn.py:48-64), 3D members only"""
+
+    def __init__(self, in_channels, out_channels, num_domains, dropout_p):
+        super(ConvBlockND, self).__init__()
+        self.conv3d_1 = nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.conv3d_2 = nn.Conv3d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.bn3d1 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+        self.bn3d2 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+        self.dropout_p = float(dropout_p)
+        self.dropout = nn.Dropout(self.dropout_p)
+        self.relu_1 = nn.PReLU()
+        self.relu_2 = nn.PReLU()
+
+
+class DownBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, num_domains, dropout_p):
+        super(DownBlock, self).__init__()
+        self.conv = ConvBlockND(in_channels, out_channels, num_domains, dropout_p)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, in_channels1, in_channels2, out_channels, num_domains, dropout_p):
+        super(UpBlock, self).__init__()
+        self.trans3d = nn.ConvTranspose3d(in_channels1, in_channels2, kernel_size=2, stride=2)
+        self.conv = ConvBlockND(in_channels2 * 2, out_channels, num_domains, dropout_p)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are fplx.engine schedules."""
+
+    @staticmethod
+    def forward(ctx, x, net, domain, train, drop_on, seed, step, keep, *params):
+        logits, sv = net.engine.forward(x, domain, train, drop_on, seed, step, keep=keep)
+        ctx.net, ctx.sv, ctx.n_params = net, sv, len(params)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        net, sv = ctx.net, ctx.sv
+        if sv is None:
+            raise RuntimeError("fplx: backward through a forward that ran under no_grad")
+        gflat = torch.empty_like(net.flat_params)
+        net.engine.backward(sv, dlogits, gflat)
+        ctx.sv = None
+        gv = net.grad_views(gflat)
+        grads = tuple(gv[name] for name in net.active_param_names(sv.domain))
+        return (None, None, None, None, None, None, None, None) + grads
+
+
+class UNet2D5_dsbn(nn.Module):
+    def __init__(self, params):
+        super(UNet2D5_dsbn, self).__init__()
+        self.params = params
+        self.in_chns = params['in_chns']
+        self.ft_chns = list(params['feature_chns'])
+        self.dropout = list(params['dropout'])
+        self.dims = list(params['conv_dims'])
+        self.n_class = params['class_num']
+        self.bilinear = params['bilinear']
+        self.num_domains = params['num_domains']
+        assert (len(self.ft_chns) == 5)                                    # unet2d5_dsbn.py:277
+        if any(d != 3 for d in self.dims):
+            raise ValueError("fplx UNet2D5_dsbn: only conv_dims = [3,3,3,3,3] is built (got {0:})".format(self.dims))
+        if self.bilinear:
+            raise ValueError("fplx UNet2D5_dsbn: only bilinear = False (transposed convolution) is built")
+        prec = params.get('precision', 'fp32')
+        if prec not in ('fp32', 'bf16'):
+            raise ValueError("fplx UNet2D5_dsbn: precision must be fp32 or bf16 (got {0:})".format(prec))
+        self.act_dtype = torch.float32 if prec == 'fp32' else torch.bfloat16
+        ft, nd, dp = self.ft_chns, self.num_domains, self.dropout
+        self.block0 = DownBlock(self.in_chns, ft[0], nd, dp[0])
+        self.block1 = DownBlock(ft[0], ft[1], nd, dp[1])
+        self.block2 = DownBlock(ft[1], ft[2], nd, dp[2])
+        self.block3 = DownBlock(ft[2], ft[3], nd, dp[3])
+        self.block4 = DownBlock(ft[3], ft[4], nd, dp[4])
+        self.up1 = UpBlock(ft[4], ft[3], ft[3], nd, dp[3])
+        self.up2 = UpBlock(ft[3], ft[2], ft[2], nd, dp[2])
+        self.up3 = UpBlock(ft[2], ft[1], ft[1], nd, dp[1])
+        self.up4 = UpBlock(ft[1], ft[0], ft[0], nd, dp[0])
+        self.out_conv = nn.Conv3d(ft[0], self.n_class, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+
+        self.block_keys = ["block0.conv", "block1.conv", "block2.conv", "block3.conv", "block4.conv",
+                           "up1.conv", "up2.conv", "up3.conv", "up4.conv"]
+        self.block_modules = [self.block0.conv, self.block1.conv, self.block2.conv, self.block3.conv,
+                              self.block4.conv, self.up1.conv, self.up2.conv, self.up3.conv, self.up4.conv]
+        self.up_modules = [self.up1, self.up2, self.up3, self.up4]
+        # dropout stream: (seed, forward counter); deterministic given the seed
+        self.dropout_seed = int(params.get('dropout_seed', 1))
+        self._fwd_counter = 0
+        self.engine = Engine(self)
+        self.flat_params = None
+        self._layout = None
+
+    # ------------------------------------------------------------------ parameter bookkeeping
+    def conv_sites(self):
+        for key, m in zip(self.block_keys, self.block_modules):
+            yield key + ".conv3d_1", m.conv3d_1
+            yield key + ".conv3d_2", m.conv3d_2
+
+    def deconv_sites(self):
+        for j, u in enumerate(self.up_modules):
+            yield "up%d.trans3d" % (j + 1), u.trans3d
+
+    def _ordered_param_names(self):
+        """Flat layout: [shared parameters in the order their gradients are PRODUCED by backward
+        (decoder first) | BN affine parameters of domain 0 | domain 1 | ...].
+        A contiguous range of the shared part is complete as early as possible (gradient
+        all-reduce buckets, fplx.ddp), and the per-domain tails let Adam skip the domains that
+        took no part in a step with one launch per segment - torch.optim.Adam skips parameters
+        whose grad is None (reference: only bns[domain_label[0]] is used, dsbn.py:56)."""
+        named = dict(self.named_parameters())
+        order = ["out_conv.weight", "out_conv.bias"]
+
+        def block(key):
+            for s in (".conv3d_2.weight", ".conv3d_2.bias", ".relu_2.weight", ".conv3d_1.weight", ".conv3d_1.bias",
+                      ".relu_1.weight"):
+                order.append(key + s)
+
+        for j in (4, 3, 2, 1):
+            block("up%d.conv" % j)
+            order.extend(["up%d.trans3d.weight" % j, "up%d.trans3d.bias" % j])
+        for i in (4, 3, 2, 1, 0):
+            block("block%d.conv" % i)
+        self._n_shared_names = len(order)
+        for d in range(self.num_domains):
+            for key in self.block_keys:
+                for bn in (".bn3d2", ".bn3d1"):
+                    order.append("%s%s.bns.%d.weight" % (key, bn, d))
+                    order.append("%s%s.bns.%d.bias" % (key, bn, d))
+        assert sorted(order) == sorted(named.keys()), "parameter bookkeeping out of sync"
+        return order
+
+    def _ensure_flat(self):
+        """All parameters live in ONE flat fp32 buffer (views), cf. fused Adam / one all-reduce."""
+        named = dict(self.named_parameters())
+        first = next(iter(named.values()))
+        fp = self.flat_params
+        ok = fp is not None and fp.device == first.device
+        if ok:
+            base, end = fp.data_ptr(), fp.data_ptr() + fp.numel() * 4
+            ok = all(base <= p.data_ptr() < end for p in named.values())
+        if ok:
+            return
+        order = self._ordered_param_names()
+        total = sum(named[k].numel() for k in order)
+        flat = torch.empty(total, dtype=torch.float32, device=first.device)
+        layout, off = {}, 0
+        for k in order:
+            p = named[k]
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off:off + n].view(p.shape)
+            layout[k] = (off, n, tuple(p.shape))
+            off += n
+        self.flat_params, self._layout, self._order = flat, layout, order
+        self._named = named
+        self.engine.invalidate()
+
+    def get_param(self, name):
+        return self._named[name]
+
+    def grad_views(self, gflat):
+        return {k: gflat[o:o + n].view(shp) for k, (o, n, shp) in self._layout.items()}
+
+    def active_param_names(self, domain):
+        tag = ".bns."
+        return [k for k in self._order if tag not in k or (".bns.%d." % domain) in k]
+
+    def segments(self):
+        """-> (shared (start, end), [domain d (start, end)]) element ranges of the flat buffer"""
+        first_bn = self._layout[self._order[self._n_shared_names]][0]
+        per = (self.flat_params.numel() - first_bn) // self.num_domains
+        return (0, first_bn), [(first_bn + d * per, first_bn + (d + 1) * per) for d in range(self.num_domains)]
+
+    def bucket_ranges(self, min_elems=1 << 20):
+        """contiguous (start, end) ranges of the SHARED part in gradient-production order, cut at
+        block boundaries, each at least min_elems long (the last one may be shorter)"""
+        shared_end = self.segments()[0][1]
+        cuts, start, last_block = [], 0, None
+        for k in self._order[:self._n_shared_names]:
+            blockname = k.split(".")[0]
+            o = self._layout[k][0]
+            if last_block is not None and blockname != last_block and o - start >= min_elems:
+                cuts.append((start, o))
+                start = o
+            last_block = blockname
+        cuts.append((start, shared_end))
+        return cuts
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def _apply(self, fn, recurse=True):
+        r = super(UNet2D5_dsbn, self)._apply(fn, recurse)
+        self.flat_params = None          # parameters were re-created: re-flatten lazily
+        return r
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        kept = {k: v for k, v in state_dict.items() if not any(m in k for m in _DEAD_KEY_MARKS)}
+        r = super(UNet2D5_dsbn, self).load_state_dict(kept, strict=strict, **kw)
+        self.engine.invalidate()
+        return r
+
+    def train(self, mode=True):
+        self.engine.invalidate()
+        return super(UNet2D5_dsbn, self).train(mode)
+
+    def dropout_active(self):
+        """per ConvBlockND: the nn.Dropout child's own training flag decides (this is what the
+        reference flips for test-time dropout, agent_seg.py:845-852)"""
+        return [m.dropout.training and m.dropout_p > 0 for m in self.block_modules]
+
+    def forward(self, x, domain_label=None):
+        if not x.is_cuda:
+            raise RuntimeError("fplx UNet2D5_dsbn runs on the GPU only (libfplx.so HIP kernels); got a CPU tensor")
+        self._ensure_flat()
+        domain = 0 if domain_label is None else int(domain_label[0])       # dsbn.py:56
+        names = self.active_param_names(domain)
+        params = [self._named[k] for k in names]
+        step = self._fwd_counter
+        self._fwd_counter += 1
+        return _UNetFunction.apply(x, self, domain, self.training, self.dropout_active(), self.dropout_seed, step,
+                                   torch.is_grad_enabled(), *params)

@@ -1,0 +1,220 @@
+"""Tensor-level wrappers over the C ABI (include/fplx.h).  PyTorch is only plumbing here:
+device memory, the current HIP stream and dtype tags.  Activations are 2-D views
+[voxels, ld] of NDHWC tensors; a column slice `buf[:, a:b]` is a channel slice.
+"""
+import torch
+from . import _lib
+from ._lib import F32, BF16, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt_of(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError("fplx: unsupported activation dtype {0:}".format(t.dtype))
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fplx: tensors must live on the GPU (HIP path only, no CPU fallback)")
+
+
+def cl_strides(D, H, W, ld):
+    """element strides (n,d,h,w,c) of an NDHWC tensor with voxel stride ld"""
+    return (D * H * W * ld, H * W * ld, W * ld, ld, 1)
+
+
+def planar_strides(C, D, H, W):
+    """element strides (n,d,h,w,c) of a contiguous NCDHW tensor"""
+    return (C * D * H * W, H * W, W, 1, D * H * W)
+
+
+def ld_of(t2d):
+    assert t2d.dim() == 2 and t2d.stride(1) == 1
+    return t2d.stride(0)
+
+
+def pack_conv_weight(w, act_dtype, want_wb=True):
+    co, ci, kd, kh, kw = w.shape
+    wf = torch.empty((kd * kh * kw, co, ci), dtype=act_dtype, device=w.device)
+    wb = torch.empty((kd * kh * kw, ci, co), dtype=act_dtype, device=w.device) if want_wb else None
+    call("fplx_pack_conv_weight", ptr(w), ptr(wf), ptr(wb), co, ci, kd, kh, kw, _DT[act_dtype], stream())
+    return wf, wb
+
+
+def pack_deconv_weight(w, act_dtype):
+    ci, co = w.shape[0], w.shape[1]
+    wf = torch.empty((8, co, ci), dtype=act_dtype, device=w.device)
+    wb = torch.empty((8, ci, co), dtype=act_dtype, device=w.device)
+    call("fplx_pack_deconv_weight", ptr(w), ptr(wf), ptr(wb), ci, co, _DT[act_dtype], stream())
+    return wf, wb
+
+
+def conv3d_stats_rows(dims, cin, cout, k, x_dt, y_dt):
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv3d_stats_rows(n, d, h, w, cin, cout, k[0], k[1], k[2], x_dt, y_dt)
+
+
+def conv3d_fwd(x, xs, x_dt, wp, bias, y, ys, y_dt, dims, cin, cout, k, stats=None):
+    n, d, h, w = dims
+    call("fplx_conv3d_fwd", ptr(x), x_dt, xs[0], xs[1], xs[2], xs[3], xs[4], ptr(wp), ptr(bias),
+         ptr(y), y_dt, ys[0], ys[1], ys[2], ys[3], ys[4], n, d, h, w, cin, cout, k[0], k[1], k[2],
+         ptr(stats), stream())
+
+
+def conv3d_wgrad_ws_bytes(dims, cin, cout, k):
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, k[0], k[1], k[2])
+
+
+def conv3d_wgrad(x, xs, x_dt, dy, ys, dy_dt, dw, db, dims, cin, cout, k, ws):
+    n, d, h, w = dims
+    call("fplx_conv3d_wgrad", ptr(x), x_dt, xs[0], xs[1], xs[2], xs[3], xs[4],
+         ptr(dy), dy_dt, ys[0], ys[1], ys[2], ys[3], ys[4], ptr(dw), ptr(db), n, d, h, w, cin, cout,
+         k[0], k[1], k[2], ptr(ws), ws.numel() * ws.element_size(), stream())
+
+
+def deconv2_fwd(x, wf, bias, y, dims, cin, cout):
+    n, d, h, w = dims
+    call("fplx_deconv2_fwd", ptr(x), ld_of(x), ptr(wf), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin, cout,
+         dt_of(x), stream())
+
+
+def deconv2_dgrad(dy, wb, dx, dims, cin, cout):
+    n, d, h, w = dims
+    call("fplx_deconv2_dgrad", ptr(dy), ld_of(dy), ptr(wb), ptr(dx), ld_of(dx), n, d, h, w, cin, cout,
+         dt_of(dy), stream())
+
+
+def deconv2_wgrad_ws_bytes(dims, cin, cout):
+    n, d, h, w = dims
+    return _lib.lib().fplx_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout)
+
+
+def deconv2_wgrad(x, dy, dw, db, dims, cin, cout, ws):
+    n, d, h, w = dims
+    call("fplx_deconv2_wgrad", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(db), n, d, h, w, cin, cout,
+         dt_of(x), ptr(ws), ws.numel() * ws.element_size(), stream())
+
+
+def bn_train_finalize(stats, rows, c, count, gamma, beta, rm, rv, nbt, bnbuf, momentum=0.1, eps=1e-5):
+    """bnbuf: fp32 [4, C] -> rows mean, rstd, scale, shift"""
+    call("fplx_bn_train_finalize", ptr(stats), rows, c, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt),
+         momentum, eps, ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), stream())
+
+
+def bn_eval_prepare(gamma, beta, rm, rv, bnbuf, eps=1e-5):
+    c = gamma.numel()
+    call("fplx_bn_eval_prepare", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, c, ptr(bnbuf[2]), ptr(bnbuf[3]),
+         stream())
+
+
+def bn_act_fwd(y, out, bnbuf, slope, p, seed, sid, c):
+    call("fplx_bn_act_fwd", ptr(y), ld_of(y), ptr(out), ld_of(out), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope),
+         float(p), int(seed), int(sid), y.shape[0], c, dt_of(y), stream())
+
+
+def num_partials(voxels):
+    return _lib.lib().fplx_num_partials(voxels)
+
+
+def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope, part, coef):
+    """three-stage backward of the fused BN-apply + PReLU + dropout pass; dy may alias dout"""
+    v = y.shape[0]
+    rows = num_partials(v)
+    call("fplx_bn_act_bwd_reduce", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(bnbuf[0]), ptr(bnbuf[1]),
+         ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), v, c, dt_of(y), ptr(part), stream())
+    call("fplx_bn_act_bwd_finalize", ptr(part), rows, c, v, 1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope),
+         ptr(coef), stream())
+    call("fplx_bn_act_bwd_apply", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]),
+         ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(coef), float(p), int(seed), int(sid), v, c,
+         dt_of(y), stream())
+
+
+def maxpool2_fwd(x, y, dims, c):
+    n, d, h, w = dims
+    call("fplx_maxpool2_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), n, d, h, w, c, dt_of(x), stream())
+
+
+def maxpool2_bwd(x, dy, dskip, dx, dims, c):
+    n, d, h, w = dims
+    call("fplx_maxpool2_bwd", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dskip), 0 if dskip is None else ld_of(dskip),
+         ptr(dx), ld_of(dx), n, d, h, w, c, dt_of(x), stream())
+
+
+def loss_rows(v):
+    return _lib.lib().fplx_loss_rows(v)
+
+
+def loss_k(c):
+    return 6 * c + 3
+
+
+def seg_loss_fwd(logits, label, pw, iw, weights, softmax, part, out, coef):
+    n, c = logits.shape[0], logits.shape[1]
+    v = logits[0, 0].numel()
+    call("fplx_seg_loss_fwd", ptr(logits), ptr(label), ptr(pw), ptr(iw), n, c, v, weights[0], weights[1], weights[2],
+         weights[3], 1 if softmax else 0, ptr(part), ptr(out), ptr(coef), stream())
+
+
+def seg_loss_bwd(logits, label, pw, coef, gscale, weights, softmax, dlogits):
+    n, c = logits.shape[0], logits.shape[1]
+    v = logits[0, 0].numel()
+    call("fplx_seg_loss_bwd", ptr(logits), ptr(label), ptr(pw), ptr(coef), ptr(gscale), n, c, v, weights[0],
+         weights[1], weights[2], weights[3], 1 if softmax else 0, ptr(dlogits), stream())
+
+
+def adam_step(p, g, m, v, lr, step, weight_decay, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+    call("fplx_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+         int(step), grad_scale, stream())
+
+
+def mc_filter(logits_tcv, thr=0.01, want_hards=True, want_maps=False):
+    """logits_tcv: fp32 [T, C, ...volume...] on the GPU -> dict (device tensors, no sync)"""
+    require_gpu(logits_tcv)
+    t, c = logits_tcv.shape[0], logits_tcv.shape[1]
+    vol = tuple(logits_tcv.shape[2:])
+    v = logits_tcv[0, 0].numel()
+    dev = logits_tcv.device
+    lg = logits_tcv.contiguous()
+    hards = torch.empty((t,) + vol, dtype=torch.uint8, device=dev) if want_hards else None
+    mean = torch.empty(vol, dtype=torch.float32, device=dev) if want_maps else None
+    unc = torch.empty(vol, dtype=torch.float32, device=dev) if want_maps else None
+    part = torch.empty((num_partials(v), 2), dtype=torch.float64, device=dev)
+    out = torch.empty(4, dtype=torch.float64, device=dev)
+    call("fplx_mc_filter", ptr(lg), t, c, v, thr, ptr(hards), ptr(mean), ptr(unc), ptr(part), ptr(out), stream())
+    return dict(hards=hards, means=mean, uncertainty=unc, stats=out)
+
+
+def hard_label(logits):
+    """save_outputs (reference agent_seg.py:1049-1050): [N,C,...] fp32 -> uint8 [N,...]"""
+    require_gpu(logits)
+    n, c = logits.shape[0], logits.shape[1]
+    lg = logits.contiguous()
+    out = torch.empty((n,) + tuple(logits.shape[2:]), dtype=torch.uint8, device=logits.device)
+    call("fplx_hard_label", ptr(lg), n, c, lg[0, 0].numel(), ptr(out), stream())
+    return out
+
+
+def pixel_weight(mask_a, mask_b, image_weight=None):
+    """reference data/get_pixel_weight.py:21-26 (+ NiftyDataset.set_weight_ when image_weight is given)"""
+    require_gpu(mask_a, mask_b)
+    if mask_a.shape != mask_b.shape:
+        raise ValueError("fplx: mask shapes differ")        # get_pixel_weight.py:19 asserts the same
+    a = mask_a.contiguous()
+    b = mask_b.contiguous()
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+    call("fplx_pixel_weight", ptr(a), ptr(b), a.numel(), 0 if image_weight is None else 1,
+         0.0 if image_weight is None else float(image_weight), ptr(out), stream())
+    return out

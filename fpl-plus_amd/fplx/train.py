@@ -1,0 +1,93 @@
+"""Engine-mode training step: forward -> fused loss -> backward -> (bucketed all-reduce) ->
+fused Adam, all on flat buffers, no autograd bookkeeping, no host synchronisation.
+
+One `step()` = one batch of ONE domain, i.e. one pass of the loop body of
+SegmentationAgent.training (reference PyMIC/pymic/net_run_dsbn/agent_seg.py:336-357) with the
+backward + optimizer.step the published loop forgot (it exists in training_all, 490-494, and in
+the vanilla agent, net_run/agent_seg.py:153-159).  `step_all()` = one iteration of training_all
+(agent_seg.py:459-495): every domain forward, loss (l0 + l1)/2, ONE Adam step.
+"""
+import torch
+
+from . import ops
+from .ddp import GradAllReducer
+from .optim import FusedAdam
+
+
+class TrainStep(object):
+    def __init__(self, net, loss_terms=(1.0, 0.0, 0.0, 0.0), softmax=True, lr=1e-4, weight_decay=1e-5,
+                 milestones=(), gamma=0.5, group=None, bucket_elems=1 << 21):
+        net._ensure_flat()
+        net.train()
+        self.net = net
+        self.terms = tuple(float(t) for t in loss_terms)
+        self.softmax = bool(softmax)
+        self.opt = FusedAdam(net, lr, weight_decay=weight_decay)
+        self.base_lr, self.milestones, self.gamma = lr, sorted(milestones), gamma
+        self.iteration = 0
+        self.gflat = torch.zeros_like(net.flat_params)
+        self.gacc = None
+        shared, doms = net.segments()
+        self.reducer = GradAllReducer(net.bucket_ranges(bucket_elems), doms, group)
+        self.opt.grad_scale = 1.0 / self.reducer.world
+        self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
+        self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
+        self._loss_bufs = {}
+
+    def _lr(self):
+        return self.base_lr * self.gamma ** sum(1 for m in self.milestones if self.iteration >= m)
+
+    def _loss_buffers(self, n, c, v, dev):
+        key = (n, c, v)
+        if key not in self._loss_bufs:
+            self._loss_bufs[key] = (
+                torch.empty((n, ops.loss_rows(v), ops.loss_k(c)), dtype=torch.float32, device=dev),
+                torch.empty(n * c * 2 + 2, dtype=torch.float32, device=dev))
+        return self._loss_bufs[key]
+
+    def _fwd_bwd(self, x, label, domain, pw, iw, gscale, gflat, reduce_hook):
+        net = self.net
+        step = net._fwd_counter
+        net._fwd_counter += 1
+        logits, sv = net.engine.forward(x, domain, True, net.dropout_active(), net.dropout_seed, step, keep=True)
+        n, c = logits.shape[0], logits.shape[1]
+        v = logits[0, 0].numel()
+        part, coef = self._loss_buffers(n, c, v, logits.device)
+        out = torch.empty(4 + c, dtype=torch.float32, device=logits.device)
+        ops.seg_loss_fwd(logits, label, pw, iw, self.terms, self.softmax, part, out, coef)
+        dlogits = torch.empty_like(logits)
+        ops.seg_loss_bwd(logits, label, pw, coef, gscale, self.terms, self.softmax, dlogits)
+        net.engine.backward(sv, dlogits, gflat, reduce_hook)
+        return out
+
+    def step(self, x, label, domain, pixel_weight=None, image_weight=None):
+        """one batch of one domain; returns the device tensor [total, dice, ce, entropy, class dice...]"""
+        self.reducer.begin(self.gflat)
+        out = self._fwd_bwd(x, label, domain, pixel_weight, image_weight, self._one, self.gflat, self.reducer.ready)
+        self.reducer.finish([domain])
+        self.opt.param_groups[0]['lr'] = self._lr()
+        self.opt.step_flat(self.gflat, [domain])
+        self.iteration += 1
+        return out
+
+    def step_all(self, batches):
+        """batches: one dict per domain with 'image', 'label_prob' (+ 'pixel_weight', 'image_weight')."""
+        nd = len(batches)
+        outs = []
+        if self.gacc is None:
+            self.gacc = torch.zeros_like(self.gflat)
+        for k, b in enumerate(batches):
+            # loss = (l0 + l1) / 2  (agent_seg.py:482): both terms carry 1/2; a single domain carries 1
+            gs = self._one if nd == 1 else self._half
+            last = k == nd - 1
+            tgt = self.gflat if k == 0 else self.gacc
+            outs.append(self._fwd_bwd(b['image'], b['label_prob'], k, b.get('pixel_weight'), b.get('image_weight'),
+                                      gs, tgt, None))
+            if k > 0:
+                self.gflat.add_(self.gacc)
+        self.reducer.begin(self.gflat)
+        self.reducer.finish(list(range(nd)))
+        self.opt.param_groups[0]['lr'] = self._lr()
+        self.opt.step_flat(self.gflat, list(range(nd)))
+        self.iteration += 1
+        return outs

@@ -1,0 +1,206 @@
+/*
+ * fplx.h - C ABI of libfplx.so: the MI355X (gfx950 / CDNA4) hot path of FPL+
+ * (3D U-Net with domain-specific BatchNorm: forward / backward, segmentation losses,
+ * pseudo-label uncertainty filter, fused Adam).
+ *
+ * The reference (HiLab-git/FPL-plus) is pure Python and has no FFI; every device kernel it
+ * runs comes from torch/ATen.  Each entry point below therefore cites the reference call
+ * site (path under /root/reference/PyMIC/pymic unless noted) whose ATen op it replaces.
+ *
+ * Conventions
+ *  - plain C: raw device pointers + sizes.  The CALLER owns every buffer (including
+ *    workspaces); the library allocates nothing and keeps no mutable global state.
+ *  - activations are NDHWC ("channels last"): element (n,d,h,w,c) of a tensor with voxel
+ *    stride `ld` (elements, >= C) lives at ((n*D+d)*H+h)*W+w)*ld + c.  ld > C addresses a
+ *    channel slice of a wider buffer (the skip/up concat of UpBlock is never materialised).
+ *  - `dt` selects the activation storage type: FPLX_F32 or FPLX_BF16.  Parameters,
+ *    statistics, reductions and gradients of parameters are always fp32.
+ *  - every launch is asynchronous on `stream` (a hipStream_t); no call synchronises.
+ *  - return value: 0 on success, negative FPLX_E_* otherwise; fplx_last_error() gives the
+ *    message of the calling thread's last failure.
+ *  - reductions use fixed-order two-stage trees (no float atomics): bitwise reproducible.
+ */
+#ifndef FPLX_H
+#define FPLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fplx_stream_t; /* hipStream_t */
+
+enum { FPLX_F32 = 0, FPLX_BF16 = 1 };
+
+enum {
+  FPLX_OK = 0,
+  FPLX_E_BADSHAPE = -1,   /* unsupported / inconsistent shape            -> ValueError   */
+  FPLX_E_BADDTYPE = -2,   /* unsupported dtype enum                      -> ValueError   */
+  FPLX_E_WORKSPACE = -3,  /* workspace too small                         -> RuntimeError */
+  FPLX_E_HIP = -4,        /* HIP launch error                            -> RuntimeError */
+  FPLX_E_NULL = -5        /* required pointer is NULL                    -> ValueError   */
+};
+
+int fplx_version(void);
+/* copies the calling thread's last error message (NUL terminated) into buf; returns its length */
+int fplx_last_error(char* buf, size_t n);
+/* number of partial-sum rows the reduction kernels write for a tensor of `voxels` voxels */
+int fplx_num_partials(int64_t voxels);
+
+/* ------------------------------------------------------------------ weight packing
+ * nn.Conv3d weight [Cout][Cin][KD][KH][KW] fp32 (net/net3d/unet2d5_dsbn.py:54-55, 293-294)
+ *   -> wf[tap][Cout][Cin]  (forward operand)
+ *   -> wb[tap][Cin][Cout]  with tap mirrored (data-gradient operand; may be NULL)
+ * both in dtype dt.  tap = (kd*KH + kh)*KW + kw. */
+int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin, int kd, int kh, int kw,
+                          int dt, fplx_stream_t stream);
+/* nn.ConvTranspose3d weight [Cin][Cout][2][2][2] fp32 (unet2d5_dsbn.py:152)
+ *   -> wf[tap][Cout][Cin] and wb[tap][Cin][Cout] (dtype dt), tap = (i*2+j)*2+k */
+int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt,
+                            fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ convolution
+ * Generic "same" convolution, stride 1, zero padding (KD/2, KH/2, KW/2):
+ *   nn.Conv3d(k=3,p=1)            unet2d5_dsbn.py:54-55 used at 75,79
+ *   nn.Conv3d(k=(1,3,3),p=(0,1,1)) unet2d5_dsbn.py:293-294, 307 (out_conv)
+ * and, with the mirrored pack `wb`, the data gradient of either.
+ *  x      input, described by explicit element strides (sn,sd,sh,sw,sc) so that both the
+ *         fp32 NCDHW network input and NDHWC activations can be read; type x_dt
+ *  wp     packed weight [taps][Cout][Cin], type = y's dt for NDHWC outputs, fp32 otherwise
+ *  bias   fp32 [Cout] or NULL
+ *  y      output, element strides (yn,yd,yh,yw,yc), type y_dt
+ *         (i.e. the packed weight has the type of y)
+ *  stats  optional fp32 [fplx_conv3d_stats_rows(...)][2][Cout]: per-row sum / sum of squares of
+ *         the (unrounded) outputs, for the BatchNorm that follows (dsbn.py:54-57).  The row
+ *         count depends on the kernel variant chosen for the shape; ask for it. */
+int fplx_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt);
+int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                    const void* wp, const float* bias,
+                    void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
+                    int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
+                    float* stats, fplx_stream_t stream);
+
+/* weight + bias gradient of the same convolution.
+ *  dw   fp32 [Cout][Cin][KD][KH][KW] (torch layout), db fp32 [Cout] or NULL
+ *  ws   workspace of at least fplx_conv3d_wgrad_ws_bytes(...) bytes */
+size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw);
+int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                      const void* dy, int dy_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
+                      float* dw, float* db, int n, int d, int h, int w, int cin, int cout,
+                      int kd, int kh, int kw, void* ws, size_t ws_bytes, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ transposed convolution
+ * nn.ConvTranspose3d(k=2,s=2) (unet2d5_dsbn.py:152,181).  x: [N,D,H,W,Cin] ld ldx;
+ * y: [N,2D,2H,2W,Cout] ld ldy (normally the upper channel half of the concat buffer, line 182). */
+int fplx_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
+                     int n, int d, int h, int w, int cin, int cout, int dt, fplx_stream_t stream);
+int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx,
+                       int n, int d, int h, int w, int cin, int cout, int dt, fplx_stream_t stream);
+size_t fplx_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+/* dw fp32 [Cin][Cout][2][2][2], db fp32 [Cout] */
+int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
+                       int n, int d, int h, int w, int cin, int cout, int dt,
+                       void* ws, size_t ws_bytes, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ DSBN + PReLU + dropout
+ * Training-mode statistics of nn.BatchNorm3d for the ACTIVE domain (dsbn.py:54-57):
+ *   stats [rows][2][C] (from fplx_conv3d_fwd) -> mean, biased var -> scale = gamma*rstd,
+ *   shift = beta - mean*scale; running_mean/var updated with momentum (unbiased var),
+ *   num_batches_tracked += 1 (int64, may be NULL).  eps as torch (1e-5). */
+int fplx_bn_train_finalize(const float* stats, int rows, int c, int64_t count,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float momentum, float eps,
+                           float* mean, float* rstd, float* scale, float* shift, fplx_stream_t stream);
+/* Statistics of an NDHWC tensor for a stand-alone DomainSpecificBatchNorm3d call (dsbn.py:54-57):
+ * stats fp32 [fplx_num_partials(voxels)][2][C], same format fplx_conv3d_fwd emits. */
+int fplx_channel_stats(const void* x, int64_t ldx, int64_t voxels, int c, int dt, float* stats,
+                       fplx_stream_t stream);
+/* Eval mode: scale/shift from the running statistics. */
+int fplx_bn_eval_prepare(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int c, float* scale, float* shift,
+                         fplx_stream_t stream);
+/* out = dropout_p(PReLU_slope(y*scale + shift))   (unet2d5_dsbn.py:76-78 / 80-81)
+ * dropout keep-mask = counter-based Philox stream (seed, stream_id, flat NDHWC index of `out`
+ * assuming ld == C numbering); p == 0 disables it.  y and out may alias. */
+int fplx_bn_act_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, const float* scale, const float* shift,
+                    const float* slope, float p, uint64_t seed, uint32_t stream_id,
+                    int64_t voxels, int c, int dt, fplx_stream_t stream);
+/* Backward, stage 1: partial sums over voxels of dz and dz*xhat per channel and of the PReLU
+ * slope gradient: part [rows][2*C+1] (rows = fplx_num_partials(voxels)). */
+int fplx_bn_act_bwd_reduce(const void* y, int64_t ldy, const void* dout, int64_t ldd,
+                           const float* mean, const float* rstd, const float* scale, const float* shift,
+                           const float* slope, float p, uint64_t seed, uint32_t stream_id,
+                           int64_t voxels, int c, int dt, float* part, fplx_stream_t stream);
+/* stage 2: dgamma, dbeta (ACCUMULATED into the fp32 grads), dslope (accumulated), and the
+ * two per-channel coefficients coef[2][C] used by stage 3.  train=0: eval-mode BN (statistics
+ * are constants): coefficients are zero. */
+int fplx_bn_act_bwd_finalize(const float* part, int rows, int c, int64_t count, int train,
+                             float* dgamma, float* dbeta, float* dslope, float* coef, fplx_stream_t stream);
+/* stage 3: dy = gamma*rstd * (dz - coef0 - xhat*coef1).  dy may alias dout. */
+int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t ldd, void* dy, int64_t ldo,
+                          const float* mean, const float* rstd, const float* scale, const float* shift,
+                          const float* slope, const float* coef, float p, uint64_t seed, uint32_t stream_id,
+                          int64_t voxels, int c, int dt, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling
+ * nn.MaxPool3d(2,2) (unet2d5_dsbn.py:106,117).  x [N,D,H,W,C] ld ldx -> y [N,D/2,H/2,W/2,C] ld ldy */
+int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
+                      int dt, fplx_stream_t stream);
+/* dx = dskip (may be NULL) + scatter(dy to the first maximum of each 2x2x2 window of x) */
+int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
+                      void* dx, int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ segmentation loss
+ * Fused softmax + Dice (loss/seg/dice.py:20-57, util.py:85-107) + cross entropy
+ * (loss/seg/ce.py:23-44) + per-sample image-weighted Dice (dice.py:106-128) + entropy
+ * regulariser (net_run_dsbn/agent_seg.py:352-354) + hard-Dice train metric
+ * (agent_seg.py:472-476).  logits / label: fp32 [N,C,D,H,W] contiguous (C <= 8);
+ * pixel_weight fp32 [N,1,D,H,W] or NULL.
+ *   part   fp32 workspace [N][rows][FPLX_LOSS_K(C)], rows = fplx_loss_rows(D*H*W)
+ *   cfg    host floats: w_dice, w_ce, w_dice_img (per-sample Dice x image_weight), w_entropy
+ *   image_weight fp32 [N] device or NULL (needed iff w_dice_img != 0)
+ *   out    fp32 device [4 + C]: total loss, dice term, ce term, entropy term, hard class Dice[C]
+ *   coef   fp32 device [N][C][2] + [2]: backward coefficients (written by the finalize kernel) */
+#define FPLX_LOSS_K(C) (6 * (C) + 3)
+int fplx_loss_rows(int64_t voxels_per_sample);
+int fplx_seg_loss_fwd(const float* logits, const float* label, const float* pixel_weight,
+                      const float* image_weight, int n, int c, int64_t voxels_per_sample,
+                      float w_dice, float w_ce, float w_dice_img, float w_entropy, int softmax,
+                      float* part, float* out, float* coef, fplx_stream_t stream);
+/* dlogits = gscale[0] * dLoss/dlogits ; gscale: device fp32 scalar (upstream gradient) */
+int fplx_seg_loss_bwd(const float* logits, const float* label, const float* pixel_weight,
+                      const float* coef, const float* gscale, int n, int c, int64_t voxels_per_sample,
+                      float w_dice, float w_ce, float w_dice_img, float w_entropy, int softmax,
+                      float* dlogits, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser
+ * torch.optim.Adam(lr, weight_decay) as built by net_run_dsbn/get_optimizer.py:17 on a flat
+ * fp32 buffer: g += wd*p; m,v moments; bias correction with `step` (1-based); p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps).
+ * grad_scale multiplies g first (1/world_size after an all-reduce sum). */
+int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, fplx_stream_t stream);
+
+/* ------------------------------------------------------------------ pseudo-label filter
+ * FPL branch of SegmentationAgent.infer (net_run_dsbn/agent_seg.py:911-931) for one volume:
+ * logits fp32 [T][C][V] (T MC/TTA passes).  Per voxel: softmax per pass (scipy.special.softmax,
+ * fp32), hard label per pass (argmax, uint8 [T][V], may be NULL), population variance over T
+ * summed over classes, mean_T p_1, u = -m*log(m+1e-6), boundary = #(u > thr).
+ *   part  workspace fp32/int [rows][2] (rows = fplx_num_partials(V))
+ *   out   device double [4]: vars, boundary, uncer_one (= 1 if boundary < 50 else vars/boundary), 0
+ *   mean_out / unc_out optional fp32 [V] maps */
+int fplx_mc_filter(const float* logits, int t, int c, int64_t v, float thr, uint8_t* hards,
+                   float* mean_out, float* unc_out, double* part, double* out, fplx_stream_t stream);
+/* save_outputs (agent_seg.py:1049-1050): softmax -> argmax -> uint8.  logits fp32 [N][C][V] */
+int fplx_hard_label(const float* logits, int n, int c, int64_t v, uint8_t* out, fplx_stream_t stream);
+/* data/get_pixel_weight.py:21-26 (/root/reference): w = 1 - 0.5*xor(a,b) (a,b uint8 {0,1}) as fp32
+ * (exact in fp32: values are 1.0 / 0.5), followed, if apply_set_weight, by
+ * NiftyDataset.set_weight_ (io/nifty_dataset.py:165-168): w<1 -> 0, w *= image_weight. */
+int fplx_pixel_weight(const uint8_t* a, const uint8_t* b, int64_t v, int apply_set_weight, float image_weight,
+                      float* out, fplx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPLX_H */

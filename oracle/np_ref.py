@@ -111,14 +111,14 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 def philox_keep_mask(seed, stream, n_elems, p):
     """keep[i] for the flat NDHWC element index i: word (i & 3) of
-    philox(counter=(i>>2, 0, stream, 0), key=(seed_lo, seed_hi)) >= floor(p * 2^32)."""
+    philox(counter=(i>>2, 0, stream, 0), key=(seed_lo, seed_hi)) >= floor(float32(p) * 2^32)."""
     n4 = (n_elems + 3) // 4
     idx = np.arange(n4, dtype=np.uint32)
     z = np.zeros(n4, np.uint32)
     r = philox4x32_10(idx, z, np.full(n4, stream, np.uint32), z,
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     words = np.stack(r, axis=1).reshape(-1)[:n_elems]
-    thr = np.uint32(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 0xFFFFFFFF))  # p travels as fp32
     return words >= thr
 
 

@@ -94,7 +94,9 @@ def conv_block(x, sd, key, domain, train, p, keep_mask, act_dtype, dropout_on=No
         if keep_mask is None:
             x = F.dropout(x, p, True)
         else:
-            x = x * keep_mask.to(x.dtype) * (1.0 / (1.0 - p))
+            # fplx passes p as fp32 and scales by float(1 / (1 - double(p)))
+            p32 = float(torch.tensor(p, dtype=torch.float32))
+            x = x * keep_mask.to(x.dtype) * float(torch.tensor(1.0 / (1.0 - p32), dtype=torch.float32))
     x = quant(x, act_dtype)
     x = F.conv3d(x, sd[key + ".conv3d_2.weight"], sd[key + ".conv3d_2.bias"], padding=1)
     x = quant(x, act_dtype)

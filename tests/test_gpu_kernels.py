@@ -1,0 +1,151 @@
+"""Kernel-level GPU tests through the C ABI: generic convolution / transposed convolution /
+pooling / Adam against plain PyTorch fp32 on the CPU, incl. ragged and strided (channel-slice) cases."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import detdata
+
+pytestmark = pytest.mark.gpu
+
+
+def cl(t):       # NCDHW -> [V, C] channels-last 2-D
+    return t.permute(0, 2, 3, 4, 1).contiguous().view(-1, t.shape[1])
+
+
+def uncl(t2, n, d, h, w):
+    return t2.view(n, d, h, w, -1).permute(0, 4, 1, 2, 3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("shape", [(1, 5, 7, 3, 9, 6), (2, 16, 8, 4, 6, 10), (1, 3, 11, 2, 2, 2)])
+def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    x = torch.from_numpy(detdata.normal("k.x%s" % (shape,), (n, cin, d, h, w)))
+    wt = torch.from_numpy(detdata.normal("k.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.2))
+    b = torch.from_numpy(detdata.normal("k.b%s" % (shape,), (cout,)))
+    dy = torch.from_numpy(detdata.normal("k.dy%s" % (shape,), (n, cout, d, h, w)))
+    if dtype == torch.bfloat16:
+        x, wt, dy = x.bfloat16().float(), wt.bfloat16().float(), dy.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=1)
+    yr.backward(dy)
+    dt = ops._DT[dtype]
+    dims = (n, d, h, w)
+    xg, dyg = cl(x).to(dtype).cuda(), cl(dy).to(dtype).cuda()
+    wf, wb = ops.pack_conv_weight(wt.cuda(), dtype)
+    # output into a channel slice of a wider buffer (ld = cout + 3)
+    ybuf = torch.zeros((xg.shape[0], cout + 3), dtype=dtype, device="cuda")
+    yv = ybuf[:, 2:2 + cout]
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), yv, ops.cl_strides(d, h, w, cout + 3), dt,
+                   dims, cin, cout, (3, 3, 3), stats)
+    got = uncl(yv.float().cpu(), n, d, h, w)
+    scale = float(yr.abs().max())
+    assert float((got - yr.detach()).abs().max()) < tol * scale
+    assert float(ybuf[:, :2].abs().max()) == 0 and float(ybuf[:, 2 + cout:].abs().max()) == 0
+    s = stats.sum(0).cpu()
+    yf = cl(yr.detach())
+    np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=tol * scale * yf.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=max(tol, 1e-4) * 4)
+    # data gradient = same kernel with the mirrored pack
+    dx = torch.empty((xg.shape[0], cin), dtype=dtype, device="cuda")
+    ops.conv3d_fwd(dyg, ops.cl_strides(d, h, w, cout), dt, wb, None, dx, ops.cl_strides(d, h, w, cin), dt, dims,
+                   cout, cin, (3, 3, 3), None)
+    assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < tol * float(xr.grad.abs().max())
+    # weight / bias gradient
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device="cuda")
+    db = torch.empty(cout, dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw, db, dims,
+                     cin, cout, (3, 3, 3), ws)
+    assert float((dw.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+    assert float((db.cpu() - br.grad).abs().max()) < max(tol, 1e-4) * float(br.grad.abs().max())
+    with pytest.raises(RuntimeError):
+        ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw, db, dims,
+                         cin, cout, (3, 3, 3), ws[:16])
+    with pytest.raises(ValueError):
+        ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, None, yv, ops.cl_strides(d, h, w, cout + 3), dt,
+                       (0, d, h, w), cin, cout, (3, 3, 3), None)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_deconv2_fwd_bwd(dtype, tol):
+    from fplx import ops
+    n, cin, cout, d, h, w = 2, 12, 7, 3, 4, 5
+    x = torch.from_numpy(detdata.normal("dc.x", (n, cin, d, h, w)))
+    wt = torch.from_numpy(detdata.normal("dc.w", (cin, cout, 2, 2, 2), 0.3))
+    b = torch.from_numpy(detdata.normal("dc.b", (cout,)))
+    dy = torch.from_numpy(detdata.normal("dc.dy", (n, cout, 2 * d, 2 * h, 2 * w)))
+    if dtype == torch.bfloat16:
+        x, wt, dy = x.bfloat16().float(), wt.bfloat16().float(), dy.bfloat16().float()
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2)
+    yr.backward(dy)
+    dims = (n, d, h, w)
+    xg, dyg = cl(x).to(dtype).cuda(), cl(dy).to(dtype).cuda()
+    wf, wb = ops.pack_deconv_weight(wt.cuda(), dtype)
+    cat = torch.zeros((dyg.shape[0], 2 * cout), dtype=dtype, device="cuda")     # write the "up" half of a concat
+    ops.deconv2_fwd(xg, wf, b.cuda(), cat[:, cout:], dims, cin, cout)
+    got = uncl(cat[:, cout:].float().cpu(), n, 2 * d, 2 * h, 2 * w)
+    assert float((got - yr.detach()).abs().max()) < tol * float(yr.abs().max())
+    assert float(cat[:, :cout].abs().max()) == 0
+    dx = torch.empty_like(xg)
+    ops.deconv2_dgrad(dyg, wb, dx, dims, cin, cout)
+    assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < tol * float(xr.grad.abs().max())
+    ws = torch.empty(ops.deconv2_wgrad_ws_bytes(dims, cin, cout), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((cin, cout, 2, 2, 2), dtype=torch.float32, device="cuda")
+    db = torch.empty(cout, dtype=torch.float32, device="cuda")
+    ops.deconv2_wgrad(xg, dyg, dw, db, dims, cin, cout, ws)
+    assert float((dw.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+    assert float((db.cpu() - br.grad).abs().max()) < max(tol, 1e-4) * float(br.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [8, 5])
+def test_maxpool_fwd_bwd_first_max_wins(dtype, c):
+    from fplx import ops
+    n, d, h, w = 2, 4, 6, 8
+    x = torch.from_numpy(detdata.normal("mp.x%d" % c, (n, c, d, h, w)))
+    x = (x * 2).round() / 2            # many exact ties
+    dy = torch.from_numpy(detdata.normal("mp.dy%d" % c, (n, c, d // 2, h // 2, w // 2)))
+    skip = torch.from_numpy(detdata.normal("mp.sk%d" % c, (n, c, d, h, w)))
+    if dtype == torch.bfloat16:
+        dy, skip = dy.bfloat16().float(), skip.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool3d(xr, 2, 2)
+    yr.backward(dy)
+    xg = cl(x).to(dtype).cuda()
+    yg = torch.empty((n * d * h * w // 8, c), dtype=dtype, device="cuda")
+    ops.maxpool2_fwd(xg, yg, (n, d, h, w), c)
+    assert torch.equal(uncl(yg.float().cpu(), n, d // 2, h // 2, w // 2), yr.detach())
+    dx = torch.empty_like(xg)
+    ops.maxpool2_bwd(xg, cl(dy).to(dtype).cuda(), cl(skip).to(dtype).cuda(), dx, (n, d, h, w), c)
+    ref = (xr.grad + skip)
+    if dtype == torch.bfloat16:
+        ref = ref.bfloat16().float()
+    assert float((uncl(dx.float().cpu(), n, d, h, w) - ref).abs().max()) <= (0 if dtype == torch.float32 else 1e-2)
+    with pytest.raises(ValueError):
+        ops.maxpool2_fwd(xg, yg, (n, 3, h, w), c)
+
+
+def test_fused_adam_matches_torch():
+    from fplx import ops
+    torch.manual_seed(3)
+    p0 = torch.randn(10007)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], 1e-3, weight_decay=1e-5)
+    p, m, v = p0.clone().cuda(), torch.zeros(10007).cuda(), torch.zeros(10007).cuda()
+    for step in range(1, 6):
+        g = torch.randn(10007)
+        p_ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, g.cuda(), m, v, 1e-3, step, 1e-5)
+        assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6
+    with pytest.raises(ValueError):
+        ops.adam_step(p, g.cuda(), m, v, 1e-3, 0, 1e-5)

@@ -1,0 +1,173 @@
+"""GPU parity of the DSBN 3D U-Net (HIP path through the C ABI) against
+ (a) the golden fixtures produced by running the reference (fp32 mode, <= 1e-3 on logits), and
+ (b) the CPU oracle with bf16 storage emulation (bf16 mode)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+import detdata
+from make_golden_cfg import NETS, SHAPES, label_for
+from util import load_det_weights, max_rel
+
+pytestmark = pytest.mark.gpu
+
+# max-normalised gradient tolerance: see tests/test_oracle_golden.py (reference's own fp32 noise) x2
+GRAD_TOL = {"tiny": 1e-3, "c4": 1e-3, "cfg1": 1e-2}
+LOGIT_TOL = 1e-3            # north_star: logits within 1e-3 in fp32
+
+
+def _net(name, precision="fp32", dropout=None):
+    import fplx
+    p = dict(NETS[name])
+    p["precision"] = precision
+    if dropout is not None:
+        p["dropout"] = dropout
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    return net, p
+
+
+@pytest.mark.parametrize("name", ["tiny", "c4", "cfg1"])
+def test_fp32_forward_backward_matches_reference(golden_dir, name):
+    import fplx
+    g = np.load(os.path.join(golden_dir, "net_%s.npz" % name))
+    x = torch.from_numpy(detdata.normal("x." + name, SHAPES[name])).cuda()
+    y = torch.from_numpy(label_for(name)).cuda()
+    n = x.shape[0]
+    for d in (0, 1):
+        net, p = _net(name)
+        net.eval()
+        with torch.no_grad():
+            le = net(x, domain_label=d * torch.ones(n, dtype=torch.long))
+        assert np.abs(le.cpu().numpy() - g["logits_eval_d%d" % d]).max() < LOGIT_TOL
+        net.train()
+        lt = net(x, domain_label=d * torch.ones(n, dtype=torch.long))
+        assert np.abs(lt.detach().cpu().numpy() - g["logits_train_d%d" % d]).max() < LOGIT_TOL
+        loss = fplx.DiceLoss()({"prediction": lt, "ground_truth": y})
+        assert abs(loss.item() - float(g["loss_dice_d%d" % d])) < 1e-5
+        loss.backward()
+        sd = net.state_dict()
+        named = dict(net.named_parameters())
+        for k in g.files:
+            pre = "d%d." % d
+            if k.startswith(pre) and ".bns." in k:
+                np.testing.assert_allclose(sd[k[len(pre):]].cpu().numpy(), g[k], atol=2e-5, rtol=1e-4, err_msg=k)
+            ref, got = None, None
+            if k.startswith("grad_d%d." % d):
+                kk = k[len("grad_d%d." % d):]
+                ref, got = g[k], named[kk].grad.cpu().numpy()
+            elif k.startswith("gradsub") and ("_d%d." % d) in k:
+                head, kk = k.split("_d%d." % d)
+                stride = int(head[len("gradsub"):])
+                ref, got = g[k], named[kk].grad.cpu().numpy().reshape(-1)[::stride]
+            if ref is not None:
+                if kk.endswith("bias") and ("conv3d_1" in kk or "conv3d_2" in kk):
+                    # conv bias feeding train-mode BatchNorm: the true gradient is exactly 0; the reference
+                    # returns fp32 cancellation noise, fplx returns 0
+                    assert np.abs(got).max() == 0.0 and np.abs(ref).max() < 1e-6, k
+                    continue
+                tol = max(GRAD_TOL[name] * np.abs(ref).max(), 2e-7)
+                np.testing.assert_allclose(got, ref, atol=tol, rtol=0, err_msg=k)
+        keys = [str(s) for s in g["gradnorm_keys_d%d" % d]]
+        vals = g["gradnorm_vals_d%d" % d]
+        ours = sorted(k for k, t in named.items() if t.grad is not None)
+        assert ours == keys          # exactly the parameters the reference gives a gradient to
+        for k, v in zip(keys, vals):
+            if k.endswith("bias") and ("conv3d_1" in k or "conv3d_2" in k):
+                continue
+            assert abs(float(named[k].grad.norm()) - v) <= max(GRAD_TOL[name] * v, 1e-6), (k, v)
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg1"])
+def test_bf16_matches_bf16_emulating_oracle(name):
+    """bf16 activations / fp32 master weights: compare with the CPU oracle rounding activations
+    to bf16 at the same points.  Tolerance: bf16 has 8 significant bits; after 18 conv layers we
+    allow 3e-2 of the logits' range, and require the fp32-vs-bf16 gap itself to be of that order."""
+    import fplx
+    from oracle import torch_ref as R
+    x = torch.from_numpy(detdata.normal("x." + name, SHAPES[name]))
+    y = torch.from_numpy(label_for(name))
+    n = x.shape[0]
+    net, p = _net(name, "bf16")
+    net.train()
+    lt = net(x.cuda(), domain_label=torch.ones(n, dtype=torch.long))
+    loss = fplx.DiceLoss()({"prediction": lt, "ground_truth": y.cuda()})
+    loss.backward()
+    sd, prm = R.split_state(detdata.state_dict_3d(p))
+    ref = R.unet_forward(sd, p, x, 1, True, act_dtype=torch.bfloat16)
+    rl = R.dice_loss(ref, y)
+    rl.backward()
+    rng = float(ref.detach().abs().max())
+    assert np.abs(lt.detach().cpu().numpy() - ref.detach().numpy()).max() < 3e-2 * rng
+    assert abs(loss.item() - rl.item()) < 2e-3
+    named = dict(net.named_parameters())
+    for k in ("out_conv.weight", "up4.conv.conv3d_1.weight", "block0.conv.conv3d_1.weight", "up1.trans3d.weight",
+              "block4.conv.conv3d_2.weight", "block0.conv.bn3d1.bns.1.weight"):
+        r = prm[k].grad.numpy()
+        assert max_rel(named[k].grad.cpu().numpy(), r) < 8e-2, k
+
+
+def test_dropout_stream_matches_oracle_philox():
+    """MC-dropout forward (eval BN, active dropout - the FPL test-time setting) with the counter-based
+    Philox masks reproduced on the CPU by oracle/np_ref.py."""
+    from oracle import torch_ref as R
+    from oracle import np_ref as N
+    name = "tiny"
+    drop = [0, 0, 0.3, 0.4, 0.5]
+    net, p = _net(name, "fp32", drop)
+    x = torch.from_numpy(detdata.normal("x." + name, SHAPES[name]))
+    net.eval()
+    for m in net.modules():
+        if type(m) == torch.nn.Dropout:
+            m.train()
+    net.dropout_seed = 77
+    with torch.no_grad():
+        out0 = net(x.cuda(), domain_label=torch.ones(2, dtype=torch.long)).cpu().numpy()
+        out1 = net(x.cuda(), domain_label=torch.ones(2, dtype=torch.long)).cpu().numpy()
+    assert np.abs(out0 - out1).max() > 1e-3            # a new mask per forward
+    sd, _ = R.split_state(detdata.state_dict_3d(p), requires_grad=False)
+    ps = R.block_dropout_p(p)
+    for step, got in ((0, out0), (1, out1)):
+        masks = [None if m is None else torch.from_numpy(m)
+                 for m in N.dropout_masks_ncdhw(77, step, p, SHAPES[name], ps)]
+        with torch.no_grad():
+            ref = R.unet_forward(sd, p, x, 1, train=False, dropout_masks=masks, dropout_on=True).numpy()
+        assert np.abs(got - ref).max() < LOGIT_TOL
+
+
+def test_error_behaviour_mirrors_reference():
+    import fplx
+    net, p = _net("tiny")
+    with pytest.raises(ValueError):          # dsbn.py:61-64: 5D input required
+        net(torch.zeros(1, 16, 32, 32).cuda(), domain_label=torch.zeros(1, dtype=torch.long))
+    with pytest.raises(RuntimeError):        # no CPU path
+        net(torch.zeros(1, 1, 16, 32, 32), domain_label=torch.zeros(1, dtype=torch.long))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 16, 32, 40).cuda(), domain_label=torch.zeros(1, dtype=torch.long))
+    with pytest.raises(IndexError):
+        net(torch.zeros(1, 1, 16, 32, 32).cuda(), domain_label=5 * torch.ones(1, dtype=torch.long))
+    bad = dict(p)
+    bad["conv_dims"] = [2, 2, 3, 3, 3]
+    with pytest.raises(ValueError):
+        fplx.UNet2D5_dsbn(bad)
+    layer = fplx.DomainSpecificBatchNorm3d(8, 2).cuda()
+    with pytest.raises(ValueError):
+        layer(torch.zeros(2, 8, 4, 4).cuda(), torch.zeros(2, dtype=torch.long))
+
+
+def test_standalone_dsbn_layer_matches_torch_batchnorm():
+    import fplx
+    torch.manual_seed(0)
+    layer = fplx.DomainSpecificBatchNorm3d(12, 2).cuda()
+    ref = torch.nn.BatchNorm3d(12)
+    ref.load_state_dict(layer.bns[1].state_dict())
+    x = torch.randn(2, 12, 4, 6, 8)
+    y, dl = layer(x.cuda(), torch.ones(2, dtype=torch.long))
+    yr = ref(x)
+    assert np.abs(y.cpu().numpy() - yr.detach().numpy()).max() < 1e-4
+    np.testing.assert_allclose(layer.bns[1].running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5)
+    assert int(layer.bns[1].num_batches_tracked) == 1 and int(layer.bns[0].num_batches_tracked) == 0
+    layer.eval(); ref.eval()
+    y, _ = layer(x.cuda(), torch.ones(2, dtype=torch.long))
+    assert np.abs(y.cpu().numpy() - ref(x).detach().numpy()).max() < 1e-4
