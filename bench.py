@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py - FPL+ hot path on MI355X: 3D volumes/sec of the DSBN 3D U-Net train step.
+
+Workload (BASELINE.json configs[1] / SURVEY.md section 8d cfg2): UNet2D5_dsbn all-3D, feature_chns
+[32,64,128,256,512], 2 domains, bf16 activations / fp32 master weights, per-GPU batch
+2 x 1 x 80 x 160 x 160 synthetic VS-like crops (N(0,1) intensities, ball label), DiceLoss, Adam(1e-4, wd 1e-5).
+One step = zero-grad -> forward -> loss -> backward -> (RCCL all-reduce) -> Adam for ONE batch of one
+domain; the domain alternates 0/1 per step.  Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(one rank per GPU, weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "fpl-plus_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TF = 2500.0    # dense bf16 MFMA ~2.5 PFLOP/s
+VALU_F32_PEAK_TF = 157.3
+
+NET = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0.0, 0.0, 0.3, 0.4, 0.5],
+           conv_dims=[3, 3, 3, 3, 3], class_num=2, bilinear=False, num_domains=2, precision="bf16",
+           net_type="UNet2D5_dsbn")
+SHAPE = (2, 1, 80, 160, 160)
+
+
+def synth_batch(shape, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    n, _, D, H, W = shape
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    lab = torch.zeros((n, 2, D, H, W))
+    for i in range(n):
+        off = torch.randint(-8, 9, (3,), generator=g)
+        m = ((zz - D / 2 - off[0]) ** 2 + (yy - H / 2 - off[1]) ** 2 + (xx - W / 2 - off[2]) ** 2) <= 100
+        lab[i, 1][m] = 1.0
+        lab[i, 0][~m] = 1.0
+    return x.to(device), lab.to(device)
+
+
+class KernelTimer(object):
+    """HIP-event timing of individual launches on the stream they are issued on (torch's current
+    stream = the stream fplx launches on).  Wraps selected fplx.ops entry points."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.on = ops, {}, False
+        self._orig = {}
+        for name in ("conv3d_fwd", "conv3d_wgrad", "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad",
+                     "deconv2_wgrad", "maxpool2_fwd", "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step"):
+            self._wrap(name)
+
+    def _key(self, name, a):
+        if name in ("conv3d_fwd",):
+            dims, cin, cout, k = a[8], a[9], a[10], a[11]
+            return (name, dims, cin, cout, k)
+        if name == "conv3d_wgrad":
+            dims, cin, cout, k = a[8], a[9], a[10], a[11]
+            return (name, dims, cin, cout, k)
+        return (name,)
+
+    def _wrap(self, name):
+        orig = getattr(self.ops, name)
+        self._orig[name] = orig
+
+        def f(*a, **kw):
+            if not self.on:
+                return orig(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **kw)
+            e1.record()
+            self.records.setdefault(self._key(name, a), []).append((e0, e1))
+            return r
+        setattr(self.ops, name, f)
+
+    def summary(self):
+        out = {}
+        for k, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[k] = (len(ms), float(np.mean(ms)), float(np.sum(ms)))
+        return out
+
+
+def roofline_of(key, n_avg_ms):
+    """algorithmic bytes / flops per launch of a convolution key (bf16 activations, SURVEY 8d rule:
+    every input read once, every output written once)."""
+    name, dims, cin, cout, k = key
+    n, d, h, w = dims
+    vox = n * d * h * w
+    taps = k[0] * k[1] * k[2]
+    flops = 2.0 * vox * cin * cout * taps
+    if name == "conv3d_fwd":
+        nbytes = vox * (cin + cout) * 2.0
+    else:  # wgrad reads x and dy, writes the tiny dW
+        nbytes = vox * (cin + cout) * 2.0 + taps * cin * cout * 4.0
+    sec = n_avg_ms * 1e-3
+    return flops, nbytes, flops / sec / 1e12, nbytes / sec / 1e9
+
+
+def cpu_baseline():
+    """The oracle (PyTorch-CPU restatement of the reference modules, oracle/torch_ref.py) timed on the
+    host cores on a bounded sample of the same workload: one fp32 train step (forward, Dice loss,
+    backward, Adam) of the 32-base network on a 1x1x32x80x80 crop = 1/10 of one 80x160x160 volume."""
+    from oracle import torch_ref as R
+    import detdata
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = dict(NET)
+    p["dropout"] = [0, 0, 0, 0, 0]
+    sd, prm = R.split_state(detdata.state_dict_3d(p))
+    opt = R.AdamRef(prm, 1e-4, 1e-5)
+    shape = (1, 1, 32, 80, 80)
+    x = torch.randn(shape)
+    lab = torch.from_numpy(detdata.ball_label(shape[2:], 8.0, n=1))
+    loss_fn = R.loss_from_config({"loss_type": "DiceLoss"})
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        R.training_all_step(sd, prm, opt, p, [{"image": x, "label_prob": lab}], loss_fn)
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": (1.0 / 10.0) / t, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": "1 fp32 train step on a 1x1x32x80x80 crop (1/10 volume), 32-base UNet-DSBN, oracle/torch_ref.py; "
+                      "median of 2 after 1 warm-up, %.2f s/step" % t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import fplx
+    from fplx import ops
+    torch.manual_seed(1)
+    net = fplx.UNet2D5_dsbn(dict(NET)).to(dev)
+    net._ensure_flat()
+    fplx.ddp.broadcast_params_from_rank0(net)
+    ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-4, weight_decay=1e-5,
+                        milestones=[10000, 20000, 30000, 40000], gamma=0.5)
+    batches = [synth_batch(SHAPE, 1000 * rank + d, dev) for d in (0, 1)]
+    timer = None if args.no_kernel_timing else KernelTimer(ops)
+
+    def run(k0, k):
+        out = None
+        for i in range(k0, k0 + k):
+            d = i % 2
+            out = ts.step(batches[d][0], batches[d][1], d)
+        return out
+
+    run(0, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(args.warmup, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out[0].item())
+
+    # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
+    roof = None
+    ktable = []
+    if timer is not None and rank == 0:
+        timer.on = True
+        run(args.warmup + args.steps, 2)
+        torch.cuda.synchronize()
+        timer.on = False
+        summ = timer.summary()
+        tot = sum(v[2] for v in summ.values())
+        for k, (cnt, avg, s) in sorted(summ.items(), key=lambda kv: -kv[1][2]):
+            ktable.append({"kernel": str(k), "launches": cnt, "avg_ms": round(avg, 4), "share": round(s / tot, 4)})
+        convs = {k: v for k, v in summ.items() if k[0] in ("conv3d_fwd", "conv3d_wgrad")}
+        if convs:
+            k = max(convs, key=lambda kk: convs[kk][2])
+            flops, nbytes, tf, gbs = roofline_of(k, convs[k][1])
+            ai = flops / nbytes
+            ridge = MFMA_BF16_PEAK_TF * 1e3 / HBM_PEAK_GBS
+            if ai >= ridge:
+                roof = {"bound": "mfma", "achieved": round(tf, 3), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(tf / MFMA_BF16_PEAK_TF, 5), "traffic": None}
+            else:
+                roof = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None}
+            roof.update({"kernel": str(k), "avg_ms": round(convs[k][1], 4), "launches_timed": convs[k][0],
+                         "algorithmic_bytes": nbytes, "algorithmic_flops": flops,
+                         "hbm_GBps": round(gbs, 2), "TFLOPps": round(tf, 3), "time_share": round(convs[k][2] / tot, 4)})
+
+    if rank == 0:
+        vols = world * SHAPE[0] * args.steps
+        res = {
+            "metric": "3D volumes/sec (train step, 80x160x160)", "value": round(vols / dt, 4), "unit": "volumes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "UNet3D-DSBN 32-base-ch bf16 (fp32 master weights), per-GPU batch 2x1x80x160x160 "
+                                   "synthetic VS crops, DiceLoss + Adam, domain alternating per step",
+                       "global_batch": world * SHAPE[0], "parallelism": "dp%d" % world,
+                       "step": "zero_grad+forward+loss+backward+allreduce+adam"},
+            "final_loss": round(loss, 6),
+            # whole-step roofline: SURVEY 8d analytic work per volume (train): 2.793 TFLOP, 10.1 GB
+            "step_roofline": {"TFLOPps": round(2.793 * vols / dt / world, 2), "hbm_GBps": round(10.1 * vols / dt / world, 1),
+                              "frac_mfma": round(2.793 * vols / dt / world / MFMA_BF16_PEAK_TF, 5),
+                              "frac_hbm": round(10.1 * vols / dt / world / HBM_PEAK_GBS, 5)},
+        }
+        if roof is not None:
+            res["roofline"] = roof
+        if ktable:
+            res["kernels"] = ktable[:8]
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,11 @@ import ctypes
 import os
 import re
 
+# torch first: libfplx.so must bind to the SAME HIP runtime (libamdhip64.so.7) the process uses
+# for its device memory and streams.  PyTorch-ROCm ships its own copy; whichever copy is loaded
+# first serves both, and the ROCm-7.2 system copy does not see the devices torch opened.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 HEADER = os.path.join(_ROOT, "include", "fplx.h")
