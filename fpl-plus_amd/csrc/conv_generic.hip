@@ -203,12 +203,12 @@ bias_grad_partial_cl(const TY* __restrict__ dy, int64_t ld, int64_t V, int C, fl
   if (threadIdx.x < 64 && c < C)
     part[(int64_t)blockIdx.x * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void bias_grad_reduce(const float* __restrict__ part, int rows, int C, float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(64) bias_grad_reduce(const float* __restrict__ part, int rows, int C, float* __restrict__ db) {
+  const int c = blockIdx.x;
   float t = 0.f;
-  for (int r = 0; r < rows; ++r) t += part[(int64_t)r * C + c];
-  db[c] = t;
+  for (int r = threadIdx.x; r < rows; r += 64) t += part[(int64_t)r * C + c];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) db[c] = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,7 +311,7 @@ void launch_bias_grad(const TY* dy, Strides ys, int n, int d, int h, int w, int 
     dim3 g(rows, c);
     bias_grad_partial<TY><<<g, 256, 0, st>>>(dy, ys, n, d, h, w, c, bpart);
   }
-  bias_grad_reduce<<<(c + 63) / 64, 64, 0, st>>>(bpart, rows, c, db);
+  bias_grad_reduce<<<c, 64, 0, st>>>(bpart, rows, c, db);
 }
 
 inline int grid_for(int64_t n, int threads, int cap) {
@@ -334,6 +334,16 @@ inline int wgrad_chunks(int64_t V) {
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, hipStream_t st);
+extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
+                                       int h, int w, int cin, int cout, hipStream_t st);
+extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
+                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st);
+extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
+                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st);
 
 extern "C" {
 
@@ -408,7 +418,9 @@ int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh,
   }
   const int64_t V = (int64_t)n * d * h * w;
   const int64_t tiles = (V + FWD_THREADS - 1) / FWD_THREADS;
-  dim3 grid(grid_for(V, FWD_THREADS, MAX_ROWS), (cout + CO_T - 1) / CO_T);
+  // the statistics row count promised by fplx_conv3d_stats_rows() must hold on this path too
+  // (the kernel is grid-strided, any grid.x works)
+  dim3 grid(fplx_conv3d_stats_rows(n, d, h, w, cin, cout, kd, kh, kw, x_dt, y_dt), (cout + CO_T - 1) / CO_T);
   Strides xs{sn, sd, sh, sw, sc}, ys{yn, yd, yh, yw, yc};
 #define LAUNCH(TX, TW, TY)                                                                                      \
   conv_fwd_generic<TX, TW, TY><<<grid, FWD_THREADS, 0, st>>>((const TX*)x, xs, (const TW*)wp, bias, (TY*)y, ys, \
@@ -427,7 +439,10 @@ size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout,
   const int64_t V = (int64_t)n * d * h * w;
   const size_t a = (size_t)wgrad_chunks(V) * kd * kh * kw * cout * cin * sizeof(float);
   const size_t b = (size_t)fplx_rows_for(V) * cout * sizeof(float);
-  return a + b + 256;
+  size_t m = 0;
+  if (kd == 3 && kh == 3 && kw == 3) m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+  const size_t g = a + b + 256;
+  return (m + b + 256) > g ? (m + b + 256) : g;
 }
 
 int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
@@ -442,10 +457,22 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
   hipStream_t st = (hipStream_t)stream;
   const int64_t V = (int64_t)n * d * h * w;
   const int taps = kd * kh * kw, chunks = wgrad_chunks(V);
-  float* part = (float*)ws;
-  float* bpart = part + (size_t)chunks * taps * cout * cin;
-  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), taps);
   Strides xs{sn, sd, sh, sw, sc}, ys{yn, yd, yh, yw, yc};
+  bool done = false;
+  size_t used = (size_t)chunks * taps * cout * cin * sizeof(float);
+  if (x_dt == FPLX_BF16 && dy_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 && sc == 1 && yc == 1 &&
+      sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
+    const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > 0) {
+      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st);
+      if (r < 0) return r;
+      if (r == 1) { done = true; used = m; }
+    }
+  }
+  float* part = (float*)ws;
+  float* bpart = (float*)((char*)ws + used);
+  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), taps);
+  if (!done) {
 #define LAUNCH(TX, TY)                                                                                         \
   wgrad_generic<TX, TY, false><<<grid, WG_THREADS, 0, st>>>((const TX*)x, xs, (const TY*)dy, ys, part, n, d, h, w, \
                                                             cin, cout, kd, kh, kw, chunks)
@@ -456,6 +483,7 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
   else return fplx_fail(FPLX_E_BADDTYPE, "conv3d_wgrad: dtypes %d/%d", x_dt, dy_dt);
 #undef LAUNCH
   wgrad_reduce<<<grid_for((int64_t)taps * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, taps, cout, cin, 0);
+  }
   if (db) {
     if (dy_dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, ys, n, d, h, w, cout, bpart, db, st);
     else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, d, h, w, cout, bpart, db, st);
@@ -469,6 +497,10 @@ int fplx_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bi
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_BF16) {
+    int r = fplx_mfma_deconv2_fwd(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
   const int64_t V = (int64_t)n * d * h * w;
   dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cout + CO_T - 1) / CO_T, 8);
   if (dt == FPLX_F32)
@@ -488,6 +520,10 @@ int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, in
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_dgrad: bad shape");
   hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_BF16) {
+    int r = fplx_mfma_deconv2_dgrad(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
   const int64_t V = (int64_t)n * d * h * w;
   dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cin + CO_T - 1) / CO_T);
   if (dt == FPLX_F32)
@@ -503,8 +539,10 @@ int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, in
 
 size_t fplx_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   const int64_t V = (int64_t)n * d * h * w;
-  return (size_t)wgrad_chunks(V) * 8 * cout * cin * sizeof(float) + (size_t)fplx_rows_for(V * 8) * cout * sizeof(float) +
-         256;
+  size_t a = (size_t)wgrad_chunks(V) * 8 * cout * cin * sizeof(float);
+  const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
+  if (m > a) a = m;
+  return a + (size_t)fplx_rows_for(V * 8) * cout * sizeof(float) + 256;
 }
 
 int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
@@ -517,11 +555,22 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
   const int64_t V = (int64_t)n * d * h * w;
   const int chunks = wgrad_chunks(V);
   float* part = (float*)ws;
-  float* bpart = part + (size_t)chunks * 8 * cout * cin;
+  size_t used = (size_t)chunks * 8 * cout * cin * sizeof(float);
   dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), 8);
   Strides xs{(int64_t)d * h * w * ldx, (int64_t)h * w * ldx, (int64_t)w * ldx, ldx, 1};
   Strides ys{(int64_t)8 * d * h * w * ldy, (int64_t)4 * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};
-  if (dt == FPLX_F32)
+  bool done = false;
+  if (dt == FPLX_BF16) {
+    const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > 0) {
+      int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, m, st);
+      if (r < 0) return r;
+      if (r == 1) { done = true; used = m; }
+    }
+  }
+  float* bpart = (float*)((char*)ws + used);
+  if (done) {
+  } else if (dt == FPLX_F32)
     wgrad_generic<float, float, true><<<grid, WG_THREADS, 0, st>>>((const float*)x, xs, (const float*)dy, ys, part, n,
                                                                    d, h, w, cin, cout, 2, 2, 2, chunks);
   else if (dt == FPLX_BF16)
@@ -529,7 +578,7 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
                                                                      n, d, h, w, cin, cout, 2, 2, 2, chunks);
   else
     return fplx_fail(FPLX_E_BADDTYPE, "deconv2_wgrad: dtype %d", dt);
-  wgrad_reduce<<<grid_for((int64_t)8 * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, 8, cout, cin, 1);
+  if (!done) wgrad_reduce<<<grid_for((int64_t)8 * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, 8, cout, cin, 1);
   if (db) {
     if (dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);
     else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);

@@ -1,9 +1,572 @@
-// MFMA (matrix-core) 3x3x3 convolution kernels for gfx950 - bf16 in, fp32 accumulate.
+// MFMA (matrix-core) 3x3x3 convolution kernels for gfx950: bf16 operands, fp32 accumulate,
+// NDHWC activations.  v_mfma_f32_32x32x16_bf16 everywhere:
+//   A fragment: lane l holds A[row l&31][k = 8*(l>>5) + j], j = 0..7   (8 contiguous bf16 = 16 B)
+//   B fragment: lane l holds B[k = 8*(l>>5) + j][col l&31]
+//   C/D       : lane l holds D[row (reg&3) + 8*(reg>>2) + 4*(l>>5)][col l&31], reg = 0..15
+//
+// conv_fwd_direct : implicit GEMM, rows = output voxels, cols = output channels, K = taps x Cin.
+//                   Operand fragments are loaded straight from global/L2 (16 B per lane), no LDS:
+//                   the universal path (any spatial size, Cin % 16 == 0, Cout % 32 == 0).  With the
+//                   mirrored pack it is also the data-gradient kernel.
 #include "common.h"
 
-extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) { return 0; }
+namespace {
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int DIRECT_THREADS = 256;
+
+// MODE 0: 3x3x3 "same" convolution (27 taps, +-1 shifts, zero padding)
+// MODE 1: data gradient of ConvTranspose3d(k=2,s=2): 8 taps, the source voxel of tap (i,j,k) is
+//         (2d+i, 2h+j, 2w+k) of the twice-as-large dy grid; rows = INPUT voxels of the deconv
+template <int MT, int NTL, int MODE>
+__global__ void __launch_bounds__(DIRECT_THREADS)
+conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                int Cin, int Cout, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh8 = (lane >> 5) * 8;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (MT * 32);
+  const int n0 = blockIdx.y * (NTL * 32);
+
+  // decode this lane's voxel for every M-tile
+  int vn[MT], vd[MT], vh[MT], vw[MT];
+  bool vok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int64_t v = m0 + t * 32 + r;
+    vok[t] = v < V;
+    if (!vok[t]) v = 0;
+    vw[t] = (int)(v % W); v /= W;
+    vh[t] = (int)(v % H); v /= H;
+    vd[t] = (int)(v % D); v /= D;
+    vn[t] = (int)v;
+  }
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][j][i] = 0.f;
+
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  constexpr int NTAPS = MODE == 0 ? 27 : 8;
+  for (int tap = 0; tap < NTAPS; ++tap) {
+    const bf16_t* ap[MT];
+    bool aok[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      int64_t vi;
+      if (MODE == 0) {
+        const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+        const int dd = vd[t] + kd, hh = vh[t] + kh, ww = vw[t] + kw;
+        aok[t] = vok[t] && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        vi = (((int64_t)vn[t] * D + dd) * H + hh) * W + ww;
+      } else {
+        aok[t] = vok[t];
+        vi = (((int64_t)vn[t] * 2 * D + 2 * vd[t] + (tap >> 2)) * 2 * H + 2 * vh[t] + ((tap >> 1) & 1)) * 2 * W +
+             2 * vw[t] + (tap & 1);
+      }
+      ap[t] = x + (aok[t] ? vi : 0) * ldx + kh8;
+    }
+    const bf16_t* bp[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) bp[j] = wp + ((int64_t)tap * Cout + n0 + j * 32 + r) * Cin + kh8;
+    for (int kc = 0; kc < Cin; kc += 16) {
+      bf16x8 a[MT], b[NTL];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[t] = aok[t] ? *reinterpret_cast<const bf16x8*>(ap[t] + kc) : zero;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) b[j] = *reinterpret_cast<const bf16x8*>(bp[j] + kc);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[t], b[j], acc[t][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: + bias, per-channel statistics of the unrounded outputs, bf16 store
+  const int rh = (lane >> 5) * 4;
+  float s[NTL], q[NTL];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int co = n0 + j * 32 + r;
+    const float bv = bias ? bias[co] : 0.f;
+    s[j] = q[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + rh;
+        const int64_t v = m0 + t * 32 + row;
+        if (v < V) {
+          const float o = acc[t][j][i] + bv;
+          y[v * ldy + co] = (bf16_t)o;
+          s[j] += o;
+          q[j] = fmaf(o, o, q[j]);
+        }
+      }
+    }
+  }
+  if (stats) {
+    __shared__ float red[4][2][NTL * 32];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const float a = s[j] + __shfl_xor(s[j], 32, 64);
+      const float b = q[j] + __shfl_xor(q[j], 32, 64);
+      if (lane < 32) { red[wave][0][j * 32 + r] = a; red[wave][1][j * 32 + r] = b; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NTL * 32; i += DIRECT_THREADS) {
+      const int which = i / (NTL * 32), c = i % (NTL * 32);
+      const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_wgrad_stream: dW[tap][ci][co] = sum over voxels of x[v + tap][ci] * dy[v][co] for one 32x32
+// (ci, co) tile pair.  A block owns an 8 x TW footprint in (h, w) and marches along d with a ring
+// of three x slabs (1-voxel halo, zero filled = the convolution's padding) and one dy slab in LDS.
+// Both MFMA operands need 8 consecutive VOXELS per lane for a fixed channel - the transpose of the
+// NDHWC image - which ds_read_b64_tr_b16 delivers for free.  The 27 taps are dealt to the 4 waves
+// (7/7/7/6), each wave keeps its taps' 32x32 fp32 tiles in registers for the whole march and
+// writes them once; a second kernel sums the per-block partials in a fixed order.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int WG_TH = 8;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
+  // two transposed 4x16 block reads: voxels +0..3 and +4..7 (64 B per voxel row)
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo + 4 * 64));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+template <int TW>
+__global__ void __launch_bounds__(256)
+conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
+                  int dsegs, int dlen) {
+  constexpr int TH = WG_TH, SW = TW + 2, SH = TH + 2, SLAB = SH * SW;   // voxels per x slab
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                                   // [3][SLAB][32] bf16
+  char* dys = smem + 3 * SLAB * 64;                  // [TH*TW][32] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = b;
+  const int ncit = Cin / 32;
+  const int cot = blockIdx.y / ncit, cit = blockIdx.y % ncit;
+  const int h0 = th * TH, w0 = tw * TW, d0 = seg * dlen;
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const bf16_t* xb = x + cit * 32;
+  const bf16_t* dyb = dy + cot * 32;
+
+  auto load_x = [&](int d) {
+    char* dst = xs + ((d + 1) % 3) * (SLAB * 64);
+    const bool dok = d >= 0 && d < D;
+    for (int i = tid; i < SLAB * 4; i += 256) {
+      const int vox = i >> 2, ch = i & 3;
+      const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
+        v = *reinterpret_cast<const uint4*>(xb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + ch * 8);
+      *reinterpret_cast<uint4*>(dst + vox * 64 + ch * 16) = v;
+    }
+  };
+  auto load_dy = [&](int d) {
+    for (int i = tid; i < TH * TW * 4; i += 256) {
+      const int vox = i >> 2, ch = i & 3;
+      const int hh = vox / TW + h0, ww = vox % TW + w0;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (hh < H && ww < W)
+        v = *reinterpret_cast<const uint4*>(dyb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldy + ch * 8);
+      *reinterpret_cast<uint4*>(dys + vox * 64 + ch * 16) = v;
+    }
+  };
+
+  // transposed-read lane geometry (see header comment of tr_frag): group g = lane / 16
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;   // bytes
+
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (d0 < d1) {
+    load_x(d0 - 1);
+    load_x(d0);
+  }
+  for (int d = d0; d < d1; ++d) {
+    load_x(d + 1);
+    load_dy(d);
+    __syncthreads();
+    for (int ks = 0; ks < TH * TW / 16; ++ks) {
+      const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
+      const bf16x8 bfrag = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        const int tap = wave + 4 * i;
+        if (tap < 27) {                                   // wave-uniform
+          const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+          const char* sl = xs + ((d + kd) % 3) * (SLAB * 64);          // slab of depth d + kd - 1
+          const bf16x8 afrag = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // partial tiles: part[blockIdx.x][pair][tap][ci][co]
+  float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
+  const int co = lane & 31, rbase = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = wave + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = (r & 3) + 8 * (r >> 2) + rbase;
+        out[(tap * 32 + ci) * 32 + co] = acc[i][r];
+      }
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum_b part[b][pair][tap][ci%32][co%32]
+__global__ void wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout,
+                                    float* __restrict__ dw) {
+  const int64_t total = (int64_t)npairs * 27 * 1024;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
+    const int co_l = i & 31, ci_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
+    const int ncit = Cin / 32;
+    const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
+    dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
+  }
+}
+
+struct WgCfg { int tw, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
+
+inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
+  WgCfg c;
+  c.tw = w >= 32 ? 32 : 16;
+  c.tilesH = (h + WG_TH - 1) / WG_TH;
+  c.tilesW = (w + c.tw - 1) / c.tw;
+  c.npairs = (cin / 32) * (cout / 32);
+  const int tiles = n * c.tilesH * c.tilesW;
+  int ds = (512 + tiles * c.npairs / 2) / (tiles * c.npairs);
+  const int maxds = d / 4 > 0 ? d / 4 : 1;
+  if (ds > maxds) ds = maxds;
+  if (ds < 1) ds = 1;
+  c.dlen = (d + ds - 1) / ds;
+  c.dsegs = (d + c.dlen - 1) / c.dlen;
+  c.nblk = tiles * c.dsegs;
+  c.ws = (size_t)c.nblk * c.npairs * 27 * 1024 * sizeof(float);
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// ConvTranspose3d(k=2,s=2) forward: rows = input voxels, K = Cin, one 32x32 accumulator per tap
+// (4 taps per block, blockIdx.z picks the half); every result row is scattered to its own output
+// voxel (2d+i, 2h+j, 2w+k) of the concat buffer.  HBM-bound (8 output voxels per input voxel).
+__global__ void __launch_bounds__(DIRECT_THREADS)
+deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wf,
+                const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                int Cin, int Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh8 = (lane >> 5) * 8;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 32, tap0 = blockIdx.z * 4;
+  const int64_t v = m0 + r;
+  const bool ok = v < V;
+  const bf16_t* ap = x + (ok ? v : 0) * ldx + kh8;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  for (int kc = 0; kc < Cin; kc += 16) {
+    const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap + kc) : zero;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap0 + t) * Cout + n0 + r) * Cin + kc + kh8);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  const int co = n0 + r, rh = (lane >> 5) * 4;
+  const float bv = bias[co];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + rh;
+    int64_t vv = m0 + row;
+    if (vv < V) {
+      const int w0 = (int)(vv % W); vv /= W;
+      const int h0 = (int)(vv % H); vv /= H;
+      const int d0 = (int)(vv % D); vv /= D;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int tap = tap0 + t;
+        const int64_t ov = ((vv * 2 * D + 2 * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
+        y[ov * ldy + co] = (bf16_t)(acc[t][i] + bv);
+      }
+    }
+  }
+}
+
+// ConvTranspose3d(k=2,s=2) weight gradient: dW[tap][ci][co] = sum_v x[v][ci] * dy[out(v,tap)][co].
+// Block = one chunk of 128 consecutive input voxels at a time (grid-strided), CIT ci-tiles x one
+// co-tile; x chunk and the 8 parity-gathered dy chunks are staged in LDS and read transposed
+// (ds_read_b64_tr_b16); wave w owns taps 2w, 2w+1.  Partials per block, fixed-order reduce.
+template <int CIT>
+__global__ void __launch_bounds__(256)
+deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout) {
+  constexpr int KV = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                           // [CIT][KV][32] bf16
+  char* dys = smem + CIT * KV * 64;          // [8][KV][32] bf16
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncig = Cin / (32 * CIT);
+  const int cot = blockIdx.y / ncig, cig = blockIdx.y % ncig;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t chunks = (V + KV - 1) / KV;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+  f32x16 acc[2][CIT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < CIT; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
+  for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+    const int64_t v0 = ch * KV;
+    for (int i = tid; i < CIT * KV * 4; i += 256) {
+      const int c = i / (KV * 4), vox = (i / 4) % KV, c16 = i & 3;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (v0 + vox < V) val = *reinterpret_cast<const uint4*>(x + (v0 + vox) * ldx + (cig * CIT + c) * 32 + c16 * 8);
+      *reinterpret_cast<uint4*>(xs + (c * KV + vox) * 64 + c16 * 16) = val;
+    }
+    for (int i = tid; i < 8 * KV * 4; i += 256) {
+      const int tap = i / (KV * 4), vox = (i / 4) % KV, c16 = i & 3;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      int64_t vv = v0 + vox;
+      if (vv < V) {
+        const int w0 = (int)(vv % W); vv /= W;
+        const int h0 = (int)(vv % H); vv /= H;
+        const int d0 = (int)(vv % D); vv /= D;
+        const int64_t ov = ((vv * 2 * D + 2 * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
+        val = *reinterpret_cast<const uint4*>(dy + ov * ldy + cot * 32 + c16 * 8);
+      }
+      *reinterpret_cast<uint4*>(dys + (tap * KV + vox) * 64 + c16 * 16) = val;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < KV / 16; ++ks) {
+      bf16x8 bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bfr[t] = tr_frag(dys + ((2 * wave + t) * KV + ks * 16) * 64 + lane_off);
+#pragma unroll
+      for (int c = 0; c < CIT; ++c) {
+        const bf16x8 afr = tr_frag(xs + (c * KV + ks * 16) * 64 + lane_off);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, bfr[t], acc[t][c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // part[blockIdx.x][blockIdx.y][tap][c][ci 32][co 32]
+  float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (8 * CIT * 1024);
+  const int co = lane & 31, rbase = (lane >> 5) * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < CIT; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2) + rbase;
+        out[(((2 * wave + t) * CIT + c) * 32 + ci) * 32 + co] = acc[t][c][i];
+      }
+}
+
+// dw[ci][co][tap] (torch ConvTranspose3d layout) = sum_b part[b][pair][tap][c][ci%32][co%32]
+__global__ void deconv_wgrad_reduce(const float* __restrict__ part, int nblk, int npairs, int cit, int Cin, int Cout,
+                                    float* __restrict__ dw) {
+  const int64_t per = (int64_t)8 * cit * 1024, total = npairs * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
+    const int co_l = i & 31, ci_l = (i >> 5) & 31, c = (int)((i >> 10) % cit), tap = (int)((i / (1024 * cit)) % 8);
+    const int pair = (int)(i / per);
+    const int ncig = Cin / (32 * cit);
+    const int co = (pair / ncig) * 32 + co_l, ci = ((pair % ncig) * cit + c) * 32 + ci_l;
+    dw[((int64_t)ci * Cout + co) * 8 + tap] = t;
+  }
+}
+
+struct DwCfg { int cit, npairs, nblk; size_t ws; };
+inline DwCfg dw_cfg(int n, int d, int h, int w, int cin, int cout) {
+  DwCfg c;
+  c.cit = (cin % 128 == 0) ? 4 : (cin % 64 == 0 ? 2 : 1);
+  c.npairs = (cin / (32 * c.cit)) * (cout / 32);
+  const int64_t chunks = ((int64_t)n * d * h * w + 127) / 128;
+  int nb = 1024 / c.npairs;
+  if (nb < 1) nb = 1;
+  if (nb > chunks) nb = (int)chunks;
+  c.nblk = nb;
+  c.ws = (size_t)c.nblk * c.npairs * 8 * c.cit * 1024 * sizeof(float);
+  return c;
+}
+
+struct DirectCfg { int mt, ntl; };
+
+inline DirectCfg direct_cfg(int cout) {
+  DirectCfg c;
+  if (cout % 64 == 0) { c.mt = 2; c.ntl = 2; }
+  else { c.mt = 4; c.ntl = 1; }
+  return c;
+}
+
+inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const void* x, const void* y, const void* wp) {
+  return cin % 16 == 0 && cout % 32 == 0 && ldx % 8 == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)wp % 16 == 0) &&
+         ((uintptr_t)y % 2 == 0) && ldy >= cout;
+}
+
+}  // namespace
+
+extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  const DirectCfg c = direct_cfg(cout);
+  const int64_t V = (int64_t)n * d * h * w;
+  return (int)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32));
+}
+
+// returns 1 if handled, 0 if not applicable (caller falls back to the generic kernel), <0 on error
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
-  return 0;  // not applicable -> generic path
+  if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
+  const DirectCfg c = direct_cfg(cout);
+  const int64_t V = (int64_t)n * d * h * w;
+  dim3 grid((unsigned)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)), cout / (c.ntl * 32));
+  if (c.ntl == 2)
+    conv_fwd_direct<2, 2, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                           ldy, n, d, h, w, cin, cout, stats);
+  else
+    conv_fwd_direct<4, 1, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                           ldy, n, d, h, w, cin, cout, stats);
+  int rc = fplx_check_launch("mfma_conv3d_fwd");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 32 != 0 || cout % 32 != 0) return 0;
+  return wg_cfg(n, d, h, w, cin, cout).ws;
+}
+
+// returns 1 if handled, 0 if not applicable, <0 on error.  dw fp32 [Cout][Cin][27]
+extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
+                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
+    return 0;
+  const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
+  if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
+  dim3 grid(c.nblk, c.npairs);
+  if (c.tw == 32) {
+    constexpr int TW = 32;
+    const size_t lds = (size_t)(3 * (WG_TH + 2) * (TW + 2) + WG_TH * TW) * 64;
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv_wgrad_stream<TW><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w,
+                                                  cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);
+  } else {
+    constexpr int TW = 16;
+    const size_t lds = (size_t)(3 * (WG_TH + 2) * (TW + 2) + WG_TH * TW) * 64;
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    conv_wgrad_stream<TW><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w,
+                                                  cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);
+  }
+  const int64_t total = (int64_t)c.npairs * 27 * 1024;
+  int g = (int)((total + 255) / 256);
+  if (g > 2048) g = 2048;
+  wgrad_stream_reduce<<<g, 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw);
+  int rc = fplx_check_launch("mfma_conv3d_wgrad");
+  return rc < 0 ? rc : 1;
+}
+
+// ---- ConvTranspose3d(k=2,s=2) fast paths; same return convention
+extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, hipStream_t st) {
+  if (cin % 16 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
+  dim3 grid((unsigned)((V + 127) / 128), cout / 32, 2);
+  deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
+                                                   h, w, cin, cout);
+  int rc = fplx_check_launch("mfma_deconv2_fwd");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
+                                       int h, int w, int cin, int cout, hipStream_t st) {
+  // GEMM view: K = 8 taps x Cout (channels of dy), columns = Cin
+  if (cout % 16 != 0 || cin % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16) || ((uintptr_t)wb % 16)) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
+  if (cin % 64 == 0) {
+    dim3 grid((unsigned)((V + 255) / 256), cin / 64);
+    conv_fwd_direct<2, 2, 1><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr,
+                                                              (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr);
+  } else {
+    dim3 grid((unsigned)((V + 511) / 512), cin / 32);
+    conv_fwd_direct<4, 1, 1><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr,
+                                                              (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr);
+  }
+  int rc = fplx_check_launch("mfma_deconv2_dgrad");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 32 != 0 || cout % 32 != 0) return 0;
+  return dw_cfg(n, d, h, w, cin, cout).ws;
+}
+
+extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
+                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
+    return 0;
+  const DwCfg c = dw_cfg(n, d, h, w, cin, cout);
+  if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_deconv2_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
+  dim3 grid(c.nblk, c.npairs);
+  const size_t lds = (size_t)(c.cit + 8) * 128 * 64;
+#define LAUNCH_DW(CIT)                                                                                              \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)deconv_wgrad_mfma<CIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    deconv_wgrad_mfma<CIT><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, \
+                                                   cin, cout);                                                      \
+  } while (0)
+  if (c.cit == 4) LAUNCH_DW(4);
+  else if (c.cit == 2) LAUNCH_DW(2);
+  else LAUNCH_DW(1);
+#undef LAUNCH_DW
+  const int64_t total = (int64_t)c.npairs * 8 * c.cit * 1024;
+  int g = (int)((total + 255) / 256);
+  if (g > 2048) g = 2048;
+  deconv_wgrad_reduce<<<g, 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw);
+  int rc = fplx_check_launch("mfma_deconv2_wgrad");
+  return rc < 0 ? rc : 1;
 }

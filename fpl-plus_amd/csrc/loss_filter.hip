@@ -105,11 +105,14 @@ __global__ void seg_loss_finalize_k(const float* __restrict__ part, int rows, in
                                     float w_ent, float* __restrict__ out, float* __restrict__ coef) {
   extern __shared__ double sums[];   // [N][K]
   const int K = 6 * C + 3;
-  for (int i = threadIdx.x; i < N * K; i += blockDim.x) {
+  // one wave per (n, k) sum: lanes stride over rows
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = wv; i < N * K; i += nw) {
     const int n = i / K, k = i % K;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)part[((int64_t)n * rows + r) * K + k];
-    sums[i] = s;
+    for (int r = lane; r < rows; r += 64) s += (double)part[((int64_t)n * rows + r) * K + k];
+    s = wave_sum_d(s);
+    if (lane == 0) sums[i] = s;
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
@@ -336,7 +339,7 @@ int fplx_seg_loss_fwd(const float* logits, const float* label, const float* pixe
   const int rows = loss_rows(v);
   dim3 grid(rows, n);
   DISPATCH_C(c, seg_loss_fwd_k, <<<grid, LT, 0, st>>>(logits, label, pixel_weight, v, softmax, part));
-  seg_loss_finalize_k<<<1, 128, (size_t)n * (6 * c + 3) * sizeof(double), st>>>(
+  seg_loss_finalize_k<<<1, 1024, (size_t)n * (6 * c + 3) * sizeof(double), st>>>(
       part, rows, n, c, (double)v, pixel_weight != nullptr, image_weight, w_dice, w_ce, w_dice_img, w_entropy, out, coef);
   return fplx_check_launch("seg_loss_fwd");
 }

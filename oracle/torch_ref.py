@@ -86,7 +86,8 @@ def conv_block(x, sd, key, domain, train, p, keep_mask, act_dtype, dropout_on=No
     """ConvBlockND.forward, 3D branch (net3d/unet2d5_dsbn.py:74-81)."""
     if dropout_on is None:
         dropout_on = train
-    x = F.conv3d(x, sd[key + ".conv3d_1.weight"], sd[key + ".conv3d_1.bias"], padding=1)
+    # the HIP path packs convolution weights into the activation dtype (bf16 operands, fp32 accumulate)
+    x = F.conv3d(x, quant(sd[key + ".conv3d_1.weight"], act_dtype), sd[key + ".conv3d_1.bias"], padding=1)
     x = quant(x, act_dtype)
     x = dsbn(x, sd, key + ".bn3d1", domain, train)
     x = prelu(x, sd[key + ".relu_1.weight"])
@@ -98,7 +99,7 @@ def conv_block(x, sd, key, domain, train, p, keep_mask, act_dtype, dropout_on=No
             p32 = float(torch.tensor(p, dtype=torch.float32))
             x = x * keep_mask.to(x.dtype) * float(torch.tensor(1.0 / (1.0 - p32), dtype=torch.float32))
     x = quant(x, act_dtype)
-    x = F.conv3d(x, sd[key + ".conv3d_2.weight"], sd[key + ".conv3d_2.bias"], padding=1)
+    x = F.conv3d(x, quant(sd[key + ".conv3d_2.weight"], act_dtype), sd[key + ".conv3d_2.bias"], padding=1)
     x = quant(x, act_dtype)
     x = dsbn(x, sd, key + ".bn3d2", domain, train)
     x = prelu(x, sd[key + ".relu_2.weight"])
@@ -137,7 +138,8 @@ def unet_forward(sd, net_params, x, domain, train=True, dropout_masks=None, act_
             h = F.max_pool3d(h, 2, 2)                                   # DownBlock, line 106/117
     for j in range(4):
         key = "up%d" % (j + 1)
-        up = F.conv_transpose3d(h, sd[key + ".trans3d.weight"], sd[key + ".trans3d.bias"], stride=2)  # line 181
+        up = F.conv_transpose3d(h, quant(sd[key + ".trans3d.weight"], act_dtype), sd[key + ".trans3d.bias"],
+                                stride=2)                                  # line 181
         up = quant(up, act_dtype)
         h = torch.cat([skips[3 - j], up], dim=1)                        # line 182
         h = conv_block(h, sd, BLOCK_KEYS[5 + j], domain, train, ps[5 + j], masks[5 + j], act_dtype, dropout_on)

@@ -19,7 +19,10 @@ def uncl(t2, n, d, h, w):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("shape", [(1, 5, 7, 3, 9, 6), (2, 16, 8, 4, 6, 10), (1, 3, 11, 2, 2, 2)])
+@pytest.mark.parametrize("shape", [(1, 5, 7, 3, 9, 6), (2, 16, 8, 4, 6, 10), (1, 3, 11, 2, 2, 2),
+                                   # Cin % 32 == 0 and Cout % 32 == 0: the bf16 runs take the MFMA kernels
+                                   (1, 32, 32, 5, 9, 35), (2, 64, 32, 3, 8, 33), (1, 32, 64, 4, 11, 17),
+                                   (1, 128, 64, 2, 5, 9), (1, 32, 32, 9, 16, 64)])
 def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
     from fplx import ops
     n, cin, cout, d, h, w = shape
@@ -75,13 +78,15 @@ def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
-def test_deconv2_fwd_bwd(dtype, tol):
+@pytest.mark.parametrize("shape", [(2, 12, 7, 3, 4, 5), (2, 64, 32, 3, 4, 5), (1, 128, 64, 2, 5, 9), (1, 32, 32, 4, 4, 7),
+                                   (1, 96, 32, 2, 3, 67)])
+def test_deconv2_fwd_bwd(dtype, tol, shape):
     from fplx import ops
-    n, cin, cout, d, h, w = 2, 12, 7, 3, 4, 5
-    x = torch.from_numpy(detdata.normal("dc.x", (n, cin, d, h, w)))
-    wt = torch.from_numpy(detdata.normal("dc.w", (cin, cout, 2, 2, 2), 0.3))
-    b = torch.from_numpy(detdata.normal("dc.b", (cout,)))
-    dy = torch.from_numpy(detdata.normal("dc.dy", (n, cout, 2 * d, 2 * h, 2 * w)))
+    n, cin, cout, d, h, w = shape
+    x = torch.from_numpy(detdata.normal("dc.x%s" % (shape,), (n, cin, d, h, w)))
+    wt = torch.from_numpy(detdata.normal("dc.w%s" % (shape,), (cin, cout, 2, 2, 2), 0.3))
+    b = torch.from_numpy(detdata.normal("dc.b%s" % (shape,), (cout,)))
+    dy = torch.from_numpy(detdata.normal("dc.dy%s" % (shape,), (n, cout, 2 * d, 2 * h, 2 * w)))
     if dtype == torch.bfloat16:
         x, wt, dy = x.bfloat16().float(), wt.bfloat16().float(), dy.bfloat16().float()
     xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)

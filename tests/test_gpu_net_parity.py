@@ -83,7 +83,7 @@ def test_fp32_forward_backward_matches_reference(golden_dir, name):
 def test_bf16_matches_bf16_emulating_oracle(name):
     """bf16 activations / fp32 master weights: compare with the CPU oracle rounding activations
     to bf16 at the same points.  Tolerance: bf16 has 8 significant bits; after 18 conv layers we
-    allow 3e-2 of the logits' range, and require the fp32-vs-bf16 gap itself to be of that order."""
+    allow 5e-2 of the logits' range, and require the fp32-vs-bf16 gap itself to be of that order."""
     import fplx
     from oracle import torch_ref as R
     x = torch.from_numpy(detdata.normal("x." + name, SHAPES[name]))
@@ -99,7 +99,7 @@ def test_bf16_matches_bf16_emulating_oracle(name):
     rl = R.dice_loss(ref, y)
     rl.backward()
     rng = float(ref.detach().abs().max())
-    assert np.abs(lt.detach().cpu().numpy() - ref.detach().numpy()).max() < 3e-2 * rng
+    assert np.abs(lt.detach().cpu().numpy() - ref.detach().numpy()).max() < 5e-2 * rng
     assert abs(loss.item() - rl.item()) < 2e-3
     named = dict(net.named_parameters())
     for k in ("out_conv.weight", "up4.conv.conv3d_1.weight", "block0.conv.conv3d_1.weight", "up1.trans3d.weight",
