@@ -244,7 +244,7 @@ def main():
         if roof is not None:
             res["roofline"] = roof
         if ktable:
-            res["kernels"] = ktable[:8]
+            res["kernels"] = ktable[:30]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -1,0 +1,477 @@
+// The two "edge" convolutions of the U-Net, both purely HBM-bound (AI 26 and 17):
+//   stem      Conv3d(in_chns -> C0, 3x3x3) reading the fp32 NCDHW network input   (unet2d5_dsbn.py:54,75)
+//   out_conv  Conv3d(C0 -> class_num, 1x3x3) writing fp32 NCDHW logits            (unet2d5_dsbn.py:293-294,307)
+// They still run on the matrix cores (padding K / N to the 32x32x16 tile) because the VALU
+// formulation is ~10x over the HBM time; with MFMA all five kernels sit at the memory roof.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr int TH = 8, TW = 32, SH = TH + 2, SW = TW + 2;
+
+__device__ __forceinline__ bf16x8 tr_frag64(const char* base_lo) {      // [voxel][32 ch] image, 64 B rows
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo + 4 * 64));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+struct Tile { int n, d, h0, w0; };
+__device__ __forceinline__ Tile tile_of(int64_t t, int D, int tilesH, int tilesW) {
+  Tile o;
+  o.w0 = (int)(t % tilesW) * TW; t /= tilesW;
+  o.h0 = (int)(t % tilesH) * TH; t /= tilesH;
+  o.d = (int)(t % D); t /= D;
+  o.n = (int)t;
+  return o;
+}
+
+// stage the fp32 planar input around a tile as bf16: xs[ci][kd 3][SH][SW]
+template <int CIN>
+__device__ __forceinline__ void stage_x_planar(const float* __restrict__ x, bf16_t* xs, const Tile& t, int D, int H,
+                                               int W) {
+  for (int i = threadIdx.x; i < CIN * 3 * SH * SW; i += 256) {
+    const int ww = i % SW, hh = (i / SW) % SH, kd = (i / (SW * SH)) % 3, ci = i / (3 * SH * SW);
+    const int d = t.d + kd - 1, h = t.h0 + hh - 1, w = t.w0 + ww - 1;
+    float v = 0.f;
+    if (d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W)
+      v = x[((((int64_t)t.n * CIN + ci) * D + d) * H + h) * W + w];
+    xs[i] = (bf16_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stem forward: rows = voxels, K = (ci, tap) padded to 16*KS, cols = 32 output channels
+template <int CIN>
+__global__ void __launch_bounds__(256)
+stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
+              bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
+              float* __restrict__ stats, int64_t ntiles, int tilesH, int tilesW) {
+  constexpr int KTOT = 27 * CIN, KS = (KTOT + 15) / 16;
+  __shared__ bf16_t xs[CIN * 3 * SH * SW];
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  // per-lane K geometry: element offsets of this lane's 8 k-values per k-step, and the B fragments
+  int koff[KS][8];
+  bf16x8 bfr[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 16 * s + 8 * khalf + j;
+      const int ci = k / 27, tap = k % 27;
+      const bool ok = k < KTOT;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      koff[s][j] = ok ? ((ci * 3 + kd) * SH + kh) * SW + kw : -1;
+      bfr[s][j] = ok ? wf[((int64_t)tap * Cout + co0 + r) * CIN + ci] : (bf16_t)0.f;
+    }
+  const int co = co0 + r;
+  const float bv = bias ? bias[co] : 0.f;
+  float ssum = 0.f, qsum = 0.f;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const Tile t = tile_of(tt, D, tilesH, tilesW);
+    __syncthreads();
+    stage_x_planar<CIN>(x, xs, t, D, H, W);
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int hr = wave * 2 + m;                     // tile row handled by this wave
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const int base = hr * SW + r;                    // lane's voxel (row hr, column r) in slab coordinates
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = koff[s][j] >= 0 ? xs[base + koff[s][j]] : (bf16_t)0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[s], acc, 0, 0, 0);
+      }
+      const int h = t.h0 + hr;
+      if (h < H) {
+        const int64_t vrow = (((int64_t)t.n * D + t.d) * H + h) * W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int w = t.w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+          if (w < W) {
+            const float o = acc[i] + bv;
+            y[(vrow + w) * ldy + co] = (bf16_t)o;
+            ssum += o;
+            qsum = fmaf(o, o, qsum);
+          }
+        }
+      }
+    }
+  }
+  if (stats) {
+    const float a = ssum + __shfl_xor(ssum, 32, 64), b = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[wave][0][r] = a; red[wave][1][r] = b; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stem weight gradient: rows = (ci, tap) padded to 32*RT, cols = 32 output channels, K = voxels
+template <int CIN>
+__global__ void __launch_bounds__(256)
+stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int64_t ldy, float* __restrict__ part,
+                int N, int D, int H, int W, int co0, int64_t ntiles, int tilesH, int tilesW) {
+  constexpr int KTOT = 27 * CIN, RT = (KTOT + 31) / 32;
+  __shared__ bf16_t xs[CIN * 3 * SH * SW + 16];
+  __shared__ __attribute__((aligned(16))) char dys[TH * TW * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+  int roff[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int k = rt * 32 + r;
+    const int ci = k / 27, tap = k % 27;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    roff[rt] = k < KTOT ? ((ci * 3 + kd) * SH + kh) * SW + kw : -1;
+  }
+  f32x16 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const Tile t = tile_of(tt, D, tilesH, tilesW);
+    __syncthreads();
+    stage_x_planar<CIN>(x, xs, t, D, H, W);
+    for (int i = threadIdx.x; i < TH * TW * 4; i += 256) {
+      const int vox = i >> 2, ch = i & 3;
+      const int h = t.h0 + vox / TW, w = t.w0 + vox % TW;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h < H && w < W)
+        v = *reinterpret_cast<const uint4*>(dy + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldy + co0 + ch * 8);
+      *reinterpret_cast<uint4*>(dys + vox * 64 + ch * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {                   // each wave takes 4 of the 16 k-steps (K split)
+      const int ks = wave * 4 + kk;
+      const int hr = ks >> 1, ws = (ks & 1) * 16;
+      const bf16x8 bfrag = tr_frag64(dys + (hr * TW + ws) * 64 + lane_off);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        bf16x8 a;
+        const int base = hr * SW + ws + 8 * khalf + (roff[rt] >= 0 ? roff[rt] : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = roff[rt] >= 0 ? xs[base + j] : (bf16_t)0.f;
+        acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[rt], 0, 0, 0);
+      }
+    }
+  }
+  // part[block][wave][rt][row 32][co 32]
+  float* out = part + ((int64_t)blockIdx.x * 4 + wave) * (RT * 1024);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+      out[(rt * 32 + row) * 32 + r] = acc[rt][i];
+    }
+}
+
+// dw[co][ci][tap] = sum over (block, wave) partials
+__global__ void stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, int co0, float* __restrict__ dw) {
+  const int total = rt * 1024;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i & 31, k = i >> 5;
+    if (k >= 27 * cin) continue;
+    float t = 0.f;
+    for (int b = 0; b < nparts; ++b) t += part[(int64_t)b * total + i];
+    const int ci = k / 27, tap = k % 27;
+    dw[((int64_t)(co0 + co) * cin + ci) * 27 + tap] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// out_conv forward: rows = voxels (direct global fragments), K = 9 in-plane taps x Cin,
+// cols = classes padded to 32 (B fragments built once from the fp32 pack [9][ncls][Cin])
+template <int KSTEPS>      // Cin / 16
+__global__ void __launch_bounds__(256)
+outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
+                 float* __restrict__ out, int N, int D, int H, int W, int ncls) {
+  constexpr int CIN = KSTEPS * 16, MT = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh8 = (lane >> 5) * 8;
+  const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (MT * 32);
+  bf16x8 bfr[9][KSTEPS];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        bfr[tap][s][j] = r < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r) * CIN + s * 16 + kh8 + j] : (bf16_t)0.f;
+  int vh[MT], vw[MT];
+  int64_t vb[MT];
+  bool vok[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int64_t v = m0 + t * 32 + r;
+    vok[t] = v < V;
+    if (!vok[t]) v = 0;
+    vb[t] = v;
+    vw[t] = (int)(v % W);
+    vh[t] = (int)((v / W) % H);
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3 - 1, kw = tap % 3 - 1;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int hh = vh[t] + kh, ww = vw[t] + kw;
+      const bool ok = vok[t] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const bf16_t* ap = x + (ok ? vb[t] + kh * W + kw : 0) * ldx + kh8;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap + s * 16) : zero;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[tap][s], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (r < ncls) {
+    const float bv = bias ? bias[r] : 0.f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t v = m0 + t * 32 + (i & 3) + 8 * (i >> 2) + (lane >> 5) * 4;
+        if (v < V) {
+          const int64_t n = v / Vs, vs = v % Vs;
+          out[(n * ncls + r) * Vs + vs] = acc[t][i] + bv;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// out_conv data gradient (class_num -> C0): thread = voxel x 8 channels, fp32 planar dlogits in,
+// bf16 NDHWC out with one 16-byte store; weights wb[tap'][ci][co] (mirrored pack) are wave-uniform
+__global__ void __launch_bounds__(256)
+outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx,
+                   int N, int D, int H, int W, int C0, int ncls) {
+  const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int ci0 = blockIdx.y * 8;
+  if (v >= V) return;
+  const int w = (int)(v % W), h = (int)((v / W) % H);
+  const int64_t n = v / Vs, vs = v % Vs;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int kh = tap / 3 - 1, kw = tap % 3 - 1;
+    const int hh = h + kh, ww = w + kw;
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+    for (int co = 0; co < ncls; ++co) {
+      const float g = dl[(n * ncls + co) * Vs + vs + kh * W + kw];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, (float)wb[((int64_t)tap * C0 + ci0 + j) * ncls + co], acc[j]);
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+  *reinterpret_cast<bf16x8*>(dx + v * ldx + ci0) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// out_conv weight gradient: rows = ci (32 per block column), cols = classes (padded to 32), K = voxels.
+// x tile [voxel][32 ch] with an in-plane halo in LDS (transposed reads), dlogits straight from the
+// fp32 planes; the 9 taps are dealt to the 4 waves (3/2/2/2).
+__global__ void __launch_bounds__(256)
+outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ dl, float* __restrict__ part,
+                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW) {
+  __shared__ __attribute__((aligned(16))) char xs[SH * SW * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+  const int cit = blockIdx.y;
+  const int64_t Vs = (int64_t)D * H * W;
+  f32x16 acc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const Tile t = tile_of(tt, D, tilesH, tilesW);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * SW * 4; i += 256) {
+      const int vox = i >> 2, ch = i & 3;
+      const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + cit * 32 + ch * 8);
+      *reinterpret_cast<uint4*>(xs + vox * 64 + ch * 16) = v;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < 16; ++ks) {
+      const int hr = ks >> 1, ws = (ks & 1) * 16;
+      const int h = t.h0 + hr, w = t.w0 + ws + 8 * khalf;
+      bf16x8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < ncls && h < H) {
+        const float* src = dl + ((int64_t)t.n * ncls + r) * Vs + ((int64_t)t.d * H + h) * W + w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfrag[j] = (w + j < W) ? (bf16_t)src[j] : (bf16_t)0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int tap = wave + 4 * a;                  // wave-uniform
+        if (tap < 9) {
+          const int kh = tap / 3, kw = tap % 3;
+          const bf16x8 afrag = tr_frag64(xs + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[a], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // part[block][cit][tap][ci 32][co 32]
+  float* out = part + ((int64_t)blockIdx.x * gridDim.y + cit) * (9 * 1024);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int tap = wave + 4 * a;
+    if (tap < 9) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+        out[(tap * 32 + ci) * 32 + r] = acc[a][i];
+      }
+    }
+  }
+}
+
+__global__ void outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0, int ncls, float* __restrict__ dw) {
+  const int total = ncit * 9 * 1024;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i & 31;
+    if (co >= ncls) continue;
+    float t = 0.f;
+    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
+    const int ci_l = (i >> 5) & 31, tap = (i >> 10) % 9, cit = i / (9 * 1024);
+    dw[((int64_t)co * C0 + cit * 32 + ci_l) * 9 + tap] = t;
+  }
+}
+
+inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
+  *th = (h + TH - 1) / TH;
+  *tw = (w + TW - 1) / TW;
+  return (int64_t)n * d * (*th) * (*tw);
+}
+inline int edge_blocks(int64_t ntiles) { return (int)(ntiles < 1024 ? ntiles : 1024); }
+
+}  // namespace
+
+// ---- entry points used by conv_generic.hip; return 1 = handled, 0 = not applicable, <0 = error
+extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout) {
+  if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
+  int th, tw;
+  return edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+}
+
+extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                                  int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+  if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = edge_blocks(nt);
+  for (int co0 = 0; co0 < cout; co0 += 32) {
+    if (cin == 1)
+      stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw);
+    else
+      stem_fwd_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw);
+  }
+  int rc = fplx_check_launch("edge_stem_fwd");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
+  int th, tw;
+  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+  return (size_t)nb * 4 * ((27 * cin + 31) / 32) * 1024 * sizeof(float);
+}
+
+extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
+                                    int cin, int cout, void* ws, hipStream_t st) {
+  if (!(cin == 1 || cin == 4) || cout % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16)) return 0;
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = edge_blocks(nt);
+  const int rt = (27 * cin + 31) / 32;
+  for (int co0 = 0; co0 < cout; co0 += 32) {
+    if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
+    else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
+    stem_wgrad_reduce<<<(rt * 1024 + 255) / 256, 256, 0, st>>>((const float*)ws, nb * 4, rt, cin, co0, dw);
+  }
+  int rc = fplx_check_launch("edge_stem_wgrad");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
+                                     int d, int h, int w, int cin, int ncls, hipStream_t st) {
+  if (!(cin == 16 || cin == 32 || cin == 64) || ncls > 32 || ldx % 8 != 0 || ((uintptr_t)x % 16)) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
+  const unsigned nb = (unsigned)((V + 511) / 512);
+  if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
+  else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
+  else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
+  int rc = fplx_check_launch("edge_outconv_fwd");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                                       int c0, int ncls, hipStream_t st) {
+  if (c0 % 8 != 0 || ldx % 8 != 0 || ((uintptr_t)dx % 16)) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
+  dim3 grid((unsigned)((V + 255) / 256), c0 / 8);
+  outconv_dgrad_valu<<<grid, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, c0, ncls);
+  int rc = fplx_check_launch("edge_outconv_dgrad");
+  return rc < 0 ? rc : 1;
+}
+
+extern "C" size_t fplx_edge_outconv_wgrad_ws_bytes(int n, int d, int h, int w, int c0, int ncls) {
+  if (c0 % 32 != 0 || ncls > 32) return 0;
+  int th, tw;
+  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+  return (size_t)nb * (c0 / 32) * 9 * 1024 * sizeof(float);
+}
+
+extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* dl, float* dw, int n, int d, int h, int w,
+                                       int c0, int ncls, void* ws, hipStream_t st) {
+  if (c0 % 32 != 0 || ncls > 32 || ldx % 8 != 0 || ((uintptr_t)x % 16)) return 0;
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = edge_blocks(nt);
+  dim3 grid(nb, c0 / 32);
+  outconv_wgrad_mfma<<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, dl, (float*)ws, n, d, h, w, ncls, nt, th, tw);
+  const int total = (c0 / 32) * 9 * 1024;
+  outconv_wgrad_reduce<<<(total + 255) / 256, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
+  int rc = fplx_check_launch("edge_outconv_wgrad");
+  return rc < 0 ? rc : 1;
+}

@@ -334,6 +334,19 @@ inline int wgrad_chunks(int64_t V) {
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                                  int h, int w, int cin, int cout, float* stats, hipStream_t st);
+extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
+                                    int cin, int cout, void* ws, hipStream_t st);
+extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
+                                     int d, int h, int w, int cin, int ncls, hipStream_t st);
+extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                                       int c0, int ncls, hipStream_t st);
+extern "C" size_t fplx_edge_outconv_wgrad_ws_bytes(int n, int d, int h, int w, int c0, int ncls);
+extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* dl, float* dw, int n, int d, int h, int w,
+                                       int c0, int ncls, void* ws, hipStream_t st);
 extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, hipStream_t st);
 extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
@@ -392,9 +405,20 @@ int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cou
   return fplx_check_launch("pack_deconv_weight");
 }
 
+static bool is_cl(int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc, int d, int h, int w) {
+  return sc == 1 && sh == sw * w && sd == sh * h && sn == sd * d;          // NDHWC with voxel stride sw
+}
+static bool is_planar(int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc, int c, int d, int h, int w) {
+  return sw == 1 && sh == w && sd == (int64_t)h * w && sc == (int64_t)d * h * w && sn == sc * c;   // contiguous NCDHW
+}
+
 int fplx_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt) {
   if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3) {
     int r = fplx_mfma_conv3d_stats_rows(n, d, h, w, cin, cout);
+    if (r > 0) return r;
+  }
+  if (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3) {   // stem: fp32 network input
+    int r = fplx_edge_stem_rows(n, d, h, w, cin, cout);
     if (r > 0) return r;
   }
   const int64_t V = (int64_t)n * d * h * w;
@@ -414,6 +438,21 @@ int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh,
   if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 && sc == 1 && yc == 1 &&
       sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
     int r = fplx_mfma_conv3d_fwd(x, sw, wp, bias, y, yw, n, d, h, w, cin, cout, stats, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
+  if (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 &&
+      is_planar(sn, sd, sh, sw, sc, cin, d, h, w) && is_cl(yn, yd, yh, yw, yc, d, h, w)) {
+    int r = fplx_edge_stem_fwd((const float*)x, wp, bias, y, yw, n, d, h, w, cin, cout, stats, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_F32 && kd == 1 && kh == 3 && kw == 3 && !stats &&
+      is_cl(sn, sd, sh, sw, sc, d, h, w) && is_planar(yn, yd, yh, yw, yc, cout, d, h, w)) {
+    int r = fplx_edge_outconv_fwd(x, sw, (const float*)wp, bias, (float*)y, n, d, h, w, cin, cout, st);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
+  if (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && kd == 1 && kh == 3 && kw == 3 && !stats && !bias &&
+      is_planar(sn, sd, sh, sw, sc, cin, d, h, w) && is_cl(yn, yd, yh, yw, yc, d, h, w)) {
+    int r = fplx_edge_outconv_dgrad((const float*)x, wp, y, yw, n, d, h, w, cout, cin, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
   const int64_t V = (int64_t)n * d * h * w;
@@ -440,7 +479,12 @@ size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout,
   const size_t a = (size_t)wgrad_chunks(V) * kd * kh * kw * cout * cin * sizeof(float);
   const size_t b = (size_t)fplx_rows_for(V) * cout * sizeof(float);
   size_t m = 0;
-  if (kd == 3 && kh == 3 && kw == 3) m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+  if (kd == 3 && kh == 3 && kw == 3) {
+    m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    const size_t e = fplx_edge_stem_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (e > m) m = e;
+  }
+  if (kd == 1 && kh == 3 && kw == 3) m = fplx_edge_outconv_wgrad_ws_bytes(n, d, h, w, cin, cout);
   const size_t g = a + b + 256;
   return (m + b + 256) > g ? (m + b + 256) : g;
 }
@@ -465,6 +509,24 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
     const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
       int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st);
+      if (r < 0) return r;
+      if (r == 1) { done = true; used = m; }
+    }
+  }
+  if (!done && x_dt == FPLX_F32 && dy_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 &&
+      is_planar(sn, sd, sh, sw, sc, cin, d, h, w) && is_cl(yn, yd, yh, yw, yc, d, h, w)) {
+    const size_t m = fplx_edge_stem_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > 0) {
+      int r = fplx_edge_stem_wgrad((const float*)x, dy, yw, dw, n, d, h, w, cin, cout, ws, st);
+      if (r < 0) return r;
+      if (r == 1) { done = true; used = m; }
+    }
+  }
+  if (!done && x_dt == FPLX_BF16 && dy_dt == FPLX_F32 && kd == 1 && kh == 3 && kw == 3 &&
+      is_cl(sn, sd, sh, sw, sc, d, h, w) && is_planar(yn, yd, yh, yw, yc, cout, d, h, w)) {
+    const size_t m = fplx_edge_outconv_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > 0) {
+      int r = fplx_edge_outconv_wgrad(x, sw, (const float*)dy, dw, n, d, h, w, cin, cout, ws, st);
       if (r < 0) return r;
       if (r == 1) { done = true; used = m; }
     }

@@ -154,3 +154,70 @@ def test_fused_adam_matches_torch():
         assert float((p.cpu() - p_ref.detach()).abs().max()) < 2e-6
     with pytest.raises(ValueError):
         ops.adam_step(p, g.cuda(), m, v, 1e-3, 0, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32)])
+def test_stem_kernels_bf16(shape):
+    """fp32 NCDHW network input -> bf16 NDHWC (MFMA stem kernels): forward + statistics, weight gradient"""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    x = torch.from_numpy(detdata.normal("st.x%s" % (shape,), (n, cin, d, h, w)))
+    wt = torch.from_numpy(detdata.normal("st.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.3)).bfloat16().float()
+    b = torch.from_numpy(detdata.normal("st.b%s" % (shape,), (cout,)))
+    dy = torch.from_numpy(detdata.normal("st.dy%s" % (shape,), (n, cout, d, h, w))).bfloat16().float()
+    xq = x.bfloat16().float()              # the kernel rounds the input to bf16 when staging it
+    xr, wr = xq.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, b, padding=1)
+    yr.backward(dy)
+    dims = (n, d, h, w)
+    wf, _ = ops.pack_conv_weight(wt.cuda(), torch.bfloat16, False)
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), ops.F32, ops.BF16)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    y = torch.zeros((n * d * h * w, cout), dtype=torch.bfloat16, device="cuda")
+    ops.conv3d_fwd(x.cuda(), ops.planar_strides(cin, d, h, w), ops.F32, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout),
+                   ops.BF16, dims, cin, cout, (3, 3, 3), stats)
+    got = uncl(y.float().cpu(), n, d, h, w)
+    scale = float(yr.detach().abs().max())
+    assert float((got - yr.detach()).abs().max()) < 1e-2 * scale
+    yf = cl(yr.detach())
+    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), yf.sum(0).numpy(), atol=2e-3 * scale * yf.shape[0] ** 0.5)
+    np.testing.assert_allclose(stats.sum(0)[1].cpu().numpy(), (yf * yf).sum(0).numpy(), rtol=1e-2)
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+    dw = torch.zeros((cout, cin, 3, 3, 3), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(x.cuda(), ops.planar_strides(cin, d, h, w), ops.F32, cl(dy).bfloat16().cuda(),
+                     ops.cl_strides(d, h, w, cout), ops.BF16, dw, None, dims, cin, cout, (3, 3, 3), ws)
+    assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 2, 3, 9, 35), (1, 32, 3, 2, 16, 64), (1, 64, 2, 2, 8, 40)])
+def test_outconv_kernels_bf16(shape):
+    """bf16 NDHWC features <-> fp32 NCDHW logits, kernel (1,3,3): forward, data gradient, weight gradient"""
+    from fplx import ops
+    n, c0, ncls, d, h, w = shape
+    x = torch.from_numpy(detdata.normal("oc.x%s" % (shape,), (n, c0, d, h, w))).bfloat16().float()
+    wt = torch.from_numpy(detdata.normal("oc.w%s" % (shape,), (ncls, c0, 1, 3, 3), 0.2))
+    b = torch.from_numpy(detdata.normal("oc.b%s" % (shape,), (ncls,)))
+    dl = torch.from_numpy(detdata.normal("oc.dl%s" % (shape,), (n, ncls, d, h, w)))
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=(0, 1, 1))
+    yr.backward(dl)
+    dims = (n, d, h, w)
+    xg = cl(x).bfloat16().cuda()
+    wf, _ = ops.pack_conv_weight(wt.cuda(), torch.float32, False)
+    _, wb = ops.pack_conv_weight(wt.cuda(), torch.bfloat16, True)
+    out = torch.zeros((n, ncls, d, h, w), dtype=torch.float32, device="cuda")
+    ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, c0), ops.BF16, wf, b.cuda(), out, ops.planar_strides(ncls, d, h, w),
+                   ops.F32, dims, c0, ncls, (1, 3, 3), None)
+    # the MFMA path rounds the fp32 weights to bf16 operands: 2^-9 relative per product
+    assert float((out.cpu() - yr.detach()).abs().max()) < 1e-2 * float(yr.detach().abs().max())
+    dx = torch.zeros((xg.shape[0], c0), dtype=torch.bfloat16, device="cuda")
+    ops.conv3d_fwd(dl.cuda(), ops.planar_strides(ncls, d, h, w), ops.F32, wb, None, dx, ops.cl_strides(d, h, w, c0),
+                   ops.BF16, dims, ncls, c0, (1, 3, 3), None)
+    assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < 2e-2 * float(xr.grad.abs().max())
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, c0, ncls, (1, 3, 3)), dtype=torch.uint8, device="cuda")
+    dw = torch.zeros((ncls, c0, 1, 3, 3), dtype=torch.float32, device="cuda")
+    db = torch.zeros(ncls, dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, c0), ops.BF16, dl.cuda(), ops.planar_strides(ncls, d, h, w), ops.F32,
+                     dw, db, dims, c0, ncls, (1, 3, 3), ws)
+    assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
+    assert float((db.cpu() - br.grad).abs().max()) < 1e-4 * float(br.grad.abs().max())
