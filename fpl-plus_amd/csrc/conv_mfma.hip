@@ -436,6 +436,207 @@ inline DwCfg dw_cfg(int n, int d, int h, int w, int cin, int cout) {
   return c;
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd_stream: the L0/L1 work-horse (Cin in {32, 64}, large H x W).  One block = an 8 x 32
+// output footprint in (h, w) x 32 output channels, marching along d:
+//   * three input slabs (10 x 34 voxels x Cin, 1-voxel halo, zero fill = padding) form a ring in
+//     LDS; every slab is fetched from HBM/L2 once per block and feeds 27 taps x 3 output depths;
+//     the next slab travels global -> registers while the current depth is computed and is
+//     written to LDS behind the depth's last barrier (async-stage split);
+//   * the weights of GT taps at a time stream L2 -> registers -> a two-buffer LDS ring, one
+//     barrier per group;
+//   * LDS rows are 16-byte-chunk XOR-swizzled so that every ds_read_b128 of an operand fragment
+//     (32 voxels / 32 output channels x 16 B) is bank-conflict free;
+//   * epilogue per depth: bias, bf16 store, per-channel sum / sum of squares kept in registers and
+//     written once per block (DSBN statistics, fixed order).
+template <int CIN>
+struct StreamGeo {
+  static constexpr int ROWB = CIN * 2, CH = ROWB / 16;
+  static constexpr int SW = 34, SH = 10, SLAB = SW * SH;
+  static constexpr int GT = CIN == 32 ? 9 : 3, NG = 27 / GT;
+  static constexpr int SLAB_BYTES = SLAB * ROWB, WBUF_BYTES = GT * 32 * ROWB;
+  static constexpr int NLD = (SLAB * CH + 255) / 256, NLW = (GT * 32 * CH + 255) / 256;
+  static constexpr int LDS = 3 * SLAB_BYTES + 2 * WBUF_BYTES;
+  static __device__ __forceinline__ int swz(int row) { return (row / (16 / CH)) % CH; }
+};
+
+template <int CIN>
+__global__ void __launch_bounds__(256)
+conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen) {
+  typedef StreamGeo<CIN> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;
+  char* wbuf = smem + 3 * G::SLAB_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  int b = blockIdx.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = b;
+  const int h0 = th * 8, w0 = tw * 32, d0 = seg * dlen;
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = blockIdx.y * 32;
+
+  uint4 sreg[G::NLD], wreg[G::NLW];
+  auto slab_fetch = [&](int d) {                 // global -> registers (zero outside the volume)
+    const bool dok = d >= 0 && d < D;
+#pragma unroll
+    for (int k = 0; k < G::NLD; ++k) {
+      const int i = tid + k * 256;
+      const int vox = i / G::CH, c = i % G::CH;
+      const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < G::SLAB * G::CH && dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
+        v = *reinterpret_cast<const uint4*>(x + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + c * 8);
+      sreg[k] = v;
+    }
+  };
+  auto slab_commit = [&](int d) {                // registers -> LDS slot of depth d
+    char* dst = slabs + ((d + 1) % 3) * G::SLAB_BYTES;
+#pragma unroll
+    for (int k = 0; k < G::NLD; ++k) {
+      const int i = tid + k * 256;
+      const int vox = i / G::CH, c = i % G::CH;
+      if (i < G::SLAB * G::CH) *reinterpret_cast<uint4*>(dst + vox * G::ROWB + ((c ^ G::swz(vox)) * 16)) = sreg[k];
+    }
+  };
+  auto w_fetch = [&](int g) {
+#pragma unroll
+    for (int k = 0; k < G::NLW; ++k) {
+      const int i = tid + k * 256;
+      const int row = i / G::CH, c = i % G::CH;                 // row = tap_local * 32 + co
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < G::GT * 32 * G::CH)
+        v = *reinterpret_cast<const uint4*>(wp + ((int64_t)(g * G::GT + (row >> 5)) * Cout + n0 + (row & 31)) * CIN + c * 8);
+      wreg[k] = v;
+    }
+  };
+  auto w_commit = [&](int g) {
+    char* dst = wbuf + (g & 1) * G::WBUF_BYTES;
+#pragma unroll
+    for (int k = 0; k < G::NLW; ++k) {
+      const int i = tid + k * 256;
+      const int row = i / G::CH, c = i % G::CH;
+      if (i < G::GT * 32 * G::CH) *reinterpret_cast<uint4*>(dst + row * G::ROWB + ((c ^ G::swz(row)) * 16)) = wreg[k];
+    }
+  };
+
+  const int co = n0 + r;
+  const float bv = bias ? bias[co] : 0.f;
+  float ssum = 0.f, qsum = 0.f;
+  int wpar = 0;                                  // weight-ring buffer holding the current group
+
+  // prologue: slabs d0-1, d0 and weight group 0
+  slab_fetch(d0 - 1); slab_commit(d0 - 1);
+  slab_fetch(d0); slab_commit(d0);
+  slab_fetch(d0 + 1);
+  w_fetch(0); w_commit(0);
+  __syncthreads();
+  slab_commit(d0 + 1);
+  __syncthreads();
+
+  for (int d = d0; d < d1; ++d) {
+    if (d + 1 < d1) slab_fetch(d + 2);           // in flight during this depth's 27 taps
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+#pragma unroll 1
+    for (int g = 0; g < G::NG; ++g) {
+      const int gn = (g + 1 == G::NG) ? 0 : g + 1;
+      w_fetch(gn);
+      const char* wb_ = wbuf + wpar * G::WBUF_BYTES;
+#pragma unroll
+      for (int tl = 0; tl < G::GT; ++tl) {
+        const int tap = g * G::GT + tl;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        const char* sl = slabs + ((d + kd) % 3) * G::SLAB_BYTES;          // depth d + kd - 1
+        const int brow = tl * 32 + r;
+#pragma unroll
+        for (int s = 0; s < CIN / 16; ++s) {
+          const int c = 2 * s + khalf;
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wb_ + brow * G::ROWB + ((c ^ G::swz(brow)) * 16));
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const int vox = (wave * 2 + m + kh) * G::SW + r + kw;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((c ^ G::swz(vox)) * 16));
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[m], 0, 0, 0);
+          }
+        }
+      }
+      // the ring alternates buffers across the wrap-around into the next depth as well (NG is odd)
+      {
+        wpar ^= 1;
+        char* dst = wbuf + wpar * G::WBUF_BYTES;
+#pragma unroll
+        for (int k = 0; k < G::NLW; ++k) {
+          const int i = tid + k * 256;
+          const int row = i / G::CH, c = i % G::CH;
+          if (i < G::GT * 32 * G::CH) *reinterpret_cast<uint4*>(dst + row * G::ROWB + ((c ^ G::swz(row)) * 16)) = wreg[k];
+        }
+      }
+      __syncthreads();
+    }
+    // epilogue of depth d
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int h = h0 + wave * 2 + m;
+      if (h < H) {
+        const int64_t vrow = (((int64_t)n * D + d) * H + h) * W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int w = w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+          if (w < W) {
+            const float o = acc[m][i] + bv;
+            y[(vrow + w) * ldy + co] = (bf16_t)o;
+            ssum += o;
+            qsum = fmaf(o, o, qsum);
+          }
+        }
+      }
+    }
+    if (d + 1 < d1) {
+      slab_commit(d + 2);                        // slot of depth d-1, free since the last barrier
+      __syncthreads();
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [4][2][32]
+    const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] =
+          red[(0 * 2 + which) * 32 + c] + red[(1 * 2 + which) * 32 + c] + red[(2 * 2 + which) * 32 + c] + red[(3 * 2 + which) * 32 + c];
+    }
+  }
+}
+
+struct StreamCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
+inline bool stream_ok(int d, int h, int w, int cin, int cout) {
+  return (cin == 32 || cin == 64) && cout % 32 == 0 && h >= 16 && w >= 64 && d >= 4;
+}
+inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
+  StreamCfg c;
+  c.tilesH = (h + 7) / 8;
+  c.tilesW = (w + 31) / 32;
+  const int tiles = n * c.tilesH * c.tilesW * (cout / 32);
+  int ds = (1024 + tiles / 2) / tiles;
+  const int maxds = d / 8 > 0 ? d / 8 : 1;
+  if (ds > maxds) ds = maxds;
+  if (ds < 1) ds = 1;
+  c.dlen = (d + ds - 1) / ds;
+  c.dsegs = (d + c.dlen - 1) / c.dlen;
+  c.nblk = n * c.tilesH * c.tilesW * c.dsegs;
+  return c;
+}
+
 struct DirectCfg { int mt, ntl; };
 
 inline DirectCfg direct_cfg(int cout) {
@@ -454,6 +655,7 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
   const DirectCfg c = direct_cfg(cout);
   const int64_t V = (int64_t)n * d * h * w;
   return (int)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32));
@@ -463,6 +665,23 @@ extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, 
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
+  if (stream_ok(d, h, w, cin, cout)) {
+    const StreamCfg sc = stream_cfg(n, d, h, w, cout);
+    dim3 grid(sc.nblk, cout / 32);
+    if (cin == 32) {
+      (void)hipFuncSetAttribute((const void*)conv_fwd_stream<32>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamGeo<32>::LDS);
+      conv_fwd_stream<32><<<grid, 256, StreamGeo<32>::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                                ldy, n, d, h, w, cout, stats, sc.tilesH, sc.tilesW,
+                                                                sc.dsegs, sc.dlen);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_fwd_stream<64>, hipFuncAttributeMaxDynamicSharedMemorySize, StreamGeo<64>::LDS);
+      conv_fwd_stream<64><<<grid, 256, StreamGeo<64>::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                                ldy, n, d, h, w, cout, stats, sc.tilesH, sc.tilesW,
+                                                                sc.dsegs, sc.dlen);
+    }
+    int rc0 = fplx_check_launch("mfma_conv3d_fwd_stream");
+    return rc0 < 0 ? rc0 : 1;
+  }
   const DirectCfg c = direct_cfg(cout);
   const int64_t V = (int64_t)n * d * h * w;
   dim3 grid((unsigned)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)), cout / (c.ntl * 32));

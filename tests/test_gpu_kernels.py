@@ -22,7 +22,9 @@ def uncl(t2, n, d, h, w):
 @pytest.mark.parametrize("shape", [(1, 5, 7, 3, 9, 6), (2, 16, 8, 4, 6, 10), (1, 3, 11, 2, 2, 2),
                                    # Cin % 32 == 0 and Cout % 32 == 0: the bf16 runs take the MFMA kernels
                                    (1, 32, 32, 5, 9, 35), (2, 64, 32, 3, 8, 33), (1, 32, 64, 4, 11, 17),
-                                   (1, 128, 64, 2, 5, 9), (1, 32, 32, 9, 16, 64)])
+                                   (1, 128, 64, 2, 5, 9), (1, 32, 32, 9, 16, 64),
+                                   # large H x W with Cin in {32, 64}: the streaming LDS kernel (ragged tiles included)
+                                   (1, 32, 32, 20, 24, 96), (2, 64, 64, 9, 18, 70), (1, 64, 32, 4, 16, 64)])
 def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
     from fplx import ops
     n, cin, cout, d, h, w = shape
