@@ -176,28 +176,48 @@ stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int6
       }
     }
   }
-  // part[block][wave][rt][row 32][co 32]
-  float* out = part + ((int64_t)blockIdx.x * 4 + wave) * (RT * 1024);
+  // combine the 4 waves' K-slices through LDS (fixed order), then part[block][rt][row 32][co 32]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(dys);            // 4 x 1024 floats = 16 KB
+  float* out = part + (int64_t)blockIdx.x * (RT * 1024);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+  for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;
-      out[(rt * 32 + row) * 32 + r] = acc[rt][i];
+      red[wave * 1024 + row * 32 + r] = acc[rt][i];
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) out[rt * 1024 + i] = red[i] + red[1024 + i] + red[2048 + i] + red[3072 + i];
+    __syncthreads();
+  }
 }
 
-// dw[co][ci][tap] = sum over (block, wave) partials
-__global__ void stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, int co0, float* __restrict__ dw) {
+// sum of `nparts` partial arrays of `total` floats each: 64 outputs x 4 partial-lanes per block,
+// lanes combined in a fixed order
+__device__ __forceinline__ float sum_partials(const float* __restrict__ part, int nparts, int64_t total, int64_t i,
+                                              float* red) {
+  const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
+  float t = 0.f;
+  if (i < total)
+    for (int b = pl; b < nparts; b += 4) t += part[(int64_t)b * total + i];
+  red[pl * 64 + o] = t;
+  __syncthreads();
+  return red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+}
+
+// dw[co][ci][tap] = sum over block partials
+__global__ void __launch_bounds__(256)
+stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, int co0, float* __restrict__ dw) {
+  __shared__ float red[256];
   const int total = rt * 1024;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i & 31, k = i >> 5;
-    if (k >= 27 * cin) continue;
-    float t = 0.f;
-    for (int b = 0; b < nparts; ++b) t += part[(int64_t)b * total + i];
-    const int ci = k / 27, tap = k % 27;
-    dw[((int64_t)(co0 + co) * cin + ci) * 27 + tap] = t;
-  }
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float t = sum_partials(part, nparts, total, i, red);
+  if (threadIdx.x >= 64 || i >= total) return;
+  const int co = i & 31, k = i >> 5;
+  if (k >= 27 * cin) return;
+  const int ci = k / 27, tap = k % 27;
+  dw[((int64_t)(co0 + co) * cin + ci) * 27 + tap] = t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -208,18 +228,20 @@ __global__ void __launch_bounds__(256)
 outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
                  float* __restrict__ out, int N, int D, int H, int W, int ncls) {
   constexpr int CIN = KSTEPS * 16, MT = 4;
+  __shared__ bf16x8 bsh[9 * KSTEPS][64];            // B fragments, lane-linear (conflict-free ds_read_b128)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh8 = (lane >> 5) * 8;
   const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
   const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (MT * 32);
-  bf16x8 bfr[9][KSTEPS];
+  for (int f = wave; f < 9 * KSTEPS; f += 4) {
+    const int tap = f / KSTEPS, s = f % KSTEPS;
+    bf16x8 b;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        bfr[tap][s][j] = r < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r) * CIN + s * 16 + kh8 + j] : (bf16_t)0.f;
+    for (int j = 0; j < 8; ++j)
+      b[j] = r < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r) * CIN + s * 16 + kh8 + j] : (bf16_t)0.f;
+    bsh[f][lane] = b;
+  }
+  __syncthreads();
   int vh[MT], vw[MT];
   int64_t vb[MT];
   bool vok[MT];
@@ -242,14 +264,15 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3 - 1, kw = tap % 3 - 1;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int hh = vh[t] + kh, ww = vw[t] + kw;
-      const bool ok = vok[t] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-      const bf16_t* ap = x + (ok ? vb[t] + kh * W + kw : 0) * ldx + kh8;
+    for (int s = 0; s < KSTEPS; ++s) {
+      const bf16x8 b = bsh[tap * KSTEPS + s][lane];
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) {
-        const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap + s * 16) : zero;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[tap][s], acc[t], 0, 0, 0);
+      for (int t = 0; t < MT; ++t) {
+        const int hh = vh[t] + kh, ww = vw[t] + kw;
+        const bool ok = vok[t] && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        const bf16_t* ap = x + (ok ? vb[t] + kh * W + kw : 0) * ldx + kh8 + s * 16;
+        const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap) : zero;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
       }
     }
   }
@@ -366,16 +389,17 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
   }
 }
 
-__global__ void outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0, int ncls, float* __restrict__ dw) {
+__global__ void __launch_bounds__(256)
+outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0, int ncls, float* __restrict__ dw) {
+  __shared__ float red[256];
   const int total = ncit * 9 * 1024;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i & 31;
-    if (co >= ncls) continue;
-    float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
-    const int ci_l = (i >> 5) & 31, tap = (i >> 10) % 9, cit = i / (9 * 1024);
-    dw[((int64_t)co * C0 + cit * 32 + ci_l) * 9 + tap] = t;
-  }
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const float t = sum_partials(part, nblk, total, i, red);
+  if (threadIdx.x >= 64 || i >= total) return;
+  const int co = i & 31;
+  if (co >= ncls) return;
+  const int ci_l = (i >> 5) & 31, tap = (i >> 10) % 9, cit = i / (9 * 1024);
+  dw[((int64_t)co * C0 + cit * 32 + ci_l) * 9 + tap] = t;
 }
 
 inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
@@ -383,7 +407,7 @@ inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   *tw = (w + TW - 1) / TW;
   return (int64_t)n * d * (*th) * (*tw);
 }
-inline int edge_blocks(int64_t ntiles) { return (int)(ntiles < 1024 ? ntiles : 1024); }
+inline int edge_blocks(int64_t ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
 
 }  // namespace
 
@@ -414,7 +438,7 @@ extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int 
   if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
   int th, tw;
   const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
-  return (size_t)nb * 4 * ((27 * cin + 31) / 32) * 1024 * sizeof(float);
+  return (size_t)nb * ((27 * cin + 31) / 32) * 1024 * sizeof(float);
 }
 
 extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
@@ -427,7 +451,7 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
     else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
-    stem_wgrad_reduce<<<(rt * 1024 + 255) / 256, 256, 0, st>>>((const float*)ws, nb * 4, rt, cin, co0, dw);
+    stem_wgrad_reduce<<<(rt * 1024 + 63) / 64, 256, 0, st>>>((const float*)ws, nb, rt, cin, co0, dw);
   }
   int rc = fplx_check_launch("edge_stem_wgrad");
   return rc < 0 ? rc : 1;
@@ -471,7 +495,7 @@ extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* 
   dim3 grid(nb, c0 / 32);
   outconv_wgrad_mfma<<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, dl, (float*)ws, n, d, h, w, ncls, nt, th, tw);
   const int total = (c0 / 32) * 9 * 1024;
-  outconv_wgrad_reduce<<<(total + 255) / 256, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
+  outconv_wgrad_reduce<<<(total + 63) / 64, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
   int rc = fplx_check_launch("edge_outconv_wgrad");
   return rc < 0 ? rc : 1;
 }

@@ -247,18 +247,24 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   }
 }
 
-// dw[co][ci][tap] = sum_b part[b][pair][tap][ci%32][co%32]
-__global__ void wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout,
-                                    float* __restrict__ dw) {
+// dw[co][ci][tap] = sum_b part[b][pair][tap][ci%32][co%32]; 64 outputs x 4 partial-lanes per block
+__global__ void __launch_bounds__(256)
+wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw) {
+  __shared__ float red[256];
   const int64_t total = (int64_t)npairs * 27 * 1024;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
-    const int co_l = i & 31, ci_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
-    const int ncit = Cin / 32;
-    const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
-    dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
-  }
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
+  float t = 0.f;
+  if (i < total)
+    for (int b = pl; b < nblk; b += 4) t += part[(int64_t)b * total + i];
+  red[pl * 64 + o] = t;
+  __syncthreads();
+  if (pl != 0 || i >= total) return;
+  t = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+  const int co_l = i & 31, ci_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
+  const int ncit = Cin / 32;
+  const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
+  dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
 }
 
 struct WgCfg { int tw, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
@@ -408,18 +414,25 @@ deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
 }
 
 // dw[ci][co][tap] (torch ConvTranspose3d layout) = sum_b part[b][pair][tap][c][ci%32][co%32]
-__global__ void deconv_wgrad_reduce(const float* __restrict__ part, int nblk, int npairs, int cit, int Cin, int Cout,
-                                    float* __restrict__ dw) {
+__global__ void __launch_bounds__(256)
+deconv_wgrad_reduce(const float* __restrict__ part, int nblk, int npairs, int cit, int Cin, int Cout,
+                    float* __restrict__ dw) {
+  __shared__ float red[256];
   const int64_t per = (int64_t)8 * cit * 1024, total = npairs * per;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float t = 0.f;
-    for (int b = 0; b < nblk; ++b) t += part[(int64_t)b * total + i];
-    const int co_l = i & 31, ci_l = (i >> 5) & 31, c = (int)((i >> 10) % cit), tap = (int)((i / (1024 * cit)) % 8);
-    const int pair = (int)(i / per);
-    const int ncig = Cin / (32 * cit);
-    const int co = (pair / ncig) * 32 + co_l, ci = ((pair % ncig) * cit + c) * 32 + ci_l;
-    dw[((int64_t)ci * Cout + co) * 8 + tap] = t;
-  }
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
+  float t = 0.f;
+  if (i < total)
+    for (int b = pl; b < nblk; b += 4) t += part[(int64_t)b * total + i];
+  red[pl * 64 + o] = t;
+  __syncthreads();
+  if (pl != 0 || i >= total) return;
+  t = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+  const int co_l = i & 31, ci_l = (i >> 5) & 31, c = (int)((i >> 10) % cit), tap = (int)((i / (1024 * cit)) % 8);
+  const int pair = (int)(i / per);
+  const int ncig = Cin / (32 * cit);
+  const int co = (pair / ncig) * 32 + co_l, ci = ((pair % ncig) * cit + c) * 32 + ci_l;
+  dw[((int64_t)ci * Cout + co) * 8 + tap] = t;
 }
 
 struct DwCfg { int cit, npairs, nblk; size_t ws; };
@@ -428,7 +441,7 @@ inline DwCfg dw_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.cit = (cin % 128 == 0) ? 4 : (cin % 64 == 0 ? 2 : 1);
   c.npairs = (cin / (32 * c.cit)) * (cout / 32);
   const int64_t chunks = ((int64_t)n * d * h * w + 127) / 128;
-  int nb = 1024 / c.npairs;
+  int nb = 512 / c.npairs;
   if (nb < 1) nb = 1;
   if (nb > chunks) nb = (int)chunks;
   c.nblk = nb;
@@ -722,9 +735,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
                                                   cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);
   }
   const int64_t total = (int64_t)c.npairs * 27 * 1024;
-  int g = (int)((total + 255) / 256);
-  if (g > 2048) g = 2048;
-  wgrad_stream_reduce<<<g, 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw);
+  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw);
   int rc = fplx_check_launch("mfma_conv3d_wgrad");
   return rc < 0 ? rc : 1;
 }
@@ -783,9 +794,7 @@ extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* d
   else LAUNCH_DW(1);
 #undef LAUNCH_DW
   const int64_t total = (int64_t)c.npairs * 8 * c.cit * 1024;
-  int g = (int)((total + 255) / 256);
-  if (g > 2048) g = 2048;
-  deconv_wgrad_reduce<<<g, 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw);
+  deconv_wgrad_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw);
   int rc = fplx_check_launch("mfma_deconv2_wgrad");
   return rc < 0 ? rc : 1;
 }
