@@ -109,6 +109,29 @@ def roofline_of(key, n_avg_ms):
     return flops, nbytes, flops / sec / 1e12, nbytes / sec / 1e9
 
 
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/r01_pmc_hbm_traffic.json, made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE passes with the gfx950 x2 FETCH correction).  None if no matching entry."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    name, dims, cin, cout, k = key
+    n, d, h, w = dims
+    if not (name == "conv3d_fwd" and k == (3, 3, 3) and cin in (32, 64) and cout % 32 == 0 and h >= 16 and w >= 64):
+        return None
+    # grid of conv_fwd_stream (fpl-plus_amd/csrc/conv_mfma.hip: stream_cfg)
+    tiles_h, tiles_w = (h + 7) // 8, (w + 31) // 32
+    tiles = n * tiles_h * tiles_w * (cout // 32)
+    ds = max(1, min((1024 + tiles // 2) // tiles, max(1, d // 8)))
+    dlen = (d + ds - 1) // ds
+    dsegs = (d + dlen - 1) // dlen
+    grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * 256
+    tab = json.load(open(path))
+    e = tab.get("conv_fwd_stream<%d>|grid=%d" % (cin, grid))
+    return None if e is None else e["hbm_bytes_per_launch"]
+
+
 def cpu_baseline():
     """The oracle (PyTorch-CPU restatement of the reference modules, oracle/torch_ref.py) timed on the
     host cores on a bounded sample of the same workload: fp32 train steps (forward, Dice loss, backward,
@@ -221,6 +244,7 @@ def main():
             else:
                 roof = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None}
+            roof["traffic"] = pmc_traffic(k)
             roof.update({"kernel": str(k), "avg_ms": round(convs[k][1], 4), "launches_timed": convs[k][0],
                          "algorithmic_bytes": nbytes, "algorithmic_flops": flops,
                          "hbm_GBps": round(gbs, 2), "TFLOPps": round(tf, 3), "time_share": round(convs[k][2] / tot, 4)})
