@@ -223,11 +223,12 @@ def main():
     # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
     roof = None
     ktable = []
-    if timer is not None and rank == 0:
-        timer.on = True
+    if timer is not None:
+        timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
         run(args.warmup + args.steps, 2)
         torch.cuda.synchronize()
         timer.on = False
+    if timer is not None and rank == 0:
         summ = timer.summary()
         tot = sum(v[2] for v in summ.values())
         for k, (cnt, avg, s) in sorted(summ.items(), key=lambda kv: -kv[1][2]):

@@ -332,7 +332,9 @@ inline int wgrad_chunks(int64_t V) {
 
 // MFMA fast paths (conv_mfma.hip); return 1 if they handled the call, 0 if not applicable, <0 on error
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                    int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
+                                    int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
+                                    size_t ws_bytes, hipStream_t st);
+extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
@@ -425,10 +427,16 @@ int fplx_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout, int kd
   return grid_for(V, FWD_THREADS, MAX_ROWS);
 }
 
+size_t fplx_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt) {
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3)
+    return fplx_mfma_conv3d_fwd_ws_bytes(n, d, h, w, cin, cout);
+  return 0;
+}
+
 int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
                     const void* wp, const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh,
                     int64_t yw, int64_t yc, int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
-                    float* stats, fplx_stream_t stream) {
+                    float* stats, void* ws, size_t ws_bytes, fplx_stream_t stream) {
   FPLX_REQUIRE(x && wp && y, FPLX_E_NULL, "conv3d_fwd: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE,
                "conv3d_fwd: bad shape n=%d d=%d h=%d w=%d cin=%d cout=%d", n, d, h, w, cin, cout);
@@ -437,7 +445,7 @@ int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh,
   hipStream_t st = (hipStream_t)stream;
   if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 && sc == 1 && yc == 1 &&
       sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
-    int r = fplx_mfma_conv3d_fwd(x, sw, wp, bias, y, yw, n, d, h, w, cin, cout, stats, st);
+    int r = fplx_mfma_conv3d_fwd(x, sw, wp, bias, y, yw, n, d, h, w, cin, cout, stats, ws, ws_bytes, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
   if (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 &&

@@ -24,7 +24,9 @@ template <int MT, int NTL, int MODE>
 __global__ void __launch_bounds__(DIRECT_THREADS)
 conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                int Cin, int Cout, float* __restrict__ stats) {
+                int Cin, int Cout, float* __restrict__ stats, float* __restrict__ partial = nullptr) {
+  // split-K: gridDim.z > 1 deals the taps to blockIdx.z (tap % gridDim.z); fp32 partial tiles go to
+  // partial[z][voxel][Cout] and splitk_finish_k adds bias, stores bf16 and produces the statistics
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh8 = (lane >> 5) * 8;
   const int64_t V = (int64_t)N * D * H * W;
@@ -54,7 +56,7 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int NTAPS = MODE == 0 ? 27 : 8;
-  for (int tap = 0; tap < NTAPS; ++tap) {
+  for (int tap = blockIdx.z; tap < NTAPS; tap += gridDim.z) {
     const bf16_t* ap[MT];
     bool aok[MT];
 #pragma unroll
@@ -88,8 +90,23 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
     }
   }
 
-  // epilogue: + bias, per-channel statistics of the unrounded outputs, bf16 store
   const int rh = (lane >> 5) * 4;
+  if (partial) {
+    float* pz = partial + (int64_t)blockIdx.z * V * Cout;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int co = n0 + j * 32 + r;
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t v = m0 + t * 32 + (i & 3) + 8 * (i >> 2) + rh;
+          if (v < V) pz[v * Cout + co] = acc[t][j][i];
+        }
+    }
+    return;
+  }
+  // epilogue: + bias, per-channel statistics of the unrounded outputs, bf16 store
   float s[NTL], q[NTL];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
@@ -650,12 +667,64 @@ inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
   return c;
 }
 
-struct DirectCfg { int mt, ntl; };
+// split-K finish: y = bf16(sum_z partial[z] + bias), statistics rows; thread = voxel-lane x 8 channels
+__global__ void __launch_bounds__(256)
+splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, const float* __restrict__ bias,
+                bf16_t* __restrict__ y, int64_t ldy, float* __restrict__ stats) {
+  const int G = Cout / 8;                      // channel groups per voxel (<= 256 by construction)
+  const int VL = 256 / G;
+  const int g = threadIdx.x % G, vl = threadIdx.x / G;
+  const int c0 = g * 8;
+  float s[8], q[8], bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = q[j] = 0.f; bv[j] = bias ? bias[c0 + j] : 0.f; }
+  if (vl < VL)
+    for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < V; v += (int64_t)gridDim.x * VL) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = bv[j];
+      for (int z = 0; z < ks; ++z) {
+        const float4 a = *reinterpret_cast<const float4*>(partial + ((int64_t)z * V + v) * Cout + c0);
+        const float4 b = *reinterpret_cast<const float4*>(partial + ((int64_t)z * V + v) * Cout + c0 + 4);
+        o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; o[4] += b.x; o[5] += b.y; o[6] += b.z; o[7] += b.w;
+      }
+      bf16x8 ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ov[j] = (bf16_t)o[j]; s[j] += o[j]; q[j] = fmaf(o[j], o[j], q[j]); }
+      *reinterpret_cast<bf16x8*>(y + v * ldy + c0) = ov;
+    }
+  if (!stats) return;
+  __shared__ float red[256][16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = vl < VL ? s[j] : 0.f; red[threadIdx.x][8 + j] = vl < VL ? q[j] : 0.f; }
+  __syncthreads();
+  if (threadIdx.x < G) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int k = 0; k < VL; ++k) { t0 += red[k * G + threadIdx.x][j]; t1 += red[k * G + threadIdx.x][8 + j]; }
+      stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c0 + j] = t0;
+      stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c0 + j] = t1;
+    }
+  }
+}
 
-inline DirectCfg direct_cfg(int cout) {
+struct DirectCfg { int mt, ntl, ksplit, fin_blocks; };
+
+inline DirectCfg direct_cfg(int64_t V, int cout) {
   DirectCfg c;
   if (cout % 64 == 0) { c.mt = 2; c.ntl = 2; }
   else { c.mt = 4; c.ntl = 1; }
+  // small volumes (deep levels) do not fill 256 CUs: deal the 27 taps to 3 / 9 / 27 blocks
+  const int64_t blocks = ((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)) * (cout / (c.ntl * 32));
+  c.ksplit = 1;
+  if (cout % 8 == 0 && cout <= 2048) {
+    if (blocks * 9 < 400) c.ksplit = 27;
+    else if (blocks * 3 < 400) c.ksplit = 9;
+    else if (blocks < 300) c.ksplit = 3;
+  }
+  int64_t fb = (V + 7) / 8;
+  c.fin_blocks = (int)(fb > 512 ? 512 : (fb < 1 ? 1 : fb));
   return c;
 }
 
@@ -669,14 +738,23 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
-  const DirectCfg c = direct_cfg(cout);
   const int64_t V = (int64_t)n * d * h * w;
+  const DirectCfg c = direct_cfg(V, cout);
+  if (c.ksplit > 1) return c.fin_blocks;
   return (int)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32));
+}
+
+extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 16 != 0 || cout % 32 != 0 || stream_ok(d, h, w, cin, cout)) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
+  const DirectCfg c = direct_cfg(V, cout);
+  return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
 }
 
 // returns 1 if handled, 0 if not applicable (caller falls back to the generic kernel), <0 on error
 extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                    int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+                                    int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
+                                    size_t ws_bytes, hipStream_t st) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
   if (stream_ok(d, h, w, cin, cout)) {
     const StreamCfg sc = stream_cfg(n, d, h, w, cout);
@@ -695,15 +773,26 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
     int rc0 = fplx_check_launch("mfma_conv3d_fwd_stream");
     return rc0 < 0 ? rc0 : 1;
   }
-  const DirectCfg c = direct_cfg(cout);
   const int64_t V = (int64_t)n * d * h * w;
-  dim3 grid((unsigned)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)), cout / (c.ntl * 32));
+  const DirectCfg c = direct_cfg(V, cout);
+  const int ks = c.ksplit;
+  float* partial = nullptr;
+  if (ks > 1) {
+    // the statistics row count was promised for the split-K path: the workspace is mandatory here
+    if (!ws || ws_bytes < (size_t)ks * V * cout * sizeof(float))
+      return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
+                       (size_t)ks * V * cout * sizeof(float));
+    partial = (float*)ws;
+  }
+  dim3 grid((unsigned)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)), cout / (c.ntl * 32), ks);
   if (c.ntl == 2)
     conv_fwd_direct<2, 2, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
-                                                           ldy, n, d, h, w, cin, cout, stats);
+                                                           ldy, n, d, h, w, cin, cout, stats, partial);
   else
     conv_fwd_direct<4, 1, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
-                                                           ldy, n, d, h, w, cin, cout, stats);
+                                                           ldy, n, d, h, w, cin, cout, stats, partial);
+  if (ks > 1)
+    splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
   int rc = fplx_check_launch("mfma_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }

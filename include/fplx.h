@@ -76,11 +76,14 @@ int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cou
  *         the (unrounded) outputs, for the BatchNorm that follows (dsbn.py:54-57).  The row
  *         count depends on the kernel variant chosen for the shape; ask for it. */
 int fplx_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt);
+/*  ws     workspace of fplx_conv3d_fwd_ws_bytes(...) bytes (0 for most shapes; small deep-level volumes
+ *         use a split-K kernel that keeps fp32 partial tiles there).  ws may be NULL when that is 0. */
+size_t fplx_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt);
 int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
                     const void* wp, const float* bias,
                     void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
                     int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
-                    float* stats, fplx_stream_t stream);
+                    float* stats, void* ws, size_t ws_bytes, fplx_stream_t stream);
 
 /* weight + bias gradient of the same convolution.
  *  dw   fp32 [Cout][Cin][KD][KH][KW] (torch layout), db fp32 [Cout] or NULL
