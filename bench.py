@@ -225,8 +225,10 @@ def main():
     ktable = []
     if timer is not None:
         timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
+        net.engine.use_side_stream = False      # one kernel at a time: clean per-launch durations
         run(args.warmup + args.steps, 2)
         torch.cuda.synchronize()
+        net.engine.use_side_stream = True
         timer.on = False
     if timer is not None and rank == 0:
         summ = timer.summary()

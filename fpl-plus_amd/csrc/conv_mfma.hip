@@ -232,19 +232,40 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
     load_x(d + 1);
     load_dy(d);
     __syncthreads();
-    for (int ks = 0; ks < TH * TW / 16; ++ks) {
+    // software pipeline over k-steps: all transposed reads of step ks+1 (1 dy fragment + up to 7 x
+    // fragments) are requested before the MFMAs of step ks are issued
+    constexpr int NKS = TH * TW / 16;
+    bf16x8 fbw[2], faw[2][7];
+    auto load_ks = [&](int ks, int buf) {
       const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-      const bf16x8 bfrag = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
+      fbw[buf] = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int tap = wave + 4 * i;
         if (tap < 27) {                                   // wave-uniform
           const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
           const char* sl = xs + ((d + kd) % 3) * (SLAB * 64);          // slab of depth d + kd - 1
-          const bf16x8 afrag = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[i], 0, 0, 0);
+          faw[buf][i] = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
         }
       }
+    };
+    load_ks(0, 0);
+#pragma unroll 2
+    for (int ks = 0; ks < NKS; ++ks) {
+      const int cur = ks & 1;
+      if (ks + 1 < NKS) {
+        if (cur == 0) load_ks(ks + 1, 1);
+        else load_ks(ks + 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (wave + 4 * i < 27) {
+          if (cur == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -580,23 +601,37 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       const int gn = (g + 1 == G::NG) ? 0 : g + 1;
       w_fetch(gn);
       const char* wb_ = wbuf + wpar * G::WBUF_BYTES;
-#pragma unroll
-      for (int tl = 0; tl < G::GT; ++tl) {
+      // software pipeline: the fragments of tap tl+1 are requested before the MFMAs of tap tl are
+      // issued, so every ds_read_b128 has a full tap of matrix work (2*KS MFMAs) to land behind
+      constexpr int KS = CIN / 16;
+      bf16x8 fb[2][KS], fa[2][KS][2];
+      auto load_tap = [&](int tl, int buf) {
         const int tap = g * G::GT + tl;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         const char* sl = slabs + ((d + kd) % 3) * G::SLAB_BYTES;          // depth d + kd - 1
         const int brow = tl * 32 + r;
 #pragma unroll
-        for (int s = 0; s < CIN / 16; ++s) {
+        for (int s = 0; s < KS; ++s) {
           const int c = 2 * s + khalf;
-          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(wb_ + brow * G::ROWB + ((c ^ G::swz(brow)) * 16));
+          fb[buf][s] = *reinterpret_cast<const bf16x8*>(wb_ + brow * G::ROWB + ((c ^ G::swz(brow)) * 16));
 #pragma unroll
           for (int m = 0; m < 2; ++m) {
             const int vox = (wave * 2 + m + kh) * G::SW + r + kw;
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((c ^ G::swz(vox)) * 16));
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[m], 0, 0, 0);
+            fa[buf][s][m] = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((c ^ G::swz(vox)) * 16));
           }
         }
+      };
+      load_tap(0, 0);
+#pragma unroll
+      for (int tl = 0; tl < G::GT; ++tl) {
+        if (tl + 1 < G::GT) load_tap(tl + 1, (tl + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tl & 1][s][m], fb[tl & 1][s], acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // the ring alternates buffers across the wrap-around into the next depth as well (NG is odd)
       {

@@ -29,12 +29,16 @@ class Engine(object):
     def __init__(self, net):
         self.net = net                     # fplx.net.UNet2D5_dsbn (parameter container)
         self.ws = None
+        self.ws_side = None
         self._pack_cache = None
+        self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
+        self.use_side_stream = True
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
         if self.ws is None or self.ws.numel() < nbytes or self.ws.device != dev:
             self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            self.ws_side = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         return self.ws
 
     def _pack(self, act_dtype):
@@ -192,16 +196,46 @@ class Engine(object):
             l = 3 - j
             need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l]))
         ws = self._workspace(need, dev)
+        # Weight-gradient kernels hang off the dependency chain (dgrad -> bn backward -> dgrad ...): they run
+        # on a second stream with their own workspace, overlapping the HBM-bound BN/pool passes with MFMA work.
+        main = torch.cuda.current_stream()
+        side_on = self.use_side_stream
+        if side_on and (self._side is None or self._side.device != dev):
+            self._side = torch.cuda.Stream(device=dev)
+        side = self._side if side_on else None
+        keep = []                          # tensors the side stream still reads: kept alive until the join
+        ws_w = self.ws_side if side_on else ws
+
+        def on_side(fn, *tensors):
+            if not side_on:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            keep.extend(tensors)
+            with torch.cuda.stream(side):
+                fn()
+
+        def join_side():
+            if side_on:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                main.wait_event(ev)
+
         maxc = max(ft) * 2
         part = torch.empty((ops.num_partials(vox[0]), 2 * maxc + 1), dtype=torch.float32, device=dev)
         coef = torch.empty((2, maxc), dtype=torch.float32, device=dev)
 
         # ---- out_conv
         last = sv.blocks[8]["out"]
-        ops.conv3d_wgrad(last, ops.cl_strides(D, H, W, ft[0]), a_dt, dlogits, ops.planar_strides(ncls, D, H, W), F32,
-                         gv["out_conv.weight"], gv["out_conv.bias"], dims[0], ft[0], ncls, (1, 3, 3), ws)
+        on_side(lambda: ops.conv3d_wgrad(last, ops.cl_strides(D, H, W, ft[0]), a_dt, dlogits,
+                                         ops.planar_strides(ncls, D, H, W), F32, gv["out_conv.weight"],
+                                         gv["out_conv.bias"], dims[0], ft[0], ncls, (1, 3, 3), ws_w), dlogits)
+
         def ready(last_name):
             if on_ready is not None:
+                join_side()                # the bucket's weight gradients were produced on the side stream
                 o, n, _ = net._layout[last_name]
                 on_ready(o + n)
 
@@ -218,8 +252,8 @@ class Engine(object):
                            gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
             db = None if sv.train else gv[key + ".bias"]
-            ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gv[key + ".weight"], db,
-                             dims[l], cin, c, (3, 3, 3), ws)
+            on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt,
+                                             gv[key + ".weight"], db, dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
             if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None)
@@ -246,7 +280,8 @@ class Engine(object):
             d_up = d_cat[:, ft[l]:]
             name = "up%d.trans3d" % (j + 1)
             xin = sv.deconv_in[j]
-            ops.deconv2_wgrad(xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws)
+            on_side(lambda xin=xin, d_up=d_up, name=name, l=l: ops.deconv2_wgrad(
+                xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws_w), d_up, d_cat, xin)
             ready(name + ".bias")
             d_cur = empty(vox[l + 1], ft[l + 1])
             ops.deconv2_dgrad(d_up, packs[name][1], d_cur, dims[l + 1], ft[l + 1], ft[l])
@@ -258,4 +293,6 @@ class Engine(object):
             ops.maxpool2_bwd(sv.cats[i][:, :ft[i]], d_pool, d_skips[i], d_a2, dims[i], ft[i])
             d_pool = block_bwd(i, d_a2, i > 0)
             ready("block%d.conv.relu_1.weight" % i)
+        join_side()
+        del keep
         return gflat

@@ -1,0 +1,127 @@
+"""Properties at BASELINE.json's full sizes (2 x 1 x 80 x 160 x 160 bf16 train step, 48 x 160 x 272 filter volume)
+that need no oracle run of that size: bitwise run-to-run reproducibility (fixed-order reductions), training makes
+progress, dropout stream determinism, and the filter against the numpy oracle (seconds at this size)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NET = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0.0, 0.0, 0.3, 0.4, 0.5],
+           conv_dims=[3, 3, 3, 3, 3], class_num=2, bilinear=False, num_domains=2, precision="bf16")
+SHAPE = (2, 1, 80, 160, 160)
+
+
+def _batch(seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(SHAPE, generator=g)
+    lab = torch.zeros((2, 2) + SHAPE[2:])
+    lab[:, 0] = 1.0
+    lab[:, 0, 30:50, 60:100, 60:100] = 0.0
+    lab[:, 1, 30:50, 60:100, 60:100] = 1.0
+    return x.cuda(), lab.cuda()
+
+
+def _run(steps, seed=1):
+    import fplx
+    torch.manual_seed(seed)
+    net = fplx.UNet2D5_dsbn(dict(NET)).cuda()
+    ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+    b = [_batch(10), _batch(11)]
+    losses = []
+    for i in range(steps):
+        out = ts.step(b[i % 2][0], b[i % 2][1], i % 2)
+        losses.append(out[0])
+    torch.cuda.synchronize()
+    return net, [float(l.item()) for l in losses], ts
+
+
+def test_full_size_train_steps_are_bitwise_reproducible_and_learn():
+    net_a, loss_a, _ = _run(6)
+    net_b, loss_b, _ = _run(6)
+    assert loss_a == loss_b                                  # fixed-order reductions: bit-identical runs
+    assert torch.equal(net_a.flat_params, net_b.flat_params)
+    assert all(np.isfinite(loss_a))
+    assert min(loss_a[4:]) < max(loss_a[:2])                 # Dice loss goes down on both domains
+    sd = net_a.state_dict()
+    # only the BN sets of the domain used in a step were touched: 3 steps each
+    assert int(sd["block0.conv.bn3d1.bns.0.num_batches_tracked"]) == 3
+    assert int(sd["block0.conv.bn3d1.bns.1.num_batches_tracked"]) == 3
+
+
+def test_full_size_forward_is_deterministic_under_dropout_seed():
+    import fplx
+    torch.manual_seed(3)
+    net = fplx.UNet2D5_dsbn(dict(NET)).cuda()
+    net.eval()
+    for m in net.modules():
+        if type(m) == torch.nn.Dropout:
+            m.train()
+    x, _ = _batch(5)
+    outs = []
+    for rep in range(2):
+        net._fwd_counter = 7
+        with torch.no_grad():
+            outs.append(net(x, domain_label=torch.ones(2, dtype=torch.long)))
+    assert torch.equal(outs[0], outs[1])
+    with torch.no_grad():
+        other = net(x, domain_label=torch.ones(2, dtype=torch.long))       # next forward counter -> new masks
+    assert not torch.equal(outs[0], other)
+
+
+def test_full_volume_filter_matches_numpy_oracle():
+    import fplx
+    from oracle import np_ref as N
+    rng = np.random.default_rng(5)
+    stack = (rng.standard_normal((6, 2, 48, 160, 272)) * 1.5).astype(np.float32)
+    stack[:, 1, :, :80] -= 6.0                                # confident background half
+    ref = N.fpl_filter(stack)
+    r = fplx.filter.fpl_filter(torch.from_numpy(stack).cuda())
+    assert np.array_equal(r["hards"].cpu().numpy(), ref["hards"])            # masks: bit exact
+    st = r["stats"].cpu().numpy()
+    assert abs(int(st[1]) - ref["boundary"]) <= 2            # voxels within 1 ulp of the 0.01 threshold
+    assert abs(st[0] - float(ref["vars"])) <= 2e-5 * float(ref["vars"])
+    assert abs(st[2] - float(ref["uncer_one"])) <= 2e-5 * float(ref["uncer_one"])
+    a = (rng.random((48, 160, 272)) > 0.5).astype(np.uint8)
+    b = (rng.random((48, 160, 272)) > 0.5).astype(np.uint8)
+    w = fplx.filter.pixel_weight_from_masks(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), 0.37).cpu().numpy()
+    assert np.array_equal(w, N.set_weight(np.float32(0.37), N.pixel_weight_from_masks(a.copy(), b.copy()).astype(np.float32)))
+
+
+def test_agent_fpl_inference_pipeline():
+    """SegmentationAgent.infer, FPL branch (reference agent_seg.py:897-961): MC passes with test-time dropout ->
+    filter -> ascending (uncertainty, name) list; re-derived from the recorded logits with the numpy oracle."""
+    import fplx
+    from oracle import np_ref as N
+    net_cfg = dict(in_chns=1, feature_chns=[8, 16, 32, 64, 128], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5,
+                   class_num=2, bilinear=False, num_domains=2, net_type="UNet2D5_dsbn")
+    cfg = {"dataset": {"tensor_type": "float"}, "network": net_cfg, "training": {},
+           "testing": {"domian_label": 1, "gpus": [0], "fpl": True, "evaluation_mode": True, "tta_mode": 1,
+                       "sliding_window_enable": True, "sliding_window_size": [16, 32, 32],
+                       "sliding_window_stride": [16, 32, 32]}}
+    agent = fplx.SegmentationAgent(cfg, "test")
+    torch.manual_seed(0)
+    agent.create_network()
+    vols = [{"image": torch.randn(1, 1, 16, 64, 32) * (1 + i), "names": ["v%d.nii.gz" % i]} for i in range(3)]
+    agent.set_loaders(test_loader=vols)
+    recorded = []
+
+    class Rec(fplx.Inferer):
+        def run(self, model, image, domain_label):
+            r = fplx.Inferer.run(self, model, image, domain_label)
+            recorded.append(r.cpu().numpy().copy())
+            return r
+
+    icfg = dict(cfg["testing"])
+    icfg["class_num"] = 2
+    agent.set_inferer(Rec(icfg))
+    srt = agent.infer()
+    assert len(recorded) == 18 and len(srt) == 3
+    assert [s[0][0] for s in srt] == sorted(s[0][0] for s in srt)
+    exp = {}
+    for i in range(3):
+        exp["v%d.nii.gz" % i] = float(N.fpl_filter(np.concatenate(recorded[6 * i:6 * i + 6], 0))["uncer_one"])
+    for (u, name) in srt:
+        assert abs(u[0] - exp[name]) <= 1e-5 * exp[name] + 1e-14      # (saturated softmax: variances ~1e-13)
+    # MC dropout really is active: the six passes of a volume differ
+    assert np.abs(recorded[0] - recorded[1]).max() > 1e-4
