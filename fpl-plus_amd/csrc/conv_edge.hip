@@ -330,6 +330,7 @@ __global__ void __launch_bounds__(256)
 outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ dl, float* __restrict__ part,
                    int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW) {
   __shared__ __attribute__((aligned(16))) char xs[SH * SW * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t dls[32][TH * TW];   // dlogits tile per class, bf16
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, khalf = lane >> 5;
@@ -353,16 +354,18 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
         v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + cit * 32 + ch * 8);
       *reinterpret_cast<uint4*>(xs + vox * 64 + ch * 16) = v;
     }
+    for (int i = threadIdx.x; i < ncls * TH * TW; i += 256) {      // coalesced along w
+      const int co = i / (TH * TW), vox = i % (TH * TW);
+      const int h = t.h0 + vox / TW, w = t.w0 + vox % TW;
+      float v = 0.f;
+      if (h < H && w < W) v = dl[((int64_t)t.n * ncls + co) * Vs + ((int64_t)t.d * H + h) * W + w];
+      dls[co][vox] = (bf16_t)v;
+    }
     __syncthreads();
     for (int ks = 0; ks < 16; ++ks) {
       const int hr = ks >> 1, ws = (ks & 1) * 16;
-      const int h = t.h0 + hr, w = t.w0 + ws + 8 * khalf;
       bf16x8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (r < ncls && h < H) {
-        const float* src = dl + ((int64_t)t.n * ncls + r) * Vs + ((int64_t)t.d * H + h) * W + w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bfrag[j] = (w + j < W) ? (bf16_t)src[j] : (bf16_t)0.f;
-      }
+      if (r < ncls) bfrag = *reinterpret_cast<const bf16x8*>(&dls[r][hr * TW + ws + 8 * khalf]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const int tap = wave + 4 * a;                  // wave-uniform

@@ -354,8 +354,9 @@ extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf,
 extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
                                        int h, int w, int cin, int cout, hipStream_t st);
 extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
-extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
-                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st);
+extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
+                                       int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                                       hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st);
@@ -633,9 +634,9 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
   if (dt == FPLX_BF16) {
     const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
-      int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, m, st);
+      int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, ws, m, st);
       if (r < 0) return r;
-      if (r == 1) { done = true; used = m; }
+      if (r == 1) { done = true; used = m; db = nullptr; }        // bias gradient came out of the same pass
     }
   }
   float* bpart = (float*)((char*)ws + used);

@@ -382,7 +382,7 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 template <int CIT>
 __global__ void __launch_bounds__(256)
 deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
-                  float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout) {
+                  float* __restrict__ part, float* __restrict__ bpart, int N, int D, int H, int W, int Cin, int Cout) {
   constexpr int KV = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                           // [CIT][KV][32] bf16
@@ -395,6 +395,12 @@ deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   const int64_t chunks = (V + KV - 1) / KV;
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+  // staging geometry: a thread always handles 16-byte chunk c16 of voxels vx0 and vx0 + 64 of the chunk
+  const int c16 = tid & 3, vx0 = tid >> 2;
+  const bool want_bias = bpart != nullptr && cig == 0;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
   f32x16 acc[2][CIT];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -404,24 +410,41 @@ deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
       for (int i = 0; i < 16; ++i) acc[t][c][i] = 0.f;
   for (int64_t ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
     const int64_t v0 = ch * KV;
-    for (int i = tid; i < CIT * KV * 4; i += 256) {
-      const int c = i / (KV * 4), vox = (i / 4) % KV, c16 = i & 3;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (v0 + vox < V) val = *reinterpret_cast<const uint4*>(x + (v0 + vox) * ldx + (cig * CIT + c) * 32 + c16 * 8);
-      *reinterpret_cast<uint4*>(xs + (c * KV + vox) * 64 + c16 * 16) = val;
-    }
-    for (int i = tid; i < 8 * KV * 4; i += 256) {
-      const int tap = i / (KV * 4), vox = (i / 4) % KV, c16 = i & 3;
-      uint4 val = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int vox = vx0 + 64 * half;
       int64_t vv = v0 + vox;
-      if (vv < V) {
+      const bool ok = vv < V;
+      uint4 xv[CIT], gv[8];
+#pragma unroll
+      for (int c = 0; c < CIT; ++c) xv[c] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) gv[tap] = make_uint4(0, 0, 0, 0);
+      if (ok) {
+#pragma unroll
+        for (int c = 0; c < CIT; ++c)
+          xv[c] = *reinterpret_cast<const uint4*>(x + vv * ldx + (cig * CIT + c) * 32 + c16 * 8);
         const int w0 = (int)(vv % W); vv /= W;
         const int h0 = (int)(vv % H); vv /= H;
         const int d0 = (int)(vv % D); vv /= D;
-        const int64_t ov = ((vv * 2 * D + 2 * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
-        val = *reinterpret_cast<const uint4*>(dy + ov * ldy + cot * 32 + c16 * 8);
+        const int64_t obase = ((vv * 2 * D + 2 * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+          const int64_t ov = obase + ((int64_t)(tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1);
+          gv[tap] = *reinterpret_cast<const uint4*>(dy + ov * ldy + cot * 32 + c16 * 8);
+        }
       }
-      *reinterpret_cast<uint4*>(dys + (tap * KV + vox) * 64 + c16 * 16) = val;
+#pragma unroll
+      for (int c = 0; c < CIT; ++c) *reinterpret_cast<uint4*>(xs + (c * KV + vox) * 64 + c16 * 16) = xv[c];
+#pragma unroll
+      for (int tap = 0; tap < 8; ++tap) {
+        *reinterpret_cast<uint4*>(dys + (tap * KV + vox) * 64 + c16 * 16) = gv[tap];
+        if (want_bias) {                                    // bias gradient = column sums of dy, for free
+          const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(&gv[tap]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum[j] += (float)b8[j];
+        }
+      }
     }
     __syncthreads();
     for (int ks = 0; ks < KV / 16; ++ks) {
@@ -449,6 +472,26 @@ deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         const int ci = (i & 3) + 8 * (i >> 2) + rbase;
         out[(((2 * wave + t) * CIT + c) * 32 + ci) * 32 + co] = acc[t][c][i];
       }
+  if (want_bias) {                                          // uniform per block
+    float* red = reinterpret_cast<float*>(smem);            // [256][8]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 32) {
+      const int cc = tid >> 3, j = tid & 7;                 // channel = cc * 8 + j, held by threads with c16 == cc
+      float t = 0.f;
+      for (int k = 0; k < 64; ++k) t += red[(k * 4 + cc) * 8 + j];
+      bpart[(int64_t)blockIdx.x * Cout + cot * 32 + tid] = t;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) deconv_bias_reduce(const float* __restrict__ bpart, int rows, int C, float* __restrict__ db) {
+  const int c = blockIdx.x;
+  float t = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 64) t += bpart[(int64_t)r * C + c];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) db[c] = t;
 }
 
 // dw[ci][co][tap] (torch ConvTranspose3d layout) = sum_b part[b][pair][tap][c][ci%32][co%32]
@@ -483,7 +526,7 @@ inline DwCfg dw_cfg(int n, int d, int h, int w, int cin, int cout) {
   if (nb < 1) nb = 1;
   if (nb > chunks) nb = (int)chunks;
   c.nblk = nb;
-  c.ws = (size_t)c.nblk * c.npairs * 8 * c.cit * 1024 * sizeof(float);
+  c.ws = (size_t)c.nblk * c.npairs * 8 * c.cit * 1024 * sizeof(float) + (size_t)c.nblk * cout * sizeof(float);
   return c;
 }
 
@@ -899,25 +942,28 @@ extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, i
   return dw_cfg(n, d, h, w, cin, cout).ws;
 }
 
-extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
-                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
+                                       int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                                       hipStream_t st) {
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
     return 0;
   const DwCfg c = dw_cfg(n, d, h, w, cin, cout);
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_deconv2_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
   dim3 grid(c.nblk, c.npairs);
   const size_t lds = (size_t)(c.cit + 8) * 128 * 64;
+  float* bpart = db ? (float*)((char*)ws + (size_t)c.nblk * c.npairs * 8 * c.cit * 1024 * sizeof(float)) : nullptr;
 #define LAUNCH_DW(CIT)                                                                                              \
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)deconv_wgrad_mfma<CIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    deconv_wgrad_mfma<CIT><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, \
-                                                   cin, cout);                                                      \
+    deconv_wgrad_mfma<CIT><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, bpart, n, d, \
+                                                   h, w, cin, cout);                                                \
   } while (0)
   if (c.cit == 4) LAUNCH_DW(4);
   else if (c.cit == 2) LAUNCH_DW(2);
   else LAUNCH_DW(1);
 #undef LAUNCH_DW
   const int64_t total = (int64_t)c.npairs * 8 * c.cit * 1024;
+  if (db) deconv_bias_reduce<<<cout, 64, 0, st>>>(bpart, c.nblk, cout, db);
   deconv_wgrad_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw);
   int rc = fplx_check_launch("mfma_deconv2_wgrad");
   return rc < 0 ? rc : 1;

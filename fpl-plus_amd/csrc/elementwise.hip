@@ -133,11 +133,7 @@ bn_act_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t 
   const int G = C / VEC;
   const int64_t total = voxels * G;
   const float slope = *slope_p;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int64_t v = i / G;
-    const int c0 = (int)(i % G) * VEC;
-    float a[VEC];
-    ldv<T, VEC>(y + v * ldy + c0, a);
+  auto one = [&](int64_t v, int c0, float (&a)[VEC]) {
     bool keep[VEC];
     if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
 #pragma unroll
@@ -148,6 +144,28 @@ bn_act_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t 
       a[j] = z;
     }
     stv<T, VEC>(out + v * ldo + c0, a);
+  };
+  const int64_t st = (int64_t)gridDim.x * EW_THREADS;
+  int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + 3 * st < total; i += 4 * st) {
+    float a[4][VEC];
+    int64_t v[4];
+    int c0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = (i + u * st) / G;
+      c0[u] = (int)((i + u * st) % G) * VEC;
+      ldv<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], c0[u], a[u]);
+  }
+  for (; i < total; i += st) {
+    const int64_t v = i / G;
+    const int c0 = (int)(i % G) * VEC;
+    float a[VEC];
+    ldv<T, VEC>(y + v * ldy + c0, a);
+    one(v, c0, a);
   }
 }
 
@@ -181,24 +199,40 @@ bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ 
     sdz[j] = sdx[j] = 0.f;
     m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
   }
+  auto consume = [&](int64_t v, const float (&a)[VEC], const float (&d)[VEC]) {
+    bool keep[VEC];
+    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z;
+      const bool kp = dc.on ? keep[j] : true;
+      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, kp, dc.inv_keep, z);
+      float da = d[j];
+      if (dc.on) da = kp ? d[j] * dc.inv_keep : 0.f;
+      sds += z > 0.f ? 0.f : da * z;
+      sdz[j] += dz;
+      sdx[j] = fmaf(dz, (a[j] - m[j]) * rs[j], sdx[j]);
+    }
+  };
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * VL + vl; v < voxels; v += (int64_t)gridDim.x * VL) {
+    // four voxels (8 x 16-byte loads) in flight per lane: the pass is pure HBM streaming
+    const int64_t st = (int64_t)gridDim.x * VL;
+    int64_t v = (int64_t)blockIdx.x * VL + vl;
+    for (; v + 3 * st < voxels; v += 4 * st) {
+      float a[4][VEC], d[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ldv<T, VEC>(y + (v + u * st) * ldy + c0, a[u]);
+        ldv<T, VEC>(dout + (v + u * st) * ldd + c0, d[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) consume(v + u * st, a[u], d[u]);
+    }
+    for (; v < voxels; v += st) {
       float a[VEC], d[VEC];
       ldv<T, VEC>(y + v * ldy + c0, a);
       ldv<T, VEC>(dout + v * ldd + c0, d);
-      bool keep[VEC];
-      if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float z;
-        const bool kp = dc.on ? keep[j] : true;
-        const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, kp, dc.inv_keep, z);
-        float da = d[j];
-        if (dc.on) da = kp ? d[j] * dc.inv_keep : 0.f;
-        sds += z > 0.f ? 0.f : da * z;
-        sdz[j] += dz;
-        sdx[j] = fmaf(dz, (a[j] - m[j]) * rs[j], sdx[j]);
-      }
+      consume(v, a, d);
     }
   }
   __shared__ float red[EW_THREADS][2 * VEC + 1];
@@ -261,12 +295,7 @@ bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ d
   const int G = C / VEC;
   const int64_t total = voxels * G;
   const float slope = *slope_p;
-  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int64_t v = i / G;
-    const int c0 = (int)(i % G) * VEC;
-    float a[VEC], d[VEC];
-    ldv<T, VEC>(y + v * ldy + c0, a);
-    ldv<T, VEC>(dout + v * ldd + c0, d);
+  auto one = [&](int64_t v, int c0, float (&a)[VEC], float (&d)[VEC]) {
     bool keep[VEC];
     if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
 #pragma unroll
@@ -278,6 +307,30 @@ bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ d
       d[j] = scale[c] * (dz - coef[c] - xh * coef[C + c]);
     }
     stv<T, VEC>(dy + v * ldo + c0, d);
+  };
+  const int64_t st = (int64_t)gridDim.x * EW_THREADS;
+  int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  for (; i + 3 * st < total; i += 4 * st) {                  // four vectors (8 loads) in flight per lane
+    float a[4][VEC], d[4][VEC];
+    int64_t v[4];
+    int c0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = (i + u * st) / G;
+      c0[u] = (int)((i + u * st) % G) * VEC;
+      ldv<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
+      ldv<T, VEC>(dout + v[u] * ldd + c0[u], d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], c0[u], a[u], d[u]);
+  }
+  for (; i < total; i += st) {
+    const int64_t v = i / G;
+    const int c0 = (int)(i % G) * VEC;
+    float a[VEC], d[VEC];
+    ldv<T, VEC>(y + v * ldy + c0, a);
+    ldv<T, VEC>(dout + v * ldd + c0, d);
+    one(v, c0, a, d);
   }
 }
 
