@@ -745,6 +745,170 @@ inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
   return c;
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd_tile: LDS-tiled implicit GEMM for the deep levels (Cin % 32 == 0, Cout % 64 == 0, small
+// volumes).  Block tile = 128 voxels x NT output channels, waves 2 (M) x 2 (N); per K-iteration
+// (one tap, 32 input channels) the shifted/zero-padded voxel rows (A) and the weight rows (B) are
+// fetched global -> registers while the previous iteration computes from the other LDS buffer,
+// then committed (64-byte rows, 16-byte-chunk XOR swizzle: conflict-free ds_read_b128) behind one
+// barrier.  blockIdx.z deals the taps (split-K) exactly like conv_fwd_direct.
+template <int NT>
+__global__ void __launch_bounds__(256)
+conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+              bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
+              float* __restrict__ stats, float* __restrict__ partial) {
+  constexpr int MTL = 128, NTW = NT / 64;                    // N tiles (32 wide) per wave
+  constexpr int A_BYTES = MTL * 64, B_BYTES = NT * 64, BUF = A_BYTES + B_BYTES;
+  constexpr int NB = NT / 64;                                // B chunks per thread (NT rows x 4 chunks / 256)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t m0 = (int64_t)blockIdx.x * MTL;
+  const int n0 = blockIdx.y * NT;
+  // staging geometry: thread -> 16-byte chunk c16 of rows row0 and row0 + 64
+  const int c16 = tid & 3, row0 = tid >> 2;
+  int an[2], ad[2], ah[2], aw[2];
+  bool aok[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    int64_t v = m0 + row0 + 64 * u;
+    aok[u] = v < V;
+    if (!aok[u]) v = 0;
+    aw[u] = (int)(v % W); v /= W;
+    ah[u] = (int)(v % H); v /= H;
+    ad[u] = (int)(v % D); v /= D;
+    an[u] = (int)v;
+  }
+  const int nkc = Cin / 32;
+  const int ntaps = (27 - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int niter = ntaps * nkc;
+  uint4 areg0, areg1, breg0, breg1;
+  breg1 = make_uint4(0, 0, 0, 0);
+// global -> registers for K-iteration IT (named registers: no runtime-indexed arrays, no scratch)
+#define TILE_FETCH(IT)                                                                                              \
+  do {                                                                                                              \
+    const int tap_ = blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * 32;                                \
+    const int kd_ = tap_ / 9 - 1, kh_ = (tap_ / 3) % 3 - 1, kw_ = tap_ % 3 - 1;                                     \
+    {                                                                                                               \
+      const int dd = ad[0] + kd_, hh = ah[0] + kh_, ww = aw[0] + kw_;                                               \
+      areg0 = make_uint4(0, 0, 0, 0);                                                                               \
+      if (aok[0] && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)                                    \
+        areg0 = *reinterpret_cast<const uint4*>(x + ((((int64_t)an[0] * D + dd) * H + hh) * W + ww) * ldx + kc_ + c16 * 8); \
+    }                                                                                                               \
+    {                                                                                                               \
+      const int dd = ad[1] + kd_, hh = ah[1] + kh_, ww = aw[1] + kw_;                                               \
+      areg1 = make_uint4(0, 0, 0, 0);                                                                               \
+      if (aok[1] && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)                                    \
+        areg1 = *reinterpret_cast<const uint4*>(x + ((((int64_t)an[1] * D + dd) * H + hh) * W + ww) * ldx + kc_ + c16 * 8); \
+    }                                                                                                               \
+    breg0 = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0) * Cin + kc_ + c16 * 8);         \
+    if (NB == 2) breg1 = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + 64) * Cin + kc_ + c16 * 8); \
+  } while (0)
+#define TILE_COMMIT(BUFI)                                                                                           \
+  do {                                                                                                              \
+    char* a_ = smem + (BUFI) * BUF;                                                                                 \
+    char* b_ = a_ + A_BYTES;                                                                                        \
+    const int r0_ = row0, r1_ = row0 + 64;                                                                          \
+    *reinterpret_cast<uint4*>(a_ + r0_ * 64 + ((c16 ^ ((r0_ >> 2) & 3)) * 16)) = areg0;                             \
+    *reinterpret_cast<uint4*>(a_ + r1_ * 64 + ((c16 ^ ((r1_ >> 2) & 3)) * 16)) = areg1;                             \
+    *reinterpret_cast<uint4*>(b_ + r0_ * 64 + ((c16 ^ ((r0_ >> 2) & 3)) * 16)) = breg0;                             \
+    if (NB == 2) *reinterpret_cast<uint4*>(b_ + r1_ * 64 + ((c16 ^ ((r1_ >> 2) & 3)) * 16)) = breg1;                \
+  } while (0)
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][j][i] = 0.f;
+
+  if (niter > 0) {
+    TILE_FETCH(0);
+    TILE_COMMIT(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    if (it + 1 < niter) TILE_FETCH(it + 1);
+    const char* a = smem + (it & 1) * BUF;
+    const char* b = a + A_BYTES;
+    bf16x8 fa[2][2], fb[2][NTW];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int c = 2 * s + khalf;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = wm * 64 + t * 32 + r;
+        fa[s][t] = *reinterpret_cast<const bf16x8*>(a + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
+      }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int row = wn * (NT / 2) + j * 32 + r;
+        fb[s][j] = *reinterpret_cast<const bf16x8*>(b + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][t], fb[s][j], acc[t][j], 0, 0, 0);
+    if (it + 1 < niter) TILE_COMMIT((it + 1) & 1);
+    __syncthreads();
+  }
+#undef TILE_FETCH
+#undef TILE_COMMIT
+
+  const int rh = khalf * 4;
+  if (partial) {
+    float* pz = partial + (int64_t)blockIdx.z * V * Cout;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int co = n0 + wn * (NT / 2) + j * 32 + r;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t v = m0 + wm * 64 + t * 32 + (i & 3) + 8 * (i >> 2) + rh;
+          if (v < V) pz[v * Cout + co] = acc[t][j][i];
+        }
+    }
+    return;
+  }
+  float* red = reinterpret_cast<float*>(smem);               // [2 (wm)][2][NT]
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int cl = wn * (NT / 2) + j * 32 + r, co = n0 + cl;
+    const float bv = bias ? bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t v = m0 + wm * 64 + t * 32 + (i & 3) + 8 * (i >> 2) + rh;
+        if (v < V) {
+          const float o = acc[t][j][i] + bv;
+          y[v * ldy + co] = (bf16_t)o;
+          s1 += o;
+          s2 = fmaf(o, o, s2);
+        }
+      }
+    if (stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) { red[(wm * 2 + 0) * NT + cl] = s1; red[(wm * 2 + 1) * NT + cl] = s2; }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int i = tid; i < 2 * NT; i += 256) {
+      const int which = i / NT, c = i % NT;
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c];
+    }
+  }
+}
+
 // split-K finish: y = bf16(sum_z partial[z] + bias), statistics rows; thread = voxel-lane x 8 channels
 __global__ void __launch_bounds__(256)
 splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, const float* __restrict__ bias,
@@ -787,14 +951,17 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
   }
 }
 
-struct DirectCfg { int mt, ntl, ksplit, fin_blocks; };
+struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt; int64_t mblocks; };
 
-inline DirectCfg direct_cfg(int64_t V, int cout) {
+inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
   DirectCfg c;
   if (cout % 64 == 0) { c.mt = 2; c.ntl = 2; }
   else { c.mt = 4; c.ntl = 1; }
+  // LDS-tiled kernel (128 voxels x 128|64 channels per block) when the shape allows
+  c.tile_nt = (cin % 32 == 0 && cout % 64 == 0) ? (cout % 128 == 0 ? 128 : 64) : 0;
+  c.mblocks = c.tile_nt ? (V + 127) / 128 : (V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32);
   // small volumes (deep levels) do not fill 256 CUs: deal the 27 taps to 3 / 9 / 27 blocks
-  const int64_t blocks = ((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)) * (cout / (c.ntl * 32));
+  const int64_t blocks = c.mblocks * (c.tile_nt ? cout / c.tile_nt : cout / (c.ntl * 32));
   c.ksplit = 1;
   if (cout % 8 == 0 && cout <= 2048) {
     if (blocks * 9 < 400) c.ksplit = 27;
@@ -817,15 +984,15 @@ extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, 
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
   const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout);
   if (c.ksplit > 1) return c.fin_blocks;
-  return (int)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32));
+  return (int)c.mblocks;
 }
 
 extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0 || stream_ok(d, h, w, cin, cout)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
 }
 
@@ -852,7 +1019,7 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
     return rc0 < 0 ? rc0 : 1;
   }
   const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout);
   const int ks = c.ksplit;
   float* partial = nullptr;
   if (ks > 1) {
@@ -861,6 +1028,21 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
       return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
                        (size_t)ks * V * cout * sizeof(float));
     partial = (float*)ws;
+  }
+  if (c.tile_nt) {
+    dim3 tg((unsigned)c.mblocks, cout / c.tile_nt, ks);
+    if (c.tile_nt == 128) {
+      constexpr int LDS = 2 * (128 * 64 + 128 * 64);
+      conv_fwd_tile<128><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w,
+                                               cin, cout, stats, partial);
+    } else {
+      constexpr int LDS = 2 * (128 * 64 + 64 * 64);
+      conv_fwd_tile<64><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w,
+                                              cin, cout, stats, partial);
+    }
+    if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
+    int rct = fplx_check_launch("mfma_conv3d_fwd_tile");
+    return rct < 0 ? rct : 1;
   }
   dim3 grid((unsigned)((V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32)), cout / (c.ntl * 32), ks);
   if (c.ntl == 2)
