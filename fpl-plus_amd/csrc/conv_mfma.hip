@@ -9,6 +9,7 @@
 //                   the universal path (any spatial size, Cin % 16 == 0, Cout % 32 == 0).  With the
 //                   mirrored pack it is also the data-gradient kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -168,8 +169,35 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
   return r;
 }
 
+// one depth step of conv_wgrad_stream for wave WV: its taps WV, WV+4, ... are compile-time constants, so the
+// k-loop is straight-line code: 2 + 14 transposed reads for step ks+1 in flight behind the 7 MFMAs of step ks
+template <int WV, int TW>
+__device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* sl0, const char* sl1, const char* sl2,
+                                                 const char* dys, int lane_off) {
+  constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16, NT = (27 - WV + 3) / 4;     // NT = 7 (6 for wave 3)
+  // Two co-resident blocks (2 waves per SIMD) hide the LDS latency of each other; a block issues the 16
+  // transposed reads of a k-step up front and its 7 MFMAs wait for their own operands only (counted waits).
+  // Register budget matters more than intra-wave double buffering here: 112 accumulator + < 144 other
+  // registers keep two waves per SIMD.
+#pragma unroll 1
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
+    bf16x8 fa[NT];
+    const bf16x8 fb = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int tap = WV + 4 * i;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;              // folded: i is unrolled, WV constant
+      const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
+      fa[i] = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i], 0, 0, 0);
+  }
+}
+
 template <int TW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
                   int dsegs, int dlen) {
@@ -232,40 +260,16 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
     load_x(d + 1);
     load_dy(d);
     __syncthreads();
-    // software pipeline over k-steps: all transposed reads of step ks+1 (1 dy fragment + up to 7 x
-    // fragments) are requested before the MFMAs of step ks are issued
-    constexpr int NKS = TH * TW / 16;
-    bf16x8 fbw[2], faw[2][7];
-    auto load_ks = [&](int ks, int buf) {
-      const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-      fbw[buf] = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int tap = wave + 4 * i;
-        if (tap < 27) {                                   // wave-uniform
-          const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-          const char* sl = xs + ((d + kd) % 3) * (SLAB * 64);          // slab of depth d + kd - 1
-          faw[buf][i] = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
-        }
+    {
+      const char* sl0 = xs + ((d + 0) % 3) * (SLAB * 64);        // depth d - 1
+      const char* sl1 = xs + ((d + 1) % 3) * (SLAB * 64);        // depth d
+      const char* sl2 = xs + ((d + 2) % 3) * (SLAB * 64);        // depth d + 1
+      switch (wave) {                                            // wave-uniform
+        case 0: wgrad_depth_step<0, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
+        case 1: wgrad_depth_step<1, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
+        case 2: wgrad_depth_step<2, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
+        default: wgrad_depth_step<3, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
       }
-    };
-    load_ks(0, 0);
-#pragma unroll 2
-    for (int ks = 0; ks < NKS; ++ks) {
-      const int cur = ks & 1;
-      if (ks + 1 < NKS) {
-        if (cur == 0) load_ks(ks + 1, 1);
-        else load_ks(ks + 1, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        if (wave + 4 * i < 27) {
-          if (cur == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
-          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -727,8 +731,19 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 }
 
 struct StreamCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
+inline int stream_min_w() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FPLX_STREAM_MIN_W");       // tuning knob (benchmarks only)
+    v = e ? atoi(e) : 64;
+  }
+  return v;
+}
 inline bool stream_ok(int d, int h, int w, int cin, int cout) {
-  return (cin == 32 || cin == 64) && cout % 32 == 0 && h >= 16 && w >= 64 && d >= 4;
+  // below W = 128 (level 1) the LDS-tiled GEMM kernel is faster whenever it applies (Cout % 64 == 0)
+  const bool tile_applies = cin % 32 == 0 && cout % 64 == 0;
+  return (cin == 32 || cin == 64) && cout % 32 == 0 && h >= 16 && w >= stream_min_w() && d >= 4 &&
+         (w >= 128 || !tile_applies);
 }
 inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
   StreamCfg c;
