@@ -551,10 +551,13 @@ template <int CIN>
 struct StreamGeo {
   static constexpr int ROWB = CIN * 2, CH = ROWB / 16;
   static constexpr int SW = 34, SH = 10, SLAB = SW * SH;
-  static constexpr int GT = CIN == 32 ? 9 : 3, NG = 27 / GT;
+  // Cin = 32: all 27 taps of the block's 32 output channels stay resident in LDS (55 KB) and the slab ring
+  // has a 4th slot, so one barrier per depth suffices.  Cin = 64: 3 taps at a time through a 2-buffer ring.
+  static constexpr int GT = CIN == 32 ? 27 : 3, NG = 27 / GT;
+  static constexpr int NSLOT = CIN == 32 ? 4 : 3, NWBUF = NG == 1 ? 1 : 2;
   static constexpr int SLAB_BYTES = SLAB * ROWB, WBUF_BYTES = GT * 32 * ROWB;
-  static constexpr int NLD = (SLAB * CH + 255) / 256, NLW = (GT * 32 * CH + 255) / 256;
-  static constexpr int LDS = 3 * SLAB_BYTES + 2 * WBUF_BYTES;
+  static constexpr int NLD = (SLAB * CH + 255) / 256, NLW = NG == 1 ? 1 : (GT * 32 * CH + 255) / 256;
+  static constexpr int LDS = NSLOT * SLAB_BYTES + NWBUF * WBUF_BYTES;
   static __device__ __forceinline__ int swz(int row) { return (row / (16 / CH)) % CH; }
 };
 
@@ -566,7 +569,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
   typedef StreamGeo<CIN> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;
-  char* wbuf = smem + 3 * G::SLAB_BYTES;
+  char* wbuf = smem + G::NSLOT * G::SLAB_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, khalf = lane >> 5;
   int b = blockIdx.x;
@@ -593,7 +596,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
     }
   };
   auto slab_commit = [&](int d) {                // registers -> LDS slot of depth d
-    char* dst = slabs + ((d + 1) % 3) * G::SLAB_BYTES;
+    char* dst = slabs + ((d + 1) % G::NSLOT) * G::SLAB_BYTES;
 #pragma unroll
     for (int k = 0; k < G::NLD; ++k) {
       const int i = tid + k * 256;
@@ -631,7 +634,15 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
   slab_fetch(d0 - 1); slab_commit(d0 - 1);
   slab_fetch(d0); slab_commit(d0);
   slab_fetch(d0 + 1);
-  w_fetch(0); w_commit(0);
+  if constexpr (G::NG == 1) {                    // resident weights: straight global -> LDS, once per block
+    for (int i = tid; i < 27 * 32 * G::CH; i += 256) {
+      const int row = i / G::CH, c = i % G::CH;
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * CIN + c * 8);
+      *reinterpret_cast<uint4*>(wbuf + row * G::ROWB + ((c ^ G::swz(row)) * 16)) = v;
+    }
+  } else {
+    w_fetch(0); w_commit(0);
+  }
   __syncthreads();
   slab_commit(d0 + 1);
   __syncthreads();
@@ -646,7 +657,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 #pragma unroll 1
     for (int g = 0; g < G::NG; ++g) {
       const int gn = (g + 1 == G::NG) ? 0 : g + 1;
-      w_fetch(gn);
+      if constexpr (G::NG > 1) w_fetch(gn);
       const char* wb_ = wbuf + wpar * G::WBUF_BYTES;
       // software pipeline: the fragments of tap tl+1 are requested before the MFMAs of tap tl are
       // issued, so every ds_read_b128 has a full tap of matrix work (2*KS MFMAs) to land behind
@@ -655,7 +666,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       auto load_tap = [&](int tl, int buf) {
         const int tap = g * G::GT + tl;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        const char* sl = slabs + ((d + kd) % 3) * G::SLAB_BYTES;          // depth d + kd - 1
+        const char* sl = slabs + ((d + kd) % G::NSLOT) * G::SLAB_BYTES;   // depth d + kd - 1
         const int brow = tl * 32 + r;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -681,7 +692,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
       // the ring alternates buffers across the wrap-around into the next depth as well (NG is odd)
-      {
+      if constexpr (G::NG > 1) {
         wpar ^= 1;
         char* dst = wbuf + wpar * G::WBUF_BYTES;
 #pragma unroll
@@ -690,8 +701,8 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
           const int row = i / G::CH, c = i % G::CH;
           if (i < G::GT * 32 * G::CH) *reinterpret_cast<uint4*>(dst + row * G::ROWB + ((c ^ G::swz(row)) * 16)) = wreg[k];
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
     // epilogue of depth d
 #pragma unroll
@@ -712,7 +723,9 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       }
     }
     if (d + 1 < d1) {
-      slab_commit(d + 2);                        // slot of depth d-1, free since the last barrier
+      // 3 slots: the slot of depth d-1, free since the last group barrier; 4 slots: the slot of depth d-2,
+      // free since the barrier that ended depth d-1 - either way one barrier publishes the new slab
+      slab_commit(d + 2);
       __syncthreads();
     }
   }
