@@ -221,18 +221,19 @@ stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, i
 }
 
 // ------------------------------------------------------------------------------------------
-// out_conv forward: rows = voxels (direct global fragments), K = 9 in-plane taps x Cin,
-// cols = classes padded to 32 (B fragments built once from the fp32 pack [9][ncls][Cin])
+// out_conv forward: one 8 x 32 in-plane tile at a time (grid-strided).  The x tile with its in-plane halo is
+// staged once in LDS (64-byte-chunk rows, XOR swizzle for CIN = 32) and feeds all 9 taps; rows = voxels,
+// K = 9 taps x Cin, cols = classes padded to 32 (B fragments built once from the fp32 pack [9][ncls][Cin]).
 template <int KSTEPS>      // Cin / 16
 __global__ void __launch_bounds__(256)
 outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
-                 float* __restrict__ out, int N, int D, int H, int W, int ncls) {
-  constexpr int CIN = KSTEPS * 16, MT = 4;
-  __shared__ bf16x8 bsh[9 * KSTEPS][64];            // B fragments, lane-linear (conflict-free ds_read_b128)
+                 float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW) {
+  constexpr int CIN = KSTEPS * 16, ROWB = CIN * 2, CH = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) char xs[SH * SW * ROWB];
+  __shared__ bf16x8 bsh[9 * KSTEPS][64];            // B fragments, lane-linear
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, kh8 = (lane >> 5) * 8;
-  const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * (MT * 32);
+  const int r = lane & 31, khalf = lane >> 5, kh8 = khalf * 8;
+  const int64_t Vs = (int64_t)D * H * W;
   for (int f = wave; f < 9 * KSTEPS; f += 4) {
     const int tap = f / KSTEPS, s = f % KSTEPS;
     bf16x8 b;
@@ -241,85 +242,98 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
       b[j] = r < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r) * CIN + s * 16 + kh8 + j] : (bf16_t)0.f;
     bsh[f][lane] = b;
   }
-  __syncthreads();
-  int vh[MT], vw[MT];
-  int64_t vb[MT];
-  bool vok[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t) {
-    int64_t v = m0 + t * 32 + r;
-    vok[t] = v < V;
-    if (!vok[t]) v = 0;
-    vb[t] = v;
-    vw[t] = (int)(v % W);
-    vh[t] = (int)((v / W) % H);
-  }
-  f32x16 acc[MT];
-#pragma unroll
-  for (int t = 0; t < MT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int kh = tap / 3 - 1, kw = tap % 3 - 1;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const bf16x8 b = bsh[tap * KSTEPS + s][lane];
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int hh = vh[t] + kh, ww = vw[t] + kw;
-        const bool ok = vok[t] && hh >= 0 && hh < H && ww >= 0 && ww < W;
-        const bf16_t* ap = x + (ok ? vb[t] + kh * W + kw : 0) * ldx + kh8 + s * 16;
-        const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap) : zero;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
-      }
+  const float bv = (r < ncls && bias) ? bias[r] : 0.f;
+  auto swz = [](int vox) { return (vox / (16 / CH)) % CH; };
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const Tile t = tile_of(tt, D, tilesH, tilesW);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * SW * CH; i += 256) {
+      const int vox = i / CH, c = i % CH;
+      const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + c * 8);
+      *reinterpret_cast<uint4*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16)) = v;
     }
-  }
-  if (r < ncls) {
-    const float bv = bias ? bias[r] : 0.f;
+    __syncthreads();
+    f32x16 acc[2];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t v = m0 + t * 32 + (i & 3) + 8 * (i >> 2) + (lane >> 5) * 4;
-        if (v < V) {
-          const int64_t n = v / Vs, vs = v % Vs;
-          out[(n * ncls + r) * Vs + vs] = acc[t][i] + bv;
+      for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const bf16x8 b = bsh[tap * KSTEPS + s][lane];
+        const int c = 2 * s + khalf;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int vox = (wave * 2 + m + kh) * SW + r + kw;
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16));
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0);
         }
       }
+    }
+    if (r < ncls) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int h = t.h0 + wave * 2 + m;
+        if (h < H) {
+          float* orow = out + ((int64_t)t.n * ncls + r) * Vs + ((int64_t)t.d * H + h) * W;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int w = t.w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+            if (w < W) orow[w] = acc[m][i] + bv;
+          }
+        }
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// out_conv data gradient (class_num -> C0): thread = voxel x 8 channels, fp32 planar dlogits in,
-// bf16 NDHWC out with one 16-byte store; weights wb[tap'][ci][co] (mirrored pack) are wave-uniform
+// out_conv data gradient (class_num -> C0): thread = one voxel x all C0 channels; the fp32 planar dlogits
+// are read once (9 taps x classes, coalesced along w), the mirrored pack wb[tap'][ci][co] sits in LDS as
+// fp32 [tap][co][ci] and is read by broadcast; one 16-byte store per 8 channels.
+template <int C0>
 __global__ void __launch_bounds__(256)
 outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx,
-                   int N, int D, int H, int W, int C0, int ncls) {
+                   int N, int D, int H, int W, int ncls) {
+  __shared__ float wsh[9 * 4 * C0];                  // ncls <= 4 on this path
+  for (int i = threadIdx.x; i < 9 * ncls * C0; i += 256) {
+    const int ci = i % C0, co = (i / C0) % ncls, tap = i / (C0 * ncls);
+    wsh[(tap * 4 + co) * C0 + ci] = (float)wb[((int64_t)tap * C0 + ci) * ncls + co];
+  }
+  __syncthreads();
   const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int ci0 = blockIdx.y * 8;
   if (v >= V) return;
   const int w = (int)(v % W), h = (int)((v / W) % H);
   const int64_t n = v / Vs, vs = v % Vs;
-  float acc[8];
+  float acc[C0];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int j = 0; j < C0; ++j) acc[j] = 0.f;
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int kh = tap / 3 - 1, kw = tap % 3 - 1;
     const int hh = h + kh, ww = w + kw;
-    if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+    const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
     for (int co = 0; co < ncls; ++co) {
-      const float g = dl[(n * ncls + co) * Vs + vs + kh * W + kw];
+      const float g = ok ? dl[(n * ncls + co) * Vs + vs + kh * W + kw] : 0.f;
+      const float* wr = wsh + (tap * 4 + co) * C0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(g, (float)wb[((int64_t)tap * C0 + ci0 + j) * ncls + co], acc[j]);
+      for (int j = 0; j < C0; ++j) acc[j] = fmaf(g, wr[j], acc[j]);
     }
   }
-  bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
-  *reinterpret_cast<bf16x8*>(dx + v * ldx + ci0) = o;
+  for (int j0 = 0; j0 < C0; j0 += 8) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j0 + j];
+    *reinterpret_cast<bf16x8*>(dx + v * ldx + j0) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -463,21 +477,24 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
 extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
                                      int d, int h, int w, int cin, int ncls, hipStream_t st) {
   if (!(cin == 16 || cin == 32 || cin == 64) || ncls > 32 || ldx % 8 != 0 || ((uintptr_t)x % 16)) return 0;
-  const int64_t V = (int64_t)n * d * h * w;
-  const unsigned nb = (unsigned)((V + 511) / 512);
-  if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
-  else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
-  else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls);
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = (int)(nt < 2048 ? nt : 2048);
+  if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
+  else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
+  else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
   int rc = fplx_check_launch("edge_outconv_fwd");
   return rc < 0 ? rc : 1;
 }
 
 extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
                                        int c0, int ncls, hipStream_t st) {
-  if (c0 % 8 != 0 || ldx % 8 != 0 || ((uintptr_t)dx % 16)) return 0;
+  if (!(c0 == 16 || c0 == 32 || c0 == 64) || ncls > 4 || ldx % 8 != 0 || ((uintptr_t)dx % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
-  dim3 grid((unsigned)((V + 255) / 256), c0 / 8);
-  outconv_dgrad_valu<<<grid, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, c0, ncls);
+  const unsigned nb = (unsigned)((V + 255) / 256);
+  if (c0 == 16) outconv_dgrad_valu<16><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
+  else if (c0 == 32) outconv_dgrad_valu<32><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
+  else outconv_dgrad_valu<64><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
   int rc = fplx_check_launch("edge_outconv_dgrad");
   return rc < 0 ? rc : 1;
 }
