@@ -225,10 +225,11 @@ def main():
     ktable = []
     if timer is not None:
         timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
+        side = net.engine.use_side_stream
         net.engine.use_side_stream = False      # one kernel at a time: clean per-launch durations
         run(args.warmup + args.steps, 2)
         torch.cuda.synchronize()
-        net.engine.use_side_stream = True
+        net.engine.use_side_stream = side
         timer.on = False
     if timer is not None and rank == 0:
         summ = timer.summary()

@@ -376,19 +376,36 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
       dls[co][vox] = (bf16_t)v;
     }
     __syncthreads();
-    for (int ks = 0; ks < 16; ++ks) {
+    // k-steps two at a time with the fragments of the next step requested before the MFMAs of the current one
+    auto load_ks = [&](int ks, bf16x8& fb, bf16x8 (&fa)[3]) {
       const int hr = ks >> 1, ws = (ks & 1) * 16;
-      bf16x8 bfrag = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (r < ncls) bfrag = *reinterpret_cast<const bf16x8*>(&dls[r][hr * TW + ws + 8 * khalf]);
+      fb = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < ncls) fb = *reinterpret_cast<const bf16x8*>(&dls[r][hr * TW + ws + 8 * khalf]);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const int tap = wave + 4 * a;                  // wave-uniform
         if (tap < 9) {
           const int kh = tap / 3, kw = tap % 3;
-          const bf16x8 afrag = tr_frag64(xs + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
-          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[a], 0, 0, 0);
+          fa[a] = tr_frag64(xs + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
         }
       }
+    };
+    bf16x8 fb0, fb1, fa0[3], fa1[3];
+    load_ks(0, fb0, fa0);
+#pragma unroll 1
+    for (int ks = 0; ks < 16; ks += 2) {
+      load_ks(ks + 1, fb1, fa1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (wave + 4 * a < 9) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[a], fb0, acc[a], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 2 < 16) load_ks(ks + 2, fb0, fa0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        if (wave + 4 * a < 9) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[a], fb1, acc[a], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // part[block][cit][tap][ci 32][co 32]

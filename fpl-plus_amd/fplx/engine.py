@@ -12,6 +12,8 @@ Reference semantics implemented here (paths under /root/reference/PyMIC/pymic):
   DownBlock / UpBlock             net/net3d/unet2d5_dsbn.py:108-129 / 156-188
   DomainSpecificBatchNorm3d       net_run_dsbn/dsbn.py:54-57 (bns[domain_label[0]] for the batch)
 """
+import os
+
 import torch
 from . import ops
 from ._lib import F32, BF16
@@ -32,7 +34,8 @@ class Engine(object):
         self.ws_side = None
         self._pack_cache = None
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
-        self.use_side_stream = True
+        # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
+        self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
