@@ -197,7 +197,7 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* s
 }
 
 template <int TW>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
                   int dsegs, int dlen) {
@@ -219,26 +219,48 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   const bf16_t* xb = x + cit * 32;
   const bf16_t* dyb = dy + cot * 32;
 
-  auto load_x = [&](int d) {
-    char* dst = xs + ((d + 1) % 3) * (SLAB * 64);
+  // async-stage split: the next depth's x slab and dy slab travel global -> registers while the current
+  // depth is computed, and are committed to LDS behind the barrier that ends the depth
+  constexpr int NLX = (SLAB * 4 + 255) / 256, NLY = TH * TW * 4 / 256;
+  uint4 xreg[NLX], yreg[NLY];
+  auto fetch_x = [&](int d) {
     const bool dok = d >= 0 && d < D;
-    for (int i = tid; i < SLAB * 4; i += 256) {
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      const int i = tid + k * 256;
       const int vox = i >> 2, ch = i & 3;
       const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
+      if (i < SLAB * 4 && dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
         v = *reinterpret_cast<const uint4*>(xb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + ch * 8);
-      *reinterpret_cast<uint4*>(dst + vox * 64 + ch * 16) = v;
+      xreg[k] = v;
     }
   };
-  auto load_dy = [&](int d) {
-    for (int i = tid; i < TH * TW * 4; i += 256) {
+  auto commit_x = [&](int d) {
+    char* dst = xs + ((d + 1) % 3) * (SLAB * 64);
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      const int i = tid + k * 256;
+      if (i < SLAB * 4) *reinterpret_cast<uint4*>(dst + (i >> 2) * 64 + (i & 3) * 16) = xreg[k];
+    }
+  };
+  auto fetch_dy = [&](int d) {
+#pragma unroll
+    for (int k = 0; k < NLY; ++k) {
+      const int i = tid + k * 256;
       const int vox = i >> 2, ch = i & 3;
       const int hh = vox / TW + h0, ww = vox % TW + w0;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (hh < H && ww < W)
+      if (d < D && hh < H && ww < W)
         v = *reinterpret_cast<const uint4*>(dyb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldy + ch * 8);
-      *reinterpret_cast<uint4*>(dys + vox * 64 + ch * 16) = v;
+      yreg[k] = v;
+    }
+  };
+  auto commit_dy = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLY; ++k) {
+      const int i = tid + k * 256;
+      *reinterpret_cast<uint4*>(dys + (i >> 2) * 64 + (i & 3) * 16) = yreg[k];
     }
   };
 
@@ -253,13 +275,18 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   if (d0 < d1) {
-    load_x(d0 - 1);
-    load_x(d0);
+    fetch_x(d0 - 1); commit_x(d0 - 1);
+    fetch_x(d0); commit_x(d0);
+    fetch_x(d0 + 1); commit_x(d0 + 1);
+    fetch_dy(d0); commit_dy();
   }
+  __syncthreads();
   for (int d = d0; d < d1; ++d) {
-    load_x(d + 1);
-    load_dy(d);
-    __syncthreads();
+    const bool more = d + 1 < d1;
+    if (more) {                                  // in flight during this depth's MFMAs
+      fetch_x(d + 2);
+      fetch_dy(d + 1);
+    }
     {
       const char* sl0 = xs + ((d + 0) % 3) * (SLAB * 64);        // depth d - 1
       const char* sl1 = xs + ((d + 1) % 3) * (SLAB * 64);        // depth d
@@ -271,7 +298,12 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         default: wgrad_depth_step<3, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
       }
     }
-    __syncthreads();
+    __syncthreads();                             // every wave is done with depth d-1's slot and the dy slab
+    if (more) {
+      commit_x(d + 2);
+      commit_dy();
+      __syncthreads();
+    }
   }
   // partial tiles: part[blockIdx.x][pair][tap][ci][co]
   float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
