@@ -175,15 +175,12 @@ template <int WV, int TW>
 __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* sl0, const char* sl1, const char* sl2,
                                                  const char* dys, int lane_off) {
   constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16, NT = (27 - WV + 3) / 4;     // NT = 7 (6 for wave 3)
-  // Two co-resident blocks (2 waves per SIMD) hide the LDS latency of each other; a block issues the 16
-  // transposed reads of a k-step up front and its 7 MFMAs wait for their own operands only (counted waits).
-  // Register budget matters more than intra-wave double buffering here: 112 accumulator + < 144 other
-  // registers keep two waves per SIMD.
-#pragma unroll 1
-  for (int ks = 0; ks < NKS; ++ks) {
+  // software pipeline over k-steps (two per trip, static buffer parity): the 2 + 2*NT transposed reads of
+  // step ks+1 are requested before the NT MFMAs of step ks are issued
+  bf16x8 fbw[2], faw[2][NT];
+  auto load_ks = [&](int ks, bf16x8& fb, bf16x8 (&fa)[NT]) {
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-    bf16x8 fa[NT];
-    const bf16x8 fb = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
+    fb = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int tap = WV + 4 * i;
@@ -191,8 +188,20 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* s
       const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
       fa[i] = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
     }
+  };
+  load_ks(0, fbw[0], faw[0]);
+#pragma unroll 1
+  for (int ks = 0; ks < NKS; ks += 2) {
+    load_ks(ks + 1, fbw[1], faw[1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb, acc[i], 0, 0, 0);
+    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ks + 2 < NKS) load_ks(ks + 2, fbw[0], faw[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
