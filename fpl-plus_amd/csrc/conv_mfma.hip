@@ -815,20 +815,23 @@ inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
 }
 
 // ------------------------------------------------------------------------------------------
-// conv_fwd_tile: LDS-tiled implicit GEMM for the deep levels (Cin % 32 == 0, Cout % 64 == 0, small
-// volumes).  Block tile = 128 voxels x NT output channels, waves 2 (M) x 2 (N); per K-iteration
-// (one tap, 32 input channels) the shifted/zero-padded voxel rows (A) and the weight rows (B) are
-// fetched global -> registers while the previous iteration computes from the other LDS buffer,
-// then committed (64-byte rows, 16-byte-chunk XOR swizzle: conflict-free ds_read_b128) behind one
-// barrier.  blockIdx.z deals the taps (split-K) exactly like conv_fwd_direct.
-template <int NT>
+// conv_fwd_tile: LDS-tiled implicit GEMM (Cin % KC == 0, Cout % 64 == 0) for every 3x3x3 layer that is not on
+// the slab-streaming kernel (levels 1-4).  Block tile = 128 voxels x NT output channels, waves 2 (M) x 2 (N).
+// Per K-iteration (one tap, KC = 32 or 64 input channels) the shifted / zero-padded voxel rows (A) and the
+// weight rows (B) travel global -> registers while the previous iteration computes out of the other LDS
+// buffer, then are committed (16-byte-chunk XOR swizzle: conflict-free ds_read_b128) behind ONE barrier.
+// KC = 64 doubles the matrix work per barrier and per global-load round trip.  blockIdx.z deals the taps
+// (split-K) exactly like conv_fwd_direct.
+template <int NT, int KC>
 __global__ void __launch_bounds__(256)
 conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
               float* __restrict__ stats, float* __restrict__ partial) {
   constexpr int MTL = 128, NTW = NT / 64;                    // N tiles (32 wide) per wave
-  constexpr int A_BYTES = MTL * 64, B_BYTES = NT * 64, BUF = A_BYTES + B_BYTES;
-  constexpr int NB = NT / 64;                                // B chunks per thread (NT rows x 4 chunks / 256)
+  constexpr int ROWB = KC * 2, CH = KC / 8, RP = 256 / CH;   // row bytes, 16-byte chunks per row, rows per pass
+  constexpr int PA = MTL / RP, PB = NT / RP;                 // staging passes (chunks per thread) for A and B
+  constexpr int KS = KC / 16;
+  constexpr int A_BYTES = MTL * ROWB, B_BYTES = NT * ROWB, BUF = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, khalf = lane >> 5;
@@ -836,54 +839,64 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   const int64_t V = (int64_t)N * D * H * W;
   const int64_t m0 = (int64_t)blockIdx.x * MTL;
   const int n0 = blockIdx.y * NT;
-  // staging geometry: thread -> 16-byte chunk c16 of rows row0 and row0 + 64
-  const int c16 = tid & 3, row0 = tid >> 2;
-  int an[2], ad[2], ah[2], aw[2];
-  bool aok[2];
+  // staging geometry: thread -> 16-byte chunk c16 of rows row0 + RP * u
+  const int c16 = tid % CH, row0 = tid / CH;
+  // per staged row: pointer to its centre-tap voxel and a 27-bit mask of the taps that stay inside the volume,
+  // so a K-iteration costs one 64-bit add and one bit test per row instead of the full index arithmetic
+  const bf16_t* abase[PA];
+  uint32_t amask[PA];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    int64_t v = m0 + row0 + 64 * u;
-    aok[u] = v < V;
-    if (!aok[u]) v = 0;
-    aw[u] = (int)(v % W); v /= W;
-    ah[u] = (int)(v % H); v /= H;
-    ad[u] = (int)(v % D); v /= D;
-    an[u] = (int)v;
+  for (int u = 0; u < PA; ++u) {
+    int64_t v = m0 + row0 + RP * u;
+    const bool ok = v < V;
+    if (!ok) v = 0;
+    abase[u] = x + v * ldx + c16 * 8;
+    const int ww0 = (int)(v % W); v /= W;
+    const int hh0 = (int)(v % H); v /= H;
+    const int dd0 = (int)(v % D);
+    uint32_t m = 0;
+    for (int t = 0; t < 27; ++t) {
+      const int dd = dd0 + t / 9 - 1, hh = hh0 + (t / 3) % 3 - 1, ww = ww0 + t % 3 - 1;
+      if (ok && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W) m |= 1u << t;
+    }
+    amask[u] = m;
   }
-  const int nkc = Cin / 32;
+  const int nkc = Cin / KC;
   const int ntaps = (27 - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
   const int niter = ntaps * nkc;
-  uint4 areg0, areg1, breg0, breg1;
-  breg1 = make_uint4(0, 0, 0, 0);
-// global -> registers for K-iteration IT (named registers: no runtime-indexed arrays, no scratch)
+  auto swz = [](int row) { return (row / (16 / CH)) % CH; };
+  // named staging registers (runtime-indexed arrays would go to scratch)
+  uint4 areg0, areg1, areg2, areg3, breg0, breg1, breg2, breg3;
+  areg2 = areg3 = breg1 = breg2 = breg3 = make_uint4(0, 0, 0, 0);
+#define TILE_A(U, REG)                                                                                              \
+  if (PA > (U)) {                                                                                                   \
+    constexpr int u_ = (U) < PA ? (U) : 0;                                                                          \
+    REG = make_uint4(0, 0, 0, 0);                                                                                   \
+    if ((amask[u_] >> tap_) & 1u) REG = *reinterpret_cast<const uint4*>(abase[u_] + aoff_);                         \
+  }
+#define TILE_B(U, REG)                                                                                              \
+  if (PB > (U)) REG = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + RP * (U)) * Cin + kc_ + c16 * 8);
 #define TILE_FETCH(IT)                                                                                              \
   do {                                                                                                              \
-    const int tap_ = blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * 32;                                \
+    const int tap_ = blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                                \
     const int kd_ = tap_ / 9 - 1, kh_ = (tap_ / 3) % 3 - 1, kw_ = tap_ % 3 - 1;                                     \
-    {                                                                                                               \
-      const int dd = ad[0] + kd_, hh = ah[0] + kh_, ww = aw[0] + kw_;                                               \
-      areg0 = make_uint4(0, 0, 0, 0);                                                                               \
-      if (aok[0] && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)                                    \
-        areg0 = *reinterpret_cast<const uint4*>(x + ((((int64_t)an[0] * D + dd) * H + hh) * W + ww) * ldx + kc_ + c16 * 8); \
-    }                                                                                                               \
-    {                                                                                                               \
-      const int dd = ad[1] + kd_, hh = ah[1] + kh_, ww = aw[1] + kw_;                                               \
-      areg1 = make_uint4(0, 0, 0, 0);                                                                               \
-      if (aok[1] && dd >= 0 && dd < D && hh >= 0 && hh < H && ww >= 0 && ww < W)                                    \
-        areg1 = *reinterpret_cast<const uint4*>(x + ((((int64_t)an[1] * D + dd) * H + hh) * W + ww) * ldx + kc_ + c16 * 8); \
-    }                                                                                                               \
-    breg0 = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0) * Cin + kc_ + c16 * 8);         \
-    if (NB == 2) breg1 = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + 64) * Cin + kc_ + c16 * 8); \
+    const int64_t aoff_ = (((int64_t)kd_ * H + kh_) * W + kw_) * ldx + kc_;     /* wave-uniform */                  \
+    TILE_A(0, areg0) TILE_A(1, areg1) TILE_A(2, areg2) TILE_A(3, areg3)                                             \
+    TILE_B(0, breg0) TILE_B(1, breg1) TILE_B(2, breg2) TILE_B(3, breg3)                                             \
   } while (0)
+#define TILE_ST(BASE, ROW, REG) *reinterpret_cast<uint4*>((BASE) + (ROW) * ROWB + ((c16 ^ swz(ROW)) * 16)) = REG
 #define TILE_COMMIT(BUFI)                                                                                           \
   do {                                                                                                              \
     char* a_ = smem + (BUFI) * BUF;                                                                                 \
     char* b_ = a_ + A_BYTES;                                                                                        \
-    const int r0_ = row0, r1_ = row0 + 64;                                                                          \
-    *reinterpret_cast<uint4*>(a_ + r0_ * 64 + ((c16 ^ ((r0_ >> 2) & 3)) * 16)) = areg0;                             \
-    *reinterpret_cast<uint4*>(a_ + r1_ * 64 + ((c16 ^ ((r1_ >> 2) & 3)) * 16)) = areg1;                             \
-    *reinterpret_cast<uint4*>(b_ + r0_ * 64 + ((c16 ^ ((r0_ >> 2) & 3)) * 16)) = breg0;                             \
-    if (NB == 2) *reinterpret_cast<uint4*>(b_ + r1_ * 64 + ((c16 ^ ((r1_ >> 2) & 3)) * 16)) = breg1;                \
+    TILE_ST(a_, row0, areg0);                                                                                       \
+    if (PA > 1) TILE_ST(a_, row0 + RP, areg1);                                                                      \
+    if (PA > 2) TILE_ST(a_, row0 + 2 * RP, areg2);                                                                  \
+    if (PA > 3) TILE_ST(a_, row0 + 3 * RP, areg3);                                                                  \
+    TILE_ST(b_, row0, breg0);                                                                                       \
+    if (PB > 1) TILE_ST(b_, row0 + RP, breg1);                                                                      \
+    if (PB > 2) TILE_ST(b_, row0 + 2 * RP, breg2);                                                                  \
+    if (PB > 3) TILE_ST(b_, row0 + 3 * RP, breg3);                                                                  \
   } while (0)
   f32x16 acc[2][NTW];
 #pragma unroll
@@ -902,23 +915,23 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     if (it + 1 < niter) TILE_FETCH(it + 1);
     const char* a = smem + (it & 1) * BUF;
     const char* b = a + A_BYTES;
-    bf16x8 fa[2][2], fb[2][NTW];
+    bf16x8 fa[KS][2], fb[KS][NTW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const int c = 2 * s + khalf;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int row = wm * 64 + t * 32 + r;
-        fa[s][t] = *reinterpret_cast<const bf16x8*>(a + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
+        fa[s][t] = *reinterpret_cast<const bf16x8*>(a + row * ROWB + ((c ^ swz(row)) * 16));
       }
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int row = wn * (NT / 2) + j * 32 + r;
-        fb[s][j] = *reinterpret_cast<const bf16x8*>(b + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
+        fb[s][j] = *reinterpret_cast<const bf16x8*>(b + row * ROWB + ((c ^ swz(row)) * 16));
       }
     }
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -926,7 +939,10 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     if (it + 1 < niter) TILE_COMMIT((it + 1) & 1);
     __syncthreads();
   }
+#undef TILE_A
+#undef TILE_B
 #undef TILE_FETCH
+#undef TILE_ST
 #undef TILE_COMMIT
 
   const int rh = khalf * 4;
@@ -1100,15 +1116,17 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
   }
   if (c.tile_nt) {
     dim3 tg((unsigned)c.mblocks, cout / c.tile_nt, ks);
-    if (c.tile_nt == 128) {
-      constexpr int LDS = 2 * (128 * 64 + 128 * 64);
-      conv_fwd_tile<128><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w,
-                                               cin, cout, stats, partial);
-    } else {
-      constexpr int LDS = 2 * (128 * 64 + 64 * 64);
-      conv_fwd_tile<64><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w,
-                                              cin, cout, stats, partial);
-    }
+#define LAUNCH_TILE(NT_, KC_)                                                                                     \
+  do {                                                                                                              \
+    constexpr int LDS = 2 * (128 + NT_) * KC_ * 2;                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_tile<NT_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    conv_fwd_tile<NT_, KC_><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, \
+                                                  h, w, cin, cout, stats, partial);                                  \
+  } while (0)
+    const bool k64 = cin % 64 == 0;
+    if (c.tile_nt == 128) { if (k64) LAUNCH_TILE(128, 64); else LAUNCH_TILE(128, 32); }
+    else { if (k64) LAUNCH_TILE(64, 64); else LAUNCH_TILE(64, 32); }
+#undef LAUNCH_TILE
     if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
     int rct = fplx_check_launch("mfma_conv3d_fwd_tile");
     return rct < 0 ? rct : 1;
