@@ -1,0 +1,343 @@
+// conv_fwd_march: the level-0 3x3x3 convolution (Cin = 32, Cout % 32 == 0, large H x W), third generation.
+//
+// One block (8 waves, two per SIMD) owns a 16 x 32 (h, w) output footprint x 32 output channels and marches along
+// d.  It is INPUT-stationary in depth: each input slab (18 x 34 voxels x 32 channels, 1-voxel halo, zero fill =
+// padding) is staged ONCE into a two-slot LDS ring and scattered into the accumulators of the three output depths
+// it touches (d+1 through kd = 0, d through kd = 1, d-1 through kd = 2), so
+//   * every voxel fragment read from LDS feeds three MFMAs (three kd taps), every weight fragment two (the wave's two
+//     M-tiles): 0.83 ds_read_b128 per MFMA instead of 1.5 in the slab-ring kernel it replaces;
+//   * only the current slab and the one in flight live in LDS (2 x 38 KB) next to the block's 27 x 32 x 32 weights
+//     (54 KB, resident), which leaves room for the 16-row footprint (halo overhead 1.20 instead of 1.33);
+//   * three accumulator sets rotate through the roles {d+1, d, d-1}; the set that completes is written out (bias,
+//     bf16, 8-byte stores: the MFMA runs with the weights as the row operand, so a lane owns 4 consecutive channels
+//     of one voxel) while the block's other waves keep the matrix cores busy.
+// DSBN statistics: per-lane sums of the raw accumulators (the bias is folded in analytically at the end), reduced
+// in a fixed order, one partial row per block.
+//
+// Replaces (for these shapes) nn.Conv3d forward and, with the mirrored pack, its data gradient —
+// reference PyMIC/pymic/net/net3d/unet2d5_dsbn.py:54-55,75,79 (ConvolutionLayer / UNetBlock_DSBN at level 0).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(16))) const unsigned int fplx_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct MG {
+  static constexpr int CIN = 32, ROWB = 64, CH = 4;
+  static constexpr int FH = 16, FW = 32, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
+  static constexpr int THREADS = 512;
+  static constexpr int SLAB_CHUNKS = SLAB * CH, SLAB_DMA = (SLAB_CHUNKS + 63) / 64;   // 1-KiB LDS-DMA pieces
+  static constexpr int SLAB_BYTES = SLAB_DMA * 1024, W_BYTES = 27 * 32 * ROWB;
+  static constexpr int NPIECE = (SLAB_DMA + 7) / 8;        // DMA wave-instructions per wave and slab
+  static constexpr int STAGE_BYTES = 32 * 32 * 2;          // one M-tile of bf16 outputs per wave (store transpose)
+  static constexpr int LDS = 2 * SLAB_BYTES + W_BYTES + 32 * 4 + NPIECE * THREADS * 4 + (THREADS / 64) * STAGE_BYTES;
+  static __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+};
+
+// one input slab -> the three output depths it touches.  A0/A1/A2 = accumulators of depth s+1 / s / s-1.
+// side(q) runs behind the MFMAs of stage q: the slab DMA for the next step and the write-out of the depth that
+// completed in the previous step are spread over the stages, so they overlap with matrix work of the SAME wave
+// (the block's waves move in lock-step from barrier to barrier: separate phases would not overlap at all).
+template <int MASK, class Side>
+__device__ __forceinline__ void march_step(const char* __restrict__ sl, const char* __restrict__ wbuf, int wave, int r,
+                                           int khalf, f32x16& A00, f32x16& A01, f32x16& A10, f32x16& A11, f32x16& A20,
+                                           f32x16& A21, Side&& side) {
+  bf16x8 fa[2][2], fb[2][3];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // lane constants are re-derived from opaque copies every slab, so that the 36 + 54 fragment addresses are
+  // computed next to their use (a handful of VALU ops under the MFMAs) instead of being hoisted out of the depth
+  // loop and spilled
+  int vb = wave * 2 * MG::SW + r, rb = r;
+  asm volatile("" : "+v"(vb), "+v"(rb));
+  // weight rows: swz(tap * 32 + r) == swz(r), so a tap is an immediate offset from two lane bases
+  const char* wl0 = wbuf + rb * MG::ROWB + ((khalf ^ MG::swz(rb)) << 4);
+  const char* wl1 = wbuf + rb * MG::ROWB + (((2 + khalf) ^ MG::swz(rb)) << 4);
+  auto load_stage = [&](int q, int buf) {
+    const int p = q >> 1, ks = q & 1;
+    const int kh = p / 3, kw = p % 3;
+    const int c = 2 * ks + khalf;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int vox = vb + (m + kh) * MG::SW + kw;
+      fa[buf][m] = *reinterpret_cast<const bf16x8*>(sl + vox * MG::ROWB + ((c ^ MG::swz(vox)) << 4));
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+      if ((MASK >> kd) & 1) fb[buf][kd] = *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (kd * 9 + p) * 32 * MG::ROWB);
+  };
+  load_stage(0, 0);
+#pragma unroll
+  for (int q = 0; q < 18; ++q) {
+    if (q + 1 < 18) load_stage(q + 1, (q + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int b = q & 1;
+    {
+      if constexpr ((MASK & 1) != 0) A00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], q == 0 ? zero : A00, 0, 0, 0);
+      if constexpr ((MASK & 2) != 0) A10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], A10, 0, 0, 0);
+      if constexpr ((MASK & 4) != 0) A20 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][2], A20, 0, 0, 0);
+      if constexpr ((MASK & 1) != 0) A01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], q == 0 ? zero : A01, 0, 0, 0);
+      if constexpr ((MASK & 2) != 0) A11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][1], A11, 0, 0, 0);
+      if constexpr ((MASK & 4) != 0) A21 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][2], A21, 0, 0, 0);
+    }
+    side(q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__global__ void __launch_bounds__(MG::THREADS)
+conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;
+  char* wbuf = smem + 2 * MG::SLAB_BYTES;
+  float* bias_s = reinterpret_cast<float*>(wbuf + MG::W_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // block-uniform values live in SGPRs
+  const int r = lane & 31, khalf = lane >> 5;
+  int b = blockIdx.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * MG::FH), w0 = __builtin_amdgcn_readfirstlane(tw * MG::FW);
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = blockIdx.y * 32;
+
+  // global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  A wave-instruction
+  // fills 1 KiB = 16 voxel rows linearly, so the XOR swizzle is applied to each lane's SOURCE chunk; halo voxels
+  // outside the volume read a 16-byte zero constant.
+  // Issued as inline asm: with the builtin in the loop hipcc stops counting lgkmcnt and drains every ds_read with
+  // lgkmcnt(0), which defeats the fragment prefetch.  The DMA is retired by the explicit vmcnt(0) in front of the
+  // barrier that publishes the slab.
+  auto lds_dma = [&](const void* g, char* l) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  // vmcnt(0) retires this wave's DMA pieces (and its output stores: loads and stores share the counter and may
+  // complete out of order, so only 0 is a safe count); the raw barrier then publishes the slab to the block
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int NPIECE = MG::NPIECE;
+  // per lane and piece: byte offset of the source chunk inside one depth slice of x, or -1 for the zero constant
+  // (halo outside the volume, and the tail of the last 1-KiB piece).  Parked in LDS: as registers they would be
+  // spilled, and a scratch reload in the loop makes hipcc wait for vmcnt(0), i.e. for the DMA just issued.
+  int* soff_s = reinterpret_cast<int*>(bias_s + 32);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) {
+    const int i = (wave + 8 * k) * 64 + lane;
+    const int vox = i >> 2, c = (i & 3) ^ MG::swz(vox);
+    const int hh = vox / MG::SW + h0 - 1, ww = vox % MG::SW + w0 - 1;
+    const bool in = i < MG::SLAB_CHUNKS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    soff_s[k * MG::THREADS + tid] = in ? (int)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : -1;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2;        // bytes per depth slice
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  auto slab_piece = [&](int s, int k, int so) {           // piece k of slab s -> slot (s + 1) & 1
+    if (wave + 8 * k < MG::SLAB_DMA) {
+      const char* xs = xn + s * xslice;                   // uniform
+      const void* src = so >= 0 ? (const void*)(xs + (unsigned)so) : (const void*)fplx_zero16;
+      lds_dma(src, slabs + ((s + 1) & 1) * MG::SLAB_BYTES + (wave + 8 * k) * 1024);
+    }
+  };
+
+  // accumulators by role (2 M-tiles each): K0 / K1 / K2 = output depth s+1 / s / s-1 of the current slab s,
+  // R = the depth that completed in the previous step and is being written out.  K0 starts every step from zero
+  // (first MFMA with C = 0); at the end of a step the roles shift by plain register moves (R <- K2 <- K1 <- K0),
+  // which keeps ONE straight-line instantiation per step mask.
+  f32x16 K0a, K0b, K1a, K1b, K2a, K2b, Ra, Rb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = K1a[i] = K1b[i] = K2a[i] = K2b[i] = Ra[i] = Rb[i] = 0.f;
+
+  // prologue: first slab, resident weights (same LDS-DMA, source-side swizzle), bias
+  if (d0 - 1 >= 0) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) slab_piece(d0 - 1, k, soff_s[k * MG::THREADS + tid]);
+  }
+  for (int j = wave; j < 27 * 32 * MG::CH / 64; j += 8) {
+    const int i = j * 64 + lane;
+    const int row = i >> 2, c = (i & 3) ^ MG::swz(row);
+    lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * MG::CIN + c * 8, wbuf + j * 1024);
+  }
+  if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  dma_wait();
+  block_sync();
+
+  // write-out of a finished depth o: lane = output channel r, registers = 16 voxels of the M-tile's w-row.
+  // retire_pair handles voxels i0, i0 + 1 of both M-tiles (called from 8 stages), retire_zero clears the set.
+  // write-out of a finished depth: the accumulator layout is lane = channel, registers = 16 voxels, i.e. 2-byte
+  // pieces per lane - as global stores that is 32 instructions per wave and depth and the memory pipeline, not the
+  // matrix core, sets the pace.  Instead the bf16 values are transposed through a 2-KiB per-wave LDS tile
+  // ([voxel][channel]) and leave as 16-byte stores: 64 lanes x 16 B = 16 voxels x 32 channels = whole 128-B lines.
+  const float bv = bias_s[r];
+  float ssum = 0.f, qsum = 0.f;
+  char* stg = reinterpret_cast<char*>(soff_s + NPIECE * MG::THREADS) + wave * MG::STAGE_BYTES;
+  char* stg_w = stg + (4 * khalf) * 64 + r * 2;           // + wu(i) * 64: an immediate
+  const char* stg_r = stg + lane * 16;                    // voxel lane >> 2 (+16), channels 8 * (lane & 3) ..
+  unsigned wmask = 0;                                     // bit i: voxel i of the w-row lies inside the volume
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf < W) wmask |= 1u << i;
+  const bool hok0 = h0 + wave * 2 < H, hok1 = h0 + wave * 2 + 1 < H;
+  const unsigned ldy2 = (unsigned)ldy * 2u;
+  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy + n0) * 2;
+  const int64_t yslice = (int64_t)H * W * ldy * 2;        // bytes per output depth
+  const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
+  const bool sok0 = w0 + (lane >> 2) < W, sok1 = w0 + (lane >> 2) + 16 < W;
+  auto retire_elem = [&](f32x16& A, int m, int i) {       // voxel i of M-tile m: statistics + bf16 into the LDS tile
+    const int wu = (i & 3) + 8 * (i >> 2);
+    const float ov = A[i] + bv;
+    *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
+    if ((m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
+      ssum += ov;
+      qsum = fmaf(ov, ov, qsum);
+    }
+  };
+  auto retire_flush = [&](int m, int o) {                 // LDS tile -> y, two 16-byte stores per lane
+    if (m ? hok1 : hok0) {
+      unsigned l2 = ldy2;
+      asm volatile("" : "+s"(l2));
+      char* rowp = yn + o * yslice + (unsigned)(m * W) * l2;            // uniform
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
+      // inline asm: a store hipcc knows about makes it guard later register reuse with vmcnt(N) waits, and since it
+      // does not know about the DMA pieces in flight, those waits end up waiting for the DMA
+      if (sok0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+    }
+  };
+
+  // slab s = d0 - 1 + t touches output depths s+1 (kd = 0), s (kd = 1), s-1 (kd = 2); MASK = which of them lie in
+  // [d0, d1): 1, 3, 7 ... 7, 6, 4 over the block's nd + 2 slabs.  The depth that completed in step t - 1 is written
+  // out during step t (stages 0..7, two voxels per M-tile and stage); the DMA of slab s + 1 goes out in stages
+  // 0..NPIECE-1; both are long finished when the step's closing vmcnt(0) + barrier is reached.
+  const int nd = d1 - d0;                         // >= 2 (march_cfg)
+  for (int t = 0; t < nd + 2; ++t) {
+    const int s = d0 - 1 + t;
+    const bool fetch = s + 1 <= d1 && s + 1 < D;
+    const bool wout = t >= 3;
+    const int o = s - 2;                           // depth written out during this step
+    const char* sl = slabs + ((s + 1) & 1) * MG::SLAB_BYTES;
+    int so[NPIECE];                                 // one batch of LDS reads, consumed over the first stages
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) so[k] = soff_s[k * MG::THREADS + tid];
+    auto side = [&](int q) {
+      if (q < NPIECE && fetch) slab_piece(s + 1, q, so[q < NPIECE ? q : 0]);
+      // write-out of the depth that completed in the previous step: stages 0-3 M-tile 0 -> LDS tile, 4 flush,
+      // 4-7 M-tile 1, 8 flush.  (Staggering the two waves of a SIMD - waves 4-7 in stages 9..17 - was tried: it
+      // keeps the set alive for the whole step and the spills cost more than the overlap gains.)
+      if (wout && q < 9) {
+        if (q < 4) { retire_elem(Ra, 0, 4 * q); retire_elem(Ra, 0, 4 * q + 1); retire_elem(Ra, 0, 4 * q + 2); retire_elem(Ra, 0, 4 * q + 3); }
+        if (q == 4) retire_flush(0, o);
+        if (q >= 4 && q < 8) { retire_elem(Rb, 1, 4 * q - 16); retire_elem(Rb, 1, 4 * q - 15); retire_elem(Rb, 1, 4 * q - 14); retire_elem(Rb, 1, 4 * q - 13); }
+        if (q == 8) retire_flush(1, o);
+      }
+    };
+#define MARCH_STEP(MASK) march_step<MASK>(sl, wbuf, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side)
+    if (s >= 0 && s < D) {                 // a padding slab contributes nothing to the accumulators
+      if (t == 0) MARCH_STEP(1);
+      else if (t == 1) MARCH_STEP(3);
+      else if (t < nd) MARCH_STEP(7);
+      else if (t == nd) MARCH_STEP(6);
+      else MARCH_STEP(4);
+    } else {                                           // ... but the DMA and the write-out still have to happen
+#pragma unroll
+      for (int q = 0; q < 9; ++q) side(q);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = 0.f;
+    }
+#undef MARCH_STEP
+    Ra = K2a; Rb = K2b; K2a = K1a; K2b = K1b; K1a = K0a; K1b = K0b;
+    dma_wait();                                        // slab s + 1 landed and the stores left stages ago
+    block_sync();
+  }
+  // drain: the last depth completed in the final step
+  {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) retire_elem(Ra, 0, i);
+    retire_flush(0, d1 - 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) retire_elem(Rb, 1, i);
+    retire_flush(1, d1 - 1);
+  }
+
+  if (stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [8 waves][2][32]; the slabs are dead
+    const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float t = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) t += red[(wv * 2 + which) * 32 + c];
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
+    }
+  }
+}
+
+struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
+
+inline int march_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("FPLX_MARCH");                 // tuning knob (benchmarks only): 0 = previous kernel
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+inline MarchCfg march_cfg(int n, int d, int h, int w, int cout) {
+  MarchCfg c;
+  c.tilesH = (h + MG::FH - 1) / MG::FH;
+  c.tilesW = (w + MG::FW - 1) / MG::FW;
+  const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * (cout / 32);
+  // one block per CU at a time: choose the depth split that minimises rounds x (slabs per block + prologue)
+  double best = 1e30;
+  int best_ds = 1;
+  for (int ds = 1; ds <= d; ++ds) {
+    const int dl = (d + ds - 1) / ds;
+    if (dl < 4 && ds > 1) break;
+    const int segs = (d + dl - 1) / dl;
+    if (d - (segs - 1) * dl < 2 && d >= 2) continue;       // every segment needs two depths (step masks 1, 3 ... 6, 4)
+    const int64_t rounds = (tiles * segs + 255) / 256;
+    const double cost = (double)rounds * (dl + 2 + 1.5);
+    if (cost < best - 1e-9) { best = cost; best_ds = segs; }
+  }
+  c.dlen = (d + best_ds - 1) / best_ds;
+  c.dsegs = (d + c.dlen - 1) / c.dlen;
+  c.nblk = n * c.tilesH * c.tilesW * c.dsegs;
+  return c;
+}
+
+}  // namespace
+
+extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout) {
+  return march_enabled() && cin == 32 && cout % 32 == 0 && h >= 16 && w >= 64 && d >= 4;
+}
+
+extern "C" int fplx_march_rows(int n, int d, int h, int w, int cout) { return march_cfg(n, d, h, w, cout).nblk; }
+
+// returns 1 if launched, 0 if the pointers do not allow the vector stores, <0 on error
+extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+  if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
+    return 0;
+  const MarchCfg c = march_cfg(n, d, h, w, cout);
+  dim3 grid(c.nblk, cout / 32);
+  (void)hipFuncSetAttribute((const void*)conv_fwd_march32, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS);
+  conv_fwd_march32<<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n,
+                                                       d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, c.dlen);
+  const int rc = fplx_check_launch("march_conv3d_fwd");
+  return rc < 0 ? rc : 1;
+}

@@ -1065,8 +1065,15 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 
 }  // namespace
 
+// conv_march.hip
+extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_march_rows(int n, int d, int h, int w, int cout);
+extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
+
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout);
@@ -1075,7 +1082,7 @@ extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, 
 }
 
 extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
-  if (cin % 16 != 0 || cout % 32 != 0 || stream_ok(d, h, w, cin, cout)) return 0;
+  if (cin % 16 != 0 || cout % 32 != 0 || fplx_march_ok(n, d, h, w, cin, cout) || stream_ok(d, h, w, cin, cout)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
@@ -1086,6 +1093,8 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
                                     size_t ws_bytes, hipStream_t st) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
+  if (fplx_march_ok(n, d, h, w, cin, cout))
+    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
   if (stream_ok(d, h, w, cin, cout)) {
     const StreamCfg sc = stream_cfg(n, d, h, w, cout);
     dim3 grid(sc.nblk, cout / 32);
