@@ -178,44 +178,57 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* s
   // software pipeline over k-steps (two per trip, static buffer parity): the 2 + 2*NT transposed reads of
   // step ks+1 are requested before the NT MFMAs of step ks are issued
   bf16x8 fbw[2], faw[2][NT];
-  auto load_ks = [&](int ks, bf16x8& fb, bf16x8 (&fa)[NT]) {
+  auto load_dy = [&](int ks) {
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-    fb = tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int tap = WV + 4 * i;
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;              // folded: i is unrolled, WV constant
-      const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
-      fa[i] = tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
-    }
+    return tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
   };
-  load_ks(0, fbw[0], faw[0]);
+  auto load_x = [&](int ks, int i) {
+    const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
+    const int tap = WV + 4 * i;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;                // folded: i is unrolled, WV constant
+    const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
+    return tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
+  };
+  fbw[0] = load_dy(0);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) faw[0][i] = load_x(0, i);
+  // one wave per SIMD: nothing else fills the matrix core while this wave issues a burst of LDS reads, so the
+  // fragments of the next k-step are requested one at a time IN the gaps between the MFMAs of the current one
+  // (the fences pin that order; the loads complete a whole k-step before their first use)
 #pragma unroll 1
   for (int ks = 0; ks < NKS; ks += 2) {
-    load_ks(ks + 1, fbw[1], faw[1]);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ks + 2 < NKS) load_ks(ks + 2, fbw[0], faw[0]);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NT; ++i) {
+      if (i == 0) fbw[1] = load_dy(ks + 1);
+      faw[1][i] = load_x(ks + 1, i);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int kn = ks + 2 < NKS ? ks + 2 : ks;      // last trip: a harmless re-read instead of branches in the gaps
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < NT; ++i) {
+      if (i == 0) fbw[0] = load_dy(kn);
+      faw[0][i] = load_x(kn, i);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
-template <int TW>
-__global__ void __launch_bounds__(256)
-conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
-                  float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
-                  int dsegs, int dlen) {
+// the whole march of wave WV (its taps are compile-time constants): the wave variants never merge before the end
+// of the kernel, so the seven accumulator tiles stay in one register class (no VGPR <-> AGPR copies per depth)
+template <int TW, int WV>
+__device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                            int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
+                                            int Cout, int tilesH, int tilesW, int dsegs, int dlen) {
   constexpr int TH = WG_TH, SW = TW + 2, SH = TH + 2, SLAB = SH * SW;   // voxels per x slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                                   // [3][SLAB][32] bf16
   char* dys = smem + 3 * SLAB * 64;                  // [TH*TW][32] bf16
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int wave = WV;
   int b = blockIdx.x;
   const int seg = b % dsegs; b /= dsegs;
   const int tw = b % tilesW; b /= tilesW;
@@ -300,12 +313,7 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
       const char* sl0 = xs + ((d + 0) % 3) * (SLAB * 64);        // depth d - 1
       const char* sl1 = xs + ((d + 1) % 3) * (SLAB * 64);        // depth d
       const char* sl2 = xs + ((d + 2) % 3) * (SLAB * 64);        // depth d + 1
-      switch (wave) {                                            // wave-uniform
-        case 0: wgrad_depth_step<0, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
-        case 1: wgrad_depth_step<1, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
-        case 2: wgrad_depth_step<2, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
-        default: wgrad_depth_step<3, TW>(acc, sl0, sl1, sl2, dys, lane_off); break;
-      }
+      wgrad_depth_step<WV, TW>(acc, sl0, sl1, sl2, dys, lane_off);
     }
     __syncthreads();                             // every wave is done with depth d-1's slot and the dy slab
     if (more) {
@@ -314,7 +322,8 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
       __syncthreads();
     }
   }
-  // partial tiles: part[blockIdx.x][pair][tap][ci][co]
+  // partial tiles: part[blockIdx.x][pair][tap][co][ci] - a lane owns 4 consecutive ci per register quad, so the
+  // tile leaves as 16-byte stores (4 per tile instead of 16 dword stores: the epilogue is store-issue bound)
   float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
   const int co = lane & 31, rbase = (lane >> 5) * 4;
 #pragma unroll
@@ -322,15 +331,27 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
     const int tap = wave + 4 * i;
     if (tap < 27) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ci = (r & 3) + 8 * (r >> 2) + rbase;
-        out[(tap * 32 + ci) * 32 + co] = acc[i][r];
-      }
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
+            make_float4(acc[i][4 * g4 + 0], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
     }
   }
 }
 
-// dw[co][ci][tap] = sum_b part[b][pair][tap][ci%32][co%32]; 64 outputs x 4 partial-lanes per block
+template <int TW>
+__global__ void __launch_bounds__(256)
+conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
+                  int dsegs, int dlen) {
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
+    case 0: wgrad_march<TW, 0>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 1: wgrad_march<TW, 1>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 2: wgrad_march<TW, 2>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    default: wgrad_march<TW, 3>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+  }
+}
+
+// dw[co][ci][tap] = sum_b part[b][pair][tap][co%32][ci%32]; 64 outputs x 4 partial-lanes per block
 __global__ void __launch_bounds__(256)
 wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw) {
   __shared__ float red[256];
@@ -344,7 +365,7 @@ wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Ci
   __syncthreads();
   if (pl != 0 || i >= total) return;
   t = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
-  const int co_l = i & 31, ci_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
+  const int ci_l = i & 31, co_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
   const int ncit = Cin / 32;
   const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
   dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
@@ -359,10 +380,24 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.tilesW = (w + c.tw - 1) / c.tw;
   c.npairs = (cin / 32) * (cout / 32);
   const int tiles = n * c.tilesH * c.tilesW;
-  int ds = (512 + tiles * c.npairs / 2) / (tiles * c.npairs);
-  const int maxds = d / 4 > 0 ? d / 4 : 1;
-  if (ds > maxds) ds = maxds;
-  if (ds < 1) ds = 1;
+  // one block per CU at a time (LDS + 512-register waves): pick the depth split that minimises
+  // rounds x (depths per block + per-block overhead).  The overhead - prologue slabs, the 110-KB partial tile
+  // and its share of the reduction pass - is worth about nine depths (measured), so few long blocks win even when
+  // they leave some CUs idle.
+  int ds = 1;
+  {
+    double best = 1e30;
+    const char* e = getenv("FPLX_WG_DS");               // tuning knob (benchmarks only)
+    for (int cand = 1; cand <= d; ++cand) {
+      const int dl = (d + cand - 1) / cand;
+      if (dl < 4 && cand > 1) break;
+      const int segs = (d + dl - 1) / dl;
+      const int64_t rounds = ((int64_t)tiles * c.npairs * segs + 255) / 256;
+      const double cost = (double)rounds * (dl + 9.0);
+      if (cost < best - 1e-9) { best = cost; ds = segs; }
+    }
+    if (e && atoi(e) > 0) ds = atoi(e);
+  }
   c.dlen = (d + ds - 1) / ds;
   c.dsegs = (d + c.dlen - 1) / c.dlen;
   c.nblk = tiles * c.dsegs;

@@ -1,4 +1,5 @@
-"""Times fplx conv3d_fwd (bf16 NDHWC) for one shape: python tools/conv_bench.py CIN COUT [N D H W] [stats]"""
+"""Times fplx conv3d_fwd / conv3d_wgrad (bf16 NDHWC) for one shape:
+python tools/conv_bench.py CIN COUT [N D H W] [stats]      (env CONV_BENCH_OP=wgrad for the weight gradient)"""
 import os
 import sys
 
@@ -26,7 +27,18 @@ def main():
     rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
     stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device=dev) if want_stats else None
 
+    dyt = torch.randn(v, cout, device=dev, generator=g).bfloat16()
+    ws = torch.empty(max(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), 16), dtype=torch.uint8, device=dev)
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev)
+    op = os.environ.get("CONV_BENCH_OP", "fwd")
+
     def run():
+        if op == "wgrad":
+            ops.conv3d_wgrad(x, ops.cl_strides(d, h, w, cin), dt, dyt, ops.cl_strides(d, h, w, cout), dt, dw,
+                             db if os.environ.get('CONV_BENCH_DB') else None, dims,
+                             cin, cout, (3, 3, 3), ws)
+            return
         ops.conv3d_fwd(x, ops.cl_strides(d, h, w, cin), dt, wf, b, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
                        (3, 3, 3), stats)
 
@@ -43,7 +55,7 @@ def main():
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * v * cin * cout * 27
     env = {k: v_ for k, v_ in os.environ.items() if k.startswith("FPLX_")}
-    print(f"cin={cin} cout={cout} dims={dims} rows={rows} env={env}"
+    print(f"{op} cin={cin} cout={cout} dims={dims} rows={rows} env={env}"
           f" {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TF/s  {(v * (cin + cout) * 2) / ms / 1e6:7.0f} GB/s")
 
 
