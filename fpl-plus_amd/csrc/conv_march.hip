@@ -286,6 +286,261 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd_march64: the same input-stationary depth march for Cin = 64 (level-0 decoder conv1 on the skip | up
+// concatenation, level-1 convs).  All 27 x 32 x 64 weights of the block's 32 output channels stay resident in LDS
+// (108 KB) as two 32-channel halves; an input slab is streamed as two 32-channel half-slabs (8 x 32 footprint:
+// 10 x 34 voxels x 64 B = 21 KB each) through a two-slot ring, so a depth step is two half-steps of 108 MFMAs per
+// wave into the same accumulators.  LDS holds 162 KB, one block of 4 waves per CU, ONE wave per SIMD: nothing hides
+// a stall, so every fragment read, DMA piece and output element is issued inside an MFMA gap (fences pin the order).
+struct MG64 {
+  static constexpr int ROWB = 64, CH = 4;                  // a half-slab / half-weight row: 32 channels
+  static constexpr int FH = 8, FW = 32, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
+  static constexpr int THREADS = 256;
+  static constexpr int SLAB_CHUNKS = SLAB * CH, SLAB_DMA = (SLAB_CHUNKS + 63) / 64;   // 1-KiB pieces (last: 16 lanes)
+  static constexpr int SLAB_BYTES = SLAB * ROWB, WH_BYTES = 27 * 32 * ROWB;           // per channel half
+  static constexpr int NPIECE = (SLAB_DMA + 3) / 4;        // DMA wave-instructions per wave and half-slab
+  static constexpr int STAGE_BYTES = 32 * 32 * 2;
+  static constexpr int LDS = 2 * SLAB_BYTES + 2 * WH_BYTES + 32 * 4 + (THREADS / 64) * STAGE_BYTES;
+  static __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+};
+
+// one half-slab -> the three output depths it touches.  FIRST: the kd = 0 accumulators start from zero.
+// side(q, g) runs in gap g (0..5) of stage q (0..17), i.e. right before MFMA g of that stage.
+template <int MASK, bool FIRST, class Side>
+__device__ __forceinline__ void march64_half(const char* __restrict__ sl, const char* __restrict__ wh, int wave, int r,
+                                             int khalf, f32x16& A00, f32x16& A01, f32x16& A10, f32x16& A11,
+                                             f32x16& A20, f32x16& A21, Side&& side) {
+  bf16x8 fa[2][2], fb[2][3];
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int vb = wave * 2 * MG64::SW + r, rb = r;
+  asm volatile("" : "+v"(vb), "+v"(rb));         // lane bases re-derived per half-step (no hoisted address zoo)
+  const char* wl0 = wh + rb * MG64::ROWB + ((khalf ^ MG64::swz(rb)) << 4);
+  const char* wl1 = wh + rb * MG64::ROWB + (((2 + khalf) ^ MG64::swz(rb)) << 4);
+  auto load_a = [&](int q, int m) {
+    const int p = q >> 1, ks = q & 1, kh = p / 3, kw = p % 3, c = 2 * ks + khalf;
+    const int vox = vb + (m + kh) * MG64::SW + kw;
+    return *reinterpret_cast<const bf16x8*>(sl + vox * MG64::ROWB + ((c ^ MG64::swz(vox)) << 4));
+  };
+  auto load_b = [&](int q, int kd) {
+    const int p = q >> 1, ks = q & 1;
+    return *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (kd * 9 + p) * 32 * MG64::ROWB);
+  };
+  fa[0][0] = load_a(0, 0); fa[0][1] = load_a(0, 1);
+#pragma unroll
+  for (int kd = 0; kd < 3; ++kd)
+    if ((MASK >> kd) & 1) fb[0][kd] = load_b(0, kd);
+#pragma unroll
+  for (int q = 0; q < 18; ++q) {
+    const int b = q & 1, nb = b ^ 1;
+    // gap g: one fragment of stage q + 1 (5 per stage), the side work, then MFMA g of stage q
+#define M64_GAP(G, LOADSTMT, MFMASTMT)                                                                              \
+    if (q + 1 < 18) { LOADSTMT; }                                                                                   \
+    side(q, G);                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                              \
+    MFMASTMT;                                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+    M64_GAP(0, fa[nb][0] = load_a(q + 1, 0),
+            if constexpr ((MASK & 1) != 0) A00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][0], (FIRST && q == 0) ? zero : A00, 0, 0, 0))
+    M64_GAP(1, fa[nb][1] = load_a(q + 1, 1),
+            if constexpr ((MASK & 2) != 0) A10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][1], A10, 0, 0, 0))
+    M64_GAP(2, if constexpr ((MASK & 1) != 0) fb[nb][0] = load_b(q + 1, 0),
+            if constexpr ((MASK & 4) != 0) A20 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][0], fb[b][2], A20, 0, 0, 0))
+    M64_GAP(3, if constexpr ((MASK & 2) != 0) fb[nb][1] = load_b(q + 1, 1),
+            if constexpr ((MASK & 1) != 0) A01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][0], (FIRST && q == 0) ? zero : A01, 0, 0, 0))
+    M64_GAP(4, if constexpr ((MASK & 4) != 0) fb[nb][2] = load_b(q + 1, 2),
+            if constexpr ((MASK & 2) != 0) A11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][1], A11, 0, 0, 0))
+    M64_GAP(5, (void)0,
+            if constexpr ((MASK & 4) != 0) A21 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][1], fb[b][2], A21, 0, 0, 0))
+#undef M64_GAP
+  }
+}
+
+__global__ void __launch_bounds__(MG64::THREADS)
+conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;                                        // [2 channel halves][SLAB][32]
+  char* wbuf = smem + 2 * MG64::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
+  float* bias_s = reinterpret_cast<float*>(wbuf + 2 * MG64::WH_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  int b = blockIdx.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * MG64::FH), w0 = __builtin_amdgcn_readfirstlane(tw * MG64::FW);
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = blockIdx.y * 32;
+
+  auto lds_dma = [&](const void* g, const char* l) {         // see conv_fwd_march32
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((const __attribute__((address_space(3))) char*)l));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int NPIECE = MG64::NPIECE;
+  // per lane and piece: byte offset of the source chunk (channel half 0) inside one depth slice of x, -1 = zero,
+  // -2 = lane past the end of the slab (the last piece is 16 lanes wide)
+  int soff[NPIECE];
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) {
+    const int i = (wave + 4 * k) * 64 + lane;
+    const int vox = i >> 2, c = (i & 3) ^ MG64::swz(vox);
+    const int hh = vox / MG64::SW + h0 - 1, ww = vox % MG64::SW + w0 - 1;
+    const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+    soff[k] = i >= MG64::SLAB_CHUNKS ? -2 : (in ? (int)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : -1);
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2;
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel half hf of slab s -> slot hf
+    if (wave + 4 * k < MG64::SLAB_DMA && soff[k] != -2) {
+      const char* xs = xn + s * xslice + hf * 64;           // uniform
+      const void* src = soff[k] >= 0 ? (const void*)(xs + (unsigned)soff[k]) : (const void*)fplx_zero16;
+      lds_dma(src, slabs + hf * MG64::SLAB_BYTES + (wave + 4 * k) * 1024);
+    }
+  };
+
+  f32x16 K0a, K0b, K1a, K1b, K2a, K2b, Ra, Rb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = K1a[i] = K1b[i] = K2a[i] = K2b[i] = Ra[i] = Rb[i] = 0.f;
+
+  // prologue: both halves of the first slab, the resident weights (source-side swizzle), bias
+  if (d0 - 1 >= 0) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) { slab_piece(d0 - 1, 0, k); }
+  }
+  for (int j = wave; j < 2 * 27 * 32 * MG64::CH / 64; j += 4) {
+    const int i = j * 64 + lane;                             // chunk index over [half][tap][co][4 chunks]
+    const int hf = i / (27 * 32 * MG64::CH), ii = i % (27 * 32 * MG64::CH);
+    const int row = ii >> 2, c = (ii & 3) ^ MG64::swz(row);
+    lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * 64 + hf * 32 + c * 8, wbuf + j * 1024);
+  }
+  if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  dma_wait();
+  block_sync();
+
+  const float bv = bias_s[r];
+  float ssum = 0.f, qsum = 0.f;
+  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * MG64::STAGE_BYTES;
+  char* stg_w = stg + (4 * khalf) * 64 + r * 2;
+  const char* stg_r = stg + lane * 16;
+  unsigned wmask = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf < W) wmask |= 1u << i;
+  const bool hok0 = h0 + wave * 2 < H, hok1 = h0 + wave * 2 + 1 < H;
+  const unsigned ldy2 = (unsigned)ldy * 2u;
+  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy + n0) * 2;
+  const int64_t yslice = (int64_t)H * W * ldy * 2;
+  const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
+  const bool sok0 = w0 + (lane >> 2) < W, sok1 = w0 + (lane >> 2) + 16 < W;
+  auto retire_elem = [&](f32x16& A, int m, int i) {
+    const int wu = (i & 3) + 8 * (i >> 2);
+    const float ov = A[i] + bv;
+    *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
+    if ((m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
+      ssum += ov;
+      qsum = fmaf(ov, ov, qsum);
+    }
+  };
+  auto retire_flush = [&](int m, int o) {
+    if (m ? hok1 : hok0) {
+      unsigned l2 = ldy2;
+      asm volatile("" : "+s"(l2));
+      char* rowp = yn + o * yslice + (unsigned)(m * W) * l2;
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
+      if (sok0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+    }
+  };
+
+  // half-step (t, hf): slab s = d0 - 1 + t, channel half hf, out of slot hf.  In its gaps: the DMA of the NEXT
+  // half-slab (the other half of s, or half 0 of s + 1) into the other slot; during half 0 also the write-out of the
+  // depth that completed in step t - 1 (R): stages 0-3 M-tile 0 -> LDS tile, flush, stages 4-7 M-tile 1, flush.
+  const int nd = d1 - d0;                         // >= 2 (march_cfg)
+  if (d0 - 1 < 0 || true) { /* slab d0 - 1 half 1 is fetched by half-step (0, 0) like every other half-slab */ }
+  for (int t = 0; t < nd + 2; ++t) {
+    const int s = d0 - 1 + t;
+    const bool live = s >= 0 && s < D;             // a padding slab contributes nothing
+    const bool wout = t >= 3;
+    const int o = s - 2;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      // next half-slab: (s, 1) after (s, 0); (s + 1, 0) after (s, 1)
+      const int ns = hf == 0 ? s : s + 1, nh = hf ^ 1;
+      const bool fetch = ns >= 0 && ns < D && ns <= d1 && (hf == 0 ? live : true);
+      auto side = [&](int q, int g) {
+        if (g == 5 && q < NPIECE && fetch) slab_piece(ns, nh, q < NPIECE ? q : 0);
+        if (hf == 0 && wout && q < 8) {
+          if (g < 4) {
+            if (q < 4) retire_elem(Ra, 0, 4 * q + g);
+            else retire_elem(Rb, 1, 4 * (q - 4) + g);
+          }
+          if (g == 4 && q == 3) retire_flush(0, o);
+          if (g == 4 && q == 7) retire_flush(1, o);
+        }
+      };
+      const char* sl = slabs + hf * MG64::SLAB_BYTES;
+      const char* wh = wbuf + hf * MG64::WH_BYTES;
+#define M64_STEP(MASK)                                                                                              \
+  do {                                                                                                              \
+    if (hf == 0) march64_half<MASK, true>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);              \
+    else march64_half<MASK, false>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);                     \
+  } while (0)
+      if (live) {
+        if (t == 0) M64_STEP(1);
+        else if (t == 1) M64_STEP(3);
+        else if (t < nd) M64_STEP(7);
+        else if (t == nd) M64_STEP(6);
+        else M64_STEP(4);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int g = 0; g < 6; ++g) side(q, g);
+        if (hf == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = 0.f;
+        }
+      }
+#undef M64_STEP
+      dma_wait();
+      block_sync();
+    }
+    Ra = K2a; Rb = K2b; K2a = K1a; K2b = K1b; K1a = K0a; K1b = K0b;
+  }
+  // drain: the last depth completed in the final step
+#pragma unroll
+  for (int i = 0; i < 16; ++i) retire_elem(Ra, 0, i);
+  retire_flush(0, d1 - 1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) retire_elem(Rb, 1, i);
+  retire_flush(1, d1 - 1);
+
+  if (stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
+    const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float tt = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) tt += red[(wv * 2 + which) * 32 + c];
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = tt;
+    }
+  }
+}
+
 struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
 
 inline int march_enabled() {
@@ -297,9 +552,10 @@ inline int march_enabled() {
   return v;
 }
 
-inline MarchCfg march_cfg(int n, int d, int h, int w, int cout) {
+inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
   MarchCfg c;
-  c.tilesH = (h + MG::FH - 1) / MG::FH;
+  const int fh = cin == 64 ? MG64::FH : MG::FH;
+  c.tilesH = (h + fh - 1) / fh;
   c.tilesW = (w + MG::FW - 1) / MG::FW;
   const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * (cout / 32);
   // one block per CU at a time: choose the depth split that minimises rounds x (slabs per block + prologue)
@@ -323,18 +579,32 @@ inline MarchCfg march_cfg(int n, int d, int h, int w, int cout) {
 }  // namespace
 
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout) {
-  return march_enabled() && cin == 32 && cout % 32 == 0 && h >= 16 && w >= 64 && d >= 4;
+  const int en = march_enabled();                            // 1: both kernels, 2: Cin = 32 only
+  if (!en || cout % 32 != 0 || d < 4 || w < 64) return 0;
+  if (cin == 32) return h >= 16;
+  if (cin == 64) return en == 1 && h >= 8 && (int64_t)h * w * 64 * 2 < (int64_t)1 << 31;
+  return 0;
 }
 
-extern "C" int fplx_march_rows(int n, int d, int h, int w, int cout) { return march_cfg(n, d, h, w, cout).nblk; }
+extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout) {
+  return march_cfg(n, d, h, w, cin, cout).nblk;
+}
 
 // returns 1 if launched, 0 if the pointers do not allow the vector stores, <0 on error
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
     return 0;
-  const MarchCfg c = march_cfg(n, d, h, w, cout);
+  const MarchCfg c = march_cfg(n, d, h, w, cin, cout);
   dim3 grid(c.nblk, cout / 32);
+  if (cin == 64) {
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march64, hipFuncAttributeMaxDynamicSharedMemorySize, MG64::LDS);
+    conv_fwd_march64<<<grid, MG64::THREADS, MG64::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                             ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs,
+                                                             c.dlen);
+    const int rc64 = fplx_check_launch("march64_conv3d_fwd");
+    return rc64 < 0 ? rc64 : 1;
+  }
   (void)hipFuncSetAttribute((const void*)conv_fwd_march32, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS);
   conv_fwd_march32<<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n,
                                                        d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, c.dlen);

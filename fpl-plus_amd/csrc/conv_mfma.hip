@@ -780,6 +780,10 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
         __syncthreads();
       }
     }
+    // 3 slots: the slot of depth d-1, free since the last group barrier; 4 slots: the slot of depth d-2, free since
+    // the barrier that ended depth d-1.  The slab is committed BEFORE the output stores are issued: loads and stores
+    // share vmcnt, so waiting for the slab's registers after the stores would wait for the stores as well.
+    if (d + 1 < d1) slab_commit(d + 2);
     // epilogue of depth d
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -799,10 +803,8 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       }
     }
     if (d + 1 < d1) {
-      // 3 slots: the slot of depth d-1, free since the last group barrier; 4 slots: the slot of depth d-2,
-      // free since the barrier that ended depth d-1 - either way one barrier publishes the new slab
-      slab_commit(d + 2);
-      __syncthreads();
+      // one barrier publishes the new slab; raw (no fence): the output stores stay in flight across it
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
   if (stats) {
@@ -1102,13 +1104,13 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 
 // conv_march.hip
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
-extern "C" int fplx_march_rows(int n, int d, int h, int w, int cout);
+extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
 
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
-  if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cout);
+  if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cin, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout);
