@@ -120,15 +120,28 @@ def pmc_traffic(key):
     n, d, h, w = dims
     if not (name == "conv3d_fwd" and k == (3, 3, 3) and cin in (32, 64) and cout % 32 == 0 and h >= 16 and w >= 64):
         return None
-    # grid of conv_fwd_stream (fpl-plus_amd/csrc/conv_mfma.hip: stream_cfg)
-    tiles_h, tiles_w = (h + 7) // 8, (w + 31) // 32
+    # launch geometry of conv_fwd_march32 / conv_fwd_march64 (fpl-plus_amd/csrc/conv_march.hip: march_cfg)
+    fh, threads = (16, 512) if cin == 32 else (8, 256)
+    if h < fh:
+        return None
+    tiles_h, tiles_w = (h + fh - 1) // fh, (w + 31) // 32
     tiles = n * tiles_h * tiles_w * (cout // 32)
-    ds = max(1, min((1024 + tiles // 2) // tiles, max(1, d // 8)))
-    dlen = (d + ds - 1) // ds
+    best, segs_best = None, 1
+    for ds in range(1, d + 1):
+        dl = (d + ds - 1) // ds
+        if dl < 4 and ds > 1:
+            break
+        segs = (d + dl - 1) // dl
+        if d - (segs - 1) * dl < 2 and d >= 2:
+            continue
+        cost = ((tiles * segs + 255) // 256) * (dl + 2 + 1.5)
+        if best is None or cost < best - 1e-9:
+            best, segs_best = cost, segs
+    dlen = (d + segs_best - 1) // segs_best
     dsegs = (d + dlen - 1) // dlen
-    grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * 256
+    grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * threads
     tab = json.load(open(path))
-    e = tab.get("conv_fwd_stream<%d>|grid=%d" % (cin, grid))
+    e = tab.get("conv_fwd_march%d|grid=%d" % (cin, grid))
     return None if e is None else e["hbm_bytes_per_launch"]
 
 

@@ -4,6 +4,7 @@
 // They still run on the matrix cores (padding K / N to the 32x32x16 tile) because the VALU
 // formulation is ~10x over the HBM time; with MFMA all five kernels sit at the memory roof.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -441,7 +442,11 @@ inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   *tw = (w + TW - 1) / TW;
   return (int64_t)n * d * (*th) * (*tw);
 }
-inline int edge_blocks(int64_t ntiles) { return (int)(ntiles < 512 ? ntiles : 512); }
+inline int edge_blocks(int64_t ntiles) {
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("FPLX_EDGE_BLOCKS"); cap = e ? atoi(e) : 1024; }   // tuning knob (benchmarks only)
+  return (int)(ntiles < cap ? ntiles : cap);
+}
 
 }  // namespace
 
