@@ -171,47 +171,47 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
 
 // one depth step of conv_wgrad_stream for wave WV: its taps WV, WV+4, ... are compile-time constants, so the
 // k-loop is straight-line code: 2 + 14 transposed reads for step ks+1 in flight behind the 7 MFMAs of step ks
-template <int WV, int TW>
-__device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* sl0, const char* sl1, const char* sl2,
-                                                 const char* dys, int lane_off) {
+template <int WV, int TW, int CIT>
+__device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const char* sl0, const char* sl1,
+                                                 const char* sl2, const char* dys, int lane_off) {
   constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16, NT = (27 - WV + 3) / 4;     // NT = 7 (6 for wave 3)
-  // software pipeline over k-steps (two per trip, static buffer parity): the 2 + 2*NT transposed reads of
-  // step ks+1 are requested before the NT MFMAs of step ks are issued
-  bf16x8 fbw[2], faw[2][NT];
+  constexpr int PLANE = (TH + 2) * SW * 64;           // one ci tile of an x slab: [voxel][32 ch]
+  bf16x8 fbw[2], faw[2][NT * CIT];
   auto load_dy = [&](int ks) {
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
     return tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
   };
-  auto load_x = [&](int ks, int i) {
+  auto load_x = [&](int ks, int j) {                  // j = c * NT + i: ci tile c, tap WV + 4 i
+    const int c = j / NT, i = j % NT;
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
     const int tap = WV + 4 * i;
-    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;                // folded: i is unrolled, WV constant
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;                // folded: j is unrolled, WV constant
     const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
-    return tr_frag(sl + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
+    return tr_frag(sl + c * PLANE + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
   };
   fbw[0] = load_dy(0);
 #pragma unroll
-  for (int i = 0; i < NT; ++i) faw[0][i] = load_x(0, i);
+  for (int j = 0; j < NT * CIT; ++j) faw[0][j] = load_x(0, j);
   // one wave per SIMD: nothing else fills the matrix core while this wave issues a burst of LDS reads, so the
   // fragments of the next k-step are requested one at a time IN the gaps between the MFMAs of the current one
   // (the fences pin that order; the loads complete a whole k-step before their first use)
 #pragma unroll 1
   for (int ks = 0; ks < NKS; ks += 2) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      if (i == 0) fbw[1] = load_dy(ks + 1);
-      faw[1][i] = load_x(ks + 1, i);
+    for (int j = 0; j < NT * CIT; ++j) {
+      if (j == 0) fbw[1] = load_dy(ks + 1);
+      faw[1][j] = load_x(ks + 1, j);
       __builtin_amdgcn_sched_barrier(0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][i], fbw[0], acc[i], 0, 0, 0);
+      acc[(j / NT) * 7 + j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][j], fbw[0], acc[(j / NT) * 7 + j % NT], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     const int kn = ks + 2 < NKS ? ks + 2 : ks;      // last trip: a harmless re-read instead of branches in the gaps
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      if (i == 0) fbw[0] = load_dy(kn);
-      faw[0][i] = load_x(kn, i);
+    for (int j = 0; j < NT * CIT; ++j) {
+      if (j == 0) fbw[0] = load_dy(kn);
+      faw[0][j] = load_x(kn, j);
       __builtin_amdgcn_sched_barrier(0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][i], fbw[1], acc[i], 0, 0, 0);
+      acc[(j / NT) * 7 + j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][j], fbw[1], acc[(j / NT) * 7 + j % NT], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -219,14 +219,15 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7], const char* s
 
 // the whole march of wave WV (its taps are compile-time constants): the wave variants never merge before the end
 // of the kernel, so the seven accumulator tiles stay in one register class (no VGPR <-> AGPR copies per depth)
-template <int TW, int WV>
+template <int TW, int WV, int CIT>
 __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                             int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
                                             int Cout, int tilesH, int tilesW, int dsegs, int dlen) {
   constexpr int TH = WG_TH, SW = TW + 2, SH = TH + 2, SLAB = SH * SW;   // voxels per x slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* xs = smem;                                   // [3][SLAB][32] bf16
-  char* dys = smem + 3 * SLAB * 64;                  // [TH*TW][32] bf16
+  constexpr int PLANE = SLAB * 64, XSLOT = CIT * PLANE;
+  char* xs = smem;                                   // [3 slots][CIT ci tiles][SLAB][32] bf16
+  char* dys = smem + 3 * XSLOT;                      // [TH*TW][32] bf16
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int wave = WV;
   int b = blockIdx.x;
@@ -234,36 +235,38 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   const int tw = b % tilesW; b /= tilesW;
   const int th = b % tilesH; b /= tilesH;
   const int n = b;
-  const int ncit = Cin / 32;
-  const int cot = blockIdx.y / ncit, cit = blockIdx.y % ncit;
+  const int ncg = Cin / (32 * CIT);                  // groups of CIT ci tiles: one block reads whole CIT*64-byte rows
+  const int cot = blockIdx.y / ncg, cg = blockIdx.y % ncg;
   const int h0 = th * TH, w0 = tw * TW, d0 = seg * dlen;
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
-  const bf16_t* xb = x + cit * 32;
+  const bf16_t* xb = x + cg * (32 * CIT);
   const bf16_t* dyb = dy + cot * 32;
 
   // async-stage split: the next depth's x slab and dy slab travel global -> registers while the current
   // depth is computed, and are committed to LDS behind the barrier that ends the depth
-  constexpr int NLX = (SLAB * 4 + 255) / 256, NLY = TH * TW * 4 / 256;
+  constexpr int XCH = 4 * CIT;                        // 16-byte chunks per x voxel
+  constexpr int NLX = (SLAB * XCH + 255) / 256, NLY = TH * TW * 4 / 256;
   uint4 xreg[NLX], yreg[NLY];
   auto fetch_x = [&](int d) {
     const bool dok = d >= 0 && d < D;
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
       const int i = tid + k * 256;
-      const int vox = i >> 2, ch = i & 3;
+      const int vox = i / XCH, ch = i % XCH;
       const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (i < SLAB * 4 && dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
+      if (i < SLAB * XCH && dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
         v = *reinterpret_cast<const uint4*>(xb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + ch * 8);
       xreg[k] = v;
     }
   };
   auto commit_x = [&](int d) {
-    char* dst = xs + ((d + 1) % 3) * (SLAB * 64);
+    char* dst = xs + ((d + 1) % 3) * XSLOT;
 #pragma unroll
     for (int k = 0; k < NLX; ++k) {
       const int i = tid + k * 256;
-      if (i < SLAB * 4) *reinterpret_cast<uint4*>(dst + (i >> 2) * 64 + (i & 3) * 16) = xreg[k];
+      const int vox = i / XCH, ch = i % XCH;            // plane ch / 4 keeps 64-byte rows (conflict-free tr reads)
+      if (i < SLAB * XCH) *reinterpret_cast<uint4*>(dst + (ch >> 2) * PLANE + vox * 64 + (ch & 3) * 16) = xreg[k];
     }
   };
   auto fetch_dy = [&](int d) {
@@ -290,9 +293,9 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;   // bytes
 
-  f32x16 acc[7];
+  f32x16 acc[7 * CIT];
 #pragma unroll
-  for (int i = 0; i < 7; ++i)
+  for (int i = 0; i < 7 * CIT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -310,10 +313,10 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
       fetch_dy(d + 1);
     }
     {
-      const char* sl0 = xs + ((d + 0) % 3) * (SLAB * 64);        // depth d - 1
-      const char* sl1 = xs + ((d + 1) % 3) * (SLAB * 64);        // depth d
-      const char* sl2 = xs + ((d + 2) % 3) * (SLAB * 64);        // depth d + 1
-      wgrad_depth_step<WV, TW>(acc, sl0, sl1, sl2, dys, lane_off);
+      const char* sl0 = xs + ((d + 0) % 3) * XSLOT;              // depth d - 1
+      const char* sl1 = xs + ((d + 1) % 3) * XSLOT;              // depth d
+      const char* sl2 = xs + ((d + 2) % 3) * XSLOT;              // depth d + 1
+      wgrad_depth_step<WV, TW, CIT>(acc, sl0, sl1, sl2, dys, lane_off);
     }
     __syncthreads();                             // every wave is done with depth d-1's slot and the dy slab
     if (more) {
@@ -324,30 +327,36 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   }
   // partial tiles: part[blockIdx.x][pair][tap][co][ci] - a lane owns 4 consecutive ci per register quad, so the
   // tile leaves as 16-byte stores (4 per tile instead of 16 dword stores: the epilogue is store-issue bound)
-  float* out = part + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (27 * 1024);
   const int co = lane & 31, rbase = (lane >> 5) * 4;
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int tap = wave + 4 * i;
-    if (tap < 27) {
+  for (int c = 0; c < CIT; ++c) {
+    // pair index of (cot, ci tile cg * CIT + c) in the [Cout/32][Cin/32] enumeration the reduction kernel uses
+    const int pair = cot * (Cin / 32) + cg * CIT + c;
+    float* out = part + ((int64_t)blockIdx.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
-            make_float4(acc[i][4 * g4 + 0], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
+    for (int i = 0; i < 7; ++i) {
+      const int tap = wave + 4 * i;
+      if (tap < 27) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
+              make_float4(acc[c * 7 + i][4 * g4 + 0], acc[c * 7 + i][4 * g4 + 1], acc[c * 7 + i][4 * g4 + 2],
+                          acc[c * 7 + i][4 * g4 + 3]);
+      }
     }
   }
 }
 
-template <int TW>
+template <int TW, int CIT>
 __global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
                   int dsegs, int dlen) {
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
-    case 0: wgrad_march<TW, 0>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    case 1: wgrad_march<TW, 1>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    case 2: wgrad_march<TW, 2>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    default: wgrad_march<TW, 3>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 0: wgrad_march<TW, 0, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 1: wgrad_march<TW, 1, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 2: wgrad_march<TW, 2, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    default: wgrad_march<TW, 3, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
   }
 }
 
@@ -371,7 +380,7 @@ wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Ci
   dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
 }
 
-struct WgCfg { int tw, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
+struct WgCfg { int tw, cit, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
 
 inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   WgCfg c;
@@ -379,6 +388,13 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.tilesH = (h + WG_TH - 1) / WG_TH;
   c.tilesW = (w + c.tw - 1) / c.tw;
   c.npairs = (cin / 32) * (cout / 32);
+  {
+    static int cit_env = -1;
+    if (cit_env < 0) { const char* e = getenv("FPLX_WG_CIT"); cit_env = e ? atoi(e) : 2; }   // tuning knob
+    // two ci tiles per block: dy is read once for both and x in whole 128-byte lines (-15 % at level 0/1); the small
+    // deep volumes need the block count more (measured: slower below 32 K voxels per sample)
+    c.cit = (cin % 64 == 0 && cit_env == 2 && (int64_t)d * h * w >= 32000) ? 2 : 1;
+  }
   const int tiles = n * c.tilesH * c.tilesW;
   // one block per CU at a time (LDS + 512-register waves): pick the depth split that minimises
   // rounds x (depths per block + per-block overhead).  The overhead - prologue slabs, the 110-KB partial tile
@@ -392,7 +408,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
       const int dl = (d + cand - 1) / cand;
       if (dl < 4 && cand > 1) break;
       const int segs = (d + dl - 1) / dl;
-      const int64_t rounds = ((int64_t)tiles * c.npairs * segs + 255) / 256;
+      const int64_t rounds = ((int64_t)tiles * (c.npairs / c.cit) * segs + 255) / 256;
       const double cost = (double)rounds * (dl + 9.0);
       if (cost < best - 1e-9) { best = cost; ds = segs; }
     }
@@ -1202,20 +1218,17 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
     return 0;
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
-  dim3 grid(c.nblk, c.npairs);
-  if (c.tw == 32) {
-    constexpr int TW = 32;
-    const size_t lds = (size_t)(3 * (WG_TH + 2) * (TW + 2) + WG_TH * TW) * 64;
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    conv_wgrad_stream<TW><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w,
-                                                  cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);
-  } else {
-    constexpr int TW = 16;
-    const size_t lds = (size_t)(3 * (WG_TH + 2) * (TW + 2) + WG_TH * TW) * 64;
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    conv_wgrad_stream<TW><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w,
-                                                  cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);
-  }
+  dim3 grid(c.nblk, c.npairs / c.cit);
+#define LAUNCH_WG(TW_, CIT_)                                                                                        \
+  do {                                                                                                              \
+    const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + WG_TH * TW_) * 64;                             \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    conv_wgrad_stream<TW_, CIT_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
+                                                         h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);     \
+  } while (0)
+  if (c.tw == 32) { if (c.cit == 2) LAUNCH_WG(32, 2); else LAUNCH_WG(32, 1); }
+  else { if (c.cit == 2) LAUNCH_WG(16, 2); else LAUNCH_WG(16, 1); }
+#undef LAUNCH_WG
   const int64_t total = (int64_t)c.npairs * 27 * 1024;
   wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw);
   int rc = fplx_check_launch("mfma_conv3d_wgrad");
