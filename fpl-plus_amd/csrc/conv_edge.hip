@@ -194,17 +194,30 @@ stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int6
   }
 }
 
-// sum of `nparts` partial arrays of `total` floats each: 64 outputs x 4 partial-lanes per block,
+// sum of `nparts` partial arrays of `total` floats each: 16 outputs x 16 partial-lanes per block (the arrays are
+// small and many: short dependent chains and enough blocks matter more than wide rows), 4 loads in flight per lane,
 // lanes combined in a fixed order
+constexpr int SP_OUT = 16;
 __device__ __forceinline__ float sum_partials(const float* __restrict__ part, int nparts, int64_t total, int64_t i,
                                               float* red) {
-  const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
-  float t = 0.f;
-  if (i < total)
-    for (int b = pl; b < nparts; b += 4) t += part[(int64_t)b * total + i];
-  red[pl * 64 + o] = t;
+  const int pl = threadIdx.x >> 4, o = threadIdx.x & 15;
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+  if (i < total) {
+    int b = pl;
+    for (; b + 48 < nparts; b += 64) {
+      t0 += part[(int64_t)b * total + i];
+      t1 += part[(int64_t)(b + 16) * total + i];
+      t2 += part[(int64_t)(b + 32) * total + i];
+      t3 += part[(int64_t)(b + 48) * total + i];
+    }
+    for (; b < nparts; b += 16) t0 += part[(int64_t)b * total + i];
+  }
+  red[pl * 16 + o] = (t0 + t1) + (t2 + t3);
   __syncthreads();
-  return red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t += red[k * 16 + o];
+  return t;
 }
 
 // dw[co][ci][tap] = sum over block partials
@@ -212,9 +225,9 @@ __global__ void __launch_bounds__(256)
 stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, int co0, float* __restrict__ dw) {
   __shared__ float red[256];
   const int total = rt * 1024;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.x * SP_OUT + (threadIdx.x & (SP_OUT - 1));
   const float t = sum_partials(part, nparts, total, i, red);
-  if (threadIdx.x >= 64 || i >= total) return;
+  if (threadIdx.x >= SP_OUT || i >= total) return;
   const int co = i & 31, k = i >> 5;
   if (k >= 27 * cin) return;
   const int ci = k / 27, tap = k % 27;
@@ -428,9 +441,9 @@ __global__ void __launch_bounds__(256)
 outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0, int ncls, float* __restrict__ dw) {
   __shared__ float red[256];
   const int total = ncit * 9 * 1024;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int i = blockIdx.x * SP_OUT + (threadIdx.x & (SP_OUT - 1));
   const float t = sum_partials(part, nblk, total, i, red);
-  if (threadIdx.x >= 64 || i >= total) return;
+  if (threadIdx.x >= SP_OUT || i >= total) return;
   const int co = i & 31;
   if (co >= ncls) return;
   const int ci_l = (i >> 5) & 31, tap = (i >> 10) % 9, cit = i / (9 * 1024);
@@ -490,7 +503,7 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
     else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
-    stem_wgrad_reduce<<<(rt * 1024 + 63) / 64, 256, 0, st>>>((const float*)ws, nb, rt, cin, co0, dw);
+    stem_wgrad_reduce<<<(rt * 1024 + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nb, rt, cin, co0, dw);
   }
   int rc = fplx_check_launch("edge_stem_wgrad");
   return rc < 0 ? rc : 1;
@@ -537,7 +550,7 @@ extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* 
   dim3 grid(nb, c0 / 32);
   outconv_wgrad_mfma<<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, dl, (float*)ws, n, d, h, w, ncls, nt, th, tw);
   const int total = (c0 / 32) * 9 * 1024;
-  outconv_wgrad_reduce<<<(total + 63) / 64, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
+  outconv_wgrad_reduce<<<(total + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
   int rc = fplx_check_launch("edge_outconv_wgrad");
   return rc < 0 ? rc : 1;
 }
