@@ -17,6 +17,7 @@ template <> struct Vec<float> {
     const float4 r = *reinterpret_cast<const float4*>(p);
     v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
   }
+  static __device__ __forceinline__ void load_nt(const float* p, float (&v)[4]) { load(p, v); }
   static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -26,6 +27,13 @@ template <> struct Vec<bf16_t> {
   typedef __attribute__((ext_vector_type(8))) __bf16 raw;
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const raw r = *reinterpret_cast<const raw*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+  }
+  // streaming variant for the last read of a tensor (BN-apply forward, second BN-backward pass): no allocation in
+  // L2 / Infinity Cache, measured +1.7 % on the whole step; the pooling kernels lose with it and keep plain loads
+  static __device__ __forceinline__ void load_nt(const bf16_t* p, float (&v)[8]) {
+    const raw r = __builtin_nontemporal_load(reinterpret_cast<const raw*>(p));
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
   }
@@ -42,6 +50,11 @@ template <typename T, int VEC>
 __device__ __forceinline__ void ldv(const T* p, float (&v)[VEC]) {
   if constexpr (VEC == 1) v[0] = Act<T>::ld(p);
   else Vec<T>::load(p, v);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void ldv_nt(const T* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) v[0] = Act<T>::ld(p);
+  else Vec<T>::load_nt(p, v);
 }
 template <typename T, int VEC>
 __device__ __forceinline__ void stv(T* p, const float (&v)[VEC]) {
@@ -155,7 +168,7 @@ bn_act_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t 
     for (int u = 0; u < 4; ++u) {
       v[u] = (i + u * st) / G;
       c0[u] = (int)((i + u * st) % G) * VEC;
-      ldv<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
+      ldv_nt<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) one(v[u], c0[u], a[u]);
@@ -164,7 +177,7 @@ bn_act_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t 
     const int64_t v = i / G;
     const int c0 = (int)(i % G) * VEC;
     float a[VEC];
-    ldv<T, VEC>(y + v * ldy + c0, a);
+    ldv_nt<T, VEC>(y + v * ldy + c0, a);
     one(v, c0, a);
   }
 }
@@ -318,8 +331,8 @@ bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ d
     for (int u = 0; u < 4; ++u) {
       v[u] = (i + u * st) / G;
       c0[u] = (int)((i + u * st) % G) * VEC;
-      ldv<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
-      ldv<T, VEC>(dout + v[u] * ldd + c0[u], d[u]);
+      ldv_nt<T, VEC>(y + v[u] * ldy + c0[u], a[u]);
+      ldv_nt<T, VEC>(dout + v[u] * ldd + c0[u], d[u]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) one(v[u], c0[u], a[u], d[u]);
@@ -328,8 +341,8 @@ bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ d
     const int64_t v = i / G;
     const int c0 = (int)(i % G) * VEC;
     float a[VEC], d[VEC];
-    ldv<T, VEC>(y + v * ldy + c0, a);
-    ldv<T, VEC>(dout + v * ldd + c0, d);
+    ldv_nt<T, VEC>(y + v * ldy + c0, a);
+    ldv_nt<T, VEC>(dout + v * ldd + c0, d);
     one(v, c0, a, d);
   }
 }
