@@ -26,6 +26,10 @@ def uncl(t2, n, d, h, w):
                                    # large H x W with Cin in {32, 64}: the streaming LDS kernel (ragged tiles included)
                                    (1, 32, 32, 20, 24, 96), (2, 64, 64, 9, 18, 70), (1, 64, 32, 4, 16, 64),
                                    (2, 32, 64, 7, 20, 70),
+                                   # depth-marching kernels: several depth segments per tile, ragged footprints, n = 3,
+                                   # Cout = 96, short volumes; (1, 64, 64, 20, 40, 40) also takes the two-ci-tile wgrad
+                                   (1, 32, 32, 40, 32, 64), (3, 32, 96, 6, 17, 65), (1, 64, 32, 37, 24, 64),
+                                   (2, 64, 96, 5, 9, 70), (1, 64, 64, 20, 40, 40),
                                    # tiny volumes, wide channels: split-K over the taps (27 / 9 / 3-way)
                                    (2, 128, 128, 2, 5, 5), (2, 64, 256, 5, 10, 10), (1, 128, 64, 10, 20, 20)])
 def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
