@@ -359,7 +359,13 @@ extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* d
                                        hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
-                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st);
+                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
+                                      const void* x1);
+extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                     const void* x1, void* y1);
 
 extern "C" {
 
@@ -498,6 +504,51 @@ size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout,
   return (m + b + 256) > g ? (m + b + 256) : g;
 }
 
+/* ---- the channel concatenation of two tensors as a convolution operand, never materialised ---- */
+int fplx_conv3d_cat2_ok(int n, int d, int h, int w, int cin, int cout) {
+  // two halves of 32 channels: the depth-marching Cin = 64 kernel streams them as its two half-slabs, the data
+  // gradient is the Cin = 32 march with two output tensors, the weight gradient the two-ci-tile kernel
+  return cin == 64 && cout == 32 && fplx_march_ok(n, d, h, w, 64, cout) && fplx_march_ok(n, d, h, w, cout, 64) &&
+         fplx_mfma_conv3d_wgrad_cit(n, d, h, w, 64, cout) == 2;
+}
+
+int fplx_conv3d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+                         fplx_stream_t stream) {
+  FPLX_REQUIRE(x0 && x1 && wp && y, FPLX_E_NULL, "conv3d_fwd_cat2: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
+               "conv3d_fwd_cat2: shape n=%d d=%d h=%d w=%d cin=%d cout=%d not supported (fplx_conv3d_cat2_ok)", n, d,
+               h, w, cin, cout);
+  const int r = fplx_march_conv3d_fwd(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (hipStream_t)stream, x1,
+                                      nullptr);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_cat2: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+
+int fplx_conv3d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, fplx_stream_t stream) {
+  FPLX_REQUIRE(dy && wb && dx0 && dx1, FPLX_E_NULL, "conv3d_dgrad_split2: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
+               "conv3d_dgrad_split2: shape not supported (fplx_conv3d_cat2_ok)");
+  // the data gradient is the convolution of dy (cout channels) with the mirrored pack, producing cin channels
+  const int r = fplx_march_conv3d_fwd(dy, ldy, wb, nullptr, dx0, ldx, n, d, h, w, cout, cin, nullptr,
+                                      (hipStream_t)stream, nullptr, dx1);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_dgrad_split2: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+
+int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x0 && x1 && dy && dw && ws, FPLX_E_NULL, "conv3d_wgrad_cat2: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
+               "conv3d_wgrad_cat2: shape not supported (fplx_conv3d_cat2_ok)");
+  const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+  FPLX_REQUIRE(ws_bytes >= m, FPLX_E_WORKSPACE, "conv3d_wgrad_cat2: workspace %zu < %zu", ws_bytes, m);
+  const int r = fplx_mfma_conv3d_wgrad(x0, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, m, (hipStream_t)stream, x1);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_wgrad_cat2: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+
 int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
                       const void* dy, int dy_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
                       float* dw, float* db, int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
@@ -517,7 +568,7 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
       sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
     const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
-      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st);
+      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st, nullptr);
       if (r < 0) return r;
       if (r == 1) { done = true; used = m; }
     }

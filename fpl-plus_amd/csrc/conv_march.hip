@@ -93,7 +93,8 @@ __device__ __forceinline__ void march_step(const char* __restrict__ sl, const ch
 __global__ void __launch_bounds__(MG::THREADS)
 conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen) {
+                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
+                 bf16_t* __restrict__ y1, int ysplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;
   char* wbuf = smem + 2 * MG::SLAB_BYTES;
@@ -189,7 +190,9 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     if (w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf < W) wmask |= 1u << i;
   const bool hok0 = h0 + wave * 2 < H, hok1 = h0 + wave * 2 + 1 < H;
   const unsigned ldy2 = (unsigned)ldy * 2u;
-  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy + n0) * 2;
+  // split output (the data gradient of a conv on concatenated inputs): channel blocks >= ysplit go to y1
+  bf16_t* ysel = (int)blockIdx.y >= ysplit ? y1 + ((int)blockIdx.y - ysplit) * 32 : y + n0;
+  char* yn = reinterpret_cast<char*>(ysel) + (((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy * 2;
   const int64_t yslice = (int64_t)H * W * ldy * 2;        // bytes per output depth
   const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
   const bool sok0 = w0 + (lane >> 2) < W, sok1 = w0 + (lane >> 2) + 16 < W;
@@ -359,7 +362,8 @@ __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const 
 __global__ void __launch_bounds__(MG64::THREADS)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen) {
+                 int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
+                 const bf16_t* __restrict__ x1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;                                        // [2 channel halves][SLAB][32]
   char* wbuf = smem + 2 * MG64::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
@@ -399,9 +403,11 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   }
   const int64_t xslice = (int64_t)H * W * ldx * 2;
   const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  // channel half 1: the next 32 channels of x, or a second tensor (torch.cat([x, x1], 1) never materialised)
+  const char* xn1 = reinterpret_cast<const char*>(x1 ? x1 : x + 32) + (int64_t)n * D * xslice;
   auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel half hf of slab s -> slot hf
     if (wave + 4 * k < MG64::SLAB_DMA && soff[k] != -2) {
-      const char* xs = xn + s * xslice + hf * 64;           // uniform
+      const char* xs = (hf ? xn1 : xn) + s * xslice;        // uniform
       const void* src = soff[k] >= 0 ? (const void*)(xs + (unsigned)soff[k]) : (const void*)fplx_zero16;
       lds_dma(src, slabs + hf * MG64::SLAB_BYTES + (wave + 4 * k) * 1024);
     }
@@ -592,22 +598,27 @@ extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout) {
 
 // returns 1 if launched, 0 if the pointers do not allow the vector stores, <0 on error
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
-  if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                     const void* x1, void* y1) {
+  if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0 ||
+      ((uintptr_t)x1 % 16) != 0 || ((uintptr_t)y1 % 16) != 0)
     return 0;
   const MarchCfg c = march_cfg(n, d, h, w, cin, cout);
   dim3 grid(c.nblk, cout / 32);
   if (cin == 64) {
+    if (y1) return 0;
     (void)hipFuncSetAttribute((const void*)conv_fwd_march64, hipFuncAttributeMaxDynamicSharedMemorySize, MG64::LDS);
     conv_fwd_march64<<<grid, MG64::THREADS, MG64::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
                                                              ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs,
-                                                             c.dlen);
+                                                             c.dlen, (const bf16_t*)x1);
     const int rc64 = fplx_check_launch("march64_conv3d_fwd");
     return rc64 < 0 ? rc64 : 1;
   }
+  if (x1) return 0;
   (void)hipFuncSetAttribute((const void*)conv_fwd_march32, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS);
   conv_fwd_march32<<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n,
-                                                       d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, c.dlen);
+                                                       d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, c.dlen,
+                                                       (bf16_t*)y1, y1 ? cout / 64 : cout / 32);
   const int rc = fplx_check_launch("march_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }

@@ -222,7 +222,8 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
 template <int TW, int WV, int CIT>
 __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                             int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
-                                            int Cout, int tilesH, int tilesW, int dsegs, int dlen) {
+                                            int Cout, int tilesH, int tilesW, int dsegs, int dlen,
+                                            const bf16_t* __restrict__ x1) {
   constexpr int TH = WG_TH, SW = TW + 2, SH = TH + 2, SLAB = SH * SW;   // voxels per x slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PLANE = SLAB * 64, XSLOT = CIT * PLANE;
@@ -256,7 +257,7 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
       const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (i < SLAB * XCH && dok && hh >= 0 && hh < H && ww >= 0 && ww < W)
-        v = *reinterpret_cast<const uint4*>(xb + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + ch * 8);
+        v = *reinterpret_cast<const uint4*>(((x1 && ch >= 4) ? x1 - 32 : xb) + ((((int64_t)n * D + d) * H + hh) * W + ww) * ldx + ch * 8);
       xreg[k] = v;
     }
   };
@@ -351,12 +352,12 @@ template <int TW, int CIT>
 __global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
-                  int dsegs, int dlen) {
+                  int dsegs, int dlen, const bf16_t* __restrict__ x1) {
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
-    case 0: wgrad_march<TW, 0, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    case 1: wgrad_march<TW, 1, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    case 2: wgrad_march<TW, 2, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
-    default: wgrad_march<TW, 3, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen); break;
+    case 0: wgrad_march<TW, 0, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 1: wgrad_march<TW, 1, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 2: wgrad_march<TW, 2, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    default: wgrad_march<TW, 3, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
   }
 }
 
@@ -1122,7 +1123,8 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                     const void* x1, void* y1);
 
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
@@ -1147,7 +1149,7 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     size_t ws_bytes, hipStream_t st) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
   if (fplx_march_ok(n, d, h, w, cin, cout))
-    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
+    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr);
   if (stream_ok(d, h, w, cin, cout)) {
     const StreamCfg sc = stream_cfg(n, d, h, w, cout);
     dim3 grid(sc.nblk, cout / 32);
@@ -1206,6 +1208,11 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
   return rc < 0 ? rc : 1;
 }
 
+extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout) {
+  if (cin % 32 != 0 || cout % 32 != 0) return 0;
+  return wg_cfg(n, d, h, w, cin, cout).cit;
+}
+
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 32 != 0 || cout % 32 != 0) return 0;
   return wg_cfg(n, d, h, w, cin, cout).ws;
@@ -1213,10 +1220,12 @@ extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, in
 
 // returns 1 if handled, 0 if not applicable, <0 on error.  dw fp32 [Cout][Cin][27]
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
-                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st) {
+                                      int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
+                                      const void* x1) {
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
     return 0;
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
+  if (x1 && (c.cit != 2 || cin != 64 || ((uintptr_t)x1 % 16))) return 0;   // split x: one group of two ci tiles
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
   dim3 grid(c.nblk, c.npairs / c.cit);
 #define LAUNCH_WG(TW_, CIT_)                                                                                        \
@@ -1224,7 +1233,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
     const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + WG_TH * TW_) * 64;                             \
     (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     conv_wgrad_stream<TW_, CIT_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
-                                                         h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen);     \
+                                                         h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
   } while (0)
   if (c.tw == 32) { if (c.cit == 2) LAUNCH_WG(32, 2); else LAUNCH_WG(32, 1); }
   else { if (c.cit == 2) LAUNCH_WG(16, 2); else LAUNCH_WG(16, 1); }

@@ -24,7 +24,7 @@ LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
 class Saved(object):
     """what one forward leaves behind for its backward"""
     __slots__ = ("x", "dims", "domain", "train", "seed", "step", "blocks", "cats", "pooled", "packs",
-                 "drop_on", "deconv_in")
+                 "drop_on", "deconv_in", "skips", "split")
 
 
 class Engine(object):
@@ -36,6 +36,7 @@ class Engine(object):
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
         # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
         self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
+        self.use_split_cat = os.environ.get("FPLX_SPLIT_CAT", "1") != "0"     # A/B knob (benchmarks only)
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
@@ -98,9 +99,24 @@ class Engine(object):
         def empty(v, c):
             return torch.empty((v, c), dtype=adt, device=dev)
 
-        # concat buffers of levels 0..3: [skip | up]
-        cats = [empty(vox[l], 2 * ft[l]) for l in range(4)]
-        sv.cats = cats
+        # levels 0..3: skip and up halves of the decoder input.  Normally two channel slices of ONE [V, 2C] buffer (the
+        # reference's torch.cat, never copied); where the halves are only 32 channels (64 bytes) wide every kernel that
+        # touches one half would move half-used 128-byte lines, so there they are two tensors and the first decoder
+        # convolution takes both (fplx_conv3d_*_cat2 / _split2)
+        # (a backward through eval-mode BatchNorm also needs the conv bias gradient: that case keeps the buffer)
+        can_split = self.use_split_cat and adt == torch.bfloat16 and (train or not keep)
+        split = [can_split and ops.conv3d_cat2_ok(dims[l], 2 * ft[l], ft[l]) for l in range(4)]
+        cats, skips, ups = [], [], []
+        for l in range(4):
+            if split[l]:
+                cats.append(None)
+                skips.append(empty(vox[l], ft[l]))
+                ups.append(empty(vox[l], ft[l]))
+            else:
+                cats.append(empty(vox[l], 2 * ft[l]))
+                skips.append(cats[l][:, :ft[l]])
+                ups.append(cats[l][:, ft[l]:])
+        sv.cats, sv.skips, sv.split = cats, skips, split
 
         def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active):
             """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view"""
@@ -114,8 +130,11 @@ class Engine(object):
                 stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
             else:
                 rows, stats = 0, None
-            ops.conv3d_fwd(xin, xs, x_dt, packs[key][0], conv.bias, y, ops.cl_strides(*dims[l][1:], cout), a_dt,
-                           dims[l], cin, cout, (3, 3, 3), stats)
+            if isinstance(xin, tuple):
+                ops.conv3d_fwd_cat2(xin[0], xin[1], packs[key][0], conv.bias, y, dims[l], cin, cout, stats)
+            else:
+                ops.conv3d_fwd(xin, xs, x_dt, packs[key][0], conv.bias, y, ops.cl_strides(*dims[l][1:], cout), a_dt,
+                               dims[l], cin, cout, (3, 3, 3), stats)
             if train:
                 ops.bn_train_finalize(stats, rows, cout, vox[l], bnm.weight, bnm.bias, bnm.running_mean,
                                       bnm.running_var, bnm.num_batches_tracked, bnbuf, bnm.momentum, bnm.eps)
@@ -141,7 +160,7 @@ class Engine(object):
         # ---- encoder
         cur, cur_s, cur_dt, cur_c = x, ops.planar_strides(Cin, D, H, W), F32, Cin
         for i in range(5):
-            out_view = cats[i][:, :ft[i]] if i < 4 else empty(vox[4], ft[4])
+            out_view = skips[i] if i < 4 else empty(vox[4], ft[4])
             conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view)
             if i < 4:
                 pooled = empty(vox[i + 1], ft[i])
@@ -155,10 +174,10 @@ class Engine(object):
             l = 3 - j
             tr = net.up_modules[j].trans3d
             sv.deconv_in.append(cur)
-            ops.deconv2_fwd(cur, packs["up%d.trans3d" % (j + 1)][0], tr.bias, cats[l][:, ft[l]:], dims[l + 1],
-                            ft[l + 1], ft[l])
+            ops.deconv2_fwd(cur, packs["up%d.trans3d" % (j + 1)][0], tr.bias, ups[l], dims[l + 1], ft[l + 1], ft[l])
             out = empty(vox[l], ft[l])
-            conv_block(5 + j, cats[l], ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
+            xin = (skips[l], ups[l]) if split[l] else cats[l]
+            conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
             cur = out
         # ---- out_conv (1x3x3) -> fp32 planar logits
         ncls = net.n_class
@@ -255,6 +274,12 @@ class Engine(object):
                            gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
             db = None if sv.train else gv[key + ".bias"]
+            if isinstance(xin, tuple):                 # cat([skip, up]) as two tensors (train-mode BN only: db is None)
+                on_side(lambda: ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, gv[key + ".weight"], dims[l], cin, c, ws_w),
+                        d_out, xin[0], xin[1])
+                if want_dx:
+                    ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c)
+                return
             on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt,
                                              gv[key + ".weight"], db, dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
             if want_dx:
@@ -269,7 +294,10 @@ class Engine(object):
             d_a1 = empty(vox[l], c)
             site_bwd(key + ".conv3d_2", key + ".bn3d2", key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0, d_out,
                      blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1)
-            d_in = empty(vox[l], cin) if want_dx else None
+            if isinstance(blk["xin"], tuple):
+                d_in = (empty(vox[l], cin // 2), empty(vox[l], cin // 2)) if want_dx else None
+            else:
+                d_in = empty(vox[l], cin) if want_dx else None
             site_bwd(key + ".conv3d_1", key + ".bn3d1", key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"], blk["sid"],
                      d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in)
             return d_in
@@ -278,9 +306,12 @@ class Engine(object):
         d_skips = [None] * 4
         for j in range(3, -1, -1):
             l = 3 - j
-            d_cat = block_bwd(5 + j, d_cur, True)                     # [V_l, 2*ft_l]
-            d_skips[l] = d_cat[:, :ft[l]]
-            d_up = d_cat[:, ft[l]:]
+            d_cat = block_bwd(5 + j, d_cur, True)                     # [V_l, 2*ft_l], or the two halves
+            if isinstance(d_cat, tuple):
+                d_skips[l], d_up = d_cat
+            else:
+                d_skips[l] = d_cat[:, :ft[l]]
+                d_up = d_cat[:, ft[l]:]
             name = "up%d.trans3d" % (j + 1)
             xin = sv.deconv_in[j]
             on_side(lambda xin=xin, d_up=d_up, name=name, l=l: ops.deconv2_wgrad(
@@ -293,7 +324,7 @@ class Engine(object):
         ready("block4.conv.relu_1.weight")
         for i in range(3, -1, -1):
             d_a2 = empty(vox[i], ft[i])
-            ops.maxpool2_bwd(sv.cats[i][:, :ft[i]], d_pool, d_skips[i], d_a2, dims[i], ft[i])
+            ops.maxpool2_bwd(sv.skips[i], d_pool, d_skips[i], d_a2, dims[i], ft[i])
             d_pool = block_bwd(i, d_a2, i > 0)
             ready("block%d.conv.relu_1.weight" % i)
         join_side()

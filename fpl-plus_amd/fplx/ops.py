@@ -101,6 +101,34 @@ def conv3d_wgrad(x, xs, x_dt, dy, ys, dy_dt, dw, db, dims, cin, cout, k, ws):
          k[0], k[1], k[2], ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
+def conv3d_cat2_ok(dims, cin, cout):
+    """True if the 3x3x3 convolution on cat([x0, x1], channel) of two cin/2-channel bf16 tensors has the split fast
+    path (level 0 of the 32-base network): the concatenation is then never materialised."""
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv3d_cat2_ok(n, d, h, w, cin, cout) == 1
+
+
+def conv3d_fwd_cat2(x0, x1, wp, bias, y, dims, cin, cout, stats=None):
+    n, d, h, w = dims
+    assert ld_of(x0) == ld_of(x1)
+    call("fplx_conv3d_fwd_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(wp), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin,
+         cout, ptr(stats), stream())
+
+
+def conv3d_dgrad_split2(dy, wb, dx0, dx1, dims, cin, cout):
+    n, d, h, w = dims
+    assert ld_of(dx0) == ld_of(dx1)
+    call("fplx_conv3d_dgrad_split2", ptr(dy), ld_of(dy), ptr(wb), ptr(dx0), ptr(dx1), ld_of(dx0), n, d, h, w, cin,
+         cout, stream())
+
+
+def conv3d_wgrad_cat2(x0, x1, dy, dw, dims, cin, cout, ws):
+    n, d, h, w = dims
+    assert ld_of(x0) == ld_of(x1)
+    call("fplx_conv3d_wgrad_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(dy), ld_of(dy), ptr(dw), n, d, h, w, cin, cout,
+         ptr(ws), ws.numel() * ws.element_size(), stream())
+
+
 def deconv2_fwd(x, wf, bias, y, dims, cin, cout):
     n, d, h, w = dims
     call("fplx_deconv2_fwd", ptr(x), ld_of(x), ptr(wf), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin, cout,

@@ -94,6 +94,22 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
                       float* dw, float* db, int n, int d, int h, int w, int cin, int cout,
                       int kd, int kh, int kw, void* ws, size_t ws_bytes, fplx_stream_t stream);
 
+/* The first convolution of an UpBlock reads torch.cat([skip, up], dim=1) (unet2d5_dsbn.py:182-183).  Where the two
+ * halves are 32 channels wide (level 0) a concat BUFFER would be addressed in half 128-byte lines by every other
+ * kernel that touches one half (pooling, transposed convolution), so there the concatenation is never built: these
+ * three entry points take / produce the two tensors separately (bf16 NDHWC, both with leading dimension ldx;
+ * cin = total input channels = 64).  fplx_conv3d_cat2_ok tells whether a shape is served; stats rows and the
+ * workspace size are those of fplx_conv3d_stats_rows / fplx_conv3d_wgrad_ws_bytes for the same (cin, cout). */
+int fplx_conv3d_cat2_ok(int n, int d, int h, int w, int cin, int cout);
+int fplx_conv3d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+                         fplx_stream_t stream);
+/* dy: [voxels][cout]; wb: the mirrored pack of the same weight; dx0 / dx1: gradients of the two input halves */
+int fplx_conv3d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, fplx_stream_t stream);
+int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ transposed convolution
  * nn.ConvTranspose3d(k=2,s=2) (unet2d5_dsbn.py:152,181).  x: [N,D,H,W,Cin] ld ldx;
  * y: [N,2D,2H,2W,Cout] ld ldy (normally the upper channel half of the concat buffer, line 182). */

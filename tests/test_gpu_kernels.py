@@ -86,6 +86,61 @@ def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
                        (0, d, h, w), cin, cout, (3, 3, 3), None)
 
 
+@pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70)])
+def test_conv3d_cat2_split_concat(shape):
+    """conv3x3x3 on cat([x0, x1], channel) with the concatenation never built (reference unet2d5_dsbn.py:182-183):
+    forward + statistics, data gradient into two tensors, weight gradient - against torch on the explicit cat"""
+    from fplx import ops
+    n, d, h, w = shape
+    cin, cout, tol = 64, 32, 2e-2
+    dims = (n, d, h, w)
+    assert ops.conv3d_cat2_ok(dims, cin, cout)
+    assert not ops.conv3d_cat2_ok((1, 4, 16, 32), cin, cout) and not ops.conv3d_cat2_ok(dims, 128, 64)
+    q = lambda t: t.bfloat16().float()
+    x0 = q(torch.from_numpy(detdata.normal("c2.x0%s" % (shape,), (n, 32, d, h, w))))
+    x1 = q(torch.from_numpy(detdata.normal("c2.x1%s" % (shape,), (n, 32, d, h, w))))
+    wt = q(torch.from_numpy(detdata.normal("c2.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.2)))
+    b = torch.from_numpy(detdata.normal("c2.b%s" % (shape,), (cout,)))
+    dy = q(torch.from_numpy(detdata.normal("c2.dy%s" % (shape,), (n, cout, d, h, w))))
+    xr = torch.cat([x0, x1], 1).requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, b, padding=1)
+    yr.backward(dy)
+    bf, dt = torch.bfloat16, ops._DT[torch.bfloat16]
+    g0, g1, dyg = cl(x0).to(bf).cuda(), cl(x1).to(bf).cuda(), cl(dy).to(bf).cuda()
+    wf, wb = ops.pack_conv_weight(wt.cuda(), bf)
+    y = torch.empty((g0.shape[0], cout), dtype=bf, device="cuda")
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    ops.conv3d_fwd_cat2(g0, g1, wf, b.cuda(), y, dims, cin, cout, stats)
+    scale = float(yr.detach().abs().max())
+    assert float((uncl(y.float().cpu(), n, d, h, w) - yr.detach()).abs().max()) < tol * scale
+    yf = cl(yr.detach())
+    sm = stats.sum(0).cpu()
+    np.testing.assert_allclose(sm[0].numpy(), yf.sum(0).numpy(), atol=tol * scale * yf.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(sm[1].numpy(), (yf * yf).sum(0).numpy(), rtol=tol * 4)
+    # the same kernel on the materialised concatenation gives the same bits
+    cat = torch.cat([g0, g1], 1).contiguous()
+    y2 = torch.empty_like(y)
+    ops.conv3d_fwd(cat, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y2, ops.cl_strides(d, h, w, cout), dt, dims, cin,
+                   cout, (3, 3, 3), None)
+    assert torch.equal(y, y2)
+    dx0 = torch.empty_like(g0)
+    dx1 = torch.empty_like(g1)
+    ops.conv3d_dgrad_split2(dyg, wb, dx0, dx1, dims, cin, cout)
+    gmax = float(xr.grad.abs().max())
+    assert float((uncl(dx0.float().cpu(), n, d, h, w) - xr.grad[:, :32]).abs().max()) < tol * gmax
+    assert float((uncl(dx1.float().cpu(), n, d, h, w) - xr.grad[:, 32:]).abs().max()) < tol * gmax
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad_cat2(g0, g1, dyg, dw, dims, cin, cout, ws)
+    assert float((dw.cpu() - wr.grad).abs().max()) < tol * float(wr.grad.abs().max())
+    with pytest.raises(ValueError):
+        ops.conv3d_fwd_cat2(g0, g1, wf, None, y, (1, 4, 16, 32), cin, cout, None)
+    with pytest.raises(RuntimeError):
+        ops.conv3d_wgrad_cat2(g0, g1, dyg, dw, dims, cin, cout, ws[:16])
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("shape", [(2, 12, 7, 3, 4, 5), (2, 64, 32, 3, 4, 5), (1, 128, 64, 2, 5, 9), (1, 32, 32, 4, 4, 7),
                                    (1, 96, 32, 2, 3, 67)])
