@@ -57,8 +57,9 @@ class KernelTimer(object):
     def __init__(self, ops):
         self.ops, self.records, self.on = ops, {}, False
         self._orig = {}
-        for name in ("conv3d_fwd", "conv3d_wgrad", "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad",
-                     "deconv2_wgrad", "maxpool2_fwd", "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step"):
+        for name in ("conv3d_fwd", "conv3d_wgrad", "conv3d_fwd_cat2", "conv3d_dgrad_split2", "conv3d_wgrad_cat2",
+                     "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad", "maxpool2_fwd",
+                     "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step"):
             self._wrap(name)
 
     def _key(self, name, a):
@@ -68,6 +69,13 @@ class KernelTimer(object):
         if name == "conv3d_wgrad":
             dims, cin, cout, k = a[8], a[9], a[10], a[11]
             return (name, dims, cin, cout, k)
+        # the split-concat entry points are the same convolutions (same kernels) with two-tensor operands
+        if name == "conv3d_fwd_cat2":           # (x0, x1, wp, bias, y, dims, cin, cout, stats)
+            return ("conv3d_fwd", a[5], a[6], a[7], (3, 3, 3))
+        if name == "conv3d_dgrad_split2":       # (dy, wb, dx0, dx1, dims, cin, cout): conv of cout -> cin channels
+            return ("conv3d_fwd", a[4], a[6], a[5], (3, 3, 3))
+        if name == "conv3d_wgrad_cat2":         # (x0, x1, dy, dw, dims, cin, cout, ws)
+            return ("conv3d_wgrad", a[4], a[5], a[6], (3, 3, 3))
         return (name,)
 
     def _wrap(self, name):
