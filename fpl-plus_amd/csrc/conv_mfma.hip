@@ -877,7 +877,7 @@ inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
 // KC = 64 doubles the matrix work per barrier and per global-load round trip.  blockIdx.z deals the taps
 // (split-K) exactly like conv_fwd_direct.
 template <int NT, int KC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
               float* __restrict__ stats, float* __restrict__ partial) {
@@ -919,38 +919,50 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   const int ntaps = (27 - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
   const int niter = ntaps * nkc;
   auto swz = [](int row) { return (row / (16 / CH)) % CH; };
-  // named staging registers (runtime-indexed arrays would go to scratch)
-  uint4 areg0, areg1, areg2, areg3, breg0, breg1, breg2, breg3;
-  areg2 = areg3 = breg1 = breg2 = breg3 = make_uint4(0, 0, 0, 0);
-#define TILE_A(U, REG)                                                                                              \
+  // named staging registers (runtime-indexed arrays would go to scratch).  The A loads are UNCONDITIONAL: a row
+  // whose tap falls outside the volume (padding) reads its centre voxel instead and is replaced by zeros when it is
+  // committed (zmask, one bit per staged row).  A conditional load with a zero default makes hipcc drain vmcnt(0)
+  // between the A and the B loads of one iteration, i.e. wait a full L2 round trip before the B loads even leave.
+  // TWO register sets (suffix 0 / 1): the loads of iteration it + 2 leave before iteration it computes, so every load
+  // has a full iteration of matrix work plus the partner blocks' time to come back (an L2 round trip is longer than
+  // one iteration's MFMAs).
+  uint4 areg00, areg01, areg02, areg03, breg00, breg01, breg02, breg03;
+  uint4 areg10, areg11, areg12, areg13, breg10, breg11, breg12, breg13;
+  areg02 = areg03 = breg01 = breg02 = breg03 = make_uint4(0, 0, 0, 0);
+  areg12 = areg13 = breg11 = breg12 = breg13 = make_uint4(0, 0, 0, 0);
+  unsigned zmask0 = 0, zmask1 = 0;
+#define TILE_A(U, S)                                                                                                \
   if (PA > (U)) {                                                                                                   \
     constexpr int u_ = (U) < PA ? (U) : 0;                                                                          \
-    REG = make_uint4(0, 0, 0, 0);                                                                                   \
-    if ((amask[u_] >> tap_) & 1u) REG = *reinterpret_cast<const uint4*>(abase[u_] + aoff_);                         \
+    const bool in_ = (amask[u_] >> tap_) & 1u;                                                                      \
+    zmask##S |= in_ ? 0u : (1u << (U));                                                                             \
+    areg##S##U = *reinterpret_cast<const uint4*>(abase[u_] + (in_ ? aoff_ : (int64_t)kc_));                         \
   }
-#define TILE_B(U, REG)                                                                                              \
-  if (PB > (U)) REG = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + RP * (U)) * Cin + kc_ + c16 * 8);
-#define TILE_FETCH(IT)                                                                                              \
+#define TILE_B(U, S)                                                                                                \
+  if (PB > (U)) breg##S##U = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + RP * (U)) * Cin + kc_ + c16 * 8);
+#define TILE_FETCH(IT, S)                                                                                           \
   do {                                                                                                              \
     const int tap_ = blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                                \
     const int kd_ = tap_ / 9 - 1, kh_ = (tap_ / 3) % 3 - 1, kw_ = tap_ % 3 - 1;                                     \
     const int64_t aoff_ = (((int64_t)kd_ * H + kh_) * W + kw_) * ldx + kc_;     /* wave-uniform */                  \
-    TILE_A(0, areg0) TILE_A(1, areg1) TILE_A(2, areg2) TILE_A(3, areg3)                                             \
-    TILE_B(0, breg0) TILE_B(1, breg1) TILE_B(2, breg2) TILE_B(3, breg3)                                             \
+    zmask##S = 0;                                                                                                   \
+    TILE_A(0, S) TILE_A(1, S) TILE_A(2, S) TILE_A(3, S)                                                             \
+    TILE_B(0, S) TILE_B(1, S) TILE_B(2, S) TILE_B(3, S)                                                             \
   } while (0)
 #define TILE_ST(BASE, ROW, REG) *reinterpret_cast<uint4*>((BASE) + (ROW) * ROWB + ((c16 ^ swz(ROW)) * 16)) = REG
-#define TILE_COMMIT(BUFI)                                                                                           \
+#define TILE_STZ(BASE, ROW, REG, U, S) TILE_ST(BASE, ROW, ((zmask##S >> (U)) & 1u) ? make_uint4(0, 0, 0, 0) : REG)
+#define TILE_COMMIT(BUFI, S)                                                                                        \
   do {                                                                                                              \
     char* a_ = smem + (BUFI) * BUF;                                                                                 \
     char* b_ = a_ + A_BYTES;                                                                                        \
-    TILE_ST(a_, row0, areg0);                                                                                       \
-    if (PA > 1) TILE_ST(a_, row0 + RP, areg1);                                                                      \
-    if (PA > 2) TILE_ST(a_, row0 + 2 * RP, areg2);                                                                  \
-    if (PA > 3) TILE_ST(a_, row0 + 3 * RP, areg3);                                                                  \
-    TILE_ST(b_, row0, breg0);                                                                                       \
-    if (PB > 1) TILE_ST(b_, row0 + RP, breg1);                                                                      \
-    if (PB > 2) TILE_ST(b_, row0 + 2 * RP, breg2);                                                                  \
-    if (PB > 3) TILE_ST(b_, row0 + 3 * RP, breg3);                                                                  \
+    TILE_STZ(a_, row0, areg##S##0, 0, S);                                                                           \
+    if (PA > 1) TILE_STZ(a_, row0 + RP, areg##S##1, 1, S);                                                          \
+    if (PA > 2) TILE_STZ(a_, row0 + 2 * RP, areg##S##2, 2, S);                                                      \
+    if (PA > 3) TILE_STZ(a_, row0 + 3 * RP, areg##S##3, 3, S);                                                      \
+    TILE_ST(b_, row0, breg##S##0);                                                                                  \
+    if (PB > 1) TILE_ST(b_, row0 + RP, breg##S##1);                                                                 \
+    if (PB > 2) TILE_ST(b_, row0 + 2 * RP, breg##S##2);                                                             \
+    if (PB > 3) TILE_ST(b_, row0 + 3 * RP, breg##S##3);                                                             \
   } while (0)
   f32x16 acc[2][NTW];
 #pragma unroll
@@ -960,44 +972,55 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][j][i] = 0.f;
 
+  // one K-iteration out of LDS buffer BUFI
+#define TILE_COMPUTE(BUFI)                                                                                          \
+  do {                                                                                                              \
+    const char* a = smem + (BUFI) * BUF;                                                                            \
+    const char* b = a + A_BYTES;                                                                                    \
+    bf16x8 fa[KS][2], fb[KS][NTW];                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                                \
+      const int c = 2 * s + khalf;                                                                                  \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                               \
+        const int row = wm * 64 + t * 32 + r;                                                                       \
+        fa[s][t] = *reinterpret_cast<const bf16x8*>(a + row * ROWB + ((c ^ swz(row)) * 16));                        \
+      }                                                                                                             \
+      _Pragma("unroll") for (int j = 0; j < NTW; ++j) {                                                             \
+        const int row = wn * (NT / 2) + j * 32 + r;                                                                 \
+        fb[s][j] = *reinterpret_cast<const bf16x8*>(b + row * ROWB + ((c ^ swz(row)) * 16));                        \
+      }                                                                                                             \
+    }                                                                                                               \
+    _Pragma("unroll") for (int s = 0; s < KS; ++s)                                                                  \
+      _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NTW; ++j)                                                             \
+          acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][t], fb[s][j], acc[t][j], 0, 0, 0);              \
+  } while (0)
+
   if (niter > 0) {
-    TILE_FETCH(0);
-    TILE_COMMIT(0);
+    TILE_FETCH(0, 0);
+    TILE_COMMIT(0, 0);
   }
+  if (niter > 1) TILE_FETCH(1, 1);                   // in flight across the barrier
   __syncthreads();
-  for (int it = 0; it < niter; ++it) {
-    if (it + 1 < niter) TILE_FETCH(it + 1);
-    const char* a = smem + (it & 1) * BUF;
-    const char* b = a + A_BYTES;
-    bf16x8 fa[KS][2], fb[KS][NTW];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int c = 2 * s + khalf;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = wm * 64 + t * 32 + r;
-        fa[s][t] = *reinterpret_cast<const bf16x8*>(a + row * ROWB + ((c ^ swz(row)) * 16));
-      }
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int row = wn * (NT / 2) + j * 32 + r;
-        fb[s][j] = *reinterpret_cast<const bf16x8*>(b + row * ROWB + ((c ^ swz(row)) * 16));
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][t], fb[s][j], acc[t][j], 0, 0, 0);
-    if (it + 1 < niter) TILE_COMMIT((it + 1) & 1);
+  for (int it = 0; it < niter; it += 2) {
+    // even iteration: LDS buffer 0 holds it, register set 1 holds it + 1
+    if (it + 2 < niter) TILE_FETCH(it + 2, 0);
+    TILE_COMPUTE(0);
+    if (it + 1 < niter) TILE_COMMIT(1, 1);
+    __syncthreads();
+    if (it + 1 >= niter) break;
+    // odd iteration: buffer 1 holds it + 1, register set 0 holds it + 2
+    if (it + 3 < niter) TILE_FETCH(it + 3, 1);
+    TILE_COMPUTE(1);
+    if (it + 2 < niter) TILE_COMMIT(0, 0);
     __syncthreads();
   }
 #undef TILE_A
 #undef TILE_B
 #undef TILE_FETCH
 #undef TILE_ST
+#undef TILE_STZ
 #undef TILE_COMMIT
+#undef TILE_COMPUTE
 
   const int rh = khalf * 4;
   if (partial) {
