@@ -2,9 +2,11 @@
 v_mfma_f32_16x16x32_bf16 tiles - the shape that sustains a ~14 % higher clock (tools/micro/mfma_peak.hip).  It contains
 the pieces that are settled: the 64-byte-row swizzle 2*((row/4)%2) (conflict-free for the 16-row fragment reads), the
 Tile16 accumulator layout, the write-out mapping and the 24-slot stage schedule.  Status: hipcc (ROCm 7.2) aborts on it
-with "Illegal instruction detected: Operand has incorrect register class" (459 VGPR+AGPR; probably an MFMA whose C and D
-end up in different register classes) - next round: keep the accumulators as f32x16 and address 4-register subvectors,
-or pin the tiles with inline-asm constraints.  Run from fpl-plus_amd/csrc to apply."""
+with "Illegal instruction detected: Operand has incorrect register class" (459 VGPR+AGPR).  Bisected: the error goes
+away when ANY ONE of {side work in the gaps, the ds_write_b16 staging, the inline-asm global stores} is removed, and an
+f32x16-with-subvectors formulation fails the same way - it looks like a register-class assignment problem under
+pressure around the inline-asm operands, not a problem of the MFMA code itself.  Next round: lower the pressure (one
+fragment buffer set less) or issue the stores without inline asm.  Run from fpl-plus_amd/csrc to apply."""
 p='conv_march.hip'
 s=open(p).read()
 a=s.index('// one half-slab -> the three output depths it touches.  FIRST: the kd = 0 accumulators start from zero.\n// side(q, g) runs in gap g (0..5) of stage q (0..17)')
