@@ -1,21 +1,24 @@
-// conv_fwd_march: the level-0 3x3x3 convolution (Cin = 32, Cout % 32 == 0, large H x W), third generation.
+// Depth-marching 3x3x3 convolutions for gfx950 (bf16 NDHWC, fp32 accumulate, v_mfma_f32_32x32x16_bf16).
 //
+// conv_fwd_march32 (Cin = 32, Cout % 32 == 0, H >= 16, W >= 64: level 0 of the 32-base network)
 // One block (8 waves, two per SIMD) owns a 16 x 32 (h, w) output footprint x 32 output channels and marches along
 // d.  It is INPUT-stationary in depth: each input slab (18 x 34 voxels x 32 channels, 1-voxel halo, zero fill =
-// padding) is staged ONCE into a two-slot LDS ring and scattered into the accumulators of the three output depths
-// it touches (d+1 through kd = 0, d through kd = 1, d-1 through kd = 2), so
+// padding) is staged ONCE - by LDS-DMA - into a two-slot LDS ring and scattered into the accumulators of the three
+// output depths it touches (d+1 through kd = 0, d through kd = 1, d-1 through kd = 2), so
 //   * every voxel fragment read from LDS feeds three MFMAs (three kd taps), every weight fragment two (the wave's two
 //     M-tiles): 0.83 ds_read_b128 per MFMA instead of 1.5 in the slab-ring kernel it replaces;
-//   * only the current slab and the one in flight live in LDS (2 x 38 KB) next to the block's 27 x 32 x 32 weights
+//   * only the current slab and the one in flight live in LDS (2 x 39 KB) next to the block's 27 x 32 x 32 weights
 //     (54 KB, resident), which leaves room for the 16-row footprint (halo overhead 1.20 instead of 1.33);
-//   * three accumulator sets rotate through the roles {d+1, d, d-1}; the set that completes is written out (bias,
-//     bf16, 8-byte stores: the MFMA runs with the weights as the row operand, so a lane owns 4 consecutive channels
-//     of one voxel) while the block's other waves keep the matrix cores busy.
-// DSBN statistics: per-lane sums of the raw accumulators (the bias is folded in analytically at the end), reduced
-// in a fixed order, one partial row per block.
+//   * four accumulator sets per wave: the depths d+1, d, d-1 of the current slab and the depth that completed in the
+//     previous step, which is written out WHILE the next slab is multiplied: bias, bf16, a transpose through a 2-KiB
+//     per-wave LDS tile, 16-byte global stores of whole 128-byte lines (2-byte stores made the CU's store path, not
+//     the matrix core, set the pace).  The roles shift by register moves at the end of a step.
+// DSBN statistics: per-lane sums (lane = output channel), reduced in a fixed order, one partial row per block.
+// conv_fwd_march64 (Cin = 64): see its own header further down.
 //
-// Replaces (for these shapes) nn.Conv3d forward and, with the mirrored pack, its data gradient —
-// reference PyMIC/pymic/net/net3d/unet2d5_dsbn.py:54-55,75,79 (ConvolutionLayer / UNetBlock_DSBN at level 0).
+// Replaces (for these shapes) nn.Conv3d forward and, with the mirrored pack, its data gradient -
+// reference PyMIC/pymic/net/net3d/unet2d5_dsbn.py:54-55,75,79 (ConvolutionLayer / ConvBlockND), and the
+// torch.cat of unet2d5_dsbn.py:182 when the input / output is given as two tensors (x1 / y1).
 #include "common.h"
 #include <stdlib.h>
 
@@ -221,7 +224,7 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 
   // slab s = d0 - 1 + t touches output depths s+1 (kd = 0), s (kd = 1), s-1 (kd = 2); MASK = which of them lie in
   // [d0, d1): 1, 3, 7 ... 7, 6, 4 over the block's nd + 2 slabs.  The depth that completed in step t - 1 is written
-  // out during step t (stages 0..7, two voxels per M-tile and stage); the DMA of slab s + 1 goes out in stages
+  // out during step t (stages 0..8: M-tile 0 -> LDS tile, flush, M-tile 1, flush); the DMA of slab s + 1 goes out in stages
   // 0..NPIECE-1; both are long finished when the step's closing vmcnt(0) + barrier is reached.
   const int nd = d1 - d0;                         // >= 2 (march_cfg)
   for (int t = 0; t < nd + 2; ++t) {
@@ -472,7 +475,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   // half-slab (the other half of s, or half 0 of s + 1) into the other slot; during half 0 also the write-out of the
   // depth that completed in step t - 1 (R): stages 0-3 M-tile 0 -> LDS tile, flush, stages 4-7 M-tile 1, flush.
   const int nd = d1 - d0;                         // >= 2 (march_cfg)
-  if (d0 - 1 < 0 || true) { /* slab d0 - 1 half 1 is fetched by half-step (0, 0) like every other half-slab */ }
+  // (half 1 of slab d0 - 1 is fetched by half-step (0, 0) like every other half-slab)
   for (int t = 0; t < nd + 2; ++t) {
     const int s = d0 - 1 + t;
     const bool live = s >= 0 && s < D;             // a padding slab contributes nothing
