@@ -628,7 +628,9 @@ inline DwCfg dw_cfg(int n, int d, int h, int w, int cin, int cout) {
 }
 
 // ------------------------------------------------------------------------------------------
-// conv_fwd_stream: the L0/L1 work-horse (Cin in {32, 64}, large H x W).  One block = an 8 x 32
+// conv_fwd_stream: the previous-generation slab kernel (Cin in {32, 64}, large H x W); the depth-marching kernels of
+// conv_march.hip take these shapes first, this one remains for what they refuse and for A/B runs (FPLX_MARCH=0).
+// One block = an 8 x 32
 // output footprint in (h, w) x 32 output channels, marching along d:
 //   * three input slabs (10 x 34 voxels x Cin, 1-voxel halo, zero fill = padding) form a ring in
 //     LDS; every slab is fetched from HBM/L2 once per block and feeds 27 taps x 3 output depths;
