@@ -579,6 +579,10 @@ inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
     const double cost = (double)rounds * (dl + 2 + 1.5);
     if (cost < best - 1e-9) { best = cost; best_ds = segs; }
   }
+  {
+    const char* e = getenv("FPLX_MARCH_DS");               // tuning knob (benchmarks only)
+    if (e && atoi(e) > 0) best_ds = atoi(e);
+  }
   c.dlen = (d + best_ds - 1) / best_ds;
   c.dsegs = (d + c.dlen - 1) / c.dlen;
   c.nblk = n * c.tilesH * c.tilesW * c.dsegs;
