@@ -262,3 +262,70 @@ def pixel_weight(mask_a, mask_b, image_weight=None):
     call("fplx_pixel_weight", ptr(a), ptr(b), a.numel(), 0 if image_weight is None else 1,
          0.0 if image_weight is None else float(image_weight), ptr(out), stream())
     return out
+
+
+# ---------------------------------------------------------------- training-sample transforms (csrc/sample.hip)
+_ELEM = {torch.float32: 4, torch.uint8: 1}
+
+
+def _elem_bytes(t):
+    try:
+        return _ELEM[t.dtype]
+    except KeyError:
+        raise ValueError("fplx: transforms take float32 or uint8 volumes, got {0:}".format(t.dtype))
+
+
+def normalize_mean_std(x, mean_std=None, out=None, want_moments=False):
+    """(x - mean) / std of one channel volume (fp32, contiguous); mean_std None -> x's own float32 mean / population std"""
+    require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    ms = None if mean_std is None else torch.tensor(list(mean_std), dtype=torch.float32, device=x.device)
+    nb = _lib.lib().fplx_normalize_ws_bytes()
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=x.device)
+    got = torch.empty(2, dtype=torch.float32, device=x.device) if want_moments else None
+    call("fplx_normalize_mean_std", ptr(x), ptr(out), x.numel(), ptr(ms), ptr(ws), nb, ptr(got), stream())
+    return (out, got) if want_moments else out
+
+
+def pad_reflect(x, lower, out_size):
+    """numpy.pad(x, mode='reflect') of a [C,D,H,W] volume to out_size (D,H,W) with lower margins `lower`"""
+    require_gpu(x)
+    assert x.dim() == 4 and x.is_contiguous()
+    c, d, h, w = x.shape
+    y = torch.empty((c,) + tuple(out_size), dtype=x.dtype, device=x.device)
+    call("fplx_pad_reflect", ptr(x), ptr(y), _elem_bytes(x), c, d, h, w, lower[0], lower[1], lower[2], out_size[0],
+         out_size[1], out_size[2], stream())
+    return y
+
+
+def crop_flip(x, crop_min, out_size, flip_mask=0):
+    """crop box [crop_min, crop_min + out_size) of a [C,D,H,W] volume, then flip (bit0 W, bit1 H, bit2 D)"""
+    require_gpu(x)
+    assert x.dim() == 4 and x.is_contiguous()
+    c, d, h, w = x.shape
+    y = torch.empty((c,) + tuple(out_size), dtype=x.dtype, device=x.device)
+    call("fplx_crop_flip", ptr(x), ptr(y), _elem_bytes(x), c, d, h, w, crop_min[0], crop_min[1], crop_min[2], out_size[0],
+         out_size[1], out_size[2], int(flip_mask), stream())
+    return y
+
+
+def label_bbox(label, mask_labels):
+    """-> (count, bb_min[4], bb_max[4]) of {label in mask_labels} on a uint8 [C,D,H,W] label (one device->host copy)"""
+    require_gpu(label)
+    assert label.dtype == torch.uint8 and label.dim() == 4 and label.is_contiguous()
+    c, d, h, w = label.shape
+    ml = torch.tensor([int(v) for v in mask_labels], dtype=torch.int32, device=label.device)
+    out = torch.empty(9, dtype=torch.int32, device=label.device)
+    call("fplx_label_bbox", ptr(label), c, d, h, w, ptr(ml), ml.numel(), ptr(out), stream())
+    o = out.tolist()
+    return o[0], o[1:5], o[5:9]
+
+
+def label_to_probability(label, class_num):
+    """uint8 label [D,H,W] (or any shape) -> fp32 one-hot [class_num, *shape]"""
+    require_gpu(label)
+    assert label.dtype == torch.uint8 and label.is_contiguous()
+    prob = torch.empty((class_num,) + tuple(label.shape), dtype=torch.float32, device=label.device)
+    call("fplx_label_to_probability", ptr(label), ptr(prob), class_num, label.numel(), stream())
+    return prob

@@ -219,6 +219,29 @@ int fplx_hard_label(const float* logits, int n, int c, int64_t v, uint8_t* out, 
 int fplx_pixel_weight(const uint8_t* a, const uint8_t* b, int64_t v, int apply_set_weight, float image_weight,
                       float* out, fplx_stream_t stream);
 
+/* ------------------------------------------------------------------ training-sample transforms
+ * The reference's numpy chain train_transform = [NormalizeWithMeanStd, Pad, RandomCrop, RandomFlip,
+ * LabelToProbability] (config_dual/data_vs/vs_t1s_g.cfg:21) on device volumes [C][D][H][W]; the random draws stay on
+ * the host (fplx/transform.py, Python `random` in the reference's order).
+ *  normalize: y = (x - mean) / std per call (one channel); mean_std == NULL -> float32 mean / population std of x
+ *             (PyMIC/pymic/transform/normalize.py:43-68); ws of fplx_normalize_ws_bytes() bytes; out_mean_std may be NULL
+ *  pad_reflect: numpy.pad(mode='reflect') with lower margins lo_* (pad.py:126-163); elem_bytes 4 (fp32) or 1 (uint8)
+ *  crop_flip: crop box [c*, c*+o*) then flip of the cropped patch, flip_mask bit0 = W, bit1 = H, bit2 = D
+ *             (crop.py:27-49, flip.py:34-62)
+ *  label_bbox: out9 = [count, min c,d,h,w, max+1 c,d,h,w] of {label in mask_labels} (util/image_process.py:8-34)
+ *  label_to_probability: one-hot fp32 [class_num][voxels] (label_convert.py:82-94) */
+size_t fplx_normalize_ws_bytes(void);
+int fplx_normalize_mean_std(const float* x, float* y, int64_t n, const float* mean_std, void* ws, size_t ws_bytes,
+                            float* out_mean_std, fplx_stream_t stream);
+int fplx_pad_reflect(const void* x, void* y, int elem_bytes, int c, int d, int h, int w, int lo_d, int lo_h, int lo_w,
+                     int od, int oh, int ow, fplx_stream_t stream);
+int fplx_crop_flip(const void* x, void* y, int elem_bytes, int c, int d, int h, int w, int cd, int ch, int cw, int od,
+                   int oh, int ow, int flip_mask, fplx_stream_t stream);
+int fplx_label_bbox(const unsigned char* label, int c, int d, int h, int w, const int* mask_labels, int nmask, int* out9,
+                    fplx_stream_t stream);
+int fplx_label_to_probability(const unsigned char* label, float* prob, int class_num, int64_t voxels,
+                              fplx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,114 @@ def dropout_masks_ncdhw(seed, step, net_params, in_shape, ps):
         keep = philox_keep_mask(seed, step * 16 + b, n * d * h * w * c, p)
         out.append(np.ascontiguousarray(keep.reshape(n, d, h, w, c).transpose(0, 4, 1, 2, 3)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Training-sample transforms.  numpy restatements of the reference chain
+# `train_transform = [NormalizeWithMeanStd, Pad, RandomCrop, RandomFlip, LabelToProbability]`
+# (config_dual/data_vs/vs_t1s_g.cfg:21); sample = dict with 'image' [C,D,H,W], 'label' [1,D,H,W], 'pixel_weight'.
+def tf_normalize(sample, chns=None, mean=None, std=None):
+    """PyMIC/pymic/transform/normalize.py:43-68 (ignore_non_positive = False)"""
+    image = sample['image']
+    chns = chns if chns is not None else range(image.shape[0])
+    for i, chn in enumerate(chns):
+        m = image[chn].mean() if mean is None or mean[i] is None else mean[i]
+        s = image[chn].std() if std is None or std[i] is None else std[i]
+        image[chn] = (image[chn] - m) / s
+    sample['image'] = image
+    return sample
+
+
+def tf_pad(sample, output_size, ceil_mode=False):
+    """pad.py:126-163: reflect padding up to output_size, lower margin = int(margin / 2)"""
+    import math
+    shape = sample['image'].shape
+    dim = len(shape) - 1
+    if ceil_mode:
+        output_size = [int(math.ceil(float(shape[1 + i]) / output_size[i])) * output_size[i] for i in range(dim)]
+    margin = [max(0, output_size[i] - shape[1 + i]) for i in range(dim)]
+    lo = [int(margin[i] / 2) for i in range(dim)]
+    hi = [margin[i] - lo[i] for i in range(dim)]
+    sample['Pad_Param'] = (lo, hi)
+    pad = tuple([(0, 0)] + [(lo[i], hi[i]) for i in range(dim)])
+    if max(margin) > 0:
+        for k in ('image', 'label', 'pixel_weight'):
+            if k in sample:
+                sample[k] = np.pad(sample[k], pad, 'reflect')
+    return sample
+
+
+def tf_random_crop(sample, output_size, fg_focus=False, fg_ratio=0.5, mask_label=(1,), rng=None):
+    """crop.py:201-236 (parameters, incl. the order of the random draws) + crop.py:27-49 (the slicing)"""
+    import random as _random
+    rng = rng or _random
+    shape = sample['image'].shape
+    dim = len(shape) - 1
+    size = list(output_size)
+    if dim == 3 and size[0] is None:
+        size = [shape[1]] + size[1:]
+    margin = [shape[i + 1] - size[i] for i in range(dim)]
+    cmin = [0 if m == 0 else rng.randint(0, m) for m in margin]
+    if fg_focus and rng.random() < fg_ratio:
+        label = sample['label']
+        mask = np.zeros_like(label)
+        for lab in mask_label:
+            mask = np.maximum(mask, label == lab)
+        if mask.sum() == 0:
+            bb_min, bb_max = [0] * (dim + 1), list(mask.shape)
+        else:
+            idx = np.nonzero(mask)                          # util/image_process.py:8-34
+            bb_min = [int(idx[i].min()) for i in range(dim + 1)]
+            bb_max = [int(idx[i].max()) + 1 for i in range(dim + 1)]
+        bb_min, bb_max = bb_min[1:], bb_max[1:]
+        cmin = [rng.randint(bb_min[i], bb_max[i]) - int(size[i] / 2) for i in range(dim)]
+        cmin = [max(0, c) for c in cmin]
+        cmin = [min(cmin[i], shape[i + 1] - size[i]) for i in range(dim)]
+    cmax = [cmin[i] + size[i] for i in range(dim)]
+    sample['RandomCrop_Param'] = (list(shape), [0] + cmin, [shape[0]] + cmax)
+    sl = tuple(slice(cmin[i], cmax[i]) for i in range(dim))
+    for k in ('image', 'label', 'pixel_weight'):
+        if k in sample:
+            sample[k] = sample[k][(slice(None),) + sl]
+    return sample
+
+
+def tf_random_flip(sample, flip_depth, flip_height, flip_width, rng=None):
+    """flip.py:34-62: one draw per enabled axis, in the order width, height, depth"""
+    import random as _random
+    rng = rng or _random
+    dim = sample['image'].ndim - 1
+    axes = []
+    if flip_width and rng.random() > 0.5:
+        axes.append(-1)
+    if flip_height and rng.random() > 0.5:
+        axes.append(-2)
+    if dim == 3 and flip_depth and rng.random() > 0.5:
+        axes.append(-3)
+    sample['RandomFlip_Param'] = axes
+    if axes:
+        for k in ('image', 'label', 'pixel_weight'):
+            if k in sample:
+                sample[k] = np.flip(sample[k], axes).copy()
+    return sample
+
+
+def tf_label_to_probability(sample, class_num):
+    """label_convert.py:82-94 (segmentation)"""
+    label = sample['label'][0]
+    prob = np.zeros((class_num,) + label.shape, dtype=np.float32)
+    for i in range(class_num):
+        prob[i] = label == i * np.ones_like(label)
+    sample['label_prob'] = prob
+    return sample
+
+
+def tf_train_chain(sample, p, rng=None):
+    """the five transforms with the reference's parameter keys (lower-cased, as parse_config delivers them)"""
+    s = tf_normalize(sample, p.get('normalizewithmeanstd_channels'), p.get('normalizewithmeanstd_mean'),
+                     p.get('normalizewithmeanstd_std'))
+    s = tf_pad(s, p['pad_output_size'], p.get('pad_ceil_mode', False))
+    s = tf_random_crop(s, p['randomcrop_output_size'], p.get('randomcrop_foreground_focus', False),
+                       p.get('randomcrop_foreground_ratio', 0.5), p.get('randomcrop_mask_label', [1]), rng)
+    s = tf_random_flip(s, p['randomflip_flip_depth'], p['randomflip_flip_height'], p['randomflip_flip_width'], rng)
+    return tf_label_to_probability(s, p['labeltoprobability_class_num'])

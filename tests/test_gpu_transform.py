@@ -1,0 +1,152 @@
+"""-m gpu parity of fplx.transform (csrc/sample.hip) against the reference-generated fixture tests/golden/transforms.npz
+and against the numpy oracle on other shapes.  Data movement (pad / crop / flip / one-hot) and the random decisions are
+bit-exact; the normalisation is float32 arithmetic on a float32 mean / std that the GPU reduces in float64 while numpy
+uses pairwise float32 sums, so it is checked to rtol 2e-6 / atol 2e-6 (values are O(1))."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NORM_RTOL, NORM_ATOL = 2e-6, 2e-6
+
+
+def _fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "transforms.npz"), allow_pickle=False)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def _params(g):
+    p = json.loads(str(g["params_json"]))
+    p["task"] = "segmentation"
+    return p
+
+
+def test_transform_chain_matches_reference_fixture(golden_dir):
+    import fplx
+    from fplx import transform as T
+    g = _fx(golden_dir)
+    p = _params(g)
+    names = ["NormalizeWithMeanStd", "Pad", "RandomCrop", "RandomFlip", "LabelToProbability"]
+    # stage by stage on the first seed
+    s = {"image": _dev(g["image"]), "label": _dev(g["label"]), "pixel_weight": _dev(g["pixel_weight"])}
+    s = T.NormalizeWithMeanStd(dict(p))(s)
+    np.testing.assert_allclose(s["image"].cpu().numpy(), g["after_NormalizeWithMeanStd_image"], rtol=NORM_RTOL,
+                               atol=NORM_ATOL)
+    s["image"] = _dev(g["after_NormalizeWithMeanStd_image"])           # exact input for the bit-exact stages
+    s = T.Pad(dict(p))(s)
+    for k in ("image", "label", "pixel_weight"):
+        assert np.array_equal(s[k].cpu().numpy(), g["after_Pad_" + k]), k
+    seeds = sorted(int(k[4:-6]) for k in g.files if k.startswith("seed") and k.endswith("_image"))
+    assert len(seeds) >= 5
+    for seed in seeds:
+        random.seed(seed)
+        s = {"image": _dev(g["image"]), "label": _dev(g["label"]), "pixel_weight": _dev(g["pixel_weight"])}
+        s = T.apply_transforms(T.build_transforms(names, dict(p)), s)
+        k = "seed%d_" % seed
+        assert json.loads(s["RandomCrop_Param"]) == json.loads(str(g[k + "crop_param"])), seed
+        assert json.loads(s["RandomFlip_Param"]) == json.loads(str(g[k + "flip_param"])), seed
+        assert json.loads(s["Pad_Param"]) == json.loads(str(g[k + "pad_param"])), seed
+        np.testing.assert_allclose(s["image"].cpu().numpy(), g[k + "image"], rtol=NORM_RTOL, atol=NORM_ATOL)
+        for name in ("label", "label_prob", "pixel_weight"):
+            assert np.array_equal(s[name].cpu().numpy(), g[k + name]), (name, seed)
+        assert s["label_prob"].dtype == torch.float32 and s["label"].dtype == torch.uint8
+
+
+@pytest.mark.parametrize("shape,out,focus", [
+    ((2, 9, 33, 21), [16, 48, 32], True),        # two channels, every axis padded (odd margins)
+    ((1, 20, 30, 40), [8, 16, 24], False),       # no padding, crop only
+    ((1, 5, 7, 6), [16, 24, 20], True),          # pad wider than the volume: multiple reflections
+    ((1, 12, 20, 20), [None, 16, 16], True),     # depth not cropped
+])
+def test_transforms_match_oracle(shape, out, focus):
+    from fplx import transform as T
+    from oracle import np_ref as R
+    rs = np.random.RandomState(hash(shape) % 1000)
+    img = (rs.randn(*shape) * 20 + 100).astype(np.float32)
+    lab = (rs.rand(1, *shape[1:]) > 0.93).astype(np.uint8) * rs.randint(1, 3, (1,) + shape[1:]).astype(np.uint8)
+    pw = rs.rand(1, *shape[1:]).astype(np.float32)
+    pad_out = [o if o is not None else shape[1] for o in out]
+    p = {"task": "segmentation", "normalizewithmeanstd_channels": None, "pad_output_size": pad_out,
+         "randomcrop_output_size": out, "randomcrop_foreground_focus": focus, "randomcrop_foreground_ratio": 0.7,
+         "randomcrop_mask_label": [2], "randomflip_flip_depth": True, "randomflip_flip_height": True,
+         "randomflip_flip_width": True, "labeltoprobability_class_num": 3}
+    names = ["NormalizeWithMeanStd", "Pad", "RandomCrop", "RandomFlip", "LabelToProbability"]
+    for seed in range(6):
+        random.seed(100 + seed)
+        want = R.tf_train_chain({"image": img.copy(), "label": lab.copy(), "pixel_weight": pw.copy()}, p)
+        random.seed(100 + seed)
+        got = T.apply_transforms(T.build_transforms(names, dict(p)),
+                                 {"image": _dev(img), "label": _dev(lab), "pixel_weight": _dev(pw)})
+        assert json.loads(got["RandomCrop_Param"]) == [list(x) for x in want["RandomCrop_Param"]]
+        assert json.loads(got["RandomFlip_Param"]) == want["RandomFlip_Param"]
+        np.testing.assert_allclose(got["image"].cpu().numpy(), want["image"], rtol=NORM_RTOL, atol=NORM_ATOL)
+        for name in ("label", "label_prob", "pixel_weight"):
+            assert np.array_equal(got[name].cpu().numpy(), want[name]), (name, seed)
+
+
+def test_normalize_given_mean_std_and_moments():
+    from fplx import ops
+    rs = np.random.RandomState(3)
+    x = (rs.randn(37, 41, 29) * 55 + 300).astype(np.float32)
+    y = ops.normalize_mean_std(_dev(x), (250.0, 40.0))
+    assert np.array_equal(y.cpu().numpy(), (x - np.float32(250.0)) / np.float32(40.0))   # same fp32 ops: exact
+    y, ms = ops.normalize_mean_std(_dev(x), None, want_moments=True)
+    m, s = ms.tolist()
+    assert abs(m - x.mean(dtype=np.float64)) < 1e-4 and abs(s - x.std(dtype=np.float64)) < 1e-4
+
+
+def test_label_bbox_and_empty_mask():
+    from fplx import ops
+    lab = np.zeros((1, 10, 12, 14), np.uint8)
+    lab[0, 2:5, 3:9, 6:7] = 1
+    lab[0, 7, 11, 13] = 2
+    cnt, lo, hi = ops.label_bbox(_dev(lab), [1])
+    assert (cnt, lo, hi) == (3 * 6 * 1, [0, 2, 3, 6], [1, 5, 9, 7])
+    cnt, lo, hi = ops.label_bbox(_dev(lab), [1, 2])
+    assert (cnt, lo, hi) == (19, [0, 2, 3, 6], [1, 8, 12, 14])
+    cnt, _, _ = ops.label_bbox(_dev(lab), [5])
+    assert cnt == 0
+
+
+def test_pad_and_flip_inverse_for_prediction():
+    """Pad_inverse = True (config_dual/data_vs/vs_t1s_g.cfg): the test-time prediction is cropped back (pad.py:165-191)"""
+    from fplx import transform as T
+    p = {"task": "segmentation", "pad_output_size": [16, 48, 48], "randomflip_flip_depth": True,
+         "randomflip_flip_height": True, "randomflip_flip_width": True}
+    rs = np.random.RandomState(0)
+    img = rs.randn(1, 11, 40, 45).astype(np.float32)
+    s = T.Pad(dict(p))({"image": _dev(img)})
+    assert tuple(s["image"].shape) == (1, 16, 48, 48)
+    pred = rs.randn(1, 2, 16, 48, 48).astype(np.float32)
+    s["predict"] = _dev(pred)
+    s = T.Pad(dict(p)).inverse_transform_for_prediction(s)
+    lo, up = json.loads(s["Pad_Param"])
+    want = pred[:, :, lo[0]:16 - up[0], lo[1]:48 - up[1], lo[2]:48 - up[2]]
+    assert np.array_equal(s["predict"].cpu().numpy(), want)
+    random.seed(4)
+    f = T.RandomFlip(dict(p))
+    s2 = f({"image": _dev(img)})
+    axes = json.loads(s2["RandomFlip_Param"])
+    assert np.array_equal(s2["image"].cpu().numpy(), np.flip(img, axes) if axes else img)
+    s2["predict"] = _dev(pred)
+    s2 = f.inverse_transform_for_prediction(s2)
+    assert np.array_equal(s2["predict"].cpu().numpy(), np.flip(pred, axes) if axes else pred)
+
+
+def test_transform_errors():
+    from fplx import transform as T
+    with pytest.raises(ValueError):
+        T.build_transforms(["NoSuchTransform"], {"task": "segmentation"})
+    with pytest.raises(ValueError):
+        T.Pad({"task": "segmentation", "pad_output_size": [4, 4, 4]})({"image": torch.zeros(1, 2, 2, 2)})   # host tensor
+    from fplx import ops
+    with pytest.raises(ValueError):
+        ops.crop_flip(torch.zeros(1, 4, 4, 4, device="cuda:0"), (2, 0, 0), (4, 4, 4))   # box outside the volume

@@ -221,3 +221,32 @@ def test_philox_known_answer():
     assert [int(v[0]) for v in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     keep = N.philox_keep_mask(1234, 5, 100000, 0.3)
     assert abs(keep.mean() - 0.7) < 0.01
+
+
+def test_transform_chain_against_reference_fixture(golden_dir):
+    """oracle/np_ref.py transforms vs the outputs of the reference's NormalizeWithMeanStd -> Pad -> RandomCrop ->
+    RandomFlip -> LabelToProbability chain (tests/golden/make_golden_transforms.py): same `random` seeds, so the crop
+    boxes and flip axes must be reproduced too; data movement is bit-exact."""
+    import json
+    import random
+    from oracle import np_ref as R
+    g = _load(golden_dir, "transforms.npz")
+    p = json.loads(str(g["params_json"]))
+    s0 = {"image": g["image"].copy()}
+    np.testing.assert_array_equal(R.tf_normalize(s0, [0])["image"], g["after_NormalizeWithMeanStd_image"])
+    s1 = R.tf_pad({"image": g["after_NormalizeWithMeanStd_image"].copy(), "label": g["label"].copy(),
+                   "pixel_weight": g["pixel_weight"].copy()}, p["pad_output_size"])
+    np.testing.assert_array_equal(s1["image"], g["after_Pad_image"])
+    np.testing.assert_array_equal(s1["label"], g["after_Pad_label"])
+    np.testing.assert_array_equal(s1["pixel_weight"], g["after_Pad_pixel_weight"])
+    seeds = sorted(int(k[4:-6]) for k in g.files if k.endswith("_image") and k.startswith("seed"))
+    assert len(seeds) >= 5
+    for seed in seeds:
+        random.seed(seed)
+        s = R.tf_train_chain({"image": g["image"].copy(), "label": g["label"].copy(),
+                              "pixel_weight": g["pixel_weight"].copy()}, p)
+        k = "seed%d_" % seed
+        assert list(map(list, json.loads(str(g[k + "crop_param"])))) == [list(x) for x in s["RandomCrop_Param"]]
+        assert json.loads(str(g[k + "flip_param"])) == s["RandomFlip_Param"]
+        for name in ("image", "label", "label_prob", "pixel_weight"):
+            np.testing.assert_array_equal(s[name], g[k + name], err_msg="%s seed %d" % (name, seed))
