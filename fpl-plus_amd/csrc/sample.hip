@@ -142,6 +142,15 @@ onehot_k(const unsigned char* __restrict__ lab, float* __restrict__ prob, int cl
     prob[i] = lab[i % voxels] == (unsigned char)(i / voxels) ? 1.f : 0.f;
 }
 
+// NiftyDataset.set_weight_: weights below 1 (the two pseudo-label masks disagree) drop to 0, the rest scale by the image weight
+__global__ void __launch_bounds__(SP_THREADS)
+set_weight_k(float* __restrict__ pw, int64_t n, float iw) {
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const float v = pw[i];
+    pw[i] = (v < 1.f ? 0.f : v) * iw;
+  }
+}
+
 inline int sp_grid(int64_t total) {
   int64_t g = (total + SP_THREADS - 1) / SP_THREADS;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -220,6 +229,12 @@ int fplx_label_to_probability(const unsigned char* label, float* prob, int class
   FPLX_REQUIRE(class_num > 0 && class_num <= 255 && voxels > 0, FPLX_E_BADSHAPE, "label_to_probability: bad shape");
   onehot_k<<<sp_grid((int64_t)class_num * voxels), SP_THREADS, 0, (hipStream_t)stream>>>(label, prob, class_num, voxels);
   return fplx_check_launch("label_to_probability");
+}
+
+int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_stream_t stream) {
+  FPLX_REQUIRE(pixel_weight && n > 0, FPLX_E_NULL, "set_weight: null pointer / empty volume");
+  set_weight_k<<<sp_grid(n), SP_THREADS, 0, (hipStream_t)stream>>>(pixel_weight, n, image_weight);
+  return fplx_check_launch("set_weight");
 }
 
 }  // extern "C"

@@ -17,9 +17,10 @@ from .agent import SegmentationAgent, SegNetDict                   # noqa: E402
 from .optim import FusedAdam, get_optimizer, get_lr_scheduler      # noqa: E402
 from .train import TrainStep                                       # noqa: E402
 from .config import parse_config, synchronize_config               # noqa: E402
-from . import filter, ops, ddp, transform                                     # noqa: E402
+from .dataset import NiftyDataset                                  # noqa: E402
+from . import filter, ops, ddp, transform, nifti                                     # noqa: E402
 
 __all__ = ["UNet2D5_dsbn", "DomainSpecificBatchNorm3d", "SegLossDict", "SegNetDict", "DiceLoss",
            "CrossEntropyLoss", "DiceLoss_weight", "CombinedLoss", "EntropyTerm", "make_loss", "Inferer",
            "SegmentationAgent", "FusedAdam", "get_optimizer", "get_lr_scheduler", "TrainStep",
-           "parse_config", "synchronize_config", "filter", "ops", "ddp", "transform"]
+           "parse_config", "synchronize_config", "filter", "ops", "ddp", "transform", "nifti", "NiftyDataset"]

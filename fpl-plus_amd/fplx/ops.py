@@ -329,3 +329,11 @@ def label_to_probability(label, class_num):
     prob = torch.empty((class_num,) + tuple(label.shape), dtype=torch.float32, device=label.device)
     call("fplx_label_to_probability", ptr(label), ptr(prob), class_num, label.numel(), stream())
     return prob
+
+
+def set_weight_(pixel_weight, image_weight):
+    """NiftyDataset.set_weight_ in place on a fp32 device volume"""
+    require_gpu(pixel_weight)
+    assert pixel_weight.dtype == torch.float32 and pixel_weight.is_contiguous()
+    call("fplx_set_weight", ptr(pixel_weight), pixel_weight.numel(), float(image_weight), stream())
+    return pixel_weight

@@ -239,3 +239,13 @@ def apply_transforms(transforms, sample):
     for t in transforms:
         sample = t(sample)
     return sample
+
+
+class Compose(object):
+    """torchvision.transforms.Compose as the reference uses it (agent_seg.py:61): a callable chain"""
+
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        return apply_transforms(self.transforms, sample)

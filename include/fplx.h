@@ -229,7 +229,8 @@ int fplx_pixel_weight(const uint8_t* a, const uint8_t* b, int64_t v, int apply_s
  *  crop_flip: crop box [c*, c*+o*) then flip of the cropped patch, flip_mask bit0 = W, bit1 = H, bit2 = D
  *             (crop.py:27-49, flip.py:34-62)
  *  label_bbox: out9 = [count, min c,d,h,w, max+1 c,d,h,w] of {label in mask_labels} (util/image_process.py:8-34)
- *  label_to_probability: one-hot fp32 [class_num][voxels] (label_convert.py:82-94) */
+ *  label_to_probability: one-hot fp32 [class_num][voxels] (label_convert.py:82-94)
+ *  set_weight: in place pw = (pw < 1 ? 0 : pw) * image_weight (PyMIC/pymic/io/nifty_dataset.py:165-168) */
 size_t fplx_normalize_ws_bytes(void);
 int fplx_normalize_mean_std(const float* x, float* y, int64_t n, const float* mean_std, void* ws, size_t ws_bytes,
                             float* out_mean_std, fplx_stream_t stream);
@@ -241,6 +242,7 @@ int fplx_label_bbox(const unsigned char* label, int c, int d, int h, int w, cons
                     fplx_stream_t stream);
 int fplx_label_to_probability(const unsigned char* label, float* prob, int class_num, int64_t voxels,
                               fplx_stream_t stream);
+int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_stream_t stream);
 
 #ifdef __cplusplus
 }
