@@ -4,19 +4,25 @@
 Kept: the plugin surface (config dict with sections dataset / network / training / testing;
 set_network / set_net_dict / set_loss_dict / set_optimizer / set_scheduler / set_inferer /
 set_datasets-style loader injection), create_network, create_optimizer, create_loss_calculator,
-get_loss_value, training_all (dual=True), training (dual=False), and infer with its FPL branch.
-Not here (out of the hot-path tier): NIfTI I/O, numpy transforms, tensorboard, validation loop.
+get_loss_value, training_all (dual=True), training (dual=False), infer with its FPL branch, and
+get_stage_dataset_from_config / create_dataset over device-resident NiftyDatasets with GPU transforms, the inverse
+transforms of the prediction and save_outputs (uint8 masks as .nii.gz with the input's geometry).
+Not here (out of the hot-path tier): tensorboard, the validation loop.
 Loaders are any iterables of batch dicts ('image', 'label_prob', optional 'pixel_weight',
-'image_weight', 'names').
+'image_weight', 'names'); create_dataset builds them from the config, set_loaders injects them.
 """
 import logging
+import os
 import numpy as np
 import torch
 import torch.nn as nn
 from torch.optim import lr_scheduler
 
 from . import filter as fpl_filter_mod
+from .dataset import NiftyDataset, BatchLoader
 from .infer import Inferer
+from .nifti import save_array_as_nifty_volume
+from .transform import TransformDict, Compose
 from .loss import SegLossDict, make_loss
 from .net import UNet2D5_dsbn
 from .optim import get_optimizer, get_lr_scheduler
@@ -44,6 +50,9 @@ class SegmentationAgent(object):
         self.fpl_uda = config['training'].get('train_fpl_uda', False) if 'training' in config else False
         self.device = torch.device("cuda:{0:}".format(self._gpus()[0]))
         self.transform_list = []
+        self.transform_dict = TransformDict
+        self.test_set = None
+        self.random_seed = config.get('training', {}).get('random_seed', 1)
         seed = config.get('training', {}).get('random_seed', 1)
         if config.get('training', {}).get('deterministic', True):
             torch.manual_seed(seed)                                          # agent_abstract.py:61-65
@@ -73,6 +82,51 @@ class SegmentationAgent(object):
 
     def set_loaders(self, train_loader_1=None, train_loader_2=None, test_loader=None):
         self.train_loader_1, self.train_loader_2, self.test_loader = train_loader_1, train_loader_2, test_loader
+
+    def set_transform_dict(self, custom_transform_dict):
+        self.transform_dict = custom_transform_dict                          # agent_abstract.py:82-88
+
+    def set_datasets(self, train_set_1=None, train_set_2=None, test_set=None):
+        self.train_set_1, self.train_set_2, self.test_set = train_set_1, train_set_2, test_set
+
+    # ---- datasets (agent_seg.py:42-77, agent_abstract.py:241-320)
+    def get_stage_dataset_from_config(self, stage):
+        assert (stage in ['1_train', '1_valid', '1_test', '2_train', '2_valid', '2_test', 'test'])
+        ds = self.config['dataset']
+        real_stage = stage.split('_')[-1]
+        transform_key = real_stage + '_transform'
+        if real_stage == "valid" and transform_key not in ds:
+            transform_key = "train_transform"
+        transform_names = ds[transform_key]
+        self.transform_list = []
+        data_transform = None
+        if transform_names is not None and len(transform_names) > 0:
+            transform_param = ds
+            transform_param['task'] = 'segmentation'
+            for name in transform_names:
+                if name not in self.transform_dict:
+                    raise ValueError("Undefined transform {0:}".format(name))
+                self.transform_list.append(self.transform_dict[name](transform_param))
+            data_transform = Compose(self.transform_list)
+        return NiftyDataset(root_dir=ds['root_dir'], csv_file=ds.get(stage + '_csv', None),
+                            modal_num=ds.get('modal_num', 1), with_label=not (stage == 'test'),
+                            transform=data_transform, device=self.device, cache=ds.get('cache_on_device', True))
+
+    def create_dataset(self):
+        ds = self.config['dataset']
+        if self.stage == 'train':
+            bn_train = ds['train_batch_size']
+            g_train = torch.Generator()
+            g_train.manual_seed(self.random_seed)
+            self.train_set_1 = self.get_stage_dataset_from_config('1_train')
+            self.train_loader_1 = BatchLoader(self.train_set_1, bn_train, True, g_train)
+            if self.config['network']['num_domains'] == 2:
+                self.train_set_2 = self.get_stage_dataset_from_config('2_train')
+                self.train_loader_2 = BatchLoader(self.train_set_2, bn_train, True, g_train)
+        else:
+            if self.test_set is None:
+                self.test_set = self.get_stage_dataset_from_config('test')
+            self.test_loader = BatchLoader(self.test_set, ds.get('test_batch_size', 1), False)
 
     # ---- construction (agent_seg.py:82-132, agent_abstract.py:320-337)
     def create_network(self):
@@ -218,7 +272,15 @@ class SegmentationAgent(object):
                         outputs[names[0]] = r
                 else:
                     pred = self.inferer.run(self.net, images, dl)
-                    outputs[names[0]] = fpl_filter_mod.hard_label(pred)     # save_outputs, 1049-1050
+                    data['predict'] = pred
+                    for transform in self.transform_list[::-1]:              # agent_seg.py:944-947
+                        if transform.inverse:
+                            data = transform.inverse_transform_for_prediction(data)
+                    hard = fpl_filter_mod.hard_label(data['predict'])        # save_outputs, 1049-1050
+                    for i, name in enumerate(names):
+                        outputs[name] = hard[i]
+                    if cfg.get('output_dir', None) is not None:
+                        self.save_outputs(data, hard)
         if self.FPL:
             srt = fpl_filter_mod.sort_uncertainty(uncertainty_list)
             path = cfg.get('fpl_uncertainty_sorted', None)
@@ -226,3 +288,31 @@ class SegmentationAgent(object):
                 np.save(path, np.array(srt, dtype=object), allow_pickle=True)
             return (srt, outputs) if return_outputs else srt
         return outputs
+
+    def save_outputs(self, data, hard=None):
+        """agent_seg.py:1022-1083: uint8 argmax masks (softmax is monotone, the argmax is taken on the device) written to
+        <output_dir>/<basename(ckpt_save_dir)>_<test csv stem>/<name> with the geometry of the input image."""
+        cfg = self.config['testing']
+        ignore_dir = cfg.get('filename_ignore_dir', True)
+        src, dst = cfg.get('filename_replace_source', None), cfg.get('filename_replace_target', None)
+        ckpt_dir = self.config.get('training', {}).get('ckpt_save_dir', 'model').split('/')[-1]
+        subset = self.config['dataset'].get('test_csv', 'test.csv').split('/')[-1][:-4]
+        output_dir = os.path.join(cfg['output_dir'], ckpt_dir + '_' + subset)
+        self.output_dir = output_dir
+        os.makedirs(output_dir, exist_ok=True)
+        names, pred = data['names'], data['predict']
+        if isinstance(pred, (list, tuple)):
+            pred = pred[0]
+        output = (fpl_filter_mod.hard_label(pred) if hard is None else hard).cpu().numpy()
+        ls, lt = cfg.get('label_source', None), cfg.get('label_target', None)
+        if ls is not None and lt is not None:                                 # util/image_process.convert_label
+            conv = np.zeros_like(output)
+            for a, b in zip(ls, lt):
+                conv[output == a] = b
+            output = conv
+        root_dir = self.config['dataset']['root_dir']
+        for i in range(len(names)):
+            save_name = names[i].split('/')[-1] if ignore_dir else names[i].replace('/', '_')
+            if src is not None and dst is not None:
+                save_name = save_name.replace(src, dst)
+            save_array_as_nifty_volume(output[i], "{0:}/{1:}".format(output_dir, save_name), root_dir + '/' + names[i])

@@ -6,6 +6,12 @@ rule (165-168) and the same 0.5 fall-back weight when a pixel-weight file cannot
 parsed on the host (fplx/nifti.py) and uploaded once; from there the sample stays in HBM: image float32 [C,D,H,W],
 label uint8 [1,D,H,W] (the reference keeps int32; class indices fit a byte and the loss kernels take bytes),
 pixel_weight float32 [1,D,H,W].  `collate` is torch's default collate for these dictionaries (stack tensors, list strings).
+
+MI355X-first: with `cache=True` every case is parsed and uploaded ONCE and the whole training set stays resident in HBM
+(the VS set is ~200 volumes x 5 MB against 288 GB); an iteration then costs a handful of small kernels and no host IO,
+which is what keeps the train step fed without the reference's 16 DataLoader worker processes.
+`BatchLoader` is the DataLoader of agent_abstract.py:269-281 for such a dataset: shuffled index order from a seeded
+torch.Generator, batches of `batch_size` collated samples, the last short batch kept (drop_last = False).
 """
 import numpy as np
 import pandas as pd
@@ -16,7 +22,8 @@ from .nifti import load_image_as_nd_array
 
 
 class NiftyDataset(object):
-    def __init__(self, root_dir, csv_file, modal_num=1, with_label=False, transform=None, device="cuda:0"):
+    def __init__(self, root_dir, csv_file, modal_num=1, with_label=False, transform=None, device="cuda:0", cache=False):
+        self.cache = {} if cache else None
         self.root_dir = root_dir
         self.csv_items = pd.read_csv(csv_file)
         self.modal_num = modal_num
@@ -48,6 +55,19 @@ class NiftyDataset(object):
         return ops.set_weight_(pixel_weight, img_weight)
 
     def __getitem__(self, idx):
+        if self.cache is None:
+            sample = self._load(idx)
+        else:
+            if idx not in self.cache:
+                self.cache[idx] = self._load(idx)
+            # the transforms replace entries of the dictionary and normalise the image in place: hand out a copy
+            sample = dict(self.cache[idx])
+            sample['image'] = sample['image'].clone()
+        if self.transform:
+            sample = self.transform(sample)
+        return sample
+
+    def _load(self, idx):
         names_list, image_list = [], []
         for i in range(self.modal_num):
             image_name = self.csv_items.iloc[idx, i]
@@ -77,8 +97,6 @@ class NiftyDataset(object):
                 sample['image1'] = self._upload(w, np.float32)
             except (OSError, ValueError):
                 sample['image1'] = image
-        if self.transform:
-            sample = self.transform(sample)
         return sample
 
 
@@ -94,3 +112,19 @@ def collate(samples):
         else:
             out[k] = v
     return out
+
+
+class BatchLoader(object):
+    """iterable of collated batches over a dataset (agent_abstract.py:263-281: batch_size, shuffle, seeded generator)"""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, generator=None):
+        self.dataset, self.batch_size, self.shuffle, self.generator = dataset, int(batch_size), shuffle, generator
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n, self.batch_size):
+            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])

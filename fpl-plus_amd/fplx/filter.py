@@ -39,3 +39,39 @@ def image_weights(rows):
         u = mx if u > mx else u
         out.append(abs((mx - u) / (mx - mn)) + 0.01)
     return out
+
+
+def write_pixel_weight_volumes(pseudo_target_root, pseudo_fake_source_root, out_dir):
+    """merge_pixelw.py:6-30 / data/get_pixel_weight.py:6-30: for every mask name present in both prediction folders the
+    weight volume 1 - 0.5 * (a XOR b), computed on the GPU, written as a float32 .nii.gz WITHOUT geometry (the reference
+    writes sitk.GetImageFromArray output as is).  Returns the names written."""
+    import os
+    import numpy as np
+    from .nifti import load_nifty_volume_as_4d_array, write_nifti
+    a_names = sorted(n for n in os.listdir(pseudo_target_root) if '.nii.gz' in n)
+    b_names = sorted(n for n in os.listdir(pseudo_fake_source_root) if '.nii.gz' in n)
+    assert len(a_names) == len(b_names)
+    os.makedirs(out_dir, exist_ok=True)
+    for name in a_names:
+        a = load_nifty_volume_as_4d_array(os.path.join(pseudo_target_root, name))['data_array'][0]
+        b = load_nifty_volume_as_4d_array(os.path.join(pseudo_fake_source_root, name))['data_array'][0]
+        assert a.shape == b.shape
+        ta = torch.from_numpy(np.ascontiguousarray(a.astype(np.uint8))).cuda()
+        tb = torch.from_numpy(np.ascontiguousarray(b.astype(np.uint8))).cuda()
+        w = ops.pixel_weight(ta, tb)
+        write_nifti(os.path.join(out_dir, name), w.cpu().numpy().reshape(a.shape))
+    return a_names
+
+
+def write_weight_csv(sorted_rows, out_csv, img_dir, label_dir, weight_dir):
+    """`data/get image_weight.py`:19-40: one csv row (image, label, pixel_weight, image_weight) per case of the sorted
+    uncertainty list; the label / weight paths are the image path with img_dir replaced."""
+    import csv
+    rows = [(u[0] if isinstance(u, (list, tuple)) else u, n) for u, n in sorted_rows]
+    weights = image_weights(rows)
+    with open(out_csv, mode='w') as f:
+        wr = csv.writer(f, delimiter=',', quotechar='"', quoting=csv.QUOTE_MINIMAL)
+        wr.writerow(['image', 'label', 'pixel_weight', 'image_weight'])
+        for (u, name), w in zip(rows, weights):
+            wr.writerow([name, name.replace(img_dir, label_dir), name.replace(img_dir, weight_dir), w])
+    return weights

@@ -234,3 +234,92 @@ def test_files_to_train_step_end_to_end(tmp_path):
     lb, pb = run()
     assert all(np.isfinite(la)) and la == lb and torch.equal(pa, pb)
     assert min(la[4:]) < la[0]
+
+
+def test_pseudo_label_stage_files_in_files_out(tmp_path):
+    """The FPL+ stage-2 hand-off end to end on files: test csv -> NiftyDataset -> [Normalize, Pad] -> sliding-window
+    inference -> inverse Pad -> uint8 .nii.gz masks with the input geometry (agent_seg.py:944-953, 1022-1083); then the
+    uncertainty list -> weight csv (data/get image_weight.py) and two mask folders -> pixel-weight volumes
+    (merge_pixelw.py), and that csv feeds NiftyDataset again (stage 3)."""
+    import fplx
+    from fplx import nifti, filter as flt
+    rs = np.random.RandomState(2)
+    root = tmp_path / "data"
+    (root / "img").mkdir(parents=True)
+    shapes = [(11, 30, 37), (9, 33, 40)]
+    for i, shp in enumerate(shapes):
+        nifti.write_nifti(str(root / "img" / ("c%d.nii.gz" % i)), rs.randn(*shp) * 40 + 150, (0.5, 0.6, 1.2), (3.0, -4.0, 5.0))
+    (tmp_path / "test.csv").write_text("image\nimg/c0.nii.gz\nimg/c1.nii.gz\n")
+    net_cfg = dict(net_type="UNet2D5_dsbn", in_chns=1, feature_chns=[8, 16, 32, 32, 32], dropout=[0.0, 0.0, 0.2, 0.2, 0.2],
+                   conv_dims=[3, 3, 3, 3, 3], class_num=2, bilinear=False, num_domains=2, precision="fp32")
+    config = {
+        "dataset": {"root_dir": str(root), "test_csv": str(tmp_path / "test.csv"), "tensor_type": "float",
+                    "test_transform": ["NormalizeWithMeanStd", "Pad"], "normalizewithmeanstd_channels": [0],
+                    "pad_output_size": [16, 32, 48], "pad_inverse": True},
+        "network": net_cfg,
+        "training": {"ckpt_save_dir": "model/vs_t1s_g", "random_seed": 1},
+        "testing": {"gpus": [0], "domian_label": 1, "output_dir": str(tmp_path / "results"), "evaluation_mode": True,
+                    "sliding_window_enable": True, "sliding_window_size": [16, 32, 32], "sliding_window_stride": [16, 16, 16],
+                    "tta_mode": 1},
+    }
+    torch.manual_seed(0)
+    agent = fplx.SegmentationAgent(config, "test")
+    agent.create_dataset()
+    agent.create_network()
+    out = agent.infer()
+    out_dir = tmp_path / "results" / "vs_t1s_g_test"
+    assert sorted(os.listdir(str(out_dir))) == ["c0.nii.gz", "c1.nii.gz"]
+    for i, shp in enumerate(shapes):
+        d = nifti.load_nifty_volume_as_4d_array(str(out_dir / ("c%d.nii.gz" % i)))
+        ref = nifti.load_nifty_volume_as_4d_array(str(root / "img" / ("c%d.nii.gz" % i)))
+        assert d["data_array"].dtype == np.uint8 and d["data_array"].shape == (1,) + shp      # inverse Pad applied
+        assert d["spacing"] == ref["spacing"] and d["origin"] == ref["origin"] and d["direction"] == ref["direction"]
+        assert np.array_equal(d["data_array"][0], out["img/c%d.nii.gz" % i].cpu().numpy())
+        # the same mask by hand: pad on the host like the reference, run, crop, argmax
+        x = ref["data_array"].astype(np.float32)
+        x = (x - x.mean()) / x.std()
+        margin = [max(0, [16, 32, 48][k] - shp[k]) for k in range(3)]
+        lo = [int(m / 2) for m in margin]
+        xp = np.pad(x, [(0, 0)] + [(lo[k], margin[k] - lo[k]) for k in range(3)], "reflect")
+        with torch.no_grad():
+            pred = agent.inferer.run(agent.net, torch.from_numpy(xp[None]).cuda(), torch.ones(1, dtype=torch.long))
+        pred = pred[0, :, lo[0]:lo[0] + shp[0], lo[1]:lo[1] + shp[1], lo[2]:lo[2] + shp[2]].cpu().numpy()
+        want = np.argmax(pred, 0).astype(np.uint8)
+        assert (want != d["data_array"][0]).mean() < 1e-3          # normalisation differs by 1 ulp: ties only
+
+    # FPL branch: MC-dropout uncertainty list, sorted ascending, saved as the reference's npy
+    config["testing"]["fpl"] = True
+    config["testing"]["fpl_uncertainty_sorted"] = str(tmp_path / "uncertainty_sorted.npy")
+    srt = agent.infer(mc_passes=4)
+    rows = np.load(str(tmp_path / "uncertainty_sorted.npy"), allow_pickle=True)
+    assert len(rows) == 2 and [r[1] for r in rows] == [r[1] for r in srt]
+    assert rows[0][0][0] <= rows[1][0][0]
+    # weight csv (get image_weight.py) from a hand-made uncertainty list with distinct values
+    fake = [([0.2], "./dataset/hrT2_train/img/a.nii.gz"), ([0.5], "./dataset/hrT2_train/img/b.nii.gz"),
+            ([1], "./dataset/hrT2_train/img/c.nii.gz")]
+    w = flt.write_weight_csv(fake, str(tmp_path / "w.csv"), "./dataset/hrT2_train/img", "./results/masks", "dataset/pw")
+    assert w == pytest.approx([1.01, 0.01, 0.01])
+    lines = (tmp_path / "w.csv").read_text().strip().splitlines()
+    assert lines[0] == "image,label,pixel_weight,image_weight"
+    assert lines[1].split(",")[:3] == ["./dataset/hrT2_train/img/a.nii.gz", "./results/masks/a.nii.gz", "dataset/pw/a.nii.gz"]
+    # pixel-weight volumes from two prediction folders
+    other = tmp_path / "results_cyc"
+    other.mkdir()
+    for i, shp in enumerate(shapes):
+        m = nifti.load_nifty_volume_as_4d_array(str(out_dir / ("c%d.nii.gz" % i)))["data_array"][0]
+        m2 = m.copy()
+        m2[2:5, 4:9, 6:20] ^= 1
+        nifti.write_nifti(str(other / ("c%d.nii.gz" % i)), m2)
+    names = flt.write_pixel_weight_volumes(str(out_dir), str(other), str(tmp_path / "pw"))
+    assert names == ["c0.nii.gz", "c1.nii.gz"]
+    pw = nifti.load_nifty_volume_as_4d_array(str(tmp_path / "pw" / "c0.nii.gz"))["data_array"][0]
+    want = np.ones(shapes[0], np.float32)
+    want[2:5, 4:9, 6:20] = 0.5
+    assert np.array_equal(pw, want)
+    # stage 3 reads what stage 2 wrote
+    (tmp_path / "s3.csv").write_text("image,label,pixel_weight,image_weight\n"
+                                     "data/img/c0.nii.gz,results/vs_t1s_g_test/c0.nii.gz,pw/c0.nii.gz,0.9\n")
+    s = fplx.NiftyDataset(str(tmp_path), str(tmp_path / "s3.csv"), with_label=True)[0]
+    got = s["pixel_weight"].cpu().numpy()[0]
+    assert np.array_equal(got, np.where(want < 1, 0, want) * np.float32(0.9))
+    assert tuple(s["label"].shape) == (1,) + shapes[0]
