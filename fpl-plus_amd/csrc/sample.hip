@@ -151,6 +151,48 @@ set_weight_k(float* __restrict__ pw, int64_t n, float iw) {
   }
 }
 
+// evaluation: per label l the voxel counts |s==l & g==l|, |s==l|, |g==l| (fuse: one row, membership in the label list)
+constexpr int EV_MAX_LABELS = 16;
+__global__ void __launch_bounds__(SP_THREADS)
+overlap_counts_k(const unsigned char* __restrict__ s, const unsigned char* __restrict__ g, int64_t n,
+                 const int* __restrict__ labels, int nlab, int fuse, unsigned long long* __restrict__ out) {
+  __shared__ unsigned red[SP_THREADS / 64][EV_MAX_LABELS * 3];
+  unsigned cnt[EV_MAX_LABELS * 3];
+  const int rows = fuse ? 1 : nlab;
+#pragma unroll
+  for (int k = 0; k < EV_MAX_LABELS * 3; ++k) cnt[k] = 0;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const int sv = s[i], gv = g[i];
+    if (fuse) {
+      bool si = false, gi = false;
+      for (int k = 0; k < nlab; ++k) { si |= sv == labels[k]; gi |= gv == labels[k]; }
+      cnt[0] += si && gi; cnt[1] += si; cnt[2] += gi;
+    } else {
+#pragma unroll
+      for (int k = 0; k < EV_MAX_LABELS; ++k)
+        if (k < nlab) {
+          const bool si = sv == labels[k], gi = gv == labels[k];
+          cnt[3 * k] += si && gi; cnt[3 * k + 1] += si; cnt[3 * k + 2] += gi;
+        }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < EV_MAX_LABELS * 3; ++k) {
+    if (k < rows * 3) {                                      // block-uniform
+      unsigned v = cnt[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) red[wave][k] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < rows * 3) {
+    unsigned long long t = 0;
+    for (int w = 0; w < SP_THREADS / 64; ++w) t += red[w][threadIdx.x];
+    if (t) atomicAdd(out + threadIdx.x, t);
+  }
+}
+
 inline int sp_grid(int64_t total) {
   int64_t g = (total + SP_THREADS - 1) / SP_THREADS;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -235,6 +277,20 @@ int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_str
   FPLX_REQUIRE(pixel_weight && n > 0, FPLX_E_NULL, "set_weight: null pointer / empty volume");
   set_weight_k<<<sp_grid(n), SP_THREADS, 0, (hipStream_t)stream>>>(pixel_weight, n, image_weight);
   return fplx_check_launch("set_weight");
+}
+
+int fplx_overlap_counts(const unsigned char* seg, const unsigned char* gt, int64_t n, const int* labels, int nlabels,
+                        int fuse, unsigned long long* out, fplx_stream_t stream) {
+  FPLX_REQUIRE(seg && gt && labels && out, FPLX_E_NULL, "overlap_counts: null pointer");
+  FPLX_REQUIRE(n > 0 && n < ((int64_t)1 << 40) && nlabels > 0 && nlabels <= EV_MAX_LABELS, FPLX_E_BADSHAPE,
+               "overlap_counts: %d labels (1..%d) over %lld voxels", nlabels, EV_MAX_LABELS, (long long)n);
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = fuse ? 1 : nlabels;
+  if (hipMemsetAsync(out, 0, sizeof(unsigned long long) * 3 * rows, st) != hipSuccess)
+    return fplx_fail(FPLX_E_HIP, "overlap_counts: memset failed");
+  // a thread sees at most n / (grid * 256) voxels: the 32-bit per-thread counters cannot overflow
+  overlap_counts_k<<<sp_grid(n), SP_THREADS, 0, st>>>(seg, gt, n, labels, nlabels, fuse, out);
+  return fplx_check_launch("overlap_counts");
 }
 
 }  // extern "C"

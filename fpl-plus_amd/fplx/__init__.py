@@ -18,9 +18,9 @@ from .optim import FusedAdam, get_optimizer, get_lr_scheduler      # noqa: E402
 from .train import TrainStep                                       # noqa: E402
 from .config import parse_config, synchronize_config               # noqa: E402
 from .dataset import NiftyDataset                                  # noqa: E402
-from . import filter, ops, ddp, transform, nifti                                     # noqa: E402
+from . import filter, ops, ddp, transform, nifti, evaluation                                     # noqa: E402
 
 __all__ = ["UNet2D5_dsbn", "DomainSpecificBatchNorm3d", "SegLossDict", "SegNetDict", "DiceLoss",
            "CrossEntropyLoss", "DiceLoss_weight", "CombinedLoss", "EntropyTerm", "make_loss", "Inferer",
            "SegmentationAgent", "FusedAdam", "get_optimizer", "get_lr_scheduler", "TrainStep",
-           "parse_config", "synchronize_config", "filter", "ops", "ddp", "transform", "nifti", "NiftyDataset"]
+           "parse_config", "synchronize_config", "filter", "ops", "ddp", "transform", "nifti", "evaluation", "NiftyDataset"]

@@ -337,3 +337,17 @@ def set_weight_(pixel_weight, image_weight):
     assert pixel_weight.dtype == torch.float32 and pixel_weight.is_contiguous()
     call("fplx_set_weight", ptr(pixel_weight), pixel_weight.numel(), float(image_weight), stream())
     return pixel_weight
+
+
+def overlap_counts(seg, gt, labels, fuse=False):
+    """exact voxel counts [rows, 3] = (|seg==l & gt==l|, |seg==l|, |gt==l|) as python ints (one device->host copy)"""
+    require_gpu(seg, gt)
+    if seg.shape != gt.shape:
+        raise ValueError("fplx: segmentation and ground truth shapes differ")
+    assert seg.dtype == torch.uint8 and gt.dtype == torch.uint8
+    s, g = seg.contiguous(), gt.contiguous()
+    lab = torch.tensor([int(v) for v in labels], dtype=torch.int32, device=s.device)
+    rows = 1 if fuse else lab.numel()
+    out = torch.empty((rows, 3), dtype=torch.int64, device=s.device)
+    call("fplx_overlap_counts", ptr(s), ptr(g), s.numel(), ptr(lab), lab.numel(), 1 if fuse else 0, ptr(out), stream())
+    return out.tolist()

@@ -244,6 +244,14 @@ int fplx_label_to_probability(const unsigned char* label, float* prob, int class
                               fplx_stream_t stream);
 int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_stream_t stream);
 
+/* ------------------------------------------------------------------ evaluation
+ * Exact voxel counts behind binary_dice / binary_iou / rve / volume (PyMIC/pymic/util/evaluation_seg_train.py:21-50,
+ * 68-81, 171-186, 220-225): out[row][3] = {|seg==l & gt==l|, |seg==l|, |gt==l|} (uint64) for each of the nlabels labels
+ * (<= 16), or ONE row counting membership in the label list when fuse != 0 (get_multi_class_evaluation_score, 231-262).
+ * The scores themselves are float64 host arithmetic on these integers (fplx/evaluation.py). */
+int fplx_overlap_counts(const unsigned char* seg, const unsigned char* gt, int64_t n, const int* labels, int nlabels,
+                        int fuse, unsigned long long* out, fplx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

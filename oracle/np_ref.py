@@ -250,3 +250,54 @@ def tf_train_chain(sample, p, rng=None):
                        p.get('randomcrop_foreground_ratio', 0.5), p.get('randomcrop_mask_label', [1]), rng)
     s = tf_random_flip(s, p['randomflip_flip_depth'], p['randomflip_flip_height'], p['randomflip_flip_width'], rng)
     return tf_label_to_probability(s, p['labeltoprobability_class_num'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# evaluation (PyMIC/pymic/util/evaluation_seg_train.py) - SURVEY 8f #3
+def ev_binary_dice(s, g):
+    """evaluation_seg_train.py:21-50"""
+    prod = np.multiply(s, g)
+    return (2.0 * prod.sum() + 1e-5) / (s.sum() + g.sum() + 1e-5)
+
+
+def ev_binary_iou(s, g):
+    """evaluation_seg_train.py:68-81 in float64 (NumPy 1.x promotion, which the reference was written for)"""
+    inter = np.multiply(s, g)
+    union = np.asarray(s + g > 0, np.float64)
+    return (inter.sum() + 1e-5) / (union.sum() + 1e-5)
+
+
+def ev_binary_rve(s, g):
+    """evaluation_seg_train.py:171-186"""
+    s_v, g_v = float(s.sum()), float(g.sum())
+    assert g_v > 0
+    return abs(s_v - g_v) / g_v
+
+
+def ev_multi_class(s_volume, g_volume, label_list, fuse_label, spacing, metric):
+    """evaluation_seg_train.py:188-262 for dice / iou / rve / volume"""
+    if fuse_label:
+        s_sub, g_sub = np.zeros_like(s_volume), np.zeros_like(g_volume)
+        for lab in label_list:
+            s_sub = s_sub + np.asarray(s_volume == lab, np.uint8)
+            g_sub = g_sub + np.asarray(g_volume == lab, np.uint8)
+        label_list = [1]
+        s_volume, g_volume = np.asarray(s_sub > 0, np.uint8), np.asarray(g_sub > 0, np.uint8)
+    out = []
+    for label in label_list:
+        s, g = s_volume == label, g_volume == label
+        m = metric.lower()
+        if m == "dice":
+            out.append(ev_binary_dice(s, g))
+        elif m == "iou":
+            out.append(ev_binary_iou(s, g))
+        elif m == "rve":
+            out.append(ev_binary_rve(s, g))
+        elif m == "volume":
+            voxel_size = 1.0
+            for dim in range(len(spacing)):
+                voxel_size = voxel_size * spacing[dim]
+            out.append(g.sum() * voxel_size)
+        else:
+            raise ValueError("unsupported evaluation metric: {0:}".format(metric))
+    return out

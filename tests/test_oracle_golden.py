@@ -250,3 +250,23 @@ def test_transform_chain_against_reference_fixture(golden_dir):
         assert json.loads(str(g[k + "flip_param"])) == s["RandomFlip_Param"]
         for name in ("image", "label", "label_prob", "pixel_weight"):
             np.testing.assert_array_equal(s[name], g[k + name], err_msg="%s seed %d" % (name, seed))
+
+
+EV_CASES = (("l12", [1, 2], False), ("l1", [1], False), ("fuse12", [1, 2], True))
+
+
+def test_evaluation_scores_against_reference_fixture(golden_dir):
+    """oracle ev_* vs get_multi_class_evaluation_score of the reference (tests/golden/make_golden_eval.py).
+    dice / rve / volume are bit-identical; iou to 1e-6 (float32 `+ 1e-5` under NumPy 2 in the reference, see np_ref)."""
+    from oracle import np_ref as R
+    g = _load(golden_dir, "evaluation.npz")
+    sp = tuple(g["spacing"])
+    for metric in ("dice", "iou", "rve", "volume"):
+        for tag, labels, fuse in EV_CASES:
+            want = g["%s_%s" % (metric, tag)]
+            got = np.array([R.ev_multi_class(g["s%d" % i][None], g["g%d" % i][None], labels, fuse, sp, metric)
+                            for i in range(6)], np.float64)
+            if metric == "iou":
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-9)
+            else:
+                np.testing.assert_array_equal(got, want)
