@@ -6,11 +6,13 @@ set_network / set_net_dict / set_loss_dict / set_optimizer / set_scheduler / set
 set_datasets-style loader injection), create_network, create_optimizer, create_loss_calculator,
 get_loss_value, training_all (dual=True), training (dual=False), infer with its FPL branch, and
 get_stage_dataset_from_config / create_dataset over device-resident NiftyDatasets with GPU transforms, the inverse
-transforms of the prediction and save_outputs (uint8 masks as .nii.gz with the input's geometry).
-Not here (out of the hot-path tier): tensorboard, the validation loop.
+transforms of the prediction and save_outputs (uint8 masks as .nii.gz with the input's geometry), and (8f #4) validation,
+train_valid with the reference's checkpoint files (`<prefix>_<it>.pt`, `_latest.txt`, `_best.txt`), get_checkpoint_name, run.
+Not here (out of the hot-path tier): tensorboard, the `dis` adversarial branch, nn.DataParallel (one process per GPU instead).
 Loaders are any iterables of batch dicts ('image', 'label_prob', optional 'pixel_weight',
 'image_weight', 'names'); create_dataset builds them from the config, set_loaders injects them.
 """
+import copy
 import logging
 import os
 import numpy as np
@@ -18,7 +20,9 @@ import torch
 import torch.nn as nn
 from torch.optim import lr_scheduler
 
+from . import checkpoint as ckpt_mod
 from . import filter as fpl_filter_mod
+from . import ops
 from .dataset import NiftyDataset, BatchLoader
 from .infer import Inferer
 from .nifti import save_array_as_nifty_volume
@@ -123,6 +127,12 @@ class SegmentationAgent(object):
             if self.config['network']['num_domains'] == 2:
                 self.train_set_2 = self.get_stage_dataset_from_config('2_train')
                 self.train_loader_2 = BatchLoader(self.train_set_2, bn_train, True, g_train)
+            bn_valid = ds.get('valid_batch_size', 1)
+            self.valid_loader_1 = self.valid_loader_2 = None
+            if ds.get('1_valid_csv', None) is not None:
+                self.valid_loader_1 = BatchLoader(self.get_stage_dataset_from_config('1_valid'), bn_valid, False)
+            if self.config['network']['num_domains'] == 2 and ds.get('2_valid_csv', None) is not None:
+                self.valid_loader_2 = BatchLoader(self.get_stage_dataset_from_config('2_valid'), bn_valid, False)
         else:
             if self.test_set is None:
                 self.test_set = self.get_stage_dataset_from_config('test')
@@ -236,9 +246,120 @@ class SegmentationAgent(object):
         regulariser of lines 352-354 is part of the loss here (create_loss_calculator(1.0))."""
         return self._train_loop(False)
 
+    # ---- validation (agent_seg.py:509-606)
+    def _valid_domain(self, loader, domain, class_num):
+        losses, dices = [], []
+        for data in loader:
+            inputs = self.convert_tensor_type(data['image']).to(self.device)
+            labels_prob = self.convert_tensor_type(data['label_prob']).to(self.device)
+            outputs = self.inferer.run(self.net, inputs, domain * torch.ones(inputs.shape[0], dtype=torch.long))
+            losses.append(float(self.get_loss_value(data, outputs, labels_prob).item()))
+            hard = fpl_filter_mod.hard_label(outputs)                         # argmax on the device, uint8 [N,D,H,W]
+            truth = fpl_filter_mod.hard_label(labels_prob)
+            for i in range(inputs.shape[0]):                                  # get_classwise_dice of one-hot maps, fp32
+                cnt = np.asarray(ops.overlap_counts(hard[i], truth[i], list(range(class_num))), np.float32)
+                dices.append((np.float32(2.0) * cnt[:, 0] + np.float32(1e-5)) / (cnt[:, 2] + cnt[:, 1] + np.float32(1e-5)))
+        return np.asarray(losses).mean(), np.asarray(dices).mean(axis=0)
+
+    def validation(self):
+        nd = int(self.config['network']['num_domains'])
+        class_num = self.config['network']['class_num']
+        if self.inferer is None:
+            infer_cfg = dict(self.config.get('testing', {}))
+            infer_cfg['class_num'] = class_num
+            self.inferer = Inferer(infer_cfg)
+        with torch.no_grad():
+            self.net.eval()
+            loss_0, cls_0 = self._valid_domain(self.valid_loader_1, 0, class_num)
+            if nd == 2:
+                loss_1, cls_1 = self._valid_domain(self.valid_loader_2, 1, class_num)
+        avg_0 = cls_0.mean()
+        if nd == 2:
+            avg_1 = cls_1.mean()
+            loss, cls, avg = (loss_0 + loss_1) / 2, (cls_0 + cls_1) / 2, (avg_0 + avg_1) / 2
+        else:
+            loss, cls, avg = loss_0, cls_0, avg_0
+        if isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau):
+            self.scheduler.step(avg)
+        tr = self.config['training']
+        if nd == 2 and tr.get('val_t2', False):
+            return {'loss': loss_1, 'avg_dice': avg_1, 'class_dice': cls_1}
+        if tr.get('val_t1', False):
+            return {'loss': loss_0, 'avg_dice': avg_0, 'class_dice': cls_0}
+        return {'loss': loss, 'avg_dice': avg, 'class_dice': cls}
+
+    # ---- train / validate / checkpoint loop (agent_seg.py:690-830)
+    def get_checkpoint_name(self):
+        return ckpt_mod.get_checkpoint_name(self.config)
+
+    def train_valid(self):
+        tr = self.config['training']
+        if tr.get('dis', False):
+            raise ValueError("fplx: the `dis` adversarial branch (agent_seg.py:249-275) is not built")
+        self.dual = tr.get('dual', True)
+        self.net.to(self.device)
+        iter_start, iter_max, iter_valid = tr['iter_start'], tr['iter_max'], tr['iter_valid']
+        iter_save = tr.get('iter_save', None)
+        early_stop_it = tr.get('early_stop_patience', None)
+        if iter_save is None:
+            iter_save_list = [iter_max]
+        elif isinstance(iter_save, (tuple, list)):
+            iter_save_list = iter_save
+        else:
+            iter_save_list = range(0, iter_max + 1, iter_save)
+        self.max_val_dice, self.max_val_it, self.best_model_wts, self.checkpoint = 0.0, 0, None, None
+        if iter_start > 0:
+            self.checkpoint = torch.load(ckpt_mod.checkpoint_file(self.config, iter_start), map_location=self.device,
+                                         weights_only=False)
+            self.checkpoint['valid_pred'] = 0                                 # agent_seg.py:723: resume restarts "best"
+            self.net.load_state_dict(self.checkpoint['model_state_dict'])
+            self.max_val_dice = self.checkpoint.get('valid_pred', 0)
+            self.max_val_it = iter_start
+            self.best_model_wts = self.checkpoint['model_state_dict']
+        self.create_optimizer(self.get_parameters_to_update())
+        self.create_loss_calculator()
+        self.glob_it = iter_start
+        history = []
+        for it in range(iter_start, iter_max, iter_valid):
+            lr_value = self.optimizer.param_groups[0]['lr']
+            train_scalars = self.training_all() if self.dual else self.training()
+            valid_scalars = self.validation()
+            self.glob_it = it + iter_valid
+            logging.info("it {0:} lr {1:} train loss {2:.4f} valid dice {3:.4f}".format(
+                self.glob_it, lr_value, train_scalars['loss'], valid_scalars['avg_dice']))
+            history.append((self.glob_it, lr_value, train_scalars, valid_scalars))
+            if valid_scalars['avg_dice'] > self.max_val_dice:
+                self.max_val_dice = valid_scalars['avg_dice']
+                self.max_val_it = self.glob_it
+                self.best_model_wts = copy.deepcopy(ckpt_mod.reference_model_state_dict(self.net))
+            stop_now = early_stop_it is not None and self.glob_it - self.max_val_it > early_stop_it
+            if (self.glob_it in iter_save_list) or stop_now:
+                ckpt_mod.save_checkpoint(self.config, self.glob_it, valid_scalars['avg_dice'],
+                                         ckpt_mod.reference_model_state_dict(self.net), self.optimizer, "latest")
+            if stop_now:
+                logging.info("The training is early stopped")
+                break
+        # the best performing checkpoint (agent_seg.py:806-826)
+        if self.best_model_wts is None:
+            self.best_model_wts = ckpt_mod.reference_model_state_dict(self.net)
+        ckpt_mod.save_checkpoint(self.config, self.max_val_it, self.max_val_dice, self.best_model_wts, self.optimizer, "best")
+        logging.info('The best performing iter is {0:}, valid dice {1:}'.format(self.max_val_it, self.max_val_dice))
+        return history
+
+    def run(self):
+        """agent_abstract.py:348-357"""
+        self.create_dataset()
+        self.create_network()
+        return self.train_valid() if self.stage == 'train' else self.infer()
+
     # ---- inference (agent_seg.py:834-964)
     def infer(self, mc_passes=6, return_outputs=False):
         cfg = self.config['testing']
+        if 'ckpt_mode' in cfg and self.checkpoint is None:                  # agent_seg.py:854-866
+            ckpt_name = self.get_checkpoint_name()
+            if isinstance(ckpt_name, (tuple, list)):
+                raise ValueError("fplx: ckpt_mode 3 (ensemble of checkpoints) is not built")
+            self.checkpoint = torch.load(ckpt_name, map_location=self.device, weights_only=False)
         domian_label = cfg['domian_label']
         self.FPL = cfg.get('fpl', False)
         self.net.to(self.device)

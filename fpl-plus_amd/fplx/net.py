@@ -224,6 +224,8 @@ class UNet2D5_dsbn(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         kept = {k: v for k, v in state_dict.items() if not any(m in k for m in _DEAD_KEY_MARKS)}
+        # the reference's dead 2D twins: kept on the host so that a re-saved checkpoint carries them unchanged
+        self._dead_state = {k: v.detach().cpu().clone() for k, v in state_dict.items() if k not in kept}
         r = super(UNet2D5_dsbn, self).load_state_dict(kept, strict=strict, **kw)
         self.engine.invalidate()
         return r

@@ -108,10 +108,19 @@ class FusedAdam(Optimizer):
                           self.exp_avg_sq[start:end], lr, self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps)
 
     def state_dict(self):
+        """torch.optim.Adam's layout over the reference's parameter list (fplx/checkpoint.py): what the reference's
+        agent saves as 'optimizer_state_dict' and what its create_optimizer loads back (agent_abstract.py:327-330)"""
+        from .checkpoint import optimizer_to_reference
+        return optimizer_to_reference(self)
+
+    def flat_state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "seg_steps": list(self.seg_steps),
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
+        if "state" in sd:                                       # a torch.optim.Adam / reference checkpoint
+            from .checkpoint import optimizer_from_reference
+            return optimizer_from_reference(self, sd)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.seg_steps = list(sd["seg_steps"])

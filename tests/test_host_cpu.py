@@ -153,3 +153,14 @@ def test_grad_allreduce_two_ranks_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_reference_key_order_rule_matches_reference_dump(golden_dir):
+    """fplx.checkpoint.reference_state_keys / reference_param_names vs the key lists dumped from the reference network
+    (tests/golden/make_golden_ckpt.py): 484 state_dict keys, 268 parameters, same order."""
+    import json
+    import os
+    from fplx import checkpoint as C
+    k = json.load(open(os.path.join(golden_dir, "ref_state_keys.json")))
+    assert C.reference_state_keys(2) == k["state_dict"] and len(k["state_dict"]) == 484
+    assert C.reference_param_names(2) == k["named_parameters"] and len(k["named_parameters"]) == 268
