@@ -1124,13 +1124,21 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
   // LDS-tiled kernel (128 voxels x 128|64 channels per block) when the shape allows
   c.tile_nt = (cin % 32 == 0 && cout % 64 == 0) ? (cout % 128 == 0 ? 128 : 64) : 0;
   c.mblocks = c.tile_nt ? (V + 127) / 128 : (V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32);
-  // small volumes (deep levels) do not fill 256 CUs: deal the 27 taps to 3 / 9 / 27 blocks
+  // small volumes (deep levels) do not fill 256 CUs: deal the 27 taps to 3 / 9 / 27 blocks - the SMALLEST split that
+  // gives every CU a block, because each split adds an fp32 partial tensor to write and re-read (measured on the level-3
+  // and level-4 shapes: 9 -> 3 and 27 -> 9 save 12-21 us per launch)
   const int64_t blocks = c.mblocks * (c.tile_nt ? cout / c.tile_nt : cout / (c.ntl * 32));
   c.ksplit = 1;
   if (cout % 8 == 0 && cout <= 2048) {
-    if (blocks * 9 < 400) c.ksplit = 27;
-    else if (blocks * 3 < 400) c.ksplit = 9;
-    else if (blocks < 300) c.ksplit = 3;
+    if (blocks * 9 < 256) c.ksplit = 27;
+    else if (blocks * 3 < 256) c.ksplit = 9;
+    else if (blocks < 256) c.ksplit = 3;
+  }
+  {  // tuning knobs: FPLX_TILE_NT=64 forces the narrow tile, FPLX_TILE_KS forces the tap split (1/3/9/27)
+    static const int knt = [] { const char* e = getenv("FPLX_TILE_NT"); return e ? atoi(e) : 0; }();
+    static const int kks = [] { const char* e = getenv("FPLX_TILE_KS"); return e ? atoi(e) : 0; }();
+    if (knt == 64 && c.tile_nt == 128) c.tile_nt = 64;
+    if (kks == 1 || kks == 3 || kks == 9 || kks == 27) c.ksplit = kks;
   }
   int64_t fb = (V + 7) / 8;
   c.fin_blocks = (int)(fb > 512 ? 512 : (fb < 1 ? 1 : fb));

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     # error path works without a GPU: bad arguments are rejected before any launch
     assert lib.fplx_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == -5
     assert "adam_step" in _lib.last_error()
-    assert lib.fplx_num_partials(1) == 1 and lib.fplx_num_partials(10 ** 9) == 2048
+    assert lib.fplx_num_partials(1) == 1 and lib.fplx_num_partials(10 ** 9) == 512
 
 
 def test_parse_config_matches_reference_parser(golden_dir):
