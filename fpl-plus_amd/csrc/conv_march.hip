@@ -299,9 +299,14 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 // 10 x 34 voxels x 64 B = 21 KB each) through a two-slot ring, so a depth step is two half-steps of 108 MFMAs per
 // wave into the same accumulators.  LDS holds 162 KB, one block of 4 waves per CU, ONE wave per SIMD: nothing hides
 // a stall, so every fragment read, DMA piece and output element is issued inside an MFMA gap (fences pin the order).
-struct MG64 {
+// Two footprints: 8 x 32 (an MFMA M-tile = 32 voxels of one row) and 16 x 16 (an M-tile = 16 voxels of two consecutive
+// rows) for widths such as 80 that 32-wide tiles cover with 17 % waste.  FW16 changes only the lane -> voxel map of the
+// A fragments and of the write-out; slab, weights, ring and MFMA schedule are the same.
+template <int FWV>
+struct MG64T {
   static constexpr int ROWB = 64, CH = 4;                  // a half-slab / half-weight row: 32 channels
-  static constexpr int FH = 8, FW = 32, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
+  static constexpr int FW = FWV, FH = 256 / FWV, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
+  static constexpr int HPM = 32 / FW;                      // rows of the footprint per M-tile (1 or 2)
   static constexpr int THREADS = 256;
   static constexpr int SLAB_CHUNKS = SLAB * CH, SLAB_DMA = (SLAB_CHUNKS + 63) / 64;   // 1-KiB pieces (last: 16 lanes)
   static constexpr int SLAB_BYTES = SLAB * ROWB, WH_BYTES = 27 * 32 * ROWB;           // per channel half
@@ -310,27 +315,29 @@ struct MG64 {
   static constexpr int LDS = 2 * SLAB_BYTES + 2 * WH_BYTES + 32 * 4 + (THREADS / 64) * STAGE_BYTES;
   static __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
 };
+using MG64 = MG64T<32>;
 
 // one half-slab -> the three output depths it touches.  FIRST: the kd = 0 accumulators start from zero.
 // side(q, g) runs in gap g (0..5) of stage q (0..17), i.e. right before MFMA g of that stage.
-template <int MASK, bool FIRST, class Side>
+template <int MASK, bool FIRST, class G, class Side>
 __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const char* __restrict__ wh, int wave, int r,
                                              int khalf, f32x16& A00, f32x16& A01, f32x16& A10, f32x16& A11,
                                              f32x16& A20, f32x16& A21, Side&& side) {
   bf16x8 fa[2][2], fb[2][3];
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int vb = wave * 2 * MG64::SW + r, rb = r;
+  // M-tile m of this wave starts at footprint row (2 * wave + m) * HPM; lane row r is voxel (r / FW, r % FW) of it
+  int vb = (wave * 2 * G::HPM + r / G::FW) * G::SW + r % G::FW, rb = r;
   asm volatile("" : "+v"(vb), "+v"(rb));         // lane bases re-derived per half-step (no hoisted address zoo)
-  const char* wl0 = wh + rb * MG64::ROWB + ((khalf ^ MG64::swz(rb)) << 4);
-  const char* wl1 = wh + rb * MG64::ROWB + (((2 + khalf) ^ MG64::swz(rb)) << 4);
+  const char* wl0 = wh + rb * G::ROWB + ((khalf ^ G::swz(rb)) << 4);
+  const char* wl1 = wh + rb * G::ROWB + (((2 + khalf) ^ G::swz(rb)) << 4);
   auto load_a = [&](int q, int m) {
     const int p = q >> 1, ks = q & 1, kh = p / 3, kw = p % 3, c = 2 * ks + khalf;
-    const int vox = vb + (m + kh) * MG64::SW + kw;
-    return *reinterpret_cast<const bf16x8*>(sl + vox * MG64::ROWB + ((c ^ MG64::swz(vox)) << 4));
+    const int vox = vb + (m * G::HPM + kh) * G::SW + kw;
+    return *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((c ^ G::swz(vox)) << 4));
   };
   auto load_b = [&](int q, int kd) {
     const int p = q >> 1, ks = q & 1;
-    return *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (kd * 9 + p) * 32 * MG64::ROWB);
+    return *reinterpret_cast<const bf16x8*>((ks ? wl1 : wl0) + (kd * 9 + p) * 32 * G::ROWB);
   };
   fa[0][0] = load_a(0, 0); fa[0][1] = load_a(0, 1);
 #pragma unroll
@@ -362,15 +369,16 @@ __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const 
   }
 }
 
-__global__ void __launch_bounds__(MG64::THREADS)
+template <class G>
+__global__ void __launch_bounds__(256)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
                  const bf16_t* __restrict__ x1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;                                        // [2 channel halves][SLAB][32]
-  char* wbuf = smem + 2 * MG64::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
-  float* bias_s = reinterpret_cast<float*>(wbuf + 2 * MG64::WH_BYTES);
+  char* wbuf = smem + 2 * G::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
+  float* bias_s = reinterpret_cast<float*>(wbuf + 2 * G::WH_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, khalf = lane >> 5;
@@ -379,7 +387,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int tw = b % tilesW; b /= tilesW;
   const int th = b % tilesH; b /= tilesH;
   const int n = __builtin_amdgcn_readfirstlane(b);
-  const int h0 = __builtin_amdgcn_readfirstlane(th * MG64::FH), w0 = __builtin_amdgcn_readfirstlane(tw * MG64::FW);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * G::FH), w0 = __builtin_amdgcn_readfirstlane(tw * G::FW);
   const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
   const int n0 = blockIdx.y * 32;
@@ -392,27 +400,27 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-  constexpr int NPIECE = MG64::NPIECE;
+  constexpr int NPIECE = G::NPIECE;
   // per lane and piece: byte offset of the source chunk (channel half 0) inside one depth slice of x, -1 = zero,
   // -2 = lane past the end of the slab (the last piece is 16 lanes wide)
   int soff[NPIECE];
 #pragma unroll
   for (int k = 0; k < NPIECE; ++k) {
     const int i = (wave + 4 * k) * 64 + lane;
-    const int vox = i >> 2, c = (i & 3) ^ MG64::swz(vox);
-    const int hh = vox / MG64::SW + h0 - 1, ww = vox % MG64::SW + w0 - 1;
+    const int vox = i >> 2, c = (i & 3) ^ G::swz(vox);
+    const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
     const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
-    soff[k] = i >= MG64::SLAB_CHUNKS ? -2 : (in ? (int)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : -1);
+    soff[k] = i >= G::SLAB_CHUNKS ? -2 : (in ? (int)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : -1);
   }
   const int64_t xslice = (int64_t)H * W * ldx * 2;
   const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
   // channel half 1: the next 32 channels of x, or a second tensor (torch.cat([x, x1], 1) never materialised)
   const char* xn1 = reinterpret_cast<const char*>(x1 ? x1 : x + 32) + (int64_t)n * D * xslice;
   auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel half hf of slab s -> slot hf
-    if (wave + 4 * k < MG64::SLAB_DMA && soff[k] != -2) {
+    if (wave + 4 * k < G::SLAB_DMA && soff[k] != -2) {
       const char* xs = (hf ? xn1 : xn) + s * xslice;        // uniform
       const void* src = soff[k] >= 0 ? (const void*)(xs + (unsigned)soff[k]) : (const void*)fplx_zero16;
-      lds_dma(src, slabs + hf * MG64::SLAB_BYTES + (wave + 4 * k) * 1024);
+      lds_dma(src, slabs + hf * G::SLAB_BYTES + (wave + 4 * k) * 1024);
     }
   };
 
@@ -425,10 +433,10 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) { slab_piece(d0 - 1, 0, k); }
   }
-  for (int j = wave; j < 2 * 27 * 32 * MG64::CH / 64; j += 4) {
+  for (int j = wave; j < 2 * 27 * 32 * G::CH / 64; j += 4) {
     const int i = j * 64 + lane;                             // chunk index over [half][tap][co][4 chunks]
-    const int hf = i / (27 * 32 * MG64::CH), ii = i % (27 * 32 * MG64::CH);
-    const int row = ii >> 2, c = (ii & 3) ^ MG64::swz(row);
+    const int hf = i / (27 * 32 * G::CH), ii = i % (27 * 32 * G::CH);
+    const int row = ii >> 2, c = (ii & 3) ^ G::swz(row);
     lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * 64 + hf * 32 + c * 8, wbuf + j * 1024);
   }
   if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
@@ -437,37 +445,53 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 
   const float bv = bias_s[r];
   float ssum = 0.f, qsum = 0.f;
-  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * MG64::STAGE_BYTES;
+  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * G::STAGE_BYTES;
   char* stg_w = stg + (4 * khalf) * 64 + r * 2;
   const char* stg_r = stg + lane * 16;
-  unsigned wmask = 0;
+  // accumulator element i of a lane is M-tile row mr = (i & 3) + 8 (i >> 2) + 4 khalf = voxel (mr / FW, mr % FW);
+  // wmask[m] bit i: that voxel of M-tile m lies inside the volume (statistics only count real voxels)
+  const int hb = h0 + wave * 2 * G::HPM;                     // first row of this wave's M-tile 0
+  unsigned wmask0 = 0, wmask1 = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
-    if (w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf < W) wmask |= 1u << i;
-  const bool hok0 = h0 + wave * 2 < H, hok1 = h0 + wave * 2 + 1 < H;
+  for (int i = 0; i < 16; ++i) {
+    const int mr = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+    if (w0 + mr % G::FW < W) {
+      if (hb + mr / G::FW < H) wmask0 |= 1u << i;
+      if (hb + G::HPM + mr / G::FW < H) wmask1 |= 1u << i;
+    }
+  }
   const unsigned ldy2 = (unsigned)ldy * 2u;
-  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy + n0) * 2;
+  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + hb) * W + w0) * ldy + n0) * 2;
   const int64_t yslice = (int64_t)H * W * ldy * 2;
+  // write-out: lane -> (staged row lane >> 2 and + 16, 16-byte chunk lane & 3).  FW32: both rows are voxels of one
+  // volume row (w and w + 16); FW16: the second one is the same w of the NEXT volume row.
   const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
-  const bool sok0 = w0 + (lane >> 2) < W, sok1 = w0 + (lane >> 2) + 16 < W;
+  const unsigned step1 = G::FW == 32 ? 16u : (unsigned)W;    // voxels between the two staged halves
+  const bool wok = w0 + (lane >> 2) < W;
+  bool sok[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    sok[m][0] = wok && hb + m * G::HPM < H;
+    sok[m][1] = G::FW == 32 ? (sok[m][0] && w0 + (lane >> 2) + 16 < W) : (wok && hb + m * G::HPM + 1 < H);
+  }
   auto retire_elem = [&](f32x16& A, int m, int i) {
     const int wu = (i & 3) + 8 * (i >> 2);
     const float ov = A[i] + bv;
     *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
-    if ((m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
+    if (((m ? wmask1 : wmask0) >> i) & 1u) {
       ssum += ov;
       qsum = fmaf(ov, ov, qsum);
     }
   };
   auto retire_flush = [&](int m, int o) {
-    if (m ? hok1 : hok0) {
+    if (sok[m][0] || sok[m][1]) {
       unsigned l2 = ldy2;
       asm volatile("" : "+s"(l2));
-      char* rowp = yn + o * yslice + (unsigned)(m * W) * l2;
+      char* rowp = yn + o * yslice + (unsigned)(m * G::HPM * W) * l2;
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
       const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
-      if (sok0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
-      if (sok1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+      if (sok[m][0]) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok[m][1]) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + step1 * l2 + soffb), "v"(v1) : "memory");
     }
   };
 
@@ -497,12 +521,12 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
           if (g == 4 && q == 7) retire_flush(1, o);
         }
       };
-      const char* sl = slabs + hf * MG64::SLAB_BYTES;
-      const char* wh = wbuf + hf * MG64::WH_BYTES;
+      const char* sl = slabs + hf * G::SLAB_BYTES;
+      const char* wh = wbuf + hf * G::WH_BYTES;
 #define M64_STEP(MASK)                                                                                              \
   do {                                                                                                              \
-    if (hf == 0) march64_half<MASK, true>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);              \
-    else march64_half<MASK, false>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);                     \
+    if (hf == 0) march64_half<MASK, true, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);           \
+    else march64_half<MASK, false, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);                  \
   } while (0)
       if (live) {
         if (t == 0) M64_STEP(1);
@@ -550,7 +574,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   }
 }
 
-struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
+struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk, fw; };
 
 inline int march_enabled() {
   static int v = -1;
@@ -563,9 +587,16 @@ inline int march_enabled() {
 
 inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
   MarchCfg c;
-  const int fh = cin == 64 ? MG64::FH : MG::FH;
+  int fh = cin == 64 ? MG64::FH : MG::FH;
+  c.fw = 32;
+  if (cin == 64) {                                           // 16 x 16 footprint when it wastes less area than 8 x 32
+    static const int kfw = [] { const char* e = getenv("FPLX_MARCH64_FW"); return e ? atoi(e) : 0; }();
+    const int64_t a32 = (int64_t)((h + 7) / 8) * 8 * ((w + 31) / 32) * 32;
+    const int64_t a16 = (int64_t)((h + 15) / 16) * 16 * ((w + 15) / 16) * 16;
+    if ((kfw == 0 && a16 < a32) || kfw == 16) { c.fw = 16; fh = 16; }
+  }
   c.tilesH = (h + fh - 1) / fh;
-  c.tilesW = (w + MG::FW - 1) / MG::FW;
+  c.tilesW = (w + c.fw - 1) / c.fw;
   const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * (cout / 32);
   // one block per CU at a time: choose the depth split that minimises rounds x (slabs per block + prologue)
   double best = 1e30;
@@ -614,10 +645,18 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   dim3 grid(c.nblk, cout / 32);
   if (cin == 64) {
     if (y1) return 0;
-    (void)hipFuncSetAttribute((const void*)conv_fwd_march64, hipFuncAttributeMaxDynamicSharedMemorySize, MG64::LDS);
-    conv_fwd_march64<<<grid, MG64::THREADS, MG64::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
-                                                             ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs,
-                                                             c.dlen, (const bf16_t*)x1);
+    if (c.fw == 16) {
+      using G16 = MG64T<16>;
+      (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G16>, hipFuncAttributeMaxDynamicSharedMemorySize, G16::LDS);
+      conv_fwd_march64<G16><<<grid, G16::THREADS, G16::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,
+                                                                  (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH,
+                                                                  c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_fwd_march64<MG64>, hipFuncAttributeMaxDynamicSharedMemorySize, MG64::LDS);
+      conv_fwd_march64<MG64><<<grid, MG64::THREADS, MG64::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,
+                                                                     (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH,
+                                                                     c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);
+    }
     const int rc64 = fplx_check_launch("march64_conv3d_fwd");
     return rc64 < 0 ? rc64 : 1;
   }

@@ -86,6 +86,38 @@ def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
                        (0, d, h, w), cin, cout, (3, 3, 3), None)
 
 
+@pytest.mark.parametrize("shape", [
+    # Cin = 64, 16 x 16 footprint (less padded area than 8 x 32): exact fit, ragged in h and w, several depth segments
+    (1, 64, 64, 6, 16, 80), (2, 64, 32, 5, 9, 70), (1, 64, 96, 21, 48, 80), (1, 64, 32, 4, 17, 65),
+    # Cin = 64, 8 x 32 footprint; Cin = 32
+    (1, 64, 32, 7, 24, 64), (1, 32, 64, 9, 20, 96)])
+def test_conv3d_march_kernels_aligned_output(shape):
+    """the depth-marching kernels need 16-byte aligned rows (the generic test writes into an odd channel slice and so
+    exercises them only through the data gradient): forward + BN statistics on a dense output, bf16, against torch"""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.from_numpy(detdata.normal("m.x%s" % (shape,), (n, cin, d, h, w))))
+    wt = q(torch.from_numpy(detdata.normal("m.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.2)))
+    b = torch.from_numpy(detdata.normal("m.b%s" % (shape,), (cout,)))
+    yr = F.conv3d(x, wt, b, padding=1)
+    bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
+    assert ops._lib.lib().fplx_march_ok(n, d, h, w, cin, cout) == 1
+    xg = cl(x).to(bf).cuda()
+    wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
+    y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin,
+                   cout, (3, 3, 3), stats)
+    scale = float(yr.abs().max())
+    assert float((uncl(y.float().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
+    s = stats.sum(0).cpu()
+    yf = cl(yr)
+    np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
+
+
 @pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70)])
 def test_conv3d_cat2_split_concat(shape):
     """conv3x3x3 on cat([x0, x1], channel) with the concatenation never built (reference unet2d5_dsbn.py:182-183):
