@@ -385,7 +385,14 @@ struct WgCfg { int tw, cit, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws
 
 inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   WgCfg c;
-  c.tw = w >= 32 ? 32 : 16;
+  // voxels are the K dimension here: padding the width to the tile is wasted MFMA work.  16-wide tiles when they pad
+  // less and the rows are short (W = 40 at level 2: 48 instead of 64 columns, measured -24..-30 %); at W = 80 the
+  // shorter k-loop per depth step costs as much as the padding saves (measured +-5 %), so 32 stays
+  c.tw = (w >= 64 || (w >= 32 && (w + 15) / 16 * 16 >= (w + 31) / 32 * 32)) ? 32 : 16;
+  {
+    static const int ktw = [] { const char* e = getenv("FPLX_WG_TW"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (ktw == 16 || ktw == 32) c.tw = ktw;
+  }
   c.tilesH = (h + WG_TH - 1) / WG_TH;
   c.tilesW = (w + c.tw - 1) / c.tw;
   c.npairs = (cin / 32) * (cout / 32);
