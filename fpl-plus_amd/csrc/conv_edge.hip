@@ -25,7 +25,9 @@ __device__ __forceinline__ bf16x8 tr_frag64(const char* base_lo) {      // [voxe
 }
 
 struct Tile { int n, d, h0, w0; };
-__device__ __forceinline__ Tile tile_of(int64_t t, int D, int tilesH, int tilesW) {
+// 32-bit index math (2^31 tiles would be 5e11 voxels): a 64-bit division is a ~100-instruction loop
+__device__ __forceinline__ Tile tile_of(int64_t t64, int D, int tilesH, int tilesW) {
+  unsigned t = (unsigned)t64;
   Tile o;
   o.w0 = (int)(t % tilesW) * TW; t /= tilesW;
   o.h0 = (int)(t % tilesH) * TH; t /= tilesH;
@@ -49,15 +51,49 @@ __device__ __forceinline__ void stage_x_planar(const float* __restrict__ x, bf16
 }
 
 // ------------------------------------------------------------------------------------------
-// stem forward: rows = voxels, K = (ci, tap) padded to 16*KS, cols = 32 output channels
+// register prefetch of the fp32 planar input around a tile (bf16 image xs[ci][kd 3][SH][SW] after the commit):
+// unconditional loads from clamped coordinates, zeroed at the commit (see outconv_fwd_mfma)
+template <int CIN>
+struct PlanarFetch {
+  static constexpr int TOT = CIN * 3 * SH * SW, NLD = (TOT + 255) / 256;
+  float reg[NLD];
+  unsigned zmask;
+  __device__ __forceinline__ void fetch(const float* __restrict__ x, const Tile& t, int D, int H, int W) {
+    zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ww = i % SW, hh = (i / SW) % SH, kd = (i / (SW * SH)) % 3, ci = (i / (3 * SH * SW)) % CIN;
+      const int d = t.d + kd - 1, h = t.h0 + hh - 1, w = t.w0 + ww - 1;
+      const bool in = i < TOT && d >= 0 && d < D && h >= 0 && h < H && w >= 0 && w < W;
+      const int dc = d < 0 ? 0 : (d >= D ? D - 1 : d), hc = h < 0 ? 0 : (h >= H ? H - 1 : h),
+                wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      reg[k] = x[((((int64_t)t.n * CIN + ci) * D + dc) * H + hc) * W + wc];
+      if (in) zmask |= 1u << k;
+    }
+  }
+  __device__ __forceinline__ void commit(bf16_t* xs) const {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < TOT) xs[i] = (bf16_t)(((zmask >> k) & 1u) ? reg[k] : 0.f);
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// stem forward: rows = voxels, K = (ci, tap) padded to 16*KS, cols = 32 output channels.  The next tile's input is
+// requested before the MFMAs of the current one; the 32 x 32 result tile of a wave goes through a 2-KB LDS transpose and
+// leaves as 16-byte stores (2-byte global stores are issue-bound: they were most of this kernel's time).
 template <int CIN>
 __global__ void __launch_bounds__(256)
 stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
-              float* __restrict__ stats, int64_t ntiles, int tilesH, int tilesW) {
+              float* __restrict__ stats, int64_t ntiles, int tilesH, int tilesW, int vec_ok) {
   constexpr int KTOT = 27 * CIN, KS = (KTOT + 15) / 16;
   __shared__ bf16_t xs[CIN * 3 * SH * SW];
   __shared__ float red[4][2][32];
+  __shared__ __attribute__((aligned(16))) char stg_all[4][32 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, khalf = lane >> 5;
   // per-lane K geometry: element offsets of this lane's 8 k-values per k-step, and the B fragments
@@ -77,11 +113,20 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   const int co = co0 + r;
   const float bv = bias ? bias[co] : 0.f;
   float ssum = 0.f, qsum = 0.f;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
-    const Tile t = tile_of(tt, D, tilesH, tilesW);
+  char* stg = stg_all[wave];
+  PlanarFetch<CIN> pf;
+  int64_t tt = blockIdx.x;
+  Tile tn = tile_of(tt < ntiles ? tt : 0, D, tilesH, tilesW);
+  if (tt < ntiles) pf.fetch(x, tn, D, H, W);
+  for (; tt < ntiles; tt += gridDim.x) {
+    const Tile t = tn;
     __syncthreads();
-    stage_x_planar<CIN>(x, xs, t, D, H, W);
+    pf.commit(xs);
     __syncthreads();
+    if (tt + gridDim.x < ntiles) {
+      tn = tile_of(tt + gridDim.x, D, tilesH, tilesW);
+      pf.fetch(x, tn, D, H, W);
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       const int hr = wave * 2 + m;                     // tile row handled by this wave
@@ -97,16 +142,31 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[s], acc, 0, 0, 0);
       }
       const int h = t.h0 + hr;
-      if (h < H) {
-        const int64_t vrow = (((int64_t)t.n * D + t.d) * H + h) * W;
+      // accumulator element i = voxel column wu of this row, channel r  ->  stg[wu][r] (64-byte rows)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int w = t.w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
-          if (w < W) {
-            const float o = acc[i] + bv;
-            y[(vrow + w) * ldy + co] = (bf16_t)o;
-            ssum += o;
-            qsum = fmaf(o, o, qsum);
+      for (int i = 0; i < 16; ++i) {
+        const int wu = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+        const float o = acc[i] + bv;
+        *reinterpret_cast<bf16_t*>(stg + wu * 64 + r * 2) = (bf16_t)o;
+        if (h < H && t.w0 + wu < W) {
+          ssum += o;
+          qsum = fmaf(o, o, qsum);
+        }
+      }
+      if (h < H) {                                     // wave-uniform
+        const int64_t vrow = (((int64_t)t.n * D + t.d) * H + h) * W + t.w0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int wu = (lane >> 2) + 16 * half;
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + wu * 64 + (lane & 3) * 16);
+          if (t.w0 + wu < W) {
+            bf16_t* dst = y + (vrow + wu) * ldy + co0 + (lane & 3) * 8;
+            if (vec_ok) *reinterpret_cast<uint4*>(dst) = v;
+            else {                                     // unaligned rows (a channel slice of a wider buffer)
+              const bf16_t* e = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) dst[j] = e[j];
+            }
           }
         }
       }
@@ -453,7 +513,7 @@ outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0,
 inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   *th = (h + TH - 1) / TH;
   *tw = (w + TW - 1) / TW;
-  return (int64_t)n * d * (*th) * (*tw);
+  return (int64_t)n * d * (*th) * (*tw);                  // < 2^31 for anything that fits in memory (256 voxels per tile)
 }
 inline int edge_blocks(int64_t ntiles) {
   static int cap = -1;
@@ -473,14 +533,15 @@ extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                                   int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
+  const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1)
-      stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw);
+      stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok);
     else
-      stem_fwd_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw);
+      stem_fwd_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok);
   }
   int rc = fplx_check_launch("edge_stem_fwd");
   return rc < 0 ? rc : 1;
