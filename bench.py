@@ -198,7 +198,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or (os.environ.get("FPLX_DDP_FORCE", "0") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -225,17 +226,17 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run(args.warmup, args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -297,7 +298,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,6 +11,8 @@ per replica under DataParallel; division by world size is folded into the Adam k
 
 Works on any backend: the CPU tests run it over gloo with world_size 2.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,7 +22,9 @@ class GradAllReducer(object):
         self.buckets = list(bucket_ranges)      # [(start, end)] ascending, contiguous from 0
         self.domain_ranges = list(domain_ranges)
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # FPLX_DDP_FORCE=1: run the collectives even with a single rank (exercises the RCCL path on a 1-GPU box)
+        forced = os.environ.get("FPLX_DDP_FORCE", "0") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self._works, self._next, self._gflat = [], 0, None
 

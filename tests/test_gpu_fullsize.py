@@ -125,3 +125,23 @@ def test_agent_fpl_inference_pipeline():
         assert abs(u[0] - exp[name]) <= 1e-5 * exp[name] + 1e-14      # (saturated softmax: variances ~1e-13)
     # MC dropout really is active: the six passes of a volume differ
     assert not np.array_equal(recorded[0], recorded[1])
+
+
+def test_bench_under_torchrun_exercises_the_rccl_path():
+    """bench.py launched the way the driver launches it (torch.distributed.run, one rank per GPU) with
+    FPLX_DDP_FORCE=1, so that on this 1-GPU box the RCCL process group, the bucketed asynchronous all-reduces of the
+    flat gradient, the barriers and the max-over-ranks timing all really run (world size 1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPLX_DDP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--no-kernel-timing", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 10 and np.isfinite(d["final_loss"])
