@@ -885,13 +885,16 @@ inline StreamCfg stream_cfg(int n, int d, int h, int w, int cout) {
 // buffer, then are committed (16-byte-chunk XOR swizzle: conflict-free ds_read_b128) behind ONE barrier.
 // KC = 64 doubles the matrix work per barrier and per global-load round trip.  blockIdx.z deals the taps
 // (split-K) exactly like conv_fwd_direct.
-template <int NT, int KC>
-__global__ void __launch_bounds__(256, 2)
+// MTL = 256 (8 waves, 4 (M) x 2 (N), one block per CU) keeps the per-wave work and the waves per SIMD of the 128-voxel
+// form but shares each weight tile among twice the voxels: 25 % fewer L2 -> LDS bytes per MFMA.  Measured: no gain
+// (see direct_cfg), so it is selected only by FPLX_TILE_MT=256.
+template <int NT, int KC, int MTL>
+__global__ void __launch_bounds__(MTL * 2, MTL == 128 ? 2 : 1)
 conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
               float* __restrict__ stats, float* __restrict__ partial) {
-  constexpr int MTL = 128, NTW = NT / 64;                    // N tiles (32 wide) per wave
-  constexpr int ROWB = KC * 2, CH = KC / 8, RP = 256 / CH;   // row bytes, 16-byte chunks per row, rows per pass
+  constexpr int THREADS = MTL * 2, NTW = NT / 64;            // N tiles (32 wide) per wave
+  constexpr int ROWB = KC * 2, CH = KC / 8, RP = THREADS / CH;   // row bytes, 16-byte chunks per row, rows per pass
   constexpr int PA = MTL / RP, PB = NT / RP;                 // staging passes (chunks per thread) for A and B
   constexpr int KS = KC / 16;
   constexpr int A_BYTES = MTL * ROWB, B_BYTES = NT * ROWB, BUF = A_BYTES + B_BYTES;
@@ -1047,7 +1050,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     }
     return;
   }
-  float* red = reinterpret_cast<float*>(smem);               // [2 (wm)][2][NT]
+  float* red = reinterpret_cast<float*>(smem);               // [MTL / 64 (wm)][2][NT]
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int cl = wn * (NT / 2) + j * 32 + r, co = n0 + cl;
@@ -1073,9 +1076,12 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   }
   if (stats) {
     __syncthreads();
-    for (int i = tid; i < 2 * NT; i += 256) {
+    for (int i = tid; i < 2 * NT; i += THREADS) {
       const int which = i / NT, c = i % NT;
-      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * NT + c] + red[(1 * 2 + which) * NT + c];
+      float t = 0.f;
+#pragma unroll
+      for (int m = 0; m < MTL / 64; ++m) t += red[(m * 2 + which) * NT + c];
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
     }
   }
 }
@@ -1122,7 +1128,7 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
   }
 }
 
-struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt; int64_t mblocks; };
+struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt, tile_mt; int64_t mblocks; };
 
 inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
   DirectCfg c;
@@ -1130,7 +1136,14 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
   else { c.mt = 4; c.ntl = 1; }
   // LDS-tiled kernel (128 voxels x 128|64 channels per block) when the shape allows
   c.tile_nt = (cin % 32 == 0 && cout % 64 == 0) ? (cout % 128 == 0 ? 128 : 64) : 0;
-  c.mblocks = c.tile_nt ? (V + 127) / 128 : (V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32);
+  c.tile_mt = 128;
+  if (c.tile_nt && cin % 64 == 0) {
+    // 256-voxel tiles: measured +-2 % at level 2 and -15 % on the 64-wide level-1 layer, so they stay a tuning knob
+    // (FPLX_TILE_MT=256; the tests run both forms) - the kernel is not simply L2-bandwidth-bound
+    static const int kmt = [] { const char* e = getenv("FPLX_TILE_MT"); return e ? atoi(e) : 0; }();
+    if (kmt == 256) c.tile_mt = 256;
+  }
+  c.mblocks = c.tile_nt ? (V + c.tile_mt - 1) / c.tile_mt : (V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32);
   // small volumes (deep levels) do not fill 256 CUs: deal the 27 taps to 3 / 9 / 27 blocks - the SMALLEST split that
   // gives every CU a block, because each split adds an fp32 partial tensor to write and re-read (measured on the level-3
   // and level-4 shapes: 9 -> 3 and 27 -> 9 save 12-21 us per launch)
@@ -1141,6 +1154,7 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
     else if (blocks * 3 < 256) c.ksplit = 9;
     else if (blocks < 256) c.ksplit = 3;
   }
+  if (c.tile_mt == 256) c.ksplit = 1;                        // chosen only where it fills the chip by itself
   {  // tuning knobs: FPLX_TILE_NT=64 forces the narrow tile, FPLX_TILE_KS forces the tap split (1/3/9/27)
     static const int knt = [] { const char* e = getenv("FPLX_TILE_NT"); return e ? atoi(e) : 0; }();
     static const int kks = [] { const char* e = getenv("FPLX_TILE_KS"); return e ? atoi(e) : 0; }();
@@ -1220,16 +1234,17 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
   }
   if (c.tile_nt) {
     dim3 tg((unsigned)c.mblocks, cout / c.tile_nt, ks);
-#define LAUNCH_TILE(NT_, KC_)                                                                                     \
+#define LAUNCH_TILE(NT_, KC_, MT_)                                                                                \
   do {                                                                                                              \
-    constexpr int LDS = 2 * (128 + NT_) * KC_ * 2;                                                                  \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_tile<NT_, KC_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-    conv_fwd_tile<NT_, KC_><<<tg, 256, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, \
-                                                  h, w, cin, cout, stats, partial);                                  \
+    constexpr int LDS = 2 * (MT_ + NT_) * KC_ * 2;                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_tile<NT_, KC_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    conv_fwd_tile<NT_, KC_, MT_><<<tg, MT_ * 2, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, \
+                                                           n, d, h, w, cin, cout, stats, partial);                   \
   } while (0)
     const bool k64 = cin % 64 == 0;
-    if (c.tile_nt == 128) { if (k64) LAUNCH_TILE(128, 64); else LAUNCH_TILE(128, 32); }
-    else { if (k64) LAUNCH_TILE(64, 64); else LAUNCH_TILE(64, 32); }
+    if (c.tile_mt == 256) { if (c.tile_nt == 128) LAUNCH_TILE(128, 64, 256); else LAUNCH_TILE(64, 64, 256); }
+    else if (c.tile_nt == 128) { if (k64) LAUNCH_TILE(128, 64, 128); else LAUNCH_TILE(128, 32, 128); }
+    else { if (k64) LAUNCH_TILE(64, 64, 128); else LAUNCH_TILE(64, 32, 128); }
 #undef LAUNCH_TILE
     if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
     int rct = fplx_check_launch("mfma_conv3d_fwd_tile");

@@ -31,7 +31,9 @@ def uncl(t2, n, d, h, w):
                                    (1, 32, 32, 40, 32, 64), (3, 32, 96, 6, 17, 65), (1, 64, 32, 37, 24, 64),
                                    (2, 64, 96, 5, 9, 70), (1, 64, 64, 20, 40, 40),
                                    # tiny volumes, wide channels: split-K over the taps (27 / 9 / 3-way)
-                                   (2, 128, 128, 2, 5, 5), (2, 64, 256, 5, 10, 10), (1, 128, 64, 10, 20, 20)])
+                                   (2, 128, 128, 2, 5, 5), (2, 64, 256, 5, 10, 10), (1, 128, 64, 10, 20, 20),
+                                   # a larger tile-kernel case with a ragged last tile
+                                   (1, 64, 256, 8, 60, 61)])
 def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
     from fplx import ops
     n, cin, cout, d, h, w = shape
