@@ -216,7 +216,8 @@ __global__ void __launch_bounds__(64) bias_grad_reduce(const float* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(FWD_THREADS)
 deconv_fwd_generic(const T* __restrict__ x, int64_t ldx, const T* __restrict__ wf, const float* __restrict__ bias,
-                   T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout) {
+                   T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout, int sd) {
+  // sd = 2: ConvTranspose3d(k=2,s=2), 8 taps; sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice, taps 0..3 (i = 0)
   const int tap = blockIdx.z, co0 = blockIdx.y * CO_T;
   const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
   const int64_t V = (int64_t)N * D * H * W;
@@ -237,7 +238,7 @@ deconv_fwd_generic(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w
     for (int a = 0; a < CO_T; ++a)
       if (co0 + a < Cout) acc[a] = fmaf(xv, Act<T>::ld(wt + (int64_t)a * Cin + ci), acc[a]);
   }
-  T* yp = y + ((((int64_t)r * 2 * D + 2 * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
+  T* yp = y + ((((int64_t)r * sd * D + sd * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
 #pragma unroll
   for (int a = 0; a < CO_T; ++a)
     if (co0 + a < Cout) Act<T>::st(yp + co0 + a, acc[a]);
@@ -247,7 +248,7 @@ deconv_fwd_generic(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w
 template <typename T>
 __global__ void __launch_bounds__(FWD_THREADS)
 deconv_dgrad_generic(const T* __restrict__ dy, int64_t ldy, const T* __restrict__ wb, T* __restrict__ dx, int64_t ldx,
-                     int N, int D, int H, int W, int Cin, int Cout) {
+                     int N, int D, int H, int W, int Cin, int Cout, int sd) {
   const int ci0 = blockIdx.y * CO_T;
   const int64_t V = (int64_t)N * D * H * W;
   const int64_t v = (int64_t)blockIdx.x * FWD_THREADS + threadIdx.x;
@@ -259,9 +260,9 @@ deconv_dgrad_generic(const T* __restrict__ dy, int64_t ldy, const T* __restrict_
   float acc[CO_T];
 #pragma unroll
   for (int a = 0; a < CO_T; ++a) acc[a] = 0.f;
-  for (int tap = 0; tap < 8; ++tap) {
+  for (int tap = 0; tap < 4 * sd; ++tap) {
     const int i = tap >> 2, j = (tap >> 1) & 1, k = tap & 1;
-    const T* gp = dy + ((((int64_t)r * 2 * D + 2 * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
+    const T* gp = dy + ((((int64_t)r * sd * D + sd * d0 + i) * 2 * H + 2 * h0 + j) * 2 * W + 2 * w0 + k) * ldy;
     const T* wt = wb + ((int64_t)tap * Cin + ci0) * Cout;
     for (int co = 0; co < Cout; ++co) {
       const float g = Act<T>::ld(gp + co);
@@ -325,14 +326,35 @@ pack_conv_w27_tiled(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t
 }
 
 template <typename T>
-__global__ void pack_deconv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin, int Cout) {
-  const int64_t total = (int64_t)Cin * Cout * 8;
+__global__ void pack_deconv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin, int Cout,
+                              int taps) {
+  const int64_t total = (int64_t)Cin * Cout * taps;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int tap = i % 8, co = (i / 8) % Cout, ci = (int)(i / (8 * (int64_t)Cout));
+    const int tap = i % taps, co = (i / taps) % Cout, ci = (int)(i / (taps * (int64_t)Cout));
     const float v = w[i];
     Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
     if (wb) Act<T>::st(wb + ((int64_t)tap * Cin + ci) * Cout + co, v);
   }
+}
+
+// 2.5D levels (conv_dims = 2): a Conv2d(3x3) on every depth slice IS a Conv3d whose kd = 0 and kd = 2 planes are zero.
+// Packing the 9 taps into the middle plane of the 27-tap layouts lets every 3x3x3 kernel (forward, data gradient)
+// run unchanged and bit-identically (products with an exact zero add nothing); the weight gradient is the middle plane
+// of the 27-tap gradient.
+template <typename T>
+__global__ void pack_conv2d_w_as3d(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cout, int Cin) {
+  const int64_t total = (int64_t)Cout * Cin * 27;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = i % 27, ci = (i / 27) % Cin, co = (int)(i / ((int64_t)27 * Cin));
+    const float v = (tap >= 9 && tap < 18) ? w[((int64_t)co * Cin + ci) * 9 + tap - 9] : 0.f;
+    Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
+    if (wb) Act<T>::st(wb + ((int64_t)(26 - tap) * Cin + ci) * Cout + co, v);
+  }
+}
+__global__ void extract_mid_plane(const float* __restrict__ dw27, float* __restrict__ dw9, int64_t pairs) {
+  const int64_t total = pairs * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    dw9[i] = dw27[(i / 9) * 27 + 9 + i % 9];
 }
 
 template <typename TY>
@@ -448,12 +470,48 @@ int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cou
   const int64_t total = (int64_t)cout * cin * 8;
   hipStream_t st = (hipStream_t)stream;
   if (dt == FPLX_F32)
-    pack_deconv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cin, cout);
+    pack_deconv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cin, cout, 8);
   else if (dt == FPLX_BF16)
-    pack_deconv_w<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cin, cout);
+    pack_deconv_w<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cin, cout, 8);
   else
     return fplx_fail(FPLX_E_BADDTYPE, "pack_deconv_weight: dtype %d", dt);
   return fplx_check_launch("pack_deconv_weight");
+}
+
+int fplx_pack_deconv122_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(w && wf, FPLX_E_NULL, "pack_deconv122_weight: null pointer");
+  FPLX_REQUIRE(cout > 0 && cin > 0, FPLX_E_BADSHAPE, "pack_deconv122_weight: bad shape");
+  const int64_t total = (int64_t)cout * cin * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_F32)
+    pack_deconv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cin, cout, 4);
+  else if (dt == FPLX_BF16)
+    pack_deconv_w<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cin, cout, 4);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "pack_deconv122_weight: dtype %d", dt);
+  return fplx_check_launch("pack_deconv122_weight");
+}
+
+int fplx_pack_conv2d_weight(const float* w, void* wf, void* wb, int cout, int cin, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(w && wf, FPLX_E_NULL, "pack_conv2d_weight: null pointer");
+  FPLX_REQUIRE(cout > 0 && cin > 0, FPLX_E_BADSHAPE, "pack_conv2d_weight: bad shape");
+  const int64_t total = (int64_t)cout * cin * 27;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == FPLX_F32)
+    pack_conv2d_w_as3d<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cout, cin);
+  else if (dt == FPLX_BF16)
+    pack_conv2d_w_as3d<bf16_t><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cout, cin);
+  else
+    return fplx_fail(FPLX_E_BADDTYPE, "pack_conv2d_weight: dtype %d", dt);
+  return fplx_check_launch("pack_conv2d_weight");
+}
+
+int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream) {
+  FPLX_REQUIRE(dw27 && dw9, FPLX_E_NULL, "conv2d_wgrad_extract: null pointer");
+  FPLX_REQUIRE(cout > 0 && cin > 0, FPLX_E_BADSHAPE, "conv2d_wgrad_extract: bad shape");
+  const int64_t pairs = (int64_t)cout * cin;
+  extract_mid_plane<<<grid_for(pairs * 9, 256, 1024), 256, 0, (hipStream_t)stream>>>(dw27, dw9, pairs);
+  return fplx_check_launch("conv2d_wgrad_extract");
 }
 
 static bool is_cl(int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc, int d, int h, int w) {
@@ -655,36 +713,38 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
   return fplx_check_launch("conv3d_wgrad");
 }
 
-int fplx_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
-                     int h, int w, int cin, int cout, int dt, fplx_stream_t stream) {
+// sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels; generic kernels -
+// the shipped 2.5D crops are 28 x 128 x 128 and these layers are a few hundred MFLOP)
+static int deconv_fwd_impl(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                           int h, int w, int cin, int cout, int dt, int sd, fplx_stream_t stream) {
   FPLX_REQUIRE(x && wf && bias && y, FPLX_E_NULL, "deconv2_fwd: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  if (dt == FPLX_BF16) {
+  if (dt == FPLX_BF16 && sd == 2) {
     int r = fplx_mfma_deconv2_fwd(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
   const int64_t V = (int64_t)n * d * h * w;
-  dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cout + CO_T - 1) / CO_T, 8);
+  dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cout + CO_T - 1) / CO_T, 4 * sd);
   if (dt == FPLX_F32)
     deconv_fwd_generic<float><<<grid, FWD_THREADS, 0, st>>>((const float*)x, ldx, (const float*)wf, bias, (float*)y,
-                                                            ldy, n, d, h, w, cin, cout);
+                                                            ldy, n, d, h, w, cin, cout, sd);
   else if (dt == FPLX_BF16)
     deconv_fwd_generic<bf16_t><<<grid, FWD_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias,
-                                                             (bf16_t*)y, ldy, n, d, h, w, cin, cout);
+                                                             (bf16_t*)y, ldy, n, d, h, w, cin, cout, sd);
   else
     return fplx_fail(FPLX_E_BADDTYPE, "deconv2_fwd: dtype %d", dt);
   return fplx_check_launch("deconv2_fwd");
 }
 
-int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
-                       int cin, int cout, int dt, fplx_stream_t stream) {
+static int deconv_dgrad_impl(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                             int cin, int cout, int dt, int sd, fplx_stream_t stream) {
   FPLX_REQUIRE(dy && wb && dx, FPLX_E_NULL, "deconv2_dgrad: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_dgrad: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  if (dt == FPLX_BF16) {
+  if (dt == FPLX_BF16 && sd == 2) {
     int r = fplx_mfma_deconv2_dgrad(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
@@ -692,39 +752,44 @@ int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, in
   dim3 grid((unsigned)((V + FWD_THREADS - 1) / FWD_THREADS), (cin + CO_T - 1) / CO_T);
   if (dt == FPLX_F32)
     deconv_dgrad_generic<float><<<grid, FWD_THREADS, 0, st>>>((const float*)dy, ldy, (const float*)wb, (float*)dx, ldx,
-                                                              n, d, h, w, cin, cout);
+                                                              n, d, h, w, cin, cout, sd);
   else if (dt == FPLX_BF16)
     deconv_dgrad_generic<bf16_t><<<grid, FWD_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx,
-                                                               ldx, n, d, h, w, cin, cout);
+                                                               ldx, n, d, h, w, cin, cout, sd);
   else
     return fplx_fail(FPLX_E_BADDTYPE, "deconv2_dgrad: dtype %d", dt);
   return fplx_check_launch("deconv2_dgrad");
 }
 
-size_t fplx_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+static size_t deconv_wgrad_ws_impl(int n, int d, int h, int w, int cin, int cout, int sd) {
   const int64_t V = (int64_t)n * d * h * w;
-  size_t a = (size_t)wgrad_chunks(V) * 8 * cout * cin * sizeof(float);
-  const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
-  if (m > a) a = m;
-  return a + (size_t)fplx_rows_for(V * 8) * cout * sizeof(float) + 256;
+  size_t a = (size_t)wgrad_chunks(V) * 4 * sd * cout * cin * sizeof(float);
+  if (sd == 2) {
+    const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > a) a = m;
+  }
+  return a + (size_t)fplx_rows_for(V * 4 * sd) * cout * sizeof(float) + 256;
 }
 
-int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
-                       int h, int w, int cin, int cout, int dt, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+static int deconv_wgrad_impl(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
+                             int h, int w, int cin, int cout, int dt, void* ws, size_t ws_bytes, int sd,
+                             fplx_stream_t stream) {
   FPLX_REQUIRE(x && dy && dw && ws, FPLX_E_NULL, "deconv2_wgrad: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "deconv2_wgrad: bad shape");
-  FPLX_REQUIRE(ws_bytes >= fplx_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout), FPLX_E_WORKSPACE,
+  FPLX_REQUIRE(ws_bytes >= deconv_wgrad_ws_impl(n, d, h, w, cin, cout, sd), FPLX_E_WORKSPACE,
                "deconv2_wgrad: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   const int64_t V = (int64_t)n * d * h * w;
   const int chunks = wgrad_chunks(V);
+  const int taps = 4 * sd;
   float* part = (float*)ws;
-  size_t used = (size_t)chunks * 8 * cout * cin * sizeof(float);
-  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), 8);
+  size_t used = (size_t)chunks * taps * cout * cin * sizeof(float);
+  dim3 grid(chunks, ((cout + WG_T - 1) / WG_T) * ((cin + WG_T - 1) / WG_T), taps);
   Strides xs{(int64_t)d * h * w * ldx, (int64_t)h * w * ldx, (int64_t)w * ldx, ldx, 1};
-  Strides ys{(int64_t)8 * d * h * w * ldy, (int64_t)4 * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};
+  // dy is [N, sd D, 2H, 2W]; the kernel addresses depth (2 d + kd): for sd = 1 (kd = 0) half the slice stride does it
+  Strides ys{(int64_t)4 * sd * d * h * w * ldy, (int64_t)(sd == 2 ? 4 : 2) * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};
   bool done = false;
-  if (dt == FPLX_BF16) {
+  if (dt == FPLX_BF16 && sd == 2) {
     const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
       int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, ws, m, st);
@@ -736,18 +801,50 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
   if (done) {
   } else if (dt == FPLX_F32)
     wgrad_generic<float, float, true><<<grid, WG_THREADS, 0, st>>>((const float*)x, xs, (const float*)dy, ys, part, n,
-                                                                   d, h, w, cin, cout, 2, 2, 2, chunks);
+                                                                   d, h, w, cin, cout, sd, 2, 2, chunks);
   else if (dt == FPLX_BF16)
     wgrad_generic<bf16_t, bf16_t, true><<<grid, WG_THREADS, 0, st>>>((const bf16_t*)x, xs, (const bf16_t*)dy, ys, part,
-                                                                     n, d, h, w, cin, cout, 2, 2, 2, chunks);
+                                                                     n, d, h, w, cin, cout, sd, 2, 2, chunks);
   else
     return fplx_fail(FPLX_E_BADDTYPE, "deconv2_wgrad: dtype %d", dt);
-  if (!done) wgrad_reduce<<<grid_for((int64_t)8 * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, 8, cout, cin, 1);
+  if (!done) wgrad_reduce<<<grid_for((int64_t)taps * cout * cin, 256, 1024), 256, 0, st>>>(part, dw, chunks, taps, cout, cin, 1);
   if (db) {
-    if (dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);
-    else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, 2 * d, 2 * h, 2 * w, cout, bpart, db, st);
+    Strides yb{(int64_t)4 * sd * d * h * w * ldy, (int64_t)4 * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};   // true strides
+    if (dt == FPLX_F32) launch_bias_grad<float>((const float*)dy, yb, n, sd * d, 2 * h, 2 * w, cout, bpart, db, st);
+    else launch_bias_grad<bf16_t>((const bf16_t*)dy, yb, n, sd * d, 2 * h, 2 * w, cout, bpart, db, st);
   }
   return fplx_check_launch("deconv2_wgrad");
+}
+
+int fplx_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                     int h, int w, int cin, int cout, int dt, fplx_stream_t stream) {
+  return deconv_fwd_impl(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, dt, 2, stream);
+}
+int fplx_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                       int cin, int cout, int dt, fplx_stream_t stream) {
+  return deconv_dgrad_impl(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, dt, 2, stream);
+}
+size_t fplx_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return deconv_wgrad_ws_impl(n, d, h, w, cin, cout, 2);
+}
+int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
+                       int h, int w, int cin, int cout, int dt, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  return deconv_wgrad_impl(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, dt, ws, ws_bytes, 2, stream);
+}
+int fplx_deconv122_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
+                       int h, int w, int cin, int cout, int dt, fplx_stream_t stream) {
+  return deconv_fwd_impl(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, dt, 1, stream);
+}
+int fplx_deconv122_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
+                         int cin, int cout, int dt, fplx_stream_t stream) {
+  return deconv_dgrad_impl(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, dt, 1, stream);
+}
+size_t fplx_deconv122_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return deconv_wgrad_ws_impl(n, d, h, w, cin, cout, 1);
+}
+int fplx_deconv122_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db, int n, int d,
+                         int h, int w, int cin, int cout, int dt, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  return deconv_wgrad_impl(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, dt, ws, ws_bytes, 1, stream);
 }
 
 }  // extern "C"

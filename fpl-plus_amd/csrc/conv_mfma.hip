@@ -1139,7 +1139,7 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
   c.tile_mt = 128;
   if (c.tile_nt && cin % 64 == 0) {
     // 256-voxel tiles: measured +-2 % at level 2 and -15 % on the 64-wide level-1 layer, so they stay a tuning knob
-    // (FPLX_TILE_MT=256; the tests run both forms) - the kernel is not simply L2-bandwidth-bound
+    // (FPLX_TILE_MT=256) - the kernel is not simply L2-bandwidth-bound
     static const int kmt = [] { const char* e = getenv("FPLX_TILE_MT"); return e ? atoi(e) : 0; }();
     if (kmt == 256) c.tile_mt = 256;
   }

@@ -350,8 +350,9 @@ bn_act_bwd_apply_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ d
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ void __launch_bounds__(EW_THREADS)
-maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int C) {
-  const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int C,
+               int pd) {      // pd = 2: MaxPool3d(2); pd = 1: MaxPool2d(2) on every depth slice (2.5D levels)
+  const int G = C / VEC, Do = D / pd, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
     const int c0 = (int)(i % G) * VEC;
@@ -365,7 +366,8 @@ maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t 
     for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int64_t vi = (((int64_t)r * D + 2 * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      if (t >= 4 * pd) break;
+      const int64_t vi = (((int64_t)r * D + pd * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
       float a[VEC];
       ldv<T, VEC>(x + vi * ldx + c0, a);
 #pragma unroll
@@ -378,8 +380,8 @@ maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t 
 template <typename T, int VEC>
 __global__ void __launch_bounds__(EW_THREADS)
 maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, int64_t ldy, const T* __restrict__ dskip,
-               int64_t lds, T* __restrict__ dx, int64_t ldo, int N, int D, int H, int W, int C) {
-  const int G = C / VEC, Do = D / 2, Ho = H / 2, Wo = W / 2;
+               int64_t lds, T* __restrict__ dx, int64_t ldo, int N, int D, int H, int W, int C, int pd) {
+  const int G = C / VEC, Do = D / pd, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
     const int c0 = (int)(i % G) * VEC;
@@ -397,7 +399,8 @@ maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, i
     int64_t vis[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      vis[t] = (((int64_t)r * D + 2 * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      if (t >= 4 * pd) break;
+      vis[t] = (((int64_t)r * D + pd * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
       ldv<T, VEC>(x + vis[t] * ldx + c0, a[t]);
 #pragma unroll
       for (int j = 0; j < VEC; ++j)
@@ -405,6 +408,7 @@ maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, i
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
       float o[VEC];
       if (dskip) ldv<T, VEC>(dskip + vis[t] * lds + c0, o);
       else {
@@ -601,46 +605,63 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
   return fplx_check_launch("bn_act_bwd_apply");
 }
 
-int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
-                      fplx_stream_t stream) {
+static int maxpool_fwd_impl(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
+                            int pd, fplx_stream_t stream) {
   FPLX_REQUIRE(x && y, FPLX_E_NULL, "maxpool2_fwd: null pointer");
-  FPLX_REQUIRE(n > 0 && c > 0 && d >= 2 && h >= 2 && w >= 2 && !(d & 1) && !(h & 1) && !(w & 1) && ldx >= c && ldy >= c,
-               FPLX_E_BADSHAPE, "maxpool2_fwd: bad shape (even D,H,W required) %dx%dx%d", d, h, w);
+  FPLX_REQUIRE(n > 0 && c > 0 && d >= pd && h >= 2 && w >= 2 && !(d % pd) && !(h & 1) && !(w & 1) && ldx >= c && ldy >= c,
+               FPLX_E_BADSHAPE, "maxpool2_fwd: bad shape (even %sH,W required) %dx%dx%d", pd == 2 ? "D," : "", d, h, w);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t vo = (int64_t)n * (d / 2) * (h / 2) * (w / 2);
+  const int64_t vo = (int64_t)n * (d / pd) * (h / 2) * (w / 2);
   if (dt == FPLX_F32) {
     const bool ok = vec_ok<float>(x, ldx, y, ldy, nullptr, 0, c);
     DISPATCH_VEC(float, ok, maxpool2_fwd_k, <<<ew_grid(vo * (ok ? c / 4 : c)), EW_THREADS, 0, st>>>(
-                                                (const float*)x, ldx, (float*)y, ldy, n, d, h, w, c));
+                                                (const float*)x, ldx, (float*)y, ldy, n, d, h, w, c, pd));
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(x, ldx, y, ldy, nullptr, 0, c);
     DISPATCH_VEC(bf16_t, ok, maxpool2_fwd_k, <<<ew_grid(vo * (ok ? c / 8 : c)), EW_THREADS, 0, st>>>(
-                                                 (const bf16_t*)x, ldx, (bf16_t*)y, ldy, n, d, h, w, c));
+                                                 (const bf16_t*)x, ldx, (bf16_t*)y, ldy, n, d, h, w, c, pd));
   } else
     return fplx_fail(FPLX_E_BADDTYPE, "maxpool2_fwd: dtype %d", dt);
   return fplx_check_launch("maxpool2_fwd");
 }
 
-int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds, void* dx,
-                      int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream) {
+static int maxpool_bwd_impl(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
+                            void* dx, int64_t ldo, int n, int d, int h, int w, int c, int dt, int pd, fplx_stream_t stream) {
   FPLX_REQUIRE(x && dy && dx, FPLX_E_NULL, "maxpool2_bwd: null pointer");
-  FPLX_REQUIRE(n > 0 && c > 0 && d >= 2 && h >= 2 && w >= 2 && !(d & 1) && !(h & 1) && !(w & 1), FPLX_E_BADSHAPE,
+  FPLX_REQUIRE(n > 0 && c > 0 && d >= pd && h >= 2 && w >= 2 && !(d % pd) && !(h & 1) && !(w & 1), FPLX_E_BADSHAPE,
                "maxpool2_bwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  const int64_t vo = (int64_t)n * (d / 2) * (h / 2) * (w / 2);
+  const int64_t vo = (int64_t)n * (d / pd) * (h / 2) * (w / 2);
   if (dt == FPLX_F32) {
     const bool ok = vec_ok<float>(x, ldx, dy, ldy, dx, ldo, c) && vec_ok<float>(dskip, lds, nullptr, 0, nullptr, 0, c);
     DISPATCH_VEC(float, ok, maxpool2_bwd_k, <<<ew_grid(vo * (ok ? c / 4 : c)), EW_THREADS, 0, st>>>(
                                                 (const float*)x, ldx, (const float*)dy, ldy, (const float*)dskip, lds,
-                                                (float*)dx, ldo, n, d, h, w, c));
+                                                (float*)dx, ldo, n, d, h, w, c, pd));
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(x, ldx, dy, ldy, dx, ldo, c) && vec_ok<bf16_t>(dskip, lds, nullptr, 0, nullptr, 0, c);
     DISPATCH_VEC(bf16_t, ok, maxpool2_bwd_k, <<<ew_grid(vo * (ok ? c / 8 : c)), EW_THREADS, 0, st>>>(
                                                  (const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (const bf16_t*)dskip,
-                                                 lds, (bf16_t*)dx, ldo, n, d, h, w, c));
+                                                 lds, (bf16_t*)dx, ldo, n, d, h, w, c, pd));
   } else
     return fplx_fail(FPLX_E_BADDTYPE, "maxpool2_bwd: dtype %d", dt);
   return fplx_check_launch("maxpool2_bwd");
+}
+
+int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
+                      fplx_stream_t stream) {
+  return maxpool_fwd_impl(x, ldx, y, ldy, n, d, h, w, c, dt, 2, stream);
+}
+int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds, void* dx,
+                      int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream) {
+  return maxpool_bwd_impl(x, ldx, dy, ldy, dskip, lds, dx, ldo, n, d, h, w, c, dt, 2, stream);
+}
+int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
+                        fplx_stream_t stream) {
+  return maxpool_fwd_impl(x, ldx, y, ldy, n, d, h, w, c, dt, 1, stream);
+}
+int fplx_maxpool122_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds, void* dx,
+                        int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream) {
+  return maxpool_bwd_impl(x, ldx, dy, ldy, dskip, lds, dx, ldo, n, d, h, w, c, dt, 1, stream);
 }
 
 int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -55,22 +55,30 @@ def reference_param_names(num_domains=2):
 
 
 def _dead_default(key, live):
-    """neutral tensor for a dead twin key, shaped after its live 3D sibling"""
-    if ".conv2d_" in key:                                     # [co, ci, 3, 3] next to conv3d_k [co, ci, 3, 3, 3]
-        w = live[key.replace("conv2d_", "conv3d_")]
-        return torch.zeros(w.shape[:-1] if w.dim() == 5 else w.shape, dtype=w.dtype)
-    if ".bn2d" in key:
-        w = live[key.replace("bn2d", "bn3d")]
+    """neutral tensor for a key that is dead in this configuration, shaped after its live sibling of the other
+    dimensionality (a dim-3 level carries dead 2D twins and the other way round; the bilinear 1x1 convs are always dead)"""
+    if ".conv2d_" in key or ".conv3d_" in key:                 # ConvBlockND convolutions
+        to3 = ".conv2d_" in key                                # the live twin is the 3D one
+        w = live[key.replace("conv2d_", "conv3d_") if to3 else key.replace("conv3d_", "conv2d_")]
+        if key.endswith("bias"):
+            return torch.zeros(w.shape, dtype=w.dtype)
+        return torch.zeros(tuple(w.shape[:4]) if to3 else tuple(w.shape) + (3,), dtype=w.dtype)
+    if ".bn2d" in key or ".bn3d" in key:
+        w = live[key.replace("bn2d", "bn3d") if ".bn2d" in key else key.replace("bn3d", "bn2d")]
         if key.endswith("weight") or key.endswith("running_var"):
             return torch.ones_like(w, device="cpu")
         return torch.zeros_like(w, device="cpu")
     up = key.split(".")[0]
-    t = live[up + ".trans3d.weight"]                           # [ci, co, 2, 2, 2]
+    t = live.get(up + ".trans3d.weight")
+    if t is None:
+        t = live[up + ".trans2d.weight"]
     ci, co = t.shape[0], t.shape[1]
     if key.endswith("bias"):
         return torch.zeros(co)
     if ".trans2d." in key:
         return torch.zeros(ci, co, 2, 2)
+    if ".trans3d." in key:
+        return torch.zeros(ci, co, 2, 2, 2)
     if ".conv2d." in key:
         return torch.zeros(co, ci, 1, 1)
     return torch.zeros(co, ci, 1, 1, 1)                        # up.conv3d: the bilinear branch's 1x1x1 conv

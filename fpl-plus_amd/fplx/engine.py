@@ -8,7 +8,9 @@ PyMIC/pymic/net/net3d/unet2d5_dsbn.py:182, is never executed).
 
 Reference semantics implemented here (paths under /root/reference/PyMIC/pymic):
   UNet2D5_dsbn.forward            net/net3d/unet2d5_dsbn.py:296-309
-  ConvBlockND.forward (3D branch) net/net3d/unet2d5_dsbn.py:74-81
+  ConvBlockND.forward             net/net3d/unet2d5_dsbn.py:66-81 (both branches: a dim-2 level runs its 3x3 convolutions
+                                  as 3x3x3 kernels with the taps in the middle depth plane, MaxPool2d / ConvTranspose2d
+                                  per depth slice; depth is halved only by dim-3 levels)
   DownBlock / UpBlock             net/net3d/unet2d5_dsbn.py:108-129 / 156-188
   DomainSpecificBatchNorm3d       net_run_dsbn/dsbn.py:54-57 (bns[domain_label[0]] for the batch)
 """
@@ -48,9 +50,13 @@ class Engine(object):
     def _pack(self, act_dtype):
         net = self.net
         packs = {}
+        first = next(iter(net.conv_sites()))[0]
         for name, conv in net.conv_sites():
-            want_wb = name != "block0.conv.conv3d_1"     # no data gradient w.r.t. the network input
-            packs[name] = ops.pack_conv_weight(conv.weight, act_dtype, want_wb)
+            want_wb = name != first                      # no data gradient w.r.t. the network input
+            if conv.weight.dim() == 4:                   # Conv2d of a 2.5D level
+                packs[name] = ops.pack_conv2d_weight(conv.weight, act_dtype, want_wb)
+            else:
+                packs[name] = ops.pack_conv_weight(conv.weight, act_dtype, want_wb)
         for name, tr in net.deconv_sites():
             packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
         oc = net.out_conv
@@ -77,8 +83,11 @@ class Engine(object):
         N, Cin, D, H, W = x.shape
         if Cin != net.in_chns:
             raise ValueError("fplx: input has {0:} channels, network expects {1:}".format(Cin, net.in_chns))
-        if (D % 16) or (H % 16) or (W % 16):
-            raise ValueError("fplx: D, H, W must be multiples of 16 (four 2x poolings), got %dx%dx%d" % (D, H, W))
+        pds = [2 if net.dims[l] == 3 else 1 for l in range(4)]          # depth factor of the pooling after level l
+        dfac = pds[0] * pds[1] * pds[2] * pds[3]
+        if (D % dfac) or (H % 16) or (W % 16):
+            raise ValueError("fplx: H, W must be multiples of 16 and D of %d (four 2x poolings, depth only at the "
+                             "3D levels), got %dx%dx%d" % (dfac, D, H, W))
         if domain < 0 or domain >= net.num_domains:
             raise IndexError("fplx: domain_label %d out of range" % domain)
         dev, adt = x.device, net.act_dtype
@@ -89,7 +98,9 @@ class Engine(object):
             self._pack_cache = None if train else (adt, packs)
         else:
             packs = self._pack_cache[1]
-        dims = [(N, D >> l, H >> l, W >> l) for l in range(5)]
+        dims = [(N, D, H, W)]
+        for l in range(4):
+            dims.append((N, dims[l][1] // pds[l], dims[l][2] // 2, dims[l][3] // 2))
         vox = [n * d * h * w for (n, d, h, w) in dims]
 
         sv = Saved()
@@ -150,10 +161,10 @@ class Engine(object):
             c = ft[l]
             a1 = empty(vox[l], c)
             sid = step * 16 + b
-            y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + ".conv3d_1", (blk.conv3d_1, blk.bn3d1, blk.relu_1), l,
-                                    a1, blk.dropout_p, sid, drop_on[b])
-            y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + ".conv3d_2",
-                                   (blk.conv3d_2, blk.bn3d2, blk.relu_2), l, out_view, 0.0, 0, False)
+            y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + "." + blk.cname(1),
+                                    (blk.conv_of(1), blk.bn_of(1), blk.relu_1), l, a1, blk.dropout_p, sid, drop_on[b])
+            y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + "." + blk.cname(2),
+                                   (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False)
             sv.blocks.append(dict(xin=xin, xs=xs, x_dt=x_dt, cin=cin, l=l, y1=y1, bn1=bn1, p1=p1, sid=sid, a1=a1,
                                   y2=y2, bn2=bn2, out=out_view))
 
@@ -164,7 +175,7 @@ class Engine(object):
             conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view)
             if i < 4:
                 pooled = empty(vox[i + 1], ft[i])
-                ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i])
+                ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i], pds[i])
                 sv.pooled.append(pooled)
                 cur, cur_s, cur_dt, cur_c = pooled, ops.cl_strides(*dims[i + 1][1:], ft[i]), a_dt, ft[i]
             else:
@@ -172,9 +183,11 @@ class Engine(object):
         # ---- decoder
         for j in range(4):
             l = 3 - j
-            tr = net.up_modules[j].trans3d
+            up = net.up_modules[j]
+            tr = up.trans()
             sv.deconv_in.append(cur)
-            ops.deconv2_fwd(cur, packs["up%d.trans3d" % (j + 1)][0], tr.bias, ups[l], dims[l + 1], ft[l + 1], ft[l])
+            ops.deconv2_fwd(cur, packs["up%d.%s" % (j + 1, up.tname())][0], tr.bias, ups[l], dims[l + 1], ft[l + 1], ft[l],
+                            pds[l])
             out = empty(vox[l], ft[l])
             xin = (skips[l], ups[l]) if split[l] else cats[l]
             conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
@@ -214,9 +227,10 @@ class Engine(object):
             cin1 = sv.blocks[b]["cin"]
             need = max(need, ops.conv3d_wgrad_ws_bytes(dims[l], cin1, ft[l], (3, 3, 3)),
                        ops.conv3d_wgrad_ws_bytes(dims[l], ft[l], ft[l], (3, 3, 3)))
+        pds = [2 if net.dims[l] == 3 else 1 for l in range(4)]
         for j in range(4):
             l = 3 - j
-            need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l]))
+            need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l], pds[l]))
         ws = self._workspace(need, dev)
         # Weight-gradient kernels hang off the dependency chain (dgrad -> bn backward -> dgrad ...): they run
         # on a second stream with their own workspace, overlapping the HBM-bound BN/pool passes with MFMA work.
@@ -274,14 +288,25 @@ class Engine(object):
                            gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
             db = None if sv.train else gv[key + ".bias"]
+            gw = gv[key + ".weight"]
+            two_d = gw.dim() == 4                      # Conv2d of a 2.5D level: 27-tap gradient, middle plane kept
+            dw = torch.empty((c, cin, 27), dtype=torch.float32, device=dev) if two_d else gw
             if isinstance(xin, tuple):                 # cat([skip, up]) as two tensors (train-mode BN only: db is None)
-                on_side(lambda: ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, gv[key + ".weight"], dims[l], cin, c, ws_w),
-                        d_out, xin[0], xin[1])
+                def wg_cat():
+                    ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, dw, dims[l], cin, c, ws_w)
+                    if two_d:
+                        ops.conv2d_wgrad_extract(dw, gw)
+                on_side(wg_cat, d_out, xin[0], xin[1], dw)
                 if want_dx:
                     ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c)
                 return
-            on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt,
-                                             gv[key + ".weight"], db, dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
+
+            def wg():
+                ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, dw, db, dims[l], cin, c,
+                                 (3, 3, 3), ws_w)
+                if two_d:
+                    ops.conv2d_wgrad_extract(dw, gw)
+            on_side(wg, d_out, xin, dw)
             if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None)
@@ -290,16 +315,17 @@ class Engine(object):
             """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""
             blk = sv.blocks[b]
             key = net.block_keys[b]
+            mod = net.block_modules[b]
             l, c, cin = blk["l"], ft[blk["l"]], blk["cin"]
             d_a1 = empty(vox[l], c)
-            site_bwd(key + ".conv3d_2", key + ".bn3d2", key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0, d_out,
-                     blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1)
+            site_bwd(key + "." + mod.cname(2), key + "." + mod.bname(2), key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0,
+                     d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1)
             if isinstance(blk["xin"], tuple):
                 d_in = (empty(vox[l], cin // 2), empty(vox[l], cin // 2)) if want_dx else None
             else:
                 d_in = empty(vox[l], cin) if want_dx else None
-            site_bwd(key + ".conv3d_1", key + ".bn3d1", key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"], blk["sid"],
-                     d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in)
+            site_bwd(key + "." + mod.cname(1), key + "." + mod.bname(1), key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"],
+                     blk["sid"], d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in)
             return d_in
 
         # ---- decoder, up4 .. up1
@@ -312,19 +338,20 @@ class Engine(object):
             else:
                 d_skips[l] = d_cat[:, :ft[l]]
                 d_up = d_cat[:, ft[l]:]
-            name = "up%d.trans3d" % (j + 1)
+            name = "up%d.%s" % (j + 1, net.up_modules[j].tname())
             xin = sv.deconv_in[j]
             on_side(lambda xin=xin, d_up=d_up, name=name, l=l: ops.deconv2_wgrad(
-                xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws_w), d_up, d_cat, xin)
+                xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws_w, pds[l]),
+                d_up, d_cat, xin)
             ready(name + ".bias")
             d_cur = empty(vox[l + 1], ft[l + 1])
-            ops.deconv2_dgrad(d_up, packs[name][1], d_cur, dims[l + 1], ft[l + 1], ft[l])
+            ops.deconv2_dgrad(d_up, packs[name][1], d_cur, dims[l + 1], ft[l + 1], ft[l], pds[l])
         # ---- encoder, block4 .. block0
         d_pool = block_bwd(4, d_cur, True)                            # grad w.r.t. pooled3 [V_4, ft_3]
         ready("block4.conv.relu_1.weight")
         for i in range(3, -1, -1):
             d_a2 = empty(vox[i], ft[i])
-            ops.maxpool2_bwd(sv.skips[i], d_pool, d_skips[i], d_a2, dims[i], ft[i])
+            ops.maxpool2_bwd(sv.skips[i], d_pool, d_skips[i], d_a2, dims[i], ft[i], pds[i])
             d_pool = block_bwd(i, d_a2, i > 0)
             ready("block%d.conv.relu_1.weight" % i)
         join_side()

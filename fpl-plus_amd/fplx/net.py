@@ -9,11 +9,14 @@ dropout switch, net_run_dsbn/agent_seg.py:843-852, behave identically); all arit
 the HIP kernels of libfplx.so through fplx.engine.  There is no CPU path.
 
 Differences, on purpose:
-  * only the configuration the FPL+ hot path uses is built: conv_dims all 3, bilinear False.
-    The reference also instantiates dead 2D twins of every layer (conv2d_*, bn2d*, trans2d,
-    conv2d, conv3d 1x1x1: 8.1 M of 30.7 M parameters at 32 base channels) that never receive a
-    gradient in this configuration; they are not created.  load_state_dict() accepts reference
-    checkpoints and ignores those keys.
+  * bilinear = False only.  conv_dims[l] = 3 (the benchmark configuration) or 2 (the 2.5D levels of the shipped
+    configs, config_dual/data_vs/vs_t1s_g.cfg:58 conv_dims = [2, 2, 3, 3, 3]): a dim-2 level holds conv2d_* / bn2d* /
+    trans2d members (same state_dict keys and shapes as the reference's) and runs Conv2d / MaxPool2d / ConvTranspose2d
+    on every depth slice, which is what the reference's fold of the depth axis into the batch computes
+    (unet2d5_dsbn.py:110-127, 160-188).
+    The reference also instantiates the twin of the OTHER dimensionality for every layer plus the bilinear branch's
+    1x1 convolutions (8.1 M of 30.7 M parameters at 32 base channels, all 3D) - they never receive a gradient and are
+    not created.  load_state_dict() accepts reference checkpoints and keeps those keys aside (fplx.checkpoint).
   * params['precision'] = 'fp32' (default, parity mode) | 'bf16' (activations stored as bf16,
     fp32 master weights, fp32 statistics / reductions).
 """
@@ -23,35 +26,64 @@ import torch.nn as nn
 from .dsbn import DomainSpecificBatchNorm3d
 from .engine import Engine
 
-_DEAD_KEY_MARKS = ("conv2d", "bn2d", "trans2d", ".conv3d.")
-
-
 class ConvBlockND(nn.Module):
-    """parameter container of reference ConvBlockND (unet2d5_dsbn.py:48-64), 3D members only"""
+    """parameter container of reference ConvBlockND (unet2d5_dsbn.py:48-64): the members of its `dim` only.
+    BatchNorm2d and BatchNorm3d hold the same parameters and buffers, so one container class serves both."""
 
-    def __init__(self, in_channels, out_channels, num_domains, dropout_p):
+    def __init__(self, in_channels, out_channels, num_domains, dropout_p, dim=3):
         super(ConvBlockND, self).__init__()
-        self.conv3d_1 = nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
-        self.conv3d_2 = nn.Conv3d(out_channels, out_channels, kernel_size=3, padding=1)
-        self.bn3d1 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
-        self.bn3d2 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+        self.dim = dim
+        if dim == 3:
+            self.conv3d_1 = nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
+            self.conv3d_2 = nn.Conv3d(out_channels, out_channels, kernel_size=3, padding=1)
+            self.bn3d1 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+            self.bn3d2 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+        else:
+            self.conv2d_1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+            self.conv2d_2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+            self.bn2d1 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
+            self.bn2d2 = DomainSpecificBatchNorm3d(out_channels, num_domains=num_domains)
         self.dropout_p = float(dropout_p)
         self.dropout = nn.Dropout(self.dropout_p)
         self.relu_1 = nn.PReLU()
         self.relu_2 = nn.PReLU()
 
+    # uniform access for the engine: member names follow the dimensionality
+    def cname(self, i):
+        return "conv%dd_%d" % (self.dim, i)
+
+    def bname(self, i):
+        return "bn%dd%d" % (self.dim, i)
+
+    def conv_of(self, i):
+        return getattr(self, self.cname(i))
+
+    def bn_of(self, i):
+        return getattr(self, self.bname(i))
+
 
 class DownBlock(nn.Module):
-    def __init__(self, in_channels, out_channels, num_domains, dropout_p):
+    def __init__(self, in_channels, out_channels, num_domains, dropout_p, dim=3):
         super(DownBlock, self).__init__()
-        self.conv = ConvBlockND(in_channels, out_channels, num_domains, dropout_p)
+        self.dim = dim
+        self.conv = ConvBlockND(in_channels, out_channels, num_domains, dropout_p, dim)
 
 
 class UpBlock(nn.Module):
-    def __init__(self, in_channels1, in_channels2, out_channels, num_domains, dropout_p):
+    def __init__(self, in_channels1, in_channels2, out_channels, num_domains, dropout_p, dim=3):
         super(UpBlock, self).__init__()
-        self.trans3d = nn.ConvTranspose3d(in_channels1, in_channels2, kernel_size=2, stride=2)
-        self.conv = ConvBlockND(in_channels2 * 2, out_channels, num_domains, dropout_p)
+        self.dim = dim
+        if dim == 3:
+            self.trans3d = nn.ConvTranspose3d(in_channels1, in_channels2, kernel_size=2, stride=2)
+        else:
+            self.trans2d = nn.ConvTranspose2d(in_channels1, in_channels2, kernel_size=2, stride=2)
+        self.conv = ConvBlockND(in_channels2 * 2, out_channels, num_domains, dropout_p, dim)
+
+    def tname(self):
+        return "trans%dd" % self.dim
+
+    def trans(self):
+        return getattr(self, self.tname())
 
 
 class _UNetFunction(torch.autograd.Function):
@@ -88,24 +120,24 @@ class UNet2D5_dsbn(nn.Module):
         self.bilinear = params['bilinear']
         self.num_domains = params['num_domains']
         assert (len(self.ft_chns) == 5)                                    # unet2d5_dsbn.py:277
-        if any(d != 3 for d in self.dims):
-            raise ValueError("fplx UNet2D5_dsbn: only conv_dims = [3,3,3,3,3] is built (got {0:})".format(self.dims))
+        if len(self.dims) != 5 or any(d not in (2, 3) for d in self.dims):
+            raise ValueError("fplx UNet2D5_dsbn: conv_dims must be five values out of {{2, 3}} (got {0:})".format(self.dims))
         if self.bilinear:
             raise ValueError("fplx UNet2D5_dsbn: only bilinear = False (transposed convolution) is built")
         prec = params.get('precision', 'fp32')
         if prec not in ('fp32', 'bf16'):
             raise ValueError("fplx UNet2D5_dsbn: precision must be fp32 or bf16 (got {0:})".format(prec))
         self.act_dtype = torch.float32 if prec == 'fp32' else torch.bfloat16
-        ft, nd, dp = self.ft_chns, self.num_domains, self.dropout
-        self.block0 = DownBlock(self.in_chns, ft[0], nd, dp[0])
-        self.block1 = DownBlock(ft[0], ft[1], nd, dp[1])
-        self.block2 = DownBlock(ft[1], ft[2], nd, dp[2])
-        self.block3 = DownBlock(ft[2], ft[3], nd, dp[3])
-        self.block4 = DownBlock(ft[3], ft[4], nd, dp[4])
-        self.up1 = UpBlock(ft[4], ft[3], ft[3], nd, dp[3])
-        self.up2 = UpBlock(ft[3], ft[2], ft[2], nd, dp[2])
-        self.up3 = UpBlock(ft[2], ft[1], ft[1], nd, dp[1])
-        self.up4 = UpBlock(ft[1], ft[0], ft[0], nd, dp[0])
+        ft, nd, dp, dm = self.ft_chns, self.num_domains, self.dropout, self.dims
+        self.block0 = DownBlock(self.in_chns, ft[0], nd, dp[0], dm[0])
+        self.block1 = DownBlock(ft[0], ft[1], nd, dp[1], dm[1])
+        self.block2 = DownBlock(ft[1], ft[2], nd, dp[2], dm[2])
+        self.block3 = DownBlock(ft[2], ft[3], nd, dp[3], dm[3])
+        self.block4 = DownBlock(ft[3], ft[4], nd, dp[4], dm[4])
+        self.up1 = UpBlock(ft[4], ft[3], ft[3], nd, dp[3], dm[3])          # unet2d5_dsbn.py:284-291: dims[3] .. dims[0]
+        self.up2 = UpBlock(ft[3], ft[2], ft[2], nd, dp[2], dm[2])
+        self.up3 = UpBlock(ft[2], ft[1], ft[1], nd, dp[1], dm[1])
+        self.up4 = UpBlock(ft[1], ft[0], ft[0], nd, dp[0], dm[0])
         self.out_conv = nn.Conv3d(ft[0], self.n_class, kernel_size=(1, 3, 3), padding=(0, 1, 1))
 
         self.block_keys = ["block0.conv", "block1.conv", "block2.conv", "block3.conv", "block4.conv",
@@ -123,12 +155,12 @@ class UNet2D5_dsbn(nn.Module):
     # ------------------------------------------------------------------ parameter bookkeeping
     def conv_sites(self):
         for key, m in zip(self.block_keys, self.block_modules):
-            yield key + ".conv3d_1", m.conv3d_1
-            yield key + ".conv3d_2", m.conv3d_2
+            yield key + "." + m.cname(1), m.conv_of(1)
+            yield key + "." + m.cname(2), m.conv_of(2)
 
     def deconv_sites(self):
         for j, u in enumerate(self.up_modules):
-            yield "up%d.trans3d" % (j + 1), u.trans3d
+            yield "up%d.%s" % (j + 1, u.tname()), u.trans()
 
     def _ordered_param_names(self):
         """Flat layout: [shared parameters in the order their gradients are PRODUCED by backward
@@ -140,20 +172,24 @@ class UNet2D5_dsbn(nn.Module):
         named = dict(self.named_parameters())
         order = ["out_conv.weight", "out_conv.bias"]
 
+        mods = dict(zip(self.block_keys, self.block_modules))
+
         def block(key):
-            for s in (".conv3d_2.weight", ".conv3d_2.bias", ".relu_2.weight", ".conv3d_1.weight", ".conv3d_1.bias",
-                      ".relu_1.weight"):
+            m = mods[key]
+            for s in ("." + m.cname(2) + ".weight", "." + m.cname(2) + ".bias", ".relu_2.weight",
+                      "." + m.cname(1) + ".weight", "." + m.cname(1) + ".bias", ".relu_1.weight"):
                 order.append(key + s)
 
         for j in (4, 3, 2, 1):
             block("up%d.conv" % j)
-            order.extend(["up%d.trans3d.weight" % j, "up%d.trans3d.bias" % j])
+            t = self.up_modules[j - 1].tname()
+            order.extend(["up%d.%s.weight" % (j, t), "up%d.%s.bias" % (j, t)])
         for i in (4, 3, 2, 1, 0):
             block("block%d.conv" % i)
         self._n_shared_names = len(order)
         for d in range(self.num_domains):
             for key in self.block_keys:
-                for bn in (".bn3d2", ".bn3d1"):
+                for bn in ("." + mods[key].bname(2), "." + mods[key].bname(1)):
                     order.append("%s%s.bns.%d.weight" % (key, bn, d))
                     order.append("%s%s.bns.%d.bias" % (key, bn, d))
         assert sorted(order) == sorted(named.keys()), "parameter bookkeeping out of sync"
@@ -223,8 +259,12 @@ class UNet2D5_dsbn(nn.Module):
         return r
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        kept = {k: v for k, v in state_dict.items() if not any(m in k for m in _DEAD_KEY_MARKS)}
-        # the reference's dead 2D twins: kept on the host so that a re-saved checkpoint carries them unchanged
+        from .checkpoint import reference_state_keys
+        own = set(super(UNet2D5_dsbn, self).state_dict().keys())
+        ref = set(reference_state_keys(self.num_domains))
+        # the reference's members that are dead in this configuration (the twins of the other dimensionality, the
+        # bilinear branch): kept on the host so that a re-saved checkpoint carries them unchanged
+        kept = {k: v for k, v in state_dict.items() if k in own or k not in ref}
         self._dead_state = {k: v.detach().cpu().clone() for k, v in state_dict.items() if k not in kept}
         r = super(UNet2D5_dsbn, self).load_state_dict(kept, strict=strict, **kw)
         self.engine.invalidate()

@@ -54,11 +54,28 @@ def pack_conv_weight(w, act_dtype, want_wb=True):
 
 
 def pack_deconv_weight(w, act_dtype):
+    """ConvTranspose3d weight [Cin,Cout,2,2,2] (8 taps) or ConvTranspose2d weight [Cin,Cout,2,2] (4 taps)"""
     ci, co = w.shape[0], w.shape[1]
-    wf = torch.empty((8, co, ci), dtype=act_dtype, device=w.device)
-    wb = torch.empty((8, ci, co), dtype=act_dtype, device=w.device)
-    call("fplx_pack_deconv_weight", ptr(w), ptr(wf), ptr(wb), ci, co, _DT[act_dtype], stream())
+    taps = 8 if w.dim() == 5 else 4
+    wf = torch.empty((taps, co, ci), dtype=act_dtype, device=w.device)
+    wb = torch.empty((taps, ci, co), dtype=act_dtype, device=w.device)
+    call("fplx_pack_deconv_weight" if taps == 8 else "fplx_pack_deconv122_weight", ptr(w), ptr(wf), ptr(wb), ci, co,
+         _DT[act_dtype], stream())
     return wf, wb
+
+
+def pack_conv2d_weight(w, act_dtype, want_wb=True):
+    """Conv2d weight [Cout,Cin,3,3] -> the 27-tap layouts of pack_conv_weight with the 9 taps in the middle depth plane"""
+    co, ci = w.shape[0], w.shape[1]
+    wf = torch.empty((27, co, ci), dtype=act_dtype, device=w.device)
+    wb = torch.empty((27, ci, co), dtype=act_dtype, device=w.device) if want_wb else None
+    call("fplx_pack_conv2d_weight", ptr(w), ptr(wf), ptr(wb), co, ci, _DT[act_dtype], stream())
+    return wf, wb
+
+
+def conv2d_wgrad_extract(dw27, dw9):
+    co, ci = dw9.shape[0], dw9.shape[1]
+    call("fplx_conv2d_wgrad_extract", ptr(dw27), ptr(dw9), co, ci, stream())
 
 
 def conv3d_stats_rows(dims, cin, cout, k, x_dt, y_dt):
@@ -129,26 +146,31 @@ def conv3d_wgrad_cat2(x0, x1, dy, dw, dims, cin, cout, ws):
          ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
-def deconv2_fwd(x, wf, bias, y, dims, cin, cout):
+def _dc(sd):
+    return "fplx_deconv2_" if sd == 2 else "fplx_deconv122_"
+
+
+def deconv2_fwd(x, wf, bias, y, dims, cin, cout, sd=2):
+    """sd = 2: ConvTranspose3d(2,2); sd = 1: ConvTranspose2d(2,2) on every depth slice (dims = INPUT dims)"""
     n, d, h, w = dims
-    call("fplx_deconv2_fwd", ptr(x), ld_of(x), ptr(wf), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin, cout,
+    call(_dc(sd) + "fwd", ptr(x), ld_of(x), ptr(wf), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin, cout,
          dt_of(x), stream())
 
 
-def deconv2_dgrad(dy, wb, dx, dims, cin, cout):
+def deconv2_dgrad(dy, wb, dx, dims, cin, cout, sd=2):
     n, d, h, w = dims
-    call("fplx_deconv2_dgrad", ptr(dy), ld_of(dy), ptr(wb), ptr(dx), ld_of(dx), n, d, h, w, cin, cout,
+    call(_dc(sd) + "dgrad", ptr(dy), ld_of(dy), ptr(wb), ptr(dx), ld_of(dx), n, d, h, w, cin, cout,
          dt_of(dy), stream())
 
 
-def deconv2_wgrad_ws_bytes(dims, cin, cout):
+def deconv2_wgrad_ws_bytes(dims, cin, cout, sd=2):
     n, d, h, w = dims
-    return _lib.lib().fplx_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout)
+    return getattr(_lib.lib(), _dc(sd) + "wgrad_ws_bytes")(n, d, h, w, cin, cout)
 
 
-def deconv2_wgrad(x, dy, dw, db, dims, cin, cout, ws):
+def deconv2_wgrad(x, dy, dw, db, dims, cin, cout, ws, sd=2):
     n, d, h, w = dims
-    call("fplx_deconv2_wgrad", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(db), n, d, h, w, cin, cout,
+    call(_dc(sd) + "wgrad", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dw), ptr(db), n, d, h, w, cin, cout,
          dt_of(x), ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
@@ -186,14 +208,15 @@ def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta,
          dt_of(y), stream())
 
 
-def maxpool2_fwd(x, y, dims, c):
+def maxpool2_fwd(x, y, dims, c, pd=2):
+    """pd = 2: MaxPool3d(2); pd = 1: MaxPool2d(2) on every depth slice"""
     n, d, h, w = dims
-    call("fplx_maxpool2_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), n, d, h, w, c, dt_of(x), stream())
+    call("fplx_maxpool2_fwd" if pd == 2 else "fplx_maxpool122_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), n, d, h, w, c, dt_of(x), stream())
 
 
-def maxpool2_bwd(x, dy, dskip, dx, dims, c):
+def maxpool2_bwd(x, dy, dskip, dx, dims, c, pd=2):
     n, d, h, w = dims
-    call("fplx_maxpool2_bwd", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dskip), 0 if dskip is None else ld_of(dskip),
+    call("fplx_maxpool2_bwd" if pd == 2 else "fplx_maxpool122_bwd", ptr(x), ld_of(x), ptr(dy), ld_of(dy), ptr(dskip), 0 if dskip is None else ld_of(dskip),
          ptr(dx), ld_of(dx), n, d, h, w, c, dt_of(x), stream())
 
 

@@ -123,6 +123,32 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
                        int n, int d, int h, int w, int cin, int cout, int dt,
                        void* ws, size_t ws_bytes, fplx_stream_t stream);
 
+/* ------------------------------------------------------------------ 2.5D levels (conv_dims[l] = 2, the shipped configs:
+ * config_dual/data_vs/vs_t1s_g.cfg:58 conv_dims = [2, 2, 3, 3, 3]).  The reference folds the depth axis into the batch and
+ * runs 2D modules (unet2d5_dsbn.py:110-127, 160-188); on [N,D,H,W,C] volumes that is
+ *  - Conv2d(3x3, pad 1)  = the 3x3x3 kernels with the 9 taps packed into the middle depth plane (pack_conv2d_weight:
+ *    w fp32 [Cout][Cin][3][3] -> the same wf / wb layouts as fplx_pack_conv_weight); weight gradient = middle plane of
+ *    the 27-tap gradient (conv2d_wgrad_extract: dw27 [Cout][Cin][27] -> dw9 [Cout][Cin][9])
+ *  - MaxPool2d(2)        = maxpool122: x [N,D,H,W,C] -> y [N,D,H/2,W/2,C]
+ *  - ConvTranspose2d(2,2) = deconv122: x [N,D,H,W,Cin] -> y [N,D,2H,2W,Cout]; weights fp32 [Cin][Cout][2][2] packed to
+ *    wf [4][Cout][Cin], wb [4][Cin][Cout]; dw fp32 [Cin][Cout][2][2]
+ *  BatchNorm2d over (N D, C, H, W) has the statistics of BatchNorm3d over (N, C, D, H, W): same kernels. */
+int fplx_pack_conv2d_weight(const float* w, void* wf, void* wb, int cout, int cin, int dt, fplx_stream_t stream);
+int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream);
+int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
+                        int dt, fplx_stream_t stream);
+int fplx_maxpool122_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
+                        void* dx, int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream);
+int fplx_pack_deconv122_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt, fplx_stream_t stream);
+int fplx_deconv122_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
+                       int n, int d, int h, int w, int cin, int cout, int dt, fplx_stream_t stream);
+int fplx_deconv122_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx,
+                         int n, int d, int h, int w, int cin, int cout, int dt, fplx_stream_t stream);
+size_t fplx_deconv122_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int fplx_deconv122_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
+                         int n, int d, int h, int w, int cin, int cout, int dt,
+                         void* ws, size_t ws_bytes, fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ DSBN + PReLU + dropout
  * Training-mode statistics of nn.BatchNorm3d for the ACTIVE domain (dsbn.py:54-57):
  *   stats [rows][2][C] (from fplx_conv3d_fwd) -> mean, biased var -> scale = gamma*rstd,

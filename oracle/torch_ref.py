@@ -82,6 +82,46 @@ def prelu(x, slope):
     return torch.where(x > 0, x, x * slope)  # nn.PReLU(), one shared slope (unet2d5_dsbn.py:62-63)
 
 
+def fold_depth(x):
+    """DownBlock / UpBlock with dim == 2 (unet2d5_dsbn.py:110-115, 160-169): [N,C,D,H,W] -> [N*D,C,H,W]"""
+    n, c, d, h, w = x.shape
+    return torch.transpose(x, 1, 2).reshape(n * d, c, h, w)
+
+
+def unfold_depth(x, n):
+    """the inverse (unet2d5_dsbn.py:121-127, 185-188): [N*D,C,H,W] -> [N,C,D,H,W]"""
+    nd, c, h, w = x.shape
+    return torch.transpose(x.reshape(n, nd // n, c, h, w), 1, 2)
+
+
+def dsbn2d(x, sd, key, domain, train):
+    """DomainSpecificBatchNorm2d on [N*D,C,H,W]: the statistics over (0,2,3) are those of the 5-D form over (0,2,3,4)"""
+    return dsbn(x.unsqueeze(2), sd, key, domain, train).squeeze(2)
+
+
+def conv_block2d(x, sd, key, domain, train, p, keep_mask, act_dtype, dropout_on=None):
+    """ConvBlockND.forward, 2D branch (net3d/unet2d5_dsbn.py:66-73) on the depth-folded tensor.  keep_mask (if any) is
+    given in the 5-D layout [N,C,D,H,W] like the 3D branch's and folded here."""
+    if dropout_on is None:
+        dropout_on = train
+    x = F.conv2d(x, quant(sd[key + ".conv2d_1.weight"], act_dtype), sd[key + ".conv2d_1.bias"], padding=1)
+    x = quant(x, act_dtype)
+    x = dsbn2d(x, sd, key + ".bn2d1", domain, train)
+    x = prelu(x, sd[key + ".relu_1.weight"])
+    if p > 0 and dropout_on:
+        if keep_mask is None:
+            x = F.dropout(x, p, True)
+        else:
+            p32 = float(torch.tensor(p, dtype=torch.float32))
+            x = x * fold_depth(keep_mask).to(x.dtype) * float(torch.tensor(1.0 / (1.0 - p32), dtype=torch.float32))
+    x = quant(x, act_dtype)
+    x = F.conv2d(x, quant(sd[key + ".conv2d_2.weight"], act_dtype), sd[key + ".conv2d_2.bias"], padding=1)
+    x = quant(x, act_dtype)
+    x = dsbn2d(x, sd, key + ".bn2d2", domain, train)
+    x = prelu(x, sd[key + ".relu_2.weight"])
+    return quant(x, act_dtype)
+
+
 def conv_block(x, sd, key, domain, train, p, keep_mask, act_dtype, dropout_on=None):
     """ConvBlockND.forward, 3D branch (net3d/unet2d5_dsbn.py:74-81)."""
     if dropout_on is None:
@@ -119,25 +159,43 @@ def block_dropout_p(net_params):
 
 def unet_forward(sd, net_params, x, domain, train=True, dropout_masks=None, act_dtype=None,
                  dropout_on=None):
-    """UNet2D5_dsbn.forward with conv_dims all 3 and bilinear=False (unet2d5_dsbn.py:296-309).
+    """UNet2D5_dsbn.forward with bilinear=False (unet2d5_dsbn.py:296-309); conv_dims[l] = 2 levels fold the depth axis
+    into the batch and use the 2D members, exactly like DownBlock / UpBlock (108-129, 156-188).
 
-    sd: dict key -> tensor (reference state_dict names, 3D branch only).
+    sd: dict key -> tensor (reference state_dict names, live members only).
     domain: python int (= domain_label[0], dsbn.py:56).
     dropout_masks: optional list of 9 keep-masks (or None entries), one per ConvBlockND.
     dropout_on: dropout active (defaults to `train`); eval-mode BN + active dropout is the
         FPL test-time setting (net_run_dsbn/agent_seg.py:843-852)."""
     ps = block_dropout_p(net_params)
     masks = dropout_masks or [None] * 9
+    dims = list(net_params.get("conv_dims", [3] * 5))
     x = quant(x, act_dtype)
+    n = x.shape[0]
     skips = []
     h = x
     for i in range(5):
-        h = conv_block(h, sd, BLOCK_KEYS[i], domain, train, ps[i], masks[i], act_dtype, dropout_on)
-        if i < 4:
-            skips.append(h)
-            h = F.max_pool3d(h, 2, 2)                                   # DownBlock, line 106/117
+        if dims[i] == 2:
+            h2 = conv_block2d(fold_depth(h), sd, BLOCK_KEYS[i], domain, train, ps[i], masks[i], act_dtype, dropout_on)
+            h = unfold_depth(h2, n)
+            if i < 4:
+                skips.append(h)
+                h = unfold_depth(F.max_pool2d(h2, 2, 2), n)              # DownBlock, line 104/117
+        else:
+            h = conv_block(h, sd, BLOCK_KEYS[i], domain, train, ps[i], masks[i], act_dtype, dropout_on)
+            if i < 4:
+                skips.append(h)
+                h = F.max_pool3d(h, 2, 2)                               # DownBlock, line 106/117
     for j in range(4):
         key = "up%d" % (j + 1)
+        if dims[3 - j] == 2:
+            up = F.conv_transpose2d(fold_depth(h), quant(sd[key + ".trans2d.weight"], act_dtype),
+                                    sd[key + ".trans2d.bias"], stride=2)   # line 179
+            up = quant(up, act_dtype)
+            hc = torch.cat([fold_depth(skips[3 - j]), up], dim=1)       # line 182
+            h = unfold_depth(conv_block2d(hc, sd, BLOCK_KEYS[5 + j], domain, train, ps[5 + j], masks[5 + j], act_dtype,
+                                          dropout_on), n)
+            continue
         up = F.conv_transpose3d(h, quant(sd[key + ".trans3d.weight"], act_dtype), sd[key + ".trans3d.bias"],
                                 stride=2)                                  # line 181
         up = quant(up, act_dtype)

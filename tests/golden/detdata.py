@@ -35,7 +35,7 @@ def ball_label(shape_dhw, radius, n=1, class_num=2, offsets=None):
 
 
 def state_dict_3d(net_params, prefix="w"):
-    """Deterministic weights for the 3D path of UNet2D5_dsbn.
+    """Deterministic weights for the live members of UNet2D5_dsbn (conv_dims[l] = 3: the 3D ones; 2: the 2D ones).
 
     Key names and shapes follow the reference's state_dict for the 3D branch
     (PyMIC/pymic/net/net3d/unet2d5_dsbn.py:48-83,131-154,265-294 and
@@ -61,22 +61,26 @@ def state_dict_3d(net_params, prefix="w"):
             sd[k + ".running_var"] = uniform(prefix + k + ".rv", (c,), 0.5, 1.5)
             sd[k + ".num_batches_tracked"] = np.zeros((), np.int64)
 
-    def block(key, ci, co):
-        conv(key + ".conv3d_1", co, ci, (3, 3, 3))
-        conv(key + ".conv3d_2", co, co, (3, 3, 3))
-        dsbn(key + ".bn3d1", co)
-        dsbn(key + ".bn3d2", co)
+    dims = list(net_params.get("conv_dims", [3] * 5))
+
+    def block(key, ci, co, dim=3):
+        k = (3,) * dim
+        conv(key + ".conv%dd_1" % dim, co, ci, k)
+        conv(key + ".conv%dd_2" % dim, co, co, k)
+        dsbn(key + ".bn%dd1" % dim, co)
+        dsbn(key + ".bn%dd2" % dim, co)
         sd[key + ".relu_1.weight"] = uniform(prefix + key + ".r1", (1,), 0.1, 0.4)
         sd[key + ".relu_2.weight"] = uniform(prefix + key + ".r2", (1,), 0.1, 0.4)
 
     chans = [cin] + list(ft)
     for i in range(5):
-        block("block%d.conv" % i, chans[i], chans[i + 1])
+        block("block%d.conv" % i, chans[i], chans[i + 1], dims[i])
     for i, (c1, c2) in enumerate([(ft[4], ft[3]), (ft[3], ft[2]), (ft[2], ft[1]), (ft[1], ft[0])]):
         key = "up%d" % (i + 1)
-        # ConvTranspose3d weight is [Cin, Cout, 2, 2, 2]
-        sd[key + ".trans3d.weight"] = normal(prefix + key + ".t.w", (c1, c2, 2, 2, 2), scale=(1.0 / c1) ** 0.5)
-        sd[key + ".trans3d.bias"] = normal(prefix + key + ".t.b", (c2,), scale=0.1)
-        block(key + ".conv", 2 * c2, c2)
+        dim = dims[3 - i]
+        # ConvTranspose{2,3}d weight is [Cin, Cout, 2, 2(, 2)]
+        sd[key + ".trans%dd.weight" % dim] = normal(prefix + key + ".t.w", (c1, c2) + (2,) * dim, scale=(1.0 / c1) ** 0.5)
+        sd[key + ".trans%dd.bias" % dim] = normal(prefix + key + ".t.b", (c2,), scale=0.1)
+        block(key + ".conv", 2 * c2, c2, dim)
     conv("out_conv", ncls, ft[0], (1, 3, 3))
     return sd

@@ -13,7 +13,9 @@ NETS = {
                conv_dims=[3, 3, 3, 3, 3], class_num=3, bilinear=False, num_domains=2,
                net_type="UNet2D5_dsbn"),
 }
-SHAPES = {"tiny": (2, 1, 16, 32, 32), "cfg1": (1, 1, 32, 64, 64), "c4": (2, 4, 16, 32, 32)}
+# the shipped configs' dimensionality pattern (config_dual/data_vs/vs_t1s_g.cfg:58): 2D convolutions at levels 0-1
+NETS["tiny25"] = dict(NETS["tiny"], conv_dims=[2, 2, 3, 3, 3])
+SHAPES = {"tiny25": (2, 1, 16, 32, 32), "tiny": (2, 1, 16, 32, 32), "cfg1": (1, 1, 32, 64, 64), "c4": (2, 4, 16, 32, 32)}
 
 
 def label_for(name):
@@ -30,3 +32,15 @@ def label_for(name):
         out[:, 2] = lab[:, 1] * (~half)
         lab = out
     return lab
+
+
+_LEVEL_OF = {"block0": 0, "block1": 1, "block2": 2, "block3": 3, "block4": 4, "up1": 3, "up2": 2, "up3": 1, "up4": 0}
+
+
+def key_for(name, params):
+    """state_dict key of a parameter given by its 3D-style name: the members of a conv_dims = 2 level are conv2d_* /
+    bn2d* / trans2d"""
+    lvl = _LEVEL_OF.get(name.split(".")[0])
+    if lvl is None or params["conv_dims"][lvl] == 3:
+        return name
+    return name.replace("conv3d_", "conv2d_").replace("bn3d", "bn2d").replace("trans3d", "trans2d")

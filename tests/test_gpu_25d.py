@@ -1,0 +1,195 @@
+"""-m gpu: the 2.5D variant of the shipped configs (conv_dims = [2, 2, 3, 3, 3], config_dual/data_vs/vs_t1s_g.cfg:58):
+the (1,2,2) pooling / transposed-convolution kernels, the 2D weight pack / gradient extraction, and the whole network and
+train step against fixtures produced by RUNNING the reference in that configuration (tests/golden/make_golden_25d.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import detdata
+from make_golden_cfg import NETS, SHAPES, key_for
+from util import load_det_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def cl(t):          # [N,C,D,H,W] -> [V, C]
+    return t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+def uncl(t2, n, d, h, w):
+    return t2.view(n, d, h, w, -1).permute(0, 4, 1, 2, 3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_maxpool122_and_deconv122_match_torch(dtype):
+    from fplx import ops
+    n, c, d, h, w, co = 2, 16, 5, 8, 12, 24
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    x = torch.from_numpy(detdata.normal("p122.x", (n, c, d, h, w)))
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    fold = lambda t: t.transpose(1, 2).reshape(t.shape[0] * t.shape[2], t.shape[1], t.shape[3], t.shape[4])
+    unfold = lambda t, n_: t.reshape(n_, t.shape[0] // n_, t.shape[1], t.shape[2], t.shape[3]).transpose(1, 2)
+    # MaxPool2d(2) on the depth-folded tensor (unet2d5_dsbn.py:104, 110-127) and its backward with a skip gradient
+    xr = x.clone().requires_grad_(True)
+    yr = unfold(F.max_pool2d(fold(xr), 2, 2), n)
+    dy = torch.from_numpy(detdata.normal("p122.dy", tuple(yr.shape)))
+    dsk = torch.from_numpy(detdata.normal("p122.ds", (n, c, d, h, w)))
+    yr.backward(dy)
+    xg = cl(x).to(dtype).cuda()
+    y = torch.empty((n * d * (h // 2) * (w // 2), c), dtype=dtype, device="cuda")
+    ops.maxpool2_fwd(xg, y, (n, d, h, w), c, pd=1)
+    assert torch.equal(uncl(y.float().cpu(), n, d, h // 2, w // 2), yr.detach())
+    dx = torch.empty_like(xg)
+    ops.maxpool2_bwd(xg, cl(dy).to(dtype).cuda(), cl(dsk).to(dtype).cuda(), dx, (n, d, h, w), c, pd=1)
+    want = xr.grad.to(dtype).float() + dsk.to(dtype).float() if dtype == torch.float32 else None
+    got = uncl(dx.float().cpu(), n, d, h, w)
+    ref = xr.grad + dsk
+    assert float((got - ref).abs().max()) < max(tol, 1e-6) * float(ref.abs().max()) * (1 if dtype == torch.float32 else 2)
+    # ConvTranspose2d(k=2, s=2) on the depth-folded tensor (unet2d5_dsbn.py:151, 179): forward, dgrad, wgrad, bias grad
+    wt = torch.from_numpy(detdata.normal("d122.w", (c, co, 2, 2), 0.3))
+    b = torch.from_numpy(detdata.normal("d122.b", (co,)))
+    if dtype == torch.bfloat16:
+        wt = wt.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    wr, br = wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = unfold(F.conv_transpose2d(fold(xr), wr, br, stride=2), n)
+    dy = torch.from_numpy(detdata.normal("d122.dy", tuple(yr.shape)))
+    if dtype == torch.bfloat16:
+        dy = dy.bfloat16().float()
+    yr.backward(dy)
+    wf, wb = ops.pack_deconv_weight(wt.cuda(), dtype)
+    assert wf.shape == (4, co, c) and wb.shape == (4, c, co)
+    yg = torch.empty((n * d * 2 * h * 2 * w, co), dtype=dtype, device="cuda")
+    ops.deconv2_fwd(xg, wf, b.cuda(), yg, (n, d, h, w), c, co, sd=1)
+    assert float((uncl(yg.float().cpu(), n, d, 2 * h, 2 * w) - yr.detach()).abs().max()) < tol * float(yr.abs().max())
+    dyg = cl(dy).to(dtype).cuda()
+    dxg = torch.empty_like(xg)
+    ops.deconv2_dgrad(dyg, wb, dxg, (n, d, h, w), c, co, sd=1)
+    assert float((uncl(dxg.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < tol * float(xr.grad.abs().max())
+    ws = torch.empty(ops.deconv2_wgrad_ws_bytes((n, d, h, w), c, co, sd=1), dtype=torch.uint8, device="cuda")
+    dw = torch.empty((c, co, 2, 2), dtype=torch.float32, device="cuda")
+    db = torch.empty(co, dtype=torch.float32, device="cuda")
+    ops.deconv2_wgrad(xg, dyg, dw, db, (n, d, h, w), c, co, ws, sd=1)
+    assert float((dw.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+    assert float((db.cpu() - br.grad).abs().max()) < max(tol, 1e-4) * float(br.grad.abs().max())
+
+
+@pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 5, 12, 3, 9, 10)), (torch.bfloat16, (1, 32, 64, 4, 16, 24)),
+                                         (torch.bfloat16, (1, 64, 32, 6, 16, 80))])
+def test_conv2d_through_the_3d_kernels(dtype, shape):
+    """Conv2d(3x3) per depth slice = the 3x3x3 kernels on weights packed into the middle depth plane: forward, data
+    gradient, and the weight gradient as the middle plane of the 27-tap gradient."""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(detdata.normal("c2d.x%s" % (shape,), (n, cin, d, h, w))))
+    wt = q(torch.from_numpy(detdata.normal("c2d.w%s" % (shape,), (cout, cin, 3, 3), 0.2)))
+    b = torch.from_numpy(detdata.normal("c2d.b%s" % (shape,), (cout,)))
+    dy = q(torch.from_numpy(detdata.normal("c2d.dy%s" % (shape,), (n, cout, d, h, w))))
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr.unsqueeze(2), b, padding=(0, 1, 1))             # == Conv2d on every depth slice
+    yr.backward(dy)
+    dt, dims = ops._DT[dtype], (n, d, h, w)
+    wf, wb = ops.pack_conv2d_weight(wt.cuda(), dtype)
+    assert float(wf[:9].float().abs().max()) == 0 and float(wf[18:].float().abs().max()) == 0
+    xg, dyg = cl(x).to(dtype).cuda(), cl(dy).to(dtype).cuda()
+    y = torch.empty((xg.shape[0], cout), dtype=dtype, device="cuda")
+    ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
+                   (3, 3, 3), None)
+    assert float((uncl(y.float().cpu(), n, d, h, w) - yr.detach()).abs().max()) < tol * float(yr.abs().max())
+    dx = torch.empty_like(xg)
+    ops.conv3d_fwd(dyg, ops.cl_strides(d, h, w, cout), dt, wb, None, dx, ops.cl_strides(d, h, w, cin), dt, dims, cout, cin,
+                   (3, 3, 3), None)
+    assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < tol * float(xr.grad.abs().max())
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+    dw27 = torch.empty((cout, cin, 27), dtype=torch.float32, device="cuda")
+    dw9 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw27, None, dims, cin,
+                     cout, (3, 3, 3), ws)
+    ops.conv2d_wgrad_extract(dw27, dw9)
+    assert float((dw9.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+
+
+def test_25d_training_all_matches_reference(golden_dir):
+    """five iterations of SegmentationAgent.training_all (pixel / image weights on domain 1) in the shipped
+    dimensionality pattern: loss, class Dice, lr schedule, parameters after 1 and 3 Adam steps."""
+    import fplx
+    g = np.load(os.path.join(golden_dir, "train_step25.npz"))
+    name = "tiny25"
+    tcfg = {"dis": False, "train_fpl_uda": True, "loss_type": "DiceLoss", "optimizer": "Adam", "learning_rate": 1e-3,
+            "momentum": 0.9, "weight_decay": 1e-5, "lr_scheduler": "MultiStepLR", "lr_gamma": 0.5, "lr_milestones": [2, 4],
+            "iter_valid": 1, "gpus": [0]}
+    cfg = {"dataset": {"tensor_type": "float"}, "network": dict(NETS[name]), "training": tcfg, "testing": {}}
+    agent = fplx.SegmentationAgent(cfg, "train")
+    agent.create_network()
+    load_det_weights(agent.net, cfg["network"], "cuda")
+    agent.create_optimizer()
+    agent.create_loss_calculator()
+    n, _, D, H, W = SHAPES[name]
+    batches = []
+    for dom in (0, 1):
+        b = {"image": torch.from_numpy(detdata.normal("ts25.x.d%d" % dom, SHAPES[name])),
+             "label_prob": torch.from_numpy(detdata.ball_label((D, H, W), 5.0, n=n, offsets=[(dom, 1, -2), (1, -3, 2 + dom)]))}
+        if dom == 1:
+            pw = (detdata.uniform("ts25.pw", (n, 1, D, H, W)) > 0.25).astype(np.float32)
+            iw = np.array([0.8, 0.45], np.float32)
+            b["pixel_weight"] = torch.from_numpy(pw * iw[:, None, None, None, None])
+            b["image_weight"] = torch.from_numpy(iw)
+        batches.append(b)
+    agent.set_loaders([batches[0]], [batches[1]])
+    lrs = []
+    for step in range(1, 6):
+        sc = agent.training_all()
+        assert abs(sc["loss"] - float(g["step%d.loss" % step])) < 5e-5, (step, sc["loss"])
+        np.testing.assert_allclose(sc["class_dice"], g["step%d.class_dice" % step], atol=3e-3)
+        lrs.append(agent.optimizer.param_groups[0]["lr"])
+        if step in (1, 3):
+            sd = agent.net.state_dict()
+            pre = "step%d." % step
+            for k in g.files:
+                if not k.startswith(pre) or k[len(pre):] not in sd:
+                    continue
+                kk = k[len(pre):]
+                if kk.endswith("bias") and ("conv3d_" in kk or "conv2d_" in kk):
+                    continue                  # conv bias under BN: see test_gpu_loss_filter_parity
+                diff = np.abs(sd[kk].cpu().numpy() - g[k])
+                assert diff.max() <= 1e-3 * step + 1e-6, (k, diff.max())
+    np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
+
+
+def test_25d_bf16_engine_step_and_checkpoint_keys(tmp_path):
+    """bf16 engine mode on a VS-config-shaped crop (depth 28 is not a multiple of 16: only the two 3D levels halve it):
+    steps run, the loss goes down, the run is reproducible, and the saved state carries the reference's 484 keys."""
+    import fplx
+    from fplx import checkpoint as C
+    p = dict(in_chns=1, feature_chns=[16, 32, 64, 64, 64], dropout=[0.0, 0.0, 0.3, 0.4, 0.5], conv_dims=[2, 2, 3, 3, 3],
+             class_num=2, bilinear=False, num_domains=2, precision="bf16")
+
+    def run():
+        torch.manual_seed(2)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-2, weight_decay=1e-5)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 1, 28, 64, 80, generator=g).cuda()
+        lab = torch.zeros(2, 2, 28, 64, 80)
+        lab[:, 0] = 1.0
+        lab[:, 0, 8:20, 20:44, 30:60] = 0.0
+        lab[:, 1, 8:20, 20:44, 30:60] = 1.0
+        lab = lab.cuda()
+        losses = [float(ts.step(x, lab, i % 2)[0].item()) for i in range(8)]
+        return net, losses
+
+    net, la = run()
+    _, lb = run()
+    assert la == lb and all(np.isfinite(la)) and min(la[4:]) < la[0]
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 30, 64, 80).cuda(), domain_label=torch.zeros(1, dtype=torch.long))   # depth 30 % 4 != 0
+    msd = C.reference_model_state_dict(net)
+    assert list(msd.keys()) == C.reference_state_keys(2)
+    assert tuple(msd["block0.conv.conv3d_1.weight"].shape) == (16, 1, 3, 3, 3)       # dead 3D twin of a 2D level
+    assert tuple(msd["up4.trans3d.weight"].shape) == (32, 16, 2, 2, 2) and tuple(msd["up4.trans2d.weight"].shape) == (32, 16, 2, 2)

@@ -13,7 +13,7 @@ from util import load_det_weights, max_rel
 pytestmark = pytest.mark.gpu
 
 # max-normalised gradient tolerance: see tests/test_oracle_golden.py (reference's own fp32 noise) x2
-GRAD_TOL = {"tiny": 1e-3, "c4": 1e-3, "cfg1": 1e-2}
+GRAD_TOL = {"tiny": 1e-3, "tiny25": 1e-2, "c4": 1e-3, "cfg1": 1e-2}
 LOGIT_TOL = 1e-3            # north_star: logits within 1e-3 in fp32
 
 
@@ -28,7 +28,7 @@ def _net(name, precision="fp32", dropout=None):
     return net, p
 
 
-@pytest.mark.parametrize("name", ["tiny", "c4", "cfg1"])
+@pytest.mark.parametrize("name", ["tiny", "tiny25", "c4", "cfg1"])     # tiny25: conv_dims = [2, 2, 3, 3, 3] (shipped cfgs)
 def test_fp32_forward_backward_matches_reference(golden_dir, name):
     import fplx
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % name))
@@ -62,7 +62,7 @@ def test_fp32_forward_backward_matches_reference(golden_dir, name):
                 stride = int(head[len("gradsub"):])
                 ref, got = g[k], named[kk].grad.cpu().numpy().reshape(-1)[::stride]
             if ref is not None:
-                if kk.endswith("bias") and ("conv3d_1" in kk or "conv3d_2" in kk):
+                if kk.endswith("bias") and ("conv3d_" in kk or "conv2d_" in kk):
                     # conv bias feeding train-mode BatchNorm: the true gradient is exactly 0; the reference
                     # returns fp32 cancellation noise, fplx returns 0
                     assert np.abs(got).max() == 0.0 and np.abs(ref).max() < 1e-6, k
@@ -74,7 +74,7 @@ def test_fp32_forward_backward_matches_reference(golden_dir, name):
         ours = sorted(k for k, t in named.items() if t.grad is not None)
         assert ours == keys          # exactly the parameters the reference gives a gradient to
         for k, v in zip(keys, vals):
-            if k.endswith("bias") and ("conv3d_1" in k or "conv3d_2" in k):
+            if k.endswith("bias") and ("conv3d_" in k or "conv2d_" in k):
                 continue
             assert abs(float(named[k].grad.norm()) - v) <= max(GRAD_TOL[name] * v, 1e-6), (k, v)
 
