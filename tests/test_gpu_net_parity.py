@@ -154,7 +154,7 @@ def test_error_behaviour_mirrors_reference():
     with pytest.raises(IndexError):
         net(torch.zeros(1, 1, 16, 32, 32).cuda(), domain_label=5 * torch.ones(1, dtype=torch.long))
     bad = dict(p)
-    bad["conv_dims"] = [2, 2, 3, 3, 3]
+    bad["bilinear"] = True
     with pytest.raises(ValueError):
         fplx.UNet2D5_dsbn(bad)
     layer = fplx.DomainSpecificBatchNorm3d(8, 2).cuda()

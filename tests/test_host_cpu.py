@@ -61,13 +61,21 @@ def test_net_module_surface():
     ref_like["up1.conv3d.weight"] = torch.zeros(64, 128, 1, 1, 1)
     net.load_state_dict(ref_like)
     np.testing.assert_array_equal(net.out_conv.weight.detach().numpy(), want["out_conv.weight"])
-    for bad in ({"conv_dims": [2, 2, 3, 3, 3]}, {"bilinear": True}, {"precision": "fp8"}):
+    for bad in ({"conv_dims": [2, 2, 3, 3]}, {"conv_dims": [1, 2, 3, 3, 3]}, {"bilinear": True}, {"precision": "fp8"}):
         q = dict(p)
         q.update(bad)
         with pytest.raises(ValueError):
             fplx.UNet2D5_dsbn(q)
     with pytest.raises(RuntimeError):          # no CPU path
         net(torch.zeros(1, 1, 16, 32, 32), domain_label=torch.zeros(1, dtype=torch.long))
+    # the shipped configs' 2.5D pattern: the live members of the 2D levels carry the reference's 2D key names / shapes
+    q = dict(p)
+    q["conv_dims"] = [2, 2, 3, 3, 3]
+    n25 = fplx.UNet2D5_dsbn(q)
+    sd25 = n25.state_dict()
+    assert len(sd25) == len(sd) and tuple(sd25["block0.conv.conv2d_1.weight"].shape) == (8, 1, 3, 3)
+    assert "up4.trans2d.weight" in sd25 and "up3.trans2d.weight" in sd25 and "up2.trans3d.weight" in sd25
+    assert "block1.conv.bn2d2.bns.1.running_var" in sd25 and "block2.conv.bn3d1.bns.0.weight" in sd25
     # test-time dropout switch of the reference (agent_seg.py:845-852) reaches our Dropout children
     q = dict(p)
     q["dropout"] = [0, 0, 0.3, 0.4, 0.5]
