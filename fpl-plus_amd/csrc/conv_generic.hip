@@ -408,13 +408,13 @@ extern "C" size_t fplx_edge_outconv_wgrad_ws_bytes(int n, int d, int h, int w, i
 extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* dl, float* dw, int n, int d, int h, int w,
                                        int c0, int ncls, void* ws, hipStream_t st);
 extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, hipStream_t st);
+                                     int n, int d, int h, int w, int cin, int cout, int sd, hipStream_t st);
 extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
-                                       int h, int w, int cin, int cout, hipStream_t st);
+                                       int h, int w, int cin, int cout, int sd, hipStream_t st);
 extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
                                        int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
-                                       hipStream_t st);
+                                       int sd, hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
@@ -713,16 +713,15 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
   return fplx_check_launch("conv3d_wgrad");
 }
 
-// sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels; generic kernels -
-// the shipped 2.5D crops are 28 x 128 x 128 and these layers are a few hundred MFLOP)
+// sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels)
 static int deconv_fwd_impl(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                            int h, int w, int cin, int cout, int dt, int sd, fplx_stream_t stream) {
   FPLX_REQUIRE(x && wf && bias && y, FPLX_E_NULL, "deconv2_fwd: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_fwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  if (dt == FPLX_BF16 && sd == 2) {
-    int r = fplx_mfma_deconv2_fwd(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, st);
+  if (dt == FPLX_BF16) {
+    int r = fplx_mfma_deconv2_fwd(x, ldx, wf, bias, y, ldy, n, d, h, w, cin, cout, sd, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
   const int64_t V = (int64_t)n * d * h * w;
@@ -744,8 +743,8 @@ static int deconv_dgrad_impl(const void* dy, int64_t ldy, const void* wb, void* 
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, FPLX_E_BADSHAPE,
                "deconv2_dgrad: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  if (dt == FPLX_BF16 && sd == 2) {
-    int r = fplx_mfma_deconv2_dgrad(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, st);
+  if (dt == FPLX_BF16) {
+    int r = fplx_mfma_deconv2_dgrad(dy, ldy, wb, dx, ldx, n, d, h, w, cin, cout, sd, st);
     if (r != 0) return r < 0 ? r : FPLX_OK;
   }
   const int64_t V = (int64_t)n * d * h * w;
@@ -764,10 +763,8 @@ static int deconv_dgrad_impl(const void* dy, int64_t ldy, const void* wb, void* 
 static size_t deconv_wgrad_ws_impl(int n, int d, int h, int w, int cin, int cout, int sd) {
   const int64_t V = (int64_t)n * d * h * w;
   size_t a = (size_t)wgrad_chunks(V) * 4 * sd * cout * cin * sizeof(float);
-  if (sd == 2) {
-    const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
-    if (m > a) a = m;
-  }
+  const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);     // 8-tap partials for either sd
+  if (m > a) a = m;
   return a + (size_t)fplx_rows_for(V * 4 * sd) * cout * sizeof(float) + 256;
 }
 
@@ -789,10 +786,10 @@ static int deconv_wgrad_impl(const void* x, int64_t ldx, const void* dy, int64_t
   // dy is [N, sd D, 2H, 2W]; the kernel addresses depth (2 d + kd): for sd = 1 (kd = 0) half the slice stride does it
   Strides ys{(int64_t)4 * sd * d * h * w * ldy, (int64_t)(sd == 2 ? 4 : 2) * h * w * ldy, (int64_t)2 * w * ldy, ldy, 1};
   bool done = false;
-  if (dt == FPLX_BF16 && sd == 2) {
+  if (dt == FPLX_BF16) {
     const size_t m = fplx_mfma_deconv2_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
-      int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, ws, m, st);
+      int r = fplx_mfma_deconv2_wgrad(x, ldx, dy, ldy, dw, db, n, d, h, w, cin, cout, ws, m, sd, st);
       if (r < 0) return r;
       if (r == 1) { done = true; used = m; db = nullptr; }        // bias gradient came out of the same pass
     }

@@ -21,6 +21,8 @@ constexpr int DIRECT_THREADS = 256;
 // MODE 0: 3x3x3 "same" convolution (27 taps, +-1 shifts, zero padding)
 // MODE 1: data gradient of ConvTranspose3d(k=2,s=2): 8 taps, the source voxel of tap (i,j,k) is
 //         (2d+i, 2h+j, 2w+k) of the twice-as-large dy grid; rows = INPUT voxels of the deconv
+// MODE 2: data gradient of ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels): 4 taps (j,k), source
+//         voxel (d, 2h+j, 2w+k)
 template <int MT, int NTL, int MODE>
 __global__ void __launch_bounds__(DIRECT_THREADS)
 conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
@@ -56,7 +58,7 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       for (int i = 0; i < 16; ++i) acc[t][j][i] = 0.f;
 
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  constexpr int NTAPS = MODE == 0 ? 27 : 8;
+  constexpr int NTAPS = MODE == 0 ? 27 : (MODE == 1 ? 8 : 4), SD = MODE == 2 ? 1 : 2;
   for (int tap = blockIdx.z; tap < NTAPS; tap += gridDim.z) {
     const bf16_t* ap[MT];
     bool aok[MT];
@@ -70,7 +72,7 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
         vi = (((int64_t)vn[t] * D + dd) * H + hh) * W + ww;
       } else {
         aok[t] = vok[t];
-        vi = (((int64_t)vn[t] * 2 * D + 2 * vd[t] + (tap >> 2)) * 2 * H + 2 * vh[t] + ((tap >> 1) & 1)) * 2 * W +
+        vi = (((int64_t)vn[t] * SD * D + SD * vd[t] + (tap >> 2)) * 2 * H + 2 * vh[t] + ((tap >> 1) & 1)) * 2 * W +
              2 * vw[t] + (tap & 1);
       }
       ap[t] = x + (aok[t] ? vi : 0) * ldx + kh8;
@@ -436,7 +438,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
 __global__ void __launch_bounds__(DIRECT_THREADS)
 deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wf,
                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                int Cin, int Cout) {
+                int Cin, int Cout, int sd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh8 = (lane >> 5) * 8;
   const int64_t V = (int64_t)N * D * H * W;
@@ -472,7 +474,7 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int tap = tap0 + t;
-        const int64_t ov = ((vv * 2 * D + 2 * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
+        const int64_t ov = ((vv * sd * D + sd * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
         y[ov * ldy + co] = (bf16_t)(acc[t][i] + bv);
       }
     }
@@ -486,7 +488,8 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 template <int CIT>
 __global__ void __launch_bounds__(256)
 deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
-                  float* __restrict__ part, float* __restrict__ bpart, int N, int D, int H, int W, int Cin, int Cout) {
+                  float* __restrict__ part, float* __restrict__ bpart, int N, int D, int H, int W, int Cin, int Cout,
+                  int sd) {        // sd = 1: ConvTranspose2d per depth slice - taps 4..7 do not exist (zero fragments)
   constexpr int KV = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* xs = smem;                           // [CIT][KV][32] bf16
@@ -531,11 +534,13 @@ deconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         const int w0 = (int)(vv % W); vv /= W;
         const int h0 = (int)(vv % H); vv /= H;
         const int d0 = (int)(vv % D); vv /= D;
-        const int64_t obase = ((vv * 2 * D + 2 * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
+        const int64_t obase = ((vv * sd * D + sd * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
 #pragma unroll
         for (int tap = 0; tap < 8; ++tap) {
-          const int64_t ov = obase + ((int64_t)(tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1);
-          gv[tap] = *reinterpret_cast<const uint4*>(dy + ov * ldy + cot * 32 + c16 * 8);
+          if (tap < 4 * sd) {
+            const int64_t ov = obase + ((int64_t)(tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1);
+            gv[tap] = *reinterpret_cast<const uint4*>(dy + ov * ldy + cot * 32 + c16 * 8);
+          }
         }
       }
 #pragma unroll
@@ -601,7 +606,7 @@ __global__ void __launch_bounds__(64) deconv_bias_reduce(const float* __restrict
 // dw[ci][co][tap] (torch ConvTranspose3d layout) = sum_b part[b][pair][tap][c][ci%32][co%32]
 __global__ void __launch_bounds__(256)
 deconv_wgrad_reduce(const float* __restrict__ part, int nblk, int npairs, int cit, int Cin, int Cout,
-                    float* __restrict__ dw) {
+                    float* __restrict__ dw, int ntaps) {      // ntaps = 8, or 4 (the partials of taps 4..7 are dropped)
   __shared__ float red[256];
   const int64_t per = (int64_t)8 * cit * 1024, total = npairs * per;
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -617,7 +622,7 @@ deconv_wgrad_reduce(const float* __restrict__ part, int nblk, int npairs, int ci
   const int pair = (int)(i / per);
   const int ncig = Cin / (32 * cit);
   const int co = (pair / ncig) * 32 + co_l, ci = ((pair % ncig) * cit + c) * 32 + ci_l;
-  dw[((int64_t)ci * Cout + co) * 8 + tap] = t;
+  if (tap < ntaps) dw[((int64_t)ci * Cout + co) * ntaps + tap] = t;
 }
 
 struct DwCfg { int cit, npairs, nblk; size_t ws; };
@@ -1300,31 +1305,34 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
 }
 
 // ---- ConvTranspose3d(k=2,s=2) fast paths; same return convention
+// sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (4 taps, packs [4][..][..])
 extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, hipStream_t st) {
+                                     int n, int d, int h, int w, int cin, int cout, int sd, hipStream_t st) {
   if (cin % 16 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
-  dim3 grid((unsigned)((V + 127) / 128), cout / 32, 2);
+  dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
   deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
-                                                   h, w, cin, cout);
+                                                   h, w, cin, cout, sd);
   int rc = fplx_check_launch("mfma_deconv2_fwd");
   return rc < 0 ? rc : 1;
 }
 
 extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* wb, void* dx, int64_t ldx, int n, int d,
-                                       int h, int w, int cin, int cout, hipStream_t st) {
-  // GEMM view: K = 8 taps x Cout (channels of dy), columns = Cin
+                                       int h, int w, int cin, int cout, int sd, hipStream_t st) {
+  // GEMM view: K = 8 (or 4) taps x Cout (channels of dy), columns = Cin
   if (cout % 16 != 0 || cin % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16) || ((uintptr_t)wb % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
+#define LAUNCH_DD(MT_, NTL_, MODE_, GRID_)                                                                          \
+  conv_fwd_direct<MT_, NTL_, MODE_><<<GRID_, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr, \
+                                                                      (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr)
   if (cin % 64 == 0) {
     dim3 grid((unsigned)((V + 255) / 256), cin / 64);
-    conv_fwd_direct<2, 2, 1><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr,
-                                                              (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr);
+    if (sd == 2) LAUNCH_DD(2, 2, 1, grid); else LAUNCH_DD(2, 2, 2, grid);
   } else {
     dim3 grid((unsigned)((V + 511) / 512), cin / 32);
-    conv_fwd_direct<4, 1, 1><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr,
-                                                              (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr);
+    if (sd == 2) LAUNCH_DD(4, 1, 1, grid); else LAUNCH_DD(4, 1, 2, grid);
   }
+#undef LAUNCH_DD
   int rc = fplx_check_launch("mfma_deconv2_dgrad");
   return rc < 0 ? rc : 1;
 }
@@ -1336,7 +1344,7 @@ extern "C" size_t fplx_mfma_deconv2_wgrad_ws_bytes(int n, int d, int h, int w, i
 
 extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, float* db,
                                        int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
-                                       hipStream_t st) {
+                                       int sd, hipStream_t st) {
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
     return 0;
   const DwCfg c = dw_cfg(n, d, h, w, cin, cout);
@@ -1348,7 +1356,7 @@ extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* d
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)deconv_wgrad_mfma<CIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     deconv_wgrad_mfma<CIT><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, bpart, n, d, \
-                                                   h, w, cin, cout);                                                \
+                                                   h, w, cin, cout, sd);                                            \
   } while (0)
   if (c.cit == 4) LAUNCH_DW(4);
   else if (c.cit == 2) LAUNCH_DW(2);
@@ -1356,7 +1364,8 @@ extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* d
 #undef LAUNCH_DW
   const int64_t total = (int64_t)c.npairs * 8 * c.cit * 1024;
   if (db) deconv_bias_reduce<<<cout, 64, 0, st>>>(bpart, c.nblk, cout, db);
-  deconv_wgrad_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw);
+  deconv_wgrad_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, c.cit, cin, cout, dw,
+                                                                      4 * sd);
   int rc = fplx_check_launch("mfma_deconv2_wgrad");
   return rc < 0 ? rc : 1;
 }

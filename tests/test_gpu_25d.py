@@ -23,10 +23,12 @@ def uncl(t2, n, d, h, w):
     return t2.view(n, d, h, w, -1).permute(0, 4, 1, 2, 3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_maxpool122_and_deconv122_match_torch(dtype):
+@pytest.mark.parametrize("dtype,chans", [(torch.float32, (16, 24)), (torch.bfloat16, (16, 24)),
+                                         (torch.bfloat16, (64, 32)), (torch.bfloat16, (32, 64))])   # the last two: MFMA paths
+def test_maxpool122_and_deconv122_match_torch(dtype, chans):
     from fplx import ops
-    n, c, d, h, w, co = 2, 16, 5, 8, 12, 24
+    n, d, h, w = 2, 5, 8, 12
+    c, co = chans
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     x = torch.from_numpy(detdata.normal("p122.x", (n, c, d, h, w)))
     if dtype == torch.bfloat16:
