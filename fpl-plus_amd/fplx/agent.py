@@ -317,7 +317,8 @@ class SegmentationAgent(object):
             self.max_val_it = iter_start
             self.best_model_wts = self.checkpoint['model_state_dict']
         self.create_optimizer(self.get_parameters_to_update())
-        self.create_loss_calculator()
+        # training() (dual = False) adds the prediction-entropy term to each domain's loss (agent_seg.py:352-354)
+        self.create_loss_calculator(0.0 if self.dual else 1.0)
         self.glob_it = iter_start
         history = []
         for it in range(iter_start, iter_max, iter_valid):

@@ -203,3 +203,148 @@ def test_25d_bf16_engine_step_and_checkpoint_keys(tmp_path):
     assert list(msd.keys()) == C.reference_state_keys(2)
     assert tuple(msd["block0.conv.conv3d_1.weight"].shape) == (16, 1, 3, 3, 3)       # dead 3D twin of a 2D level
     assert tuple(msd["up4.trans3d.weight"].shape) == (32, 16, 2, 2, 2) and tuple(msd["up4.trans2d.weight"].shape) == (32, 16, 2, 2)
+
+
+SHIPPED_STYLE_CFG = """
+[dataset]
+tensor_type = float
+task_type = seg
+root_dir  = {root}
+1_train_csv = {root}/train_1.csv
+1_valid_csv = {root}/valid_1.csv
+2_train_csv = {root}/train_2.csv
+2_valid_csv = {root}/valid_2.csv
+test_csv  = {root}/test.csv
+train_batch_size = 2
+modal_num = 1
+
+# data transforms (the chain of config_dual/data_vs/vs_t1s_g.cfg)
+train_transform = [NormalizeWithMeanStd, Pad, RandomCrop, RandomFlip, LabelToProbability]
+valid_transform = [NormalizeWithMeanStd, Pad, LabelToProbability]
+test_transform  = [NormalizeWithMeanStd, Pad]
+NormalizeWithMeanStd_channels = [0]
+NormalizeWithMeanStd_mean = None
+NormalizeWithMeanStd_std  = None
+NormalizeWithMeanStd_inverse = False
+Pad_output_size = [12, 32, 48]
+Pad_ceil_mode   = False
+Pad_inverse     = True
+RandomCrop_output_size = [12, 32, 32]
+RandomCrop_foreground_focus = True
+RandomCrop_foreground_ratio = 0.5
+Randomcrop_mask_label       = [1, 2]
+RandomCrop_inverse     = False
+RandomFlip_flip_depth  = False
+RandomFlip_flip_height = True
+RandomFlip_flip_width  = True
+RandomFlip_inverse     = False
+LabelToProbability_class_num = 2
+LabelToProbability_inverse   = False
+
+[network]
+net_type = UNet2D5_dsbn
+num_domains = 2
+class_num     = 2
+in_chns       = 1
+feature_chns  = [8, 16, 32, 32, 32]
+conv_dims     = [2, 2, 3, 3, 3]
+dropout       = [0.0, 0.0, 0.3, 0.4, 0.5]
+bilinear      = False
+deep_supervise = False
+aes = False
+
+[training]
+aes = False
+train_fpl_uda  = True
+dis = False
+val_t1 = False
+val_t2 = True
+dual = False
+gpus       = [0]
+loss_type     = DiceLoss
+optimizer     = Adam
+learning_rate = 1e-2
+momentum      = 0.9
+weight_decay  = 1e-5
+lr_scheduler  = MultiStepLR
+lr_gamma      = 0.5
+lr_milestones = [10000, 20000]
+ckpt_save_dir    = {root}/model_dual/vs_t1s_g
+ckpt_save_prefix = ignored_like_in_the_reference
+iter_start = 0
+iter_max   = 4
+iter_valid = 2
+iter_save  = 2
+early_stop_patience = 100
+
+[testing]
+fpl = False
+gpus       = [0]
+domian_label = 1
+ae = None
+ckpt_mode         = 1
+output_dir        = {root}/results_dual/
+evaluation_mode   = True
+test_time_dropout = False
+tta_mode = 1
+sliding_window_enable = True
+sliding_window_size   = [12, 32, 32]
+sliding_window_stride = [12, 32, 32]
+
+[evaluation]
+metric_1 = dice
+metric_2 = assd
+label_list = [1]
+organ_name = tumor
+ground_truth_folder_root = {root}/lab
+test_evaluation_image_pair  = {root}/pair.csv
+valid_evaluation_image_pair = {root}/pair.csv
+"""
+
+
+def test_shipped_style_cfg_runs_train_test_evaluate(tmp_path):
+    """`python -m fplx.net_run train config.cfg` on a .cfg with the key surface of config_dual/data_vs/vs_t1s_g.cfg
+    (2.5D network, dual = False, val_t2, TTA + sliding window, ckpt_mode 1, Dice + ASSD evaluation) over synthetic
+    .nii.gz cases: training with validation and checkpoints, then inference with the best checkpoint, uint8 masks with
+    the inputs' geometry, and the Dice report."""
+    from fplx import net_run, nifti
+    root = tmp_path
+    rs = np.random.RandomState(9)
+    (root / "img").mkdir()
+    (root / "lab").mkdir()
+    names = []
+    for i in range(5):
+        shp = (12, 30 + 2 * (i % 2), 44)
+        lab = np.zeros(shp, np.uint8)
+        lab[3:9, 8 + i:20 + i, 10:30] = 1
+        img = rs.randn(*shp) * 15 + 90 + 70.0 * lab
+        nifti.write_nifti(str(root / "img" / ("c%d.nii.gz" % i)), img.astype(np.float32), (0.5, 0.5, 1.5))
+        nifti.write_nifti(str(root / "lab" / ("c%d.nii.gz" % i)), lab, (0.5, 0.5, 1.5))
+        names.append("c%d.nii.gz" % i)
+    rows = ["img/%s,lab/%s" % (n, n) for n in names]
+    (root / "train_1.csv").write_text("image,label\n" + "\n".join(rows[:3]) + "\n")
+    (root / "train_2.csv").write_text("image,label,pixel_weight,image_weight\n" + "\n".join(
+        "%s,lab/%s,0.9" % (r, n) for r, n in zip(rows[2:], names[2:])) + "\n")        # weights: the label volume itself
+    (root / "valid_1.csv").write_text("image,label\n" + rows[0] + "\n")
+    (root / "valid_2.csv").write_text("image,label\n" + rows[4] + "\n")
+    (root / "test.csv").write_text("image\n" + "\n".join("img/" + n for n in names[3:]) + "\n")
+    (root / "pair.csv").write_text("ground_truth,segmentation\n" + "\n".join("%s,%s" % (n, n) for n in names[3:]) + "\n")
+    cfg = root / "vs_like.cfg"
+    cfg.write_text(SHIPPED_STYLE_CFG.format(root=str(root)))
+    import random
+    random.seed(3)
+    res = net_run.main(["fplx.net_run", "train", str(cfg)])
+    ck = root / "model_dual" / "vs_t1s_g"
+    files = sorted(os.listdir(str(ck)))
+    assert "vs_t1s_g_latest.txt" in files and "vs_t1s_g_best.txt" in files and "log_train.txt" in files
+    assert any(f.endswith(".pt") for f in files)
+    out = root / "results_dual" / "vs_t1s_g_test"
+    for n in names[3:]:
+        m = nifti.load_nifty_volume_as_4d_array(str(out / n))
+        ref = nifti.load_nifty_volume_as_4d_array(str(root / "img" / n))
+        assert m["data_array"].dtype == np.uint8 and m["data_array"].shape == ref["data_array"].shape
+        assert m["spacing"] == ref["spacing"]
+    rep = (out / "test_tumor_dice_all.csv").read_text().strip().splitlines()
+    assert rep[0] == "image,class_1" and rep[-2].startswith("mean,") and rep[-1].startswith("std,")
+    assert res["test"][0].shape == (1,) and 0.0 <= float(res["test"][0][0]) <= 1.0
+    assert "evaluation_2 skipped" in (ck / "log_train.txt").read_text()          # metric_2 = assd needs GeodisTK
