@@ -348,3 +348,48 @@ def test_shipped_style_cfg_runs_train_test_evaluate(tmp_path):
     assert rep[0] == "image,class_1" and rep[-2].startswith("mean,") and rep[-1].startswith("std,")
     assert res["test"][0].shape == (1,) and 0.0 <= float(res["test"][0][0]) <= 1.0
     assert "evaluation_2 skipped" in (ck / "log_train.txt").read_text()          # metric_2 = assd needs GeodisTK
+
+
+def test_25d_split_concat_path_agrees_with_the_single_buffer_path():
+    """shipped channel widths (32 at level 0): the level-0 decoder convolution of a dim-2 level takes skip and up as two
+    tensors (fplx_conv3d_*_cat2) and its 27-tap weight gradient is reduced to the middle plane - same gradients as the
+    path that materialises the concatenation (FPLX_SPLIT_CAT=0), and the bf16-emulating oracle agrees."""
+    import fplx
+    from fplx import ops
+    from oracle import torch_ref as R
+    p = dict(in_chns=1, feature_chns=[32, 64, 64, 64, 64], dropout=[0, 0, 0, 0, 0], conv_dims=[2, 2, 3, 3, 3], class_num=2,
+             bilinear=False, num_domains=2, precision="bf16")
+    shape = (1, 1, 8, 64, 64)
+    assert ops.conv3d_cat2_ok((1, 8, 64, 64), 64, 32)
+    x = torch.from_numpy(detdata.normal("sc25.x", shape))
+    y = torch.zeros(1, 2, 8, 64, 64)
+    y[:, 0] = 1.0
+    y[:, 0, 2:6, 20:44, 16:50] = 0.0
+    y[:, 1, 2:6, 20:44, 16:50] = 1.0
+    grads = []
+    for split in (True, False):
+        net = fplx.UNet2D5_dsbn(dict(p))
+        load_det_weights(net, p, "cuda")
+        net.engine.use_split_cat = split
+        net.train()
+        lt = net(x.cuda(), domain_label=torch.ones(1, dtype=torch.long))
+        loss = fplx.DiceLoss()({"prediction": lt, "ground_truth": y.cuda()})
+        loss.backward()
+        grads.append(({k: t.grad.float().cpu().numpy().astype(np.float64) for k, t in net.named_parameters()
+                       if t.grad is not None}, float(loss.item()), lt.detach().float().cpu().numpy()))
+    (ga, la, oa), (gb, lb, ob) = grads
+    assert abs(la - lb) < 2e-3 and np.abs(oa - ob).max() < 5e-2 * np.abs(ob).max()
+    for k in ("up4.conv.conv2d_1.weight", "up4.trans2d.weight", "block0.conv.conv2d_2.weight", "up4.conv.conv2d_2.weight",
+              "block1.conv.conv2d_1.weight", "out_conv.weight"):
+        a, b = ga[k].reshape(-1), gb[k].reshape(-1)
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos > 0.98 and abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.1, (k, cos)
+    sd, prm = R.split_state(detdata.state_dict_3d(p))
+    ref = R.unet_forward(sd, p, x, 1, True, act_dtype=torch.bfloat16)
+    rl = R.dice_loss(ref, y)
+    rl.backward()
+    assert abs(la - rl.item()) < 2e-3
+    for k in ("up4.conv.conv2d_1.weight", "up4.trans2d.weight", "block0.conv.conv2d_2.weight"):
+        r, g = prm[k].grad.numpy().reshape(-1).astype(np.float64), ga[k].reshape(-1)
+        cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r)))
+        assert cos > 0.9, (k, cos)
