@@ -416,6 +416,11 @@ extern "C" int fplx_mfma_deconv2_wgrad(const void* x, int64_t ldx, const void* d
                                        int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
                                        int sd, hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_conv3d_mid_stats_rows(int n, int d, int h, int w, int cin, int cout);
+extern "C" size_t fplx_mfma_conv3d_mid_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y,
+                                        int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
+                                        size_t ws_bytes, hipStream_t st);
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
                                       const void* x1);
@@ -587,6 +592,42 @@ int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh,
   else return fplx_fail(FPLX_E_BADDTYPE, "conv3d_fwd: dtypes %d/%d", x_dt, y_dt);
 #undef LAUNCH
   return fplx_check_launch("conv3d_fwd");
+}
+
+/* ---- Conv2d(3x3) on every depth slice, given as a 27-tap pack that is zero outside the middle depth plane
+ * (fplx_pack_conv2d_weight).  Same arguments and results as fplx_conv3d_* with a 3x3x3 kernel; the hint lets the
+ * implicit-GEMM kernel skip the 18 dead taps. */
+int fplx_conv2d_stats_rows(int n, int d, int h, int w, int cin, int cout, int x_dt, int y_dt) {
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16) {
+    int r = fplx_mfma_conv3d_mid_stats_rows(n, d, h, w, cin, cout);
+    if (r > 0) return r;
+  }
+  return fplx_conv3d_stats_rows(n, d, h, w, cin, cout, 3, 3, 3, x_dt, y_dt);
+}
+
+size_t fplx_conv2d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout, int x_dt, int y_dt) {
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16) return fplx_mfma_conv3d_mid_fwd_ws_bytes(n, d, h, w, cin, cout);
+  return 0;
+}
+
+int fplx_conv2d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc, const void* wp,
+                    const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
+                    int n, int d, int h, int w, int cin, int cout, float* stats, void* ws, size_t ws_bytes,
+                    fplx_stream_t stream) {
+  FPLX_REQUIRE(x && wp && y, FPLX_E_NULL, "conv2d_fwd: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "conv2d_fwd: bad shape");
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && sc == 1 && yc == 1 && sh == sw * w && sd == sh * h && sn == sd * d &&
+      yh == yw * w && yd == yh * h && yn == yd * d) {
+    int r = fplx_mfma_conv3d_mid_fwd(x, sw, wp, bias, y, yw, n, d, h, w, cin, cout, stats, ws, ws_bytes, (hipStream_t)stream);
+    if (r != 0) return r < 0 ? r : FPLX_OK;
+  }
+  // not on the MFMA path (dtype / layout / alignment): all 27 taps through fplx_conv3d_fwd - the same result; the
+  // statistics rows promised by fplx_conv2d_stats_rows must then be the 3x3x3 path's
+  FPLX_REQUIRE(!stats || fplx_conv2d_stats_rows(n, d, h, w, cin, cout, x_dt, y_dt) ==
+                             fplx_conv3d_stats_rows(n, d, h, w, cin, cout, 3, 3, 3, x_dt, y_dt),
+               FPLX_E_BADSHAPE, "conv2d_fwd: operands are not laid out for the MFMA path the statistics rows were sized for");
+  return fplx_conv3d_fwd(x, x_dt, sn, sd, sh, sw, sc, wp, bias, y, y_dt, yn, yd, yh, yw, yc, n, d, h, w, cin, cout, 3, 3, 3,
+                         stats, ws, ws_bytes, stream);
 }
 
 size_t fplx_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw) {

@@ -897,7 +897,9 @@ template <int NT, int KC, int MTL>
 __global__ void __launch_bounds__(MTL * 2, MTL == 128 ? 2 : 1)
 conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-              float* __restrict__ stats, float* __restrict__ partial) {
+              float* __restrict__ stats, float* __restrict__ partial, int tap_lo, int tap_cnt) {
+  // tap_lo / tap_cnt: the taps to run - 0 / 27, or 9 / 9 for the 2.5D levels whose 27-tap packs are zero outside the
+  // middle depth plane (a third of the work, the same result)
   constexpr int THREADS = MTL * 2, NTW = NT / 64;            // N tiles (32 wide) per wave
   constexpr int ROWB = KC * 2, CH = KC / 8, RP = THREADS / CH;   // row bytes, 16-byte chunks per row, rows per pass
   constexpr int PA = MTL / RP, PB = NT / RP;                 // staging passes (chunks per thread) for A and B
@@ -933,7 +935,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     amask[u] = m;
   }
   const int nkc = Cin / KC;
-  const int ntaps = (27 - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int ntaps = (tap_cnt - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
   const int niter = ntaps * nkc;
   auto swz = [](int row) { return (row / (16 / CH)) % CH; };
   // named staging registers (runtime-indexed arrays would go to scratch).  The A loads are UNCONDITIONAL: a row
@@ -959,7 +961,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   if (PB > (U)) breg##S##U = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + RP * (U)) * Cin + kc_ + c16 * 8);
 #define TILE_FETCH(IT, S)                                                                                           \
   do {                                                                                                              \
-    const int tap_ = blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                                \
+    const int tap_ = tap_lo + blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                       \
     const int kd_ = tap_ / 9 - 1, kh_ = (tap_ / 3) % 3 - 1, kw_ = tap_ % 3 - 1;                                     \
     const int64_t aoff_ = (((int64_t)kd_ * H + kh_) * W + kw_) * ldx + kc_;     /* wave-uniform */                  \
     zmask##S = 0;                                                                                                   \
@@ -1135,7 +1137,7 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
 
 struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt, tile_mt; int64_t mblocks; };
 
-inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
+inline DirectCfg direct_cfg(int64_t V, int cin, int cout, int taps = 27) {
   DirectCfg c;
   if (cout % 64 == 0) { c.mt = 2; c.ntl = 2; }
   else { c.mt = 4; c.ntl = 1; }
@@ -1158,6 +1160,7 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout) {
     if (blocks * 9 < 256) c.ksplit = 27;
     else if (blocks * 3 < 256) c.ksplit = 9;
     else if (blocks < 256) c.ksplit = 3;
+    if (c.ksplit > taps) c.ksplit = taps;
   }
   if (c.tile_mt == 256) c.ksplit = 1;                        // chosen only where it fills the chip by itself
   {  // tuning knobs: FPLX_TILE_NT=64 forces the narrow tile, FPLX_TILE_KS forces the tap split (1/3/9/27)
@@ -1185,28 +1188,53 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
                                      const void* x1, void* y1);
 
-extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
+// mid != 0: the 27-tap pack is zero outside the middle depth plane (a Conv2d per depth slice, 2.5D levels).  Layers that
+// would go to the tile kernel run taps 9..17 only (measured 348 -> 155 us on the 128 -> 64 level-1 layer of the shipped
+// config); where a march kernel applies it keeps all 27 taps - its 1.0 PFLOP/s on three times the work still beats the
+// tile kernel's short-K form (111 vs 117 us at 64 -> 64, 52 vs 70 us at 32 -> 64).  Same result either way.
+static inline bool mid_tile(int mid, int n, int d, int h, int w, int cin, int cout) {
+  static const bool on = [] { const char* e = getenv("FPLX_MID_TILE"); return !e || atoi(e) != 0; }();   // A/B knob
+  return mid && on && cin % 32 == 0 && cout % 64 == 0 && !fplx_march_ok(n, d, h, w, cin, cout) &&
+         !stream_ok(d, h, w, cin, cout);
+}
+
+static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  const int64_t V = (int64_t)n * d * h * w;
   if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cin, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
-  const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cin, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   if (c.ksplit > 1) return c.fin_blocks;
   return (int)c.mblocks;
 }
 
-extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
-  if (cin % 16 != 0 || cout % 32 != 0 || fplx_march_ok(n, d, h, w, cin, cout) || stream_ok(d, h, w, cin, cout)) return 0;
+static size_t fwd_ws_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
+  if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  if (fplx_march_ok(n, d, h, w, cin, cout) || stream_ok(d, h, w, cin, cout)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cin, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
 }
 
-// returns 1 if handled, 0 if not applicable (caller falls back to the generic kernel), <0 on error
-extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                    int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
-                                    size_t ws_bytes, hipStream_t st) {
+extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
+  return stats_rows_impl(n, d, h, w, cin, cout, 0);
+}
+extern "C" int fplx_mfma_conv3d_mid_stats_rows(int n, int d, int h, int w, int cin, int cout) {
+  return stats_rows_impl(n, d, h, w, cin, cout, 1);
+}
+extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return fwd_ws_impl(n, d, h, w, cin, cout, 0);
+}
+extern "C" size_t fplx_mfma_conv3d_mid_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return fwd_ws_impl(n, d, h, w, cin, cout, 1);
+}
+
+static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy, int n, int d,
+                         int h, int w, int cin, int cout, float* stats, void* ws, size_t ws_bytes, int mid,
+                         hipStream_t st) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
+  const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
+  const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
   if (fplx_march_ok(n, d, h, w, cin, cout))
     return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr);
   if (stream_ok(d, h, w, cin, cout)) {
@@ -1227,7 +1255,7 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
     return rc0 < 0 ? rc0 : 1;
   }
   const int64_t V = (int64_t)n * d * h * w;
-  const DirectCfg c = direct_cfg(V, cin, cout);
+  const DirectCfg c = direct_cfg(V, cin, cout, tap_cnt);
   const int ks = c.ksplit;
   float* partial = nullptr;
   if (ks > 1) {
@@ -1244,7 +1272,7 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
     constexpr int LDS = 2 * (MT_ + NT_) * KC_ * 2;                                                                  \
     (void)hipFuncSetAttribute((const void*)conv_fwd_tile<NT_, KC_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
     conv_fwd_tile<NT_, KC_, MT_><<<tg, MT_ * 2, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, \
-                                                           n, d, h, w, cin, cout, stats, partial);                   \
+                                                           n, d, h, w, cin, cout, stats, partial, tap_lo, tap_cnt);  \
   } while (0)
     const bool k64 = cin % 64 == 0;
     if (c.tile_mt == 256) { if (c.tile_nt == 128) LAUNCH_TILE(128, 64, 256); else LAUNCH_TILE(64, 64, 256); }
@@ -1266,6 +1294,18 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
     splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
   int rc = fplx_check_launch("mfma_conv3d_fwd");
   return rc < 0 ? rc : 1;
+}
+
+// returns 1 if handled, 0 if not applicable (caller falls back to the generic kernel), <0 on error
+extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                    int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
+                                    size_t ws_bytes, hipStream_t st) {
+  return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, ws, ws_bytes, 0, st);
+}
+extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y,
+                                        int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
+                                        size_t ws_bytes, hipStream_t st) {
+  return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, ws, ws_bytes, 1, st);
 }
 
 extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout) {

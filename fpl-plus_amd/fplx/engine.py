@@ -133,11 +133,13 @@ class Engine(object):
             """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view"""
             conv, bn, prelu = site
             cout = conv.weight.shape[0]
+            mid = conv.weight.dim() == 4           # Conv2d of a 2.5D level: its pack lives in the middle depth plane
             y = empty(vox[l], cout)
             bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
             bnm = bn.bns[domain]
             if train:
-                rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt)
+                rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt,
+                                             mid and not isinstance(xin, tuple))
                 stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
             else:
                 rows, stats = 0, None
@@ -145,7 +147,7 @@ class Engine(object):
                 ops.conv3d_fwd_cat2(xin[0], xin[1], packs[key][0], conv.bias, y, dims[l], cin, cout, stats)
             else:
                 ops.conv3d_fwd(xin, xs, x_dt, packs[key][0], conv.bias, y, ops.cl_strides(*dims[l][1:], cout), a_dt,
-                               dims[l], cin, cout, (3, 3, 3), stats)
+                               dims[l], cin, cout, (3, 3, 3), stats, mid=mid)
             if train:
                 ops.bn_train_finalize(stats, rows, cout, vox[l], bnm.weight, bnm.bias, bnm.running_mean,
                                       bnm.running_var, bnm.num_batches_tracked, bnbuf, bnm.momentum, bnm.eps)
@@ -309,7 +311,8 @@ class Engine(object):
             on_side(wg, d_out, xin, dw)
             if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
-                               ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None)
+                               ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None,
+                               mid=two_d)
 
         def block_bwd(b, d_out, want_dx):
             """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""

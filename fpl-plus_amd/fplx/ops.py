@@ -78,32 +78,43 @@ def conv2d_wgrad_extract(dw27, dw9):
     call("fplx_conv2d_wgrad_extract", ptr(dw27), ptr(dw9), co, ci, stream())
 
 
-def conv3d_stats_rows(dims, cin, cout, k, x_dt, y_dt):
+def conv3d_stats_rows(dims, cin, cout, k, x_dt, y_dt, mid=False):
+    """mid: the pack is a Conv2d in the middle depth plane (pack_conv2d_weight) - the fplx_conv2d_* form"""
     n, d, h, w = dims
+    if mid:
+        return _lib.lib().fplx_conv2d_stats_rows(n, d, h, w, cin, cout, x_dt, y_dt)
     return _lib.lib().fplx_conv3d_stats_rows(n, d, h, w, cin, cout, k[0], k[1], k[2], x_dt, y_dt)
 
 
 _fwd_ws = {}
 
 
-def conv3d_fwd_ws_bytes(dims, cin, cout, k, x_dt, y_dt):
+def conv3d_fwd_ws_bytes(dims, cin, cout, k, x_dt, y_dt, mid=False):
     n, d, h, w = dims
+    if mid:
+        return _lib.lib().fplx_conv2d_fwd_ws_bytes(n, d, h, w, cin, cout, x_dt, y_dt)
     return _lib.lib().fplx_conv3d_fwd_ws_bytes(n, d, h, w, cin, cout, k[0], k[1], k[2], x_dt, y_dt)
 
 
-def conv3d_fwd(x, xs, x_dt, wp, bias, y, ys, y_dt, dims, cin, cout, k, stats=None, ws=None):
+def conv3d_fwd(x, xs, x_dt, wp, bias, y, ys, y_dt, dims, cin, cout, k, stats=None, ws=None, mid=False):
     n, d, h, w = dims
     if ws is None:
-        need = conv3d_fwd_ws_bytes(dims, cin, cout, k, x_dt, y_dt)
+        need = conv3d_fwd_ws_bytes(dims, cin, cout, k, x_dt, y_dt, mid)
         if need:
             # per-device scratch for the split-K kernels; consecutive launches on one stream may share it
             key = y.device
             if key not in _fwd_ws or _fwd_ws[key].numel() < need:
                 _fwd_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=y.device)
             ws = _fwd_ws[key]
+    nws = 0 if ws is None else ws.numel() * ws.element_size()
+    if mid:
+        assert tuple(k) == (3, 3, 3)
+        call("fplx_conv2d_fwd", ptr(x), x_dt, xs[0], xs[1], xs[2], xs[3], xs[4], ptr(wp), ptr(bias),
+             ptr(y), y_dt, ys[0], ys[1], ys[2], ys[3], ys[4], n, d, h, w, cin, cout, ptr(stats), ptr(ws), nws, stream())
+        return
     call("fplx_conv3d_fwd", ptr(x), x_dt, xs[0], xs[1], xs[2], xs[3], xs[4], ptr(wp), ptr(bias),
          ptr(y), y_dt, ys[0], ys[1], ys[2], ys[3], ys[4], n, d, h, w, cin, cout, k[0], k[1], k[2],
-         ptr(stats), ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(), stream())
+         ptr(stats), ptr(ws), nws, stream())
 
 
 def conv3d_wgrad_ws_bytes(dims, cin, cout, k):

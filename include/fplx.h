@@ -132,8 +132,16 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
  *  - MaxPool2d(2)        = maxpool122: x [N,D,H,W,C] -> y [N,D,H/2,W/2,C]
  *  - ConvTranspose2d(2,2) = deconv122: x [N,D,H,W,Cin] -> y [N,D,2H,2W,Cout]; weights fp32 [Cin][Cout][2][2] packed to
  *    wf [4][Cout][Cin], wb [4][Cin][Cout]; dw fp32 [Cin][Cout][2][2]
- *  BatchNorm2d over (N D, C, H, W) has the statistics of BatchNorm3d over (N, C, D, H, W): same kernels. */
+ *  BatchNorm2d over (N D, C, H, W) has the statistics of BatchNorm3d over (N, C, D, H, W): same kernels.
+ *  fplx_conv2d_* = fplx_conv3d_* (3x3x3) for such packs, same arguments and results; knowing that only the middle plane
+ *  is live, the implicit-GEMM kernel runs 9 taps instead of 27. */
 int fplx_pack_conv2d_weight(const float* w, void* wf, void* wb, int cout, int cin, int dt, fplx_stream_t stream);
+int fplx_conv2d_stats_rows(int n, int d, int h, int w, int cin, int cout, int x_dt, int y_dt);
+size_t fplx_conv2d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout, int x_dt, int y_dt);
+int fplx_conv2d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                    const void* wp, const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh,
+                    int64_t yw, int64_t yc, int n, int d, int h, int w, int cin, int cout,
+                    float* stats, void* ws, size_t ws_bytes, fplx_stream_t stream);
 int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream);
 int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
                         int dt, fplx_stream_t stream);

@@ -80,7 +80,8 @@ def test_maxpool122_and_deconv122_match_torch(dtype, chans):
 
 
 @pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 5, 12, 3, 9, 10)), (torch.bfloat16, (1, 32, 64, 4, 16, 24)),
-                                         (torch.bfloat16, (1, 64, 32, 6, 16, 80))])
+                                         (torch.bfloat16, (1, 64, 32, 6, 16, 80)), (torch.bfloat16, (2, 64, 64, 6, 16, 80)),
+                                         (torch.bfloat16, (1, 128, 64, 3, 8, 9)), (torch.bfloat16, (2, 64, 128, 2, 5, 6))])
 def test_conv2d_through_the_3d_kernels(dtype, shape):
     """Conv2d(3x3) per depth slice = the 3x3x3 kernels on weights packed into the middle depth plane: forward, data
     gradient, and the weight gradient as the middle plane of the 27-tap gradient."""
@@ -103,6 +104,17 @@ def test_conv2d_through_the_3d_kernels(dtype, shape):
     ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
                    (3, 3, 3), None)
     assert float((uncl(y.float().cpu(), n, d, h, w) - yr.detach()).abs().max()) < tol * float(yr.abs().max())
+    # the fplx_conv2d_* form (hint: only the middle plane is live -> 9 taps where the tile kernel applies), + statistics
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt, mid=True)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+    y2 = torch.empty_like(y)
+    ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y2, ops.cl_strides(d, h, w, cout), dt, dims, cin,
+                   cout, (3, 3, 3), stats, mid=True)
+    assert float((uncl(y2.float().cpu(), n, d, h, w) - yr.detach()).abs().max()) < tol * float(yr.abs().max())
+    yf = cl(yr.detach())
+    np.testing.assert_allclose(stats.sum(0)[0].cpu().numpy(), yf.sum(0).numpy(),
+                               atol=tol * float(yr.abs().max()) * yf.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(stats.sum(0)[1].cpu().numpy(), (yf * yf).sum(0).numpy(), rtol=max(tol, 1e-4) * 4)
     dx = torch.empty_like(xg)
     ops.conv3d_fwd(dyg, ops.cl_strides(d, h, w, cout), dt, wb, None, dx, ops.cl_strides(d, h, w, cin), dt, dims, cout, cin,
                    (3, 3, 3), None)
