@@ -428,7 +428,7 @@ extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, i
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
-                                     const void* x1, void* y1);
+                                     const void* x1, void* y1, int twod);
 
 extern "C" {
 
@@ -653,29 +653,49 @@ int fplx_conv3d_cat2_ok(int n, int d, int h, int w, int cin, int cout) {
          fplx_mfma_conv3d_wgrad_cit(n, d, h, w, 64, cout) == 2;
 }
 
-int fplx_conv3d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
-                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+static int fwd_cat2_impl(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats, int mid,
                          fplx_stream_t stream) {
   FPLX_REQUIRE(x0 && x1 && wp && y, FPLX_E_NULL, "conv3d_fwd_cat2: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
                "conv3d_fwd_cat2: shape n=%d d=%d h=%d w=%d cin=%d cout=%d not supported (fplx_conv3d_cat2_ok)", n, d,
                h, w, cin, cout);
   const int r = fplx_march_conv3d_fwd(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (hipStream_t)stream, x1,
-                                      nullptr);
+                                      nullptr, mid);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_cat2: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
 }
 
-int fplx_conv3d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
-                             int d, int h, int w, int cin, int cout, fplx_stream_t stream) {
+static int dgrad_split2_impl(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, int mid, fplx_stream_t stream) {
   FPLX_REQUIRE(dy && wb && dx0 && dx1, FPLX_E_NULL, "conv3d_dgrad_split2: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
                "conv3d_dgrad_split2: shape not supported (fplx_conv3d_cat2_ok)");
   // the data gradient is the convolution of dy (cout channels) with the mirrored pack, producing cin channels
   const int r = fplx_march_conv3d_fwd(dy, ldy, wb, nullptr, dx0, ldx, n, d, h, w, cout, cin, nullptr,
-                                      (hipStream_t)stream, nullptr, dx1);
+                                      (hipStream_t)stream, nullptr, dx1, mid);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_dgrad_split2: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
+}
+
+int fplx_conv3d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+                         fplx_stream_t stream) {
+  return fwd_cat2_impl(x0, x1, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, 0, stream);
+}
+int fplx_conv3d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, fplx_stream_t stream) {
+  return dgrad_split2_impl(dy, ldy, wb, dx0, dx1, ldx, n, d, h, w, cin, cout, 0, stream);
+}
+/* the same two operations for a pack that is a Conv2d in the middle depth plane (fplx_conv2d_*) */
+int fplx_conv2d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+                         fplx_stream_t stream) {
+  return fwd_cat2_impl(x0, x1, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, 1, stream);
+}
+int fplx_conv2d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, fplx_stream_t stream) {
+  return dgrad_split2_impl(dy, ldy, wb, dx0, dx1, ldx, n, d, h, w, cin, cout, 1, stream);
 }
 
 int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,

@@ -93,6 +93,10 @@ __device__ __forceinline__ void march_step(const char* __restrict__ sl, const ch
   }
 }
 
+// TWOD: the pack is a Conv2d in the middle depth plane (2.5D levels, fplx_pack_conv2d_weight): a slab feeds only its own
+// output depth, through the kd = 1 taps - step mask 2, a third of the MFMAs, no depth halo; the accumulator roles and
+// the write-out pipeline are the same (K0 stays zero and keeps re-initialising K1 through the role shift).
+template <bool TWOD>
 __global__ void __launch_bounds__(MG::THREADS)
 conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
@@ -163,9 +167,10 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = K1a[i] = K1b[i] = K2a[i] = K2b[i] = Ra[i] = Rb[i] = 0.f;
 
   // prologue: first slab, resident weights (same LDS-DMA, source-side swizzle), bias
-  if (d0 - 1 >= 0) {
+  const int sbase = TWOD ? d0 : d0 - 1;           // first slab of the march
+  if (sbase >= 0) {
 #pragma unroll
-    for (int k = 0; k < NPIECE; ++k) slab_piece(d0 - 1, k, soff_s[k * MG::THREADS + tid]);
+    for (int k = 0; k < NPIECE; ++k) slab_piece(sbase, k, soff_s[k * MG::THREADS + tid]);
   }
   for (int j = wave; j < 27 * 32 * MG::CH / 64; j += 8) {
     const int i = j * 64 + lane;
@@ -226,11 +231,14 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   // [d0, d1): 1, 3, 7 ... 7, 6, 4 over the block's nd + 2 slabs.  The depth that completed in step t - 1 is written
   // out during step t (stages 0..8: M-tile 0 -> LDS tile, flush, M-tile 1, flush); the DMA of slab s + 1 goes out in stages
   // 0..NPIECE-1; both are long finished when the step's closing vmcnt(0) + barrier is reached.
+  // TWOD: slabs d0 .. d1-1 (step mask 2) and one closing step; a result is written out two steps after its slab, like
+  // the kd = 1 plane of the 3D march (K1 -> K2 -> R).
   const int nd = d1 - d0;                         // >= 2 (march_cfg)
-  for (int t = 0; t < nd + 2; ++t) {
-    const int s = d0 - 1 + t;
-    const bool fetch = s + 1 <= d1 && s + 1 < D;
-    const bool wout = t >= 3;
+  const int nsteps = TWOD ? nd + 1 : nd + 2;
+  for (int t = 0; t < nsteps; ++t) {
+    const int s = sbase + t;
+    const bool fetch = TWOD ? s + 1 < d1 : (s + 1 <= d1 && s + 1 < D);
+    const bool wout = t >= (TWOD ? 2 : 3);
     const int o = s - 2;                           // depth written out during this step
     const char* sl = slabs + ((s + 1) & 1) * MG::SLAB_BYTES;
     int so[NPIECE];                                 // one batch of LDS reads, consumed over the first stages
@@ -249,12 +257,16 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       }
     };
 #define MARCH_STEP(MASK) march_step<MASK>(sl, wbuf, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side)
-    if (s >= 0 && s < D) {                 // a padding slab contributes nothing to the accumulators
-      if (t == 0) MARCH_STEP(1);
-      else if (t == 1) MARCH_STEP(3);
-      else if (t < nd) MARCH_STEP(7);
-      else if (t == nd) MARCH_STEP(6);
-      else MARCH_STEP(4);
+    if (TWOD ? t < nd : (s >= 0 && s < D)) {   // a padding slab contributes nothing to the accumulators
+      if constexpr (TWOD) {
+        MARCH_STEP(2);
+      } else {
+        if (t == 0) MARCH_STEP(1);
+        else if (t == 1) MARCH_STEP(3);
+        else if (t < nd) MARCH_STEP(7);
+        else if (t == nd) MARCH_STEP(6);
+        else MARCH_STEP(4);
+      }
     } else {                                           // ... but the DMA and the write-out still have to happen
 #pragma unroll
       for (int q = 0; q < 9; ++q) side(q);
@@ -369,7 +381,7 @@ __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const 
   }
 }
 
-template <class G>
+template <class G, bool TWOD>          // TWOD: see conv_fwd_march32
 __global__ void __launch_bounds__(256)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
@@ -429,9 +441,10 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = K1a[i] = K1b[i] = K2a[i] = K2b[i] = Ra[i] = Rb[i] = 0.f;
 
   // prologue: both halves of the first slab, the resident weights (source-side swizzle), bias
-  if (d0 - 1 >= 0) {
+  const int sbase = TWOD ? d0 : d0 - 1;
+  if (sbase >= 0) {
 #pragma unroll
-    for (int k = 0; k < NPIECE; ++k) { slab_piece(d0 - 1, 0, k); }
+    for (int k = 0; k < NPIECE; ++k) { slab_piece(sbase, 0, k); }
   }
   for (int j = wave; j < 2 * 27 * 32 * G::CH / 64; j += 4) {
     const int i = j * 64 + lane;                             // chunk index over [half][tap][co][4 chunks]
@@ -499,17 +512,19 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   // half-slab (the other half of s, or half 0 of s + 1) into the other slot; during half 0 also the write-out of the
   // depth that completed in step t - 1 (R): stages 0-3 M-tile 0 -> LDS tile, flush, stages 4-7 M-tile 1, flush.
   const int nd = d1 - d0;                         // >= 2 (march_cfg)
-  // (half 1 of slab d0 - 1 is fetched by half-step (0, 0) like every other half-slab)
-  for (int t = 0; t < nd + 2; ++t) {
-    const int s = d0 - 1 + t;
-    const bool live = s >= 0 && s < D;             // a padding slab contributes nothing
-    const bool wout = t >= 3;
+  // (half 1 of the first slab is fetched by half-step (0, 0) like every other half-slab)
+  const int nsteps = TWOD ? nd + 1 : nd + 2;
+  for (int t = 0; t < nsteps; ++t) {
+    const int s = sbase + t;
+    const bool live = TWOD ? t < nd : (s >= 0 && s < D);   // a padding slab contributes nothing
+    const bool wout = t >= (TWOD ? 2 : 3);
     const int o = s - 2;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       // next half-slab: (s, 1) after (s, 0); (s + 1, 0) after (s, 1)
       const int ns = hf == 0 ? s : s + 1, nh = hf ^ 1;
-      const bool fetch = ns >= 0 && ns < D && ns <= d1 && (hf == 0 ? live : true);
+      const bool fetch = TWOD ? (hf == 0 ? live : ns < d1)
+                              : (ns >= 0 && ns < D && ns <= d1 && (hf == 0 ? live : true));
       auto side = [&](int q, int g) {
         if (g == 5 && q < NPIECE && fetch) slab_piece(ns, nh, q < NPIECE ? q : 0);
         if (hf == 0 && wout && q < 8) {
@@ -529,11 +544,15 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     else march64_half<MASK, false, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);                  \
   } while (0)
       if (live) {
-        if (t == 0) M64_STEP(1);
-        else if (t == 1) M64_STEP(3);
-        else if (t < nd) M64_STEP(7);
-        else if (t == nd) M64_STEP(6);
-        else M64_STEP(4);
+        if constexpr (TWOD) {
+          M64_STEP(2);
+        } else {
+          if (t == 0) M64_STEP(1);
+          else if (t == 1) M64_STEP(3);
+          else if (t < nd) M64_STEP(7);
+          else if (t == nd) M64_STEP(6);
+          else M64_STEP(4);
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -635,9 +654,11 @@ extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout) {
 }
 
 // returns 1 if launched, 0 if the pointers do not allow the vector stores, <0 on error
+// twod: the pack is a Conv2d in the middle depth plane (fplx_pack_conv2d_weight) - the Cin = 32 march then runs its
+// kd = 1 taps only (same result, a third of the MFMAs)
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
-                                     const void* x1, void* y1) {
+                                     const void* x1, void* y1, int twod) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0 ||
       ((uintptr_t)x1 % 16) != 0 || ((uintptr_t)y1 % 16) != 0)
     return 0;
@@ -645,26 +666,30 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   dim3 grid(c.nblk, cout / 32);
   if (cin == 64) {
     if (y1) return 0;
-    if (c.fw == 16) {
-      using G16 = MG64T<16>;
-      (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G16>, hipFuncAttributeMaxDynamicSharedMemorySize, G16::LDS);
-      conv_fwd_march64<G16><<<grid, G16::THREADS, G16::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,
-                                                                  (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH,
-                                                                  c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);
-    } else {
-      (void)hipFuncSetAttribute((const void*)conv_fwd_march64<MG64>, hipFuncAttributeMaxDynamicSharedMemorySize, MG64::LDS);
-      conv_fwd_march64<MG64><<<grid, MG64::THREADS, MG64::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,
-                                                                     (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH,
-                                                                     c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);
-    }
+#define LAUNCH_M64(G_, TWOD_)                                                                                       \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_fwd_march64<G_, TWOD_><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,    \
+                                                                    (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
+                                                                    c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);   \
+  } while (0)
+    using G16 = MG64T<16>;
+    if (c.fw == 16) { if (twod) LAUNCH_M64(G16, true); else LAUNCH_M64(G16, false); }
+    else { if (twod) LAUNCH_M64(MG64, true); else LAUNCH_M64(MG64, false); }
+#undef LAUNCH_M64
     const int rc64 = fplx_check_launch("march64_conv3d_fwd");
     return rc64 < 0 ? rc64 : 1;
   }
   if (x1) return 0;
-  (void)hipFuncSetAttribute((const void*)conv_fwd_march32, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS);
-  conv_fwd_march32<<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n,
-                                                       d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, c.dlen,
-                                                       (bf16_t*)y1, y1 ? cout / 64 : cout / 32);
+#define LAUNCH_M32(TWOD_)                                                                                           \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march32<TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS); \
+    conv_fwd_march32<TWOD_><<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+                                                                ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32);    \
+  } while (0)
+  if (twod) LAUNCH_M32(true); else LAUNCH_M32(false);
+#undef LAUNCH_M32
   const int rc = fplx_check_launch("march_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }

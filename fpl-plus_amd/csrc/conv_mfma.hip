@@ -1186,7 +1186,7 @@ extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
-                                     const void* x1, void* y1);
+                                     const void* x1, void* y1, int twod);
 
 // mid != 0: the 27-tap pack is zero outside the middle depth plane (a Conv2d per depth slice, 2.5D levels).  Layers that
 // would go to the tile kernel run taps 9..17 only (measured 348 -> 155 us on the 128 -> 64 level-1 layer of the shipped
@@ -1236,7 +1236,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
   if (fplx_march_ok(n, d, h, w, cin, cout))
-    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr);
+    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, mid);
   if (stream_ok(d, h, w, cin, cout)) {
     const StreamCfg sc = stream_cfg(n, d, h, w, cout);
     dim3 grid(sc.nblk, cout / 32);

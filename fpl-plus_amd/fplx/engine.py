@@ -138,13 +138,12 @@ class Engine(object):
             bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
             bnm = bn.bns[domain]
             if train:
-                rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt,
-                                             mid and not isinstance(xin, tuple))
+                rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt, mid)
                 stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
             else:
                 rows, stats = 0, None
             if isinstance(xin, tuple):
-                ops.conv3d_fwd_cat2(xin[0], xin[1], packs[key][0], conv.bias, y, dims[l], cin, cout, stats)
+                ops.conv3d_fwd_cat2(xin[0], xin[1], packs[key][0], conv.bias, y, dims[l], cin, cout, stats, mid)
             else:
                 ops.conv3d_fwd(xin, xs, x_dt, packs[key][0], conv.bias, y, ops.cl_strides(*dims[l][1:], cout), a_dt,
                                dims[l], cin, cout, (3, 3, 3), stats, mid=mid)
@@ -300,7 +299,7 @@ class Engine(object):
                         ops.conv2d_wgrad_extract(dw, gw)
                 on_side(wg_cat, d_out, xin[0], xin[1], dw)
                 if want_dx:
-                    ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c)
+                    ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c, two_d)
                 return
 
             def wg():

@@ -136,17 +136,17 @@ def conv3d_cat2_ok(dims, cin, cout):
     return _lib.lib().fplx_conv3d_cat2_ok(n, d, h, w, cin, cout) == 1
 
 
-def conv3d_fwd_cat2(x0, x1, wp, bias, y, dims, cin, cout, stats=None):
+def conv3d_fwd_cat2(x0, x1, wp, bias, y, dims, cin, cout, stats=None, mid=False):
     n, d, h, w = dims
     assert ld_of(x0) == ld_of(x1)
-    call("fplx_conv3d_fwd_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(wp), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin,
+    call("fplx_conv2d_fwd_cat2" if mid else "fplx_conv3d_fwd_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(wp), ptr(bias), ptr(y), ld_of(y), n, d, h, w, cin,
          cout, ptr(stats), stream())
 
 
-def conv3d_dgrad_split2(dy, wb, dx0, dx1, dims, cin, cout):
+def conv3d_dgrad_split2(dy, wb, dx0, dx1, dims, cin, cout, mid=False):
     n, d, h, w = dims
     assert ld_of(dx0) == ld_of(dx1)
-    call("fplx_conv3d_dgrad_split2", ptr(dy), ld_of(dy), ptr(wb), ptr(dx0), ptr(dx1), ld_of(dx0), n, d, h, w, cin,
+    call("fplx_conv2d_dgrad_split2" if mid else "fplx_conv3d_dgrad_split2", ptr(dy), ld_of(dy), ptr(wb), ptr(dx0), ptr(dx1), ld_of(dx0), n, d, h, w, cin,
          cout, stream())
 
 

@@ -142,6 +142,11 @@ int fplx_conv2d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh,
                     const void* wp, const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh,
                     int64_t yw, int64_t yc, int n, int d, int h, int w, int cin, int cout,
                     float* stats, void* ws, size_t ws_bytes, fplx_stream_t stream);
+int fplx_conv2d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, void* y,
+                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats,
+                         fplx_stream_t stream);                     /* = fplx_conv3d_fwd_cat2 for such packs */
+int fplx_conv2d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
+                             int d, int h, int w, int cin, int cout, fplx_stream_t stream);
 int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream);
 int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
                         int dt, fplx_stream_t stream);

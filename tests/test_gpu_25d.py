@@ -81,7 +81,10 @@ def test_maxpool122_and_deconv122_match_torch(dtype, chans):
 
 @pytest.mark.parametrize("dtype,shape", [(torch.float32, (2, 5, 12, 3, 9, 10)), (torch.bfloat16, (1, 32, 64, 4, 16, 24)),
                                          (torch.bfloat16, (1, 64, 32, 6, 16, 80)), (torch.bfloat16, (2, 64, 64, 6, 16, 80)),
-                                         (torch.bfloat16, (1, 128, 64, 3, 8, 9)), (torch.bfloat16, (2, 64, 128, 2, 5, 6))])
+                                         (torch.bfloat16, (1, 128, 64, 3, 8, 9)), (torch.bfloat16, (2, 64, 128, 2, 5, 6)),
+                                         # the march kernels' middle-plane mode: Cin 32 / 64, ragged tiles, depth segments
+                                         (torch.bfloat16, (1, 32, 32, 5, 16, 64)), (torch.bfloat16, (2, 32, 64, 21, 20, 70)),
+                                         (torch.bfloat16, (1, 64, 96, 9, 24, 64)), (torch.bfloat16, (1, 64, 32, 4, 9, 70))])
 def test_conv2d_through_the_3d_kernels(dtype, shape):
     """Conv2d(3x3) per depth slice = the 3x3x3 kernels on weights packed into the middle depth plane: forward, data
     gradient, and the weight gradient as the middle plane of the 27-tap gradient."""
