@@ -423,7 +423,7 @@ extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* 
                                         size_t ws_bytes, hipStream_t st);
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
-                                      const void* x1);
+                                      const void* x1, int mid);
 extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
@@ -698,16 +698,25 @@ int fplx_conv2d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* 
   return dgrad_split2_impl(dy, ldy, wb, dx0, dx1, ldx, n, d, h, w, cin, cout, 1, stream);
 }
 
-int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
-                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+static int wgrad_cat2_impl(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, int mid, fplx_stream_t stream) {
   FPLX_REQUIRE(x0 && x1 && dy && dw && ws, FPLX_E_NULL, "conv3d_wgrad_cat2: null pointer");
   FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout), FPLX_E_BADSHAPE,
                "conv3d_wgrad_cat2: shape not supported (fplx_conv3d_cat2_ok)");
   const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
   FPLX_REQUIRE(ws_bytes >= m, FPLX_E_WORKSPACE, "conv3d_wgrad_cat2: workspace %zu < %zu", ws_bytes, m);
-  const int r = fplx_mfma_conv3d_wgrad(x0, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, m, (hipStream_t)stream, x1);
+  const int r = fplx_mfma_conv3d_wgrad(x0, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, m, (hipStream_t)stream, x1, mid);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_wgrad_cat2: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
+}
+int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  return wgrad_cat2_impl(x0, x1, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, 0, stream);
+}
+/* dw fp32 [Cout][Cin][3][3]: the weight gradient of a Conv2d per depth slice (only the middle-plane taps are computed) */
+int fplx_conv2d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  return wgrad_cat2_impl(x0, x1, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, 1, stream);
 }
 
 int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
@@ -729,7 +738,7 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
       sh == sw * w && sd == sh * h && sn == sd * d && yh == yw * w && yd == yh * h && yn == yd * d) {
     const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
     if (m > 0) {
-      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st, nullptr);
+      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st, nullptr, 0);
       if (r < 0) return r;
       if (r == 1) { done = true; used = m; }
     }
@@ -772,6 +781,44 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
     else launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, d, h, w, cout, bpart, db, st);
   }
   return fplx_check_launch("conv3d_wgrad");
+}
+
+/* ---- weight gradient of a Conv2d(3x3) per depth slice: dw fp32 [Cout][Cin][3][3], db fp32 [Cout] or NULL.
+ * bf16 NDHWC operands: the MFMA stream kernel in its middle-plane mode (9 of 27 taps).  Anything else: the 3x3x3 path
+ * into a 27-tap scratch at the end of the workspace, then its middle plane. */
+size_t fplx_conv2d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return fplx_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, 3, 3) + (size_t)27 * cout * cin * sizeof(float) + 256;
+}
+
+int fplx_conv2d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc, const void* dy,
+                      int dy_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc, float* dw, float* db, int n,
+                      int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && dy && dw && ws, FPLX_E_NULL, "conv2d_wgrad: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "conv2d_wgrad: bad shape");
+  FPLX_REQUIRE(ws_bytes >= fplx_conv2d_wgrad_ws_bytes(n, d, h, w, cin, cout), FPLX_E_WORKSPACE,
+               "conv2d_wgrad: workspace %zu < %zu", ws_bytes, fplx_conv2d_wgrad_ws_bytes(n, d, h, w, cin, cout));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t w3 = fplx_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout, 3, 3, 3);
+  if (x_dt == FPLX_BF16 && dy_dt == FPLX_BF16 && sc == 1 && yc == 1 && sh == sw * w && sd == sh * h && sn == sd * d &&
+      yh == yw * w && yd == yh * h && yn == yd * d) {
+    const size_t m = fplx_mfma_conv3d_wgrad_ws_bytes(n, d, h, w, cin, cout);
+    if (m > 0) {
+      int r = fplx_mfma_conv3d_wgrad(x, sw, dy, yw, dw, n, d, h, w, cin, cout, ws, m, st, nullptr, 1);
+      if (r < 0) return r;
+      if (r == 1) {
+        if (db) {
+          Strides ys{yn, yd, yh, yw, yc};
+          launch_bias_grad<bf16_t>((const bf16_t*)dy, ys, n, d, h, w, cout, (float*)((char*)ws + m), db, st);
+        }
+        return fplx_check_launch("conv2d_wgrad");
+      }
+    }
+  }
+  float* dw27 = (float*)((char*)ws + ((w3 + 255) / 256) * 256);
+  int rc = fplx_conv3d_wgrad(x, x_dt, sn, sd, sh, sw, sc, dy, dy_dt, yn, yd, yh, yw, yc, dw27, db, n, d, h, w, cin, cout, 3,
+                             3, 3, ws, w3, stream);
+  if (rc != FPLX_OK) return rc;
+  return fplx_conv2d_wgrad_extract(dw27, dw, cout, cin, stream);
 }
 
 // sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels)

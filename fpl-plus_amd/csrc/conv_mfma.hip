@@ -173,10 +173,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
 
 // one depth step of conv_wgrad_stream for wave WV: its taps WV, WV+4, ... are compile-time constants, so the
 // k-loop is straight-line code: 2 + 14 transposed reads for step ks+1 in flight behind the 7 MFMAs of step ks
-template <int WV, int TW, int CIT>
+// TWOD: the layer is a Conv2d per depth slice (2.5D levels): only the middle-plane taps 9..17 exist - wave WV owns
+// 9 + WV, 13 + WV (and 17 for wave 0): a third of the MFMAs, the other accumulators stay untouched
+template <int WV, int TW, int CIT, bool TWOD>
 __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const char* sl0, const char* sl1,
                                                  const char* sl2, const char* dys, int lane_off) {
-  constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16, NT = (27 - WV + 3) / 4;     // NT = 7 (6 for wave 3)
+  constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16;
+  constexpr int NT = TWOD ? (9 - WV + 3) / 4 : (27 - WV + 3) / 4;     // 3D: 7 (6 for wave 3); 2D: 3 (wave 0) or 2
   constexpr int PLANE = (TH + 2) * SW * 64;           // one ci tile of an x slab: [voxel][32 ch]
   bf16x8 fbw[2], faw[2][NT * CIT];
   auto load_dy = [&](int ks) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
   auto load_x = [&](int ks, int j) {                  // j = c * NT + i: ci tile c, tap WV + 4 i
     const int c = j / NT, i = j % NT;
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-    const int tap = WV + 4 * i;
+    const int tap = (TWOD ? 9 : 0) + WV + 4 * i;
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;                // folded: j is unrolled, WV constant
     const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
     return tr_frag(sl + c * PLANE + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
@@ -221,7 +224,7 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
 
 // the whole march of wave WV (its taps are compile-time constants): the wave variants never merge before the end
 // of the kernel, so the seven accumulator tiles stay in one register class (no VGPR <-> AGPR copies per depth)
-template <int TW, int WV, int CIT>
+template <int TW, int WV, int CIT, bool TWOD>
 __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                             int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
                                             int Cout, int tilesH, int tilesW, int dsegs, int dlen,
@@ -319,7 +322,7 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
       const char* sl0 = xs + ((d + 0) % 3) * XSLOT;              // depth d - 1
       const char* sl1 = xs + ((d + 1) % 3) * XSLOT;              // depth d
       const char* sl2 = xs + ((d + 2) % 3) * XSLOT;              // depth d + 1
-      wgrad_depth_step<WV, TW, CIT>(acc, sl0, sl1, sl2, dys, lane_off);
+      wgrad_depth_step<WV, TW, CIT, TWOD>(acc, sl0, sl1, sl2, dys, lane_off);
     }
     __syncthreads();                             // every wave is done with depth d-1's slot and the dy slab
     if (more) {
@@ -338,8 +341,8 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
     float* out = part + ((int64_t)blockIdx.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const int tap = wave + 4 * i;
-      if (tap < 27) {
+      const int tap = (TWOD ? 9 : 0) + wave + 4 * i;        // TWOD: only taps 9..17 are written (and later reduced)
+      if (tap < (TWOD ? 18 : 27)) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
           *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
@@ -350,37 +353,41 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   }
 }
 
-template <int TW, int CIT>
+template <int TW, int CIT, bool TWOD>
 __global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
                   int dsegs, int dlen, const bf16_t* __restrict__ x1) {
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
-    case 0: wgrad_march<TW, 0, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    case 1: wgrad_march<TW, 1, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    case 2: wgrad_march<TW, 2, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    default: wgrad_march<TW, 3, CIT>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 0: wgrad_march<TW, 0, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 1: wgrad_march<TW, 1, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 2: wgrad_march<TW, 2, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    default: wgrad_march<TW, 3, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
   }
 }
 
 // dw[co][ci][tap] = sum_b part[b][pair][tap][co%32][ci%32]; 64 outputs x 4 partial-lanes per block
 __global__ void __launch_bounds__(256)
-wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw) {
+wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw,
+                    int mid) {       // mid: only taps 9..17 were produced; dw is the 9-tap tensor [Cout][Cin][3][3]
   __shared__ float red[256];
   const int64_t total = (int64_t)npairs * 27 * 1024;
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const int tap0 = i < total ? (int)((i >> 10) % 27) : 0;
+  const bool live = i < total && (!mid || (tap0 >= 9 && tap0 < 18));     // uniform per 1024-element tile
   float t = 0.f;
-  if (i < total)
+  if (live)
     for (int b = pl; b < nblk; b += 4) t += part[(int64_t)b * total + i];
   red[pl * 64 + o] = t;
   __syncthreads();
-  if (pl != 0 || i >= total) return;
+  if (pl != 0 || !live) return;
   t = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
   const int ci_l = i & 31, co_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
   const int ncit = Cin / 32;
   const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
-  dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
+  if (mid) dw[((int64_t)co * Cin + ci) * 9 + tap - 9] = t;
+  else dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
 }
 
 struct WgCfg { int tw, cit, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
@@ -1319,27 +1326,30 @@ extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, in
 }
 
 // returns 1 if handled, 0 if not applicable, <0 on error.  dw fp32 [Cout][Cin][27]
+// mid != 0: a Conv2d per depth slice - only the middle-plane taps are computed and dw is [Cout][Cin][3][3]
 extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d,
                                       int h, int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st,
-                                      const void* x1) {
+                                      const void* x1, int mid) {
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
     return 0;
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
   if (x1 && (c.cit != 2 || cin != 64 || ((uintptr_t)x1 % 16))) return 0;   // split x: one group of two ci tiles
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
   dim3 grid(c.nblk, c.npairs / c.cit);
-#define LAUNCH_WG(TW_, CIT_)                                                                                        \
+#define LAUNCH_WG2(TW_, CIT_, TWOD_)                                                                                \
   do {                                                                                                              \
     const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + WG_TH * TW_) * 64;                             \
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    conv_wgrad_stream<TW_, CIT_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
-                                                         h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    conv_wgrad_stream<TW_, CIT_, TWOD_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
+                                                                h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
   } while (0)
+#define LAUNCH_WG(TW_, CIT_) do { if (mid) LAUNCH_WG2(TW_, CIT_, true); else LAUNCH_WG2(TW_, CIT_, false); } while (0)
   if (c.tw == 32) { if (c.cit == 2) LAUNCH_WG(32, 2); else LAUNCH_WG(32, 1); }
   else { if (c.cit == 2) LAUNCH_WG(16, 2); else LAUNCH_WG(16, 1); }
 #undef LAUNCH_WG
+#undef LAUNCH_WG2
   const int64_t total = (int64_t)c.npairs * 27 * 1024;
-  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw);
+  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw, mid);
   int rc = fplx_check_launch("mfma_conv3d_wgrad");
   return rc < 0 ? rc : 1;
 }

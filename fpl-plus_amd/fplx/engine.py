@@ -228,6 +228,8 @@ class Engine(object):
             cin1 = sv.blocks[b]["cin"]
             need = max(need, ops.conv3d_wgrad_ws_bytes(dims[l], cin1, ft[l], (3, 3, 3)),
                        ops.conv3d_wgrad_ws_bytes(dims[l], ft[l], ft[l], (3, 3, 3)))
+            if net.block_modules[b].dim == 2:
+                need = max(need, ops.conv2d_wgrad_ws_bytes(dims[l], cin1, ft[l]), ops.conv2d_wgrad_ws_bytes(dims[l], ft[l], ft[l]))
         pds = [2 if net.dims[l] == 3 else 1 for l in range(4)]
         for j in range(4):
             l = 3 - j
@@ -290,24 +292,19 @@ class Engine(object):
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
             db = None if sv.train else gv[key + ".bias"]
             gw = gv[key + ".weight"]
-            two_d = gw.dim() == 4                      # Conv2d of a 2.5D level: 27-tap gradient, middle plane kept
-            dw = torch.empty((c, cin, 27), dtype=torch.float32, device=dev) if two_d else gw
+            two_d = gw.dim() == 4                      # Conv2d of a 2.5D level: only the middle-plane taps exist
             if isinstance(xin, tuple):                 # cat([skip, up]) as two tensors (train-mode BN only: db is None)
-                def wg_cat():
-                    ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, dw, dims[l], cin, c, ws_w)
-                    if two_d:
-                        ops.conv2d_wgrad_extract(dw, gw)
-                on_side(wg_cat, d_out, xin[0], xin[1], dw)
+                on_side(lambda: ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, gw, dims[l], cin, c, ws_w, two_d),
+                        d_out, xin[0], xin[1])
                 if want_dx:
                     ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c, two_d)
                 return
-
-            def wg():
-                ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, dw, db, dims[l], cin, c,
-                                 (3, 3, 3), ws_w)
-                if two_d:
-                    ops.conv2d_wgrad_extract(dw, gw)
-            on_side(wg, d_out, xin, dw)
+            if two_d:
+                on_side(lambda: ops.conv2d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
+                                                 dims[l], cin, c, ws_w), d_out, xin)
+            else:
+                on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
+                                                 dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
             if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None,

@@ -129,6 +129,18 @@ def conv3d_wgrad(x, xs, x_dt, dy, ys, dy_dt, dw, db, dims, cin, cout, k, ws):
          k[0], k[1], k[2], ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
+def conv2d_wgrad_ws_bytes(dims, cin, cout):
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv2d_wgrad_ws_bytes(n, d, h, w, cin, cout)
+
+
+def conv2d_wgrad(x, xs, x_dt, dy, ys, dy_dt, dw9, db, dims, cin, cout, ws):
+    """weight gradient of a Conv2d(3x3) per depth slice: dw9 fp32 [Cout, Cin, 3, 3] (9 of 27 taps on the MFMA path)"""
+    n, d, h, w = dims
+    call("fplx_conv2d_wgrad", ptr(x), x_dt, xs[0], xs[1], xs[2], xs[3], xs[4], ptr(dy), dy_dt, ys[0], ys[1], ys[2], ys[3],
+         ys[4], ptr(dw9), ptr(db), n, d, h, w, cin, cout, ptr(ws), ws.numel() * ws.element_size(), stream())
+
+
 def conv3d_cat2_ok(dims, cin, cout):
     """True if the 3x3x3 convolution on cat([x0, x1], channel) of two cin/2-channel bf16 tensors has the split fast
     path (level 0 of the 32-base network): the concatenation is then never materialised."""
@@ -150,11 +162,12 @@ def conv3d_dgrad_split2(dy, wb, dx0, dx1, dims, cin, cout, mid=False):
          cout, stream())
 
 
-def conv3d_wgrad_cat2(x0, x1, dy, dw, dims, cin, cout, ws):
+def conv3d_wgrad_cat2(x0, x1, dy, dw, dims, cin, cout, ws, mid=False):
+    """mid: dw is the 9-tap Conv2d gradient [Cout, Cin, 3, 3]"""
     n, d, h, w = dims
     assert ld_of(x0) == ld_of(x1)
-    call("fplx_conv3d_wgrad_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(dy), ld_of(dy), ptr(dw), n, d, h, w, cin, cout,
-         ptr(ws), ws.numel() * ws.element_size(), stream())
+    call("fplx_conv2d_wgrad_cat2" if mid else "fplx_conv3d_wgrad_cat2", ptr(x0), ptr(x1), ld_of(x0), ptr(dy), ld_of(dy),
+         ptr(dw), n, d, h, w, cin, cout, ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
 def _dc(sd):

@@ -147,6 +147,14 @@ int fplx_conv2d_fwd_cat2(const void* x0, const void* x1, int64_t ldx, const void
                          fplx_stream_t stream);                     /* = fplx_conv3d_fwd_cat2 for such packs */
 int fplx_conv2d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* dx0, void* dx1, int64_t ldx, int n,
                              int d, int h, int w, int cin, int cout, fplx_stream_t stream);
+/* weight gradient of the Conv2d: dw fp32 [Cout][Cin][3][3], db fp32 [Cout] or NULL (9 of 27 taps on the MFMA path) */
+size_t fplx_conv2d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+int fplx_conv2d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
+                      const void* dy, int dy_dt, int64_t yn, int64_t yd, int64_t yh, int64_t yw, int64_t yc,
+                      float* dw, float* db, int n, int d, int h, int w, int cin, int cout,
+                      void* ws, size_t ws_bytes, fplx_stream_t stream);
+int fplx_conv2d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
+                           int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream);
 int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream);
 int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
                         int dt, fplx_stream_t stream);

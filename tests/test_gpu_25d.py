@@ -129,6 +129,14 @@ def test_conv2d_through_the_3d_kernels(dtype, shape):
                      cout, (3, 3, 3), ws)
     ops.conv2d_wgrad_extract(dw27, dw9)
     assert float((dw9.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+    # the fplx_conv2d_wgrad form: 9-tap gradient directly (+ bias gradient); MFMA stream kernel in middle-plane mode
+    ws2 = torch.empty(ops.conv2d_wgrad_ws_bytes(dims, cin, cout), dtype=torch.uint8, device="cuda")
+    dw9b = torch.full((cout, cin, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+    db = torch.empty(cout, dtype=torch.float32, device="cuda")
+    ops.conv2d_wgrad(xg, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw9b, db, dims, cin, cout,
+                     ws2)
+    assert float((dw9b.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
+    assert float((db.cpu() - cl(dy).sum(0)).abs().max()) < max(tol, 1e-4) * float(cl(dy).sum(0).abs().max())
 
 
 def test_25d_training_all_matches_reference(golden_dir):
