@@ -109,8 +109,13 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
     }
     return;
   }
-  // epilogue: + bias, per-channel statistics of the unrounded outputs, bf16 store
+  // epilogue: + bias, per-channel statistics of the unrounded outputs, bf16 store.  Aligned outputs go through a 2-KB
+  // per-wave LDS transpose and leave as 16-byte stores (2-byte global stores are issue-bound); channel slices of odd
+  // buffers keep the element stores.
   float s[NTL], q[NTL];
+  const bool vec_ok = ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0;        // uniform
+  __shared__ __attribute__((aligned(16))) char stg_all[4][32 * 64];
+  char* stg = stg_all[wave];
 #pragma unroll
   for (int j = 0; j < NTL; ++j) {
     const int co = n0 + j * 32 + r;
@@ -122,11 +127,21 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + rh;
         const int64_t v = m0 + t * 32 + row;
+        const float o = acc[t][j][i] + bv;
+        if (vec_ok) *reinterpret_cast<bf16_t*>(stg + row * 64 + r * 2) = (bf16_t)o;
         if (v < V) {
-          const float o = acc[t][j][i] + bv;
-          y[v * ldy + co] = (bf16_t)o;
+          if (!vec_ok) y[v * ldy + co] = (bf16_t)o;
           s[j] += o;
           q[j] = fmaf(o, o, q[j]);
+        }
+      }
+      if (vec_ok) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int row = (lane >> 2) + 16 * half;
+          const int64_t v = m0 + t * 32 + row;
+          const uint4 pk = *reinterpret_cast<const uint4*>(stg + row * 64 + (lane & 3) * 16);
+          if (v < V) *reinterpret_cast<uint4*>(y + v * ldy + n0 + j * 32 + (lane & 3) * 8) = pk;
         }
       }
     }
@@ -445,7 +460,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
 __global__ void __launch_bounds__(DIRECT_THREADS)
 deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wf,
                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                int Cin, int Cout, int sd) {
+                int Cin, int Cout, int sd, int vec_ok) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh8 = (lane >> 5) * 8;
   const int64_t V = (int64_t)N * D * H * W;
@@ -470,6 +485,39 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
   }
   const int co = n0 + r, rh = (lane >> 5) * 4;
   const float bv = bias[co];
+  if (vec_ok) {
+    // the accumulator layout is lane = channel, registers = voxels: 2-byte pieces per lane.  As global stores that is 64
+    // instructions per wave and the store path sets the pace (the kernel ran at 2.4x its memory time); each tap's
+    // 32 x 32 tile goes through a 2-KB per-wave LDS transpose instead and leaves as 16-byte stores.
+    __shared__ __attribute__((aligned(16))) char stg_all[4][32 * 64];
+    char* stg = stg_all[wave];
+    int64_t obase[2];
+    bool ook[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                    // this lane stores voxels (lane >> 2) and (lane >> 2) + 16
+      int64_t vv = m0 + (lane >> 2) + 16 * half;
+      ook[half] = vv < V;
+      if (!ook[half]) vv = 0;
+      const int w0 = (int)(vv % W); vv /= W;
+      const int h0 = (int)(vv % H); vv /= H;
+      const int d0 = (int)(vv % D); vv /= D;
+      obase[half] = ((vv * sd * D + sd * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tap = tap0 + t;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        *reinterpret_cast<bf16_t*>(stg + ((i & 3) + 8 * (i >> 2) + rh) * 64 + r * 2) = (bf16_t)(acc[t][i] + bv);
+      const int64_t toff = ((int64_t)(tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + ((lane >> 2) + 16 * half) * 64 + (lane & 3) * 16);
+        if (ook[half]) *reinterpret_cast<uint4*>(y + (obase[half] + toff) * ldy + n0 + (lane & 3) * 8) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int row = (i & 3) + 8 * (i >> 2) + rh;
@@ -1050,38 +1098,62 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
 
   const int rh = khalf * 4;
   if (partial) {
+    // fp32 partial tiles [voxel][Cout]: transposed through a 4-KB per-wave LDS tile, 16-byte stores (the operand tiles
+    // are dead after the loop's last barrier)
     float* pz = partial + (int64_t)blockIdx.z * V * Cout;
+    float* stf = reinterpret_cast<float*>(smem + 4096 + wave * 4096);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      const int co = n0 + wn * (NT / 2) + j * 32 + r;
+      const int cb = n0 + wn * (NT / 2) + j * 32;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int64_t v = m0 + wm * 64 + t * 32 + (i & 3) + 8 * (i >> 2) + rh;
-          if (v < V) pz[v * Cout + co] = acc[t][j][i];
+        for (int i = 0; i < 16; ++i) stf[((i & 3) + 8 * (i >> 2) + rh) * 32 + r] = acc[t][j][i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // lane -> voxel (lane >> 3) + 8 q, channels 4 (lane & 7) ..
+          const int row = (lane >> 3) + 8 * q;
+          const int64_t v = m0 + wm * 64 + t * 32 + row;
+          const float4 pk = *reinterpret_cast<const float4*>(stf + row * 32 + (lane & 7) * 4);
+          if (v < V) *reinterpret_cast<float4*>(pz + v * Cout + cb + (lane & 7) * 4) = pk;
         }
+      }
     }
     return;
   }
-  float* red = reinterpret_cast<float*>(smem);               // [MTL / 64 (wm)][2][NT]
+  float* red = reinterpret_cast<float*>(smem);               // [MTL / 64 (wm)][2][NT]: at most 4 KB
+  // bf16 outputs: lane = channel, registers = voxels -> 2-byte pieces; aligned outputs are transposed through a 2-KB
+  // per-wave LDS tile (the operand tiles are dead after the loop's last barrier) and leave as 16-byte stores
+  const bool vec_ok = ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0;        // uniform
+  char* stg = smem + 4096 + wave * 2048;
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int cl = wn * (NT / 2) + j * 32 + r, co = n0 + cl;
     const float bv = bias ? bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t v = m0 + wm * 64 + t * 32 + (i & 3) + 8 * (i >> 2) + rh;
+        const int row = (i & 3) + 8 * (i >> 2) + rh;
+        const int64_t v = m0 + wm * 64 + t * 32 + row;
+        const float o = acc[t][j][i] + bv;
+        if (vec_ok) *reinterpret_cast<bf16_t*>(stg + row * 64 + r * 2) = (bf16_t)o;
         if (v < V) {
-          const float o = acc[t][j][i] + bv;
-          y[v * ldy + co] = (bf16_t)o;
+          if (!vec_ok) y[v * ldy + co] = (bf16_t)o;
           s1 += o;
           s2 = fmaf(o, o, s2);
         }
       }
+      if (vec_ok) {                                          // 32 x 32 tile: LDS transpose, two 16-byte stores per lane
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int row = (lane >> 2) + 16 * half;
+          const int64_t v = m0 + wm * 64 + t * 32 + row;
+          const uint4 pk = *reinterpret_cast<const uint4*>(stg + row * 64 + (lane & 3) * 16);
+          if (v < V) *reinterpret_cast<uint4*>(y + v * ldy + n0 + wn * (NT / 2) + j * 32 + (lane & 3) * 8) = pk;
+        }
+      }
+    }
     if (stats) {
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
@@ -1361,8 +1433,9 @@ extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf,
   if (cin % 16 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
+  const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
   deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
-                                                   h, w, cin, cout, sd);
+                                                   h, w, cin, cout, sd, vec_ok);
   int rc = fplx_check_launch("mfma_deconv2_fwd");
   return rc < 0 ? rc : 1;
 }
