@@ -276,7 +276,7 @@ class Engine(object):
             if on_ready is not None:
                 join_side()                # the bucket's weight gradients were produced on the side stream
                 o, n, _ = net._layout[last_name]
-                on_ready(o + n)
+                on_ready((o + n + 3) // 4 * 4)             # parameters start on 4-float boundaries (net._ensure_flat)
 
         ready("out_conv.bias")
         d_cur = empty(vox[0], ft[0])

@@ -207,8 +207,11 @@ class UNet2D5_dsbn(nn.Module):
         if ok:
             return
         order = self._ordered_param_names()
-        total = sum(named[k].numel() for k in order)
-        flat = torch.empty(total, dtype=torch.float32, device=first.device)
+        # every parameter starts on a 16-byte boundary (4 floats): the vectorised kernels (LDS-tiled weight pack, Adam)
+        # need it, and a 1- or 2-element tensor (PReLU slope, out_conv bias) would otherwise knock everything behind it
+        # off.  The padding elements are zero, get zero gradients and stay zero.
+        total = sum((named[k].numel() + 3) // 4 * 4 for k in order)
+        flat = torch.zeros(total, dtype=torch.float32, device=first.device)
         layout, off = {}, 0
         for k in order:
             p = named[k]
@@ -216,7 +219,7 @@ class UNet2D5_dsbn(nn.Module):
             flat[off:off + n].copy_(p.data.reshape(-1).float())
             p.data = flat[off:off + n].view(p.shape)
             layout[k] = (off, n, tuple(p.shape))
-            off += n
+            off += (n + 3) // 4 * 4
         self.flat_params, self._layout, self._order = flat, layout, order
         self._named = named
         self.engine.invalidate()

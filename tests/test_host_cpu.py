@@ -92,12 +92,16 @@ def test_flat_layout_and_buckets():
     net = fplx.UNet2D5_dsbn(p)
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
     net._ensure_flat()
-    total = sum(v.numel() for v in before.values())
+    total = sum((v.numel() + 3) // 4 * 4 for v in before.values())      # every parameter starts on a 16-byte boundary
     assert net.flat_params.numel() == total
     for k, v in net.named_parameters():          # values preserved, storage shared
         assert torch.equal(v, before[k])
         o, n, shp = net._layout[k]
-        assert v.data_ptr() == net.flat_params.data_ptr() + 4 * o
+        assert o % 4 == 0 and v.data_ptr() == net.flat_params.data_ptr() + 4 * o
+    used = torch.zeros(total, dtype=torch.bool)
+    for o, n, _ in net._layout.values():
+        used[o:o + n] = True
+    assert float(net.flat_params[~used].abs().sum()) == 0.0              # the padding is zero
     shared, doms = net.segments()
     assert shared[0] == 0 and doms[-1][1] == total and len(doms) == 2
     assert doms[0][1] - doms[0][0] == doms[1][1] - doms[1][0] == 2 * 2 * sum([8, 16, 32, 64, 128, 64, 32, 16, 8])
