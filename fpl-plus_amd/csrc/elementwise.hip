@@ -192,6 +192,95 @@ __device__ __forceinline__ float dz_of(float yv, float dout, float sc, float sh,
   return z > 0.f ? da : da * slope;
 }
 
+// Channel-group-stationary forms of the two apply passes (the vector path when C / VEC divides the block): a thread keeps
+// ONE group of VEC channels for its whole life, like bn_act_bwd_reduce_k, so the per-channel constants sit in registers
+// and the voxel index advances by a constant - the flat-index forms above re-derive (voxel, channel) with a 64-bit
+// division and re-load up to six constants per element, which costs the backward apply pass 15 % of its bandwidth.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_fwd_g_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t ldo, const float* __restrict__ scale,
+               const float* __restrict__ shift, const float* __restrict__ slope_p, DropCfg dc, int64_t voxels, int C) {
+  const int G = C / VEC, VL = EW_THREADS / G;            // host: EW_THREADS % G == 0
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const float slope = *slope_p;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  auto one = [&](int64_t v, float (&a)[VEC]) {
+    bool keep[VEC];
+    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z = fmaf(a[j], sc[j], sh[j]);
+      z = z > 0.f ? z : z * slope;
+      if (dc.on) z = keep[j] ? z * dc.inv_keep : 0.f;
+      a[j] = z;
+    }
+    stv<T, VEC>(out + v * ldo + c0, a);
+  };
+  const int64_t st = (int64_t)gridDim.x * VL;
+  int64_t v = (int64_t)blockIdx.x * VL + vl;
+  for (; v + 3 * st < voxels; v += 4 * st) {
+    float a[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ldv_nt<T, VEC>(y + (v + u * st) * ldy + c0, a[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v + u * st, a[u]);
+  }
+  for (; v < voxels; v += st) {
+    float a[VEC];
+    ldv_nt<T, VEC>(y + v * ldy + c0, a);
+    one(v, a);
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_bwd_apply_g_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dout, int64_t ldd, T* __restrict__ dy,
+                     int64_t ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
+                     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ slope_p,
+                     const float* __restrict__ coef, DropCfg dc, int64_t voxels, int C) {
+  const int G = C / VEC, VL = EW_THREADS / G;
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const float slope = *slope_p;
+  float sc[VEC], sh[VEC], m[VEC], rs[VEC], k0[VEC], k1[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j];
+    k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j];
+  }
+  auto one = [&](int64_t v, float (&a)[VEC], float (&d)[VEC]) {
+    bool keep[VEC];
+    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z;
+      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, dc.on ? keep[j] : true, dc.inv_keep, z);
+      const float xh = (a[j] - m[j]) * rs[j];
+      d[j] = sc[j] * (dz - k0[j] - xh * k1[j]);
+    }
+    stv<T, VEC>(dy + v * ldo + c0, d);
+  };
+  const int64_t st = (int64_t)gridDim.x * VL;
+  int64_t v = (int64_t)blockIdx.x * VL + vl;
+  for (; v + 3 * st < voxels; v += 4 * st) {               // four voxels (8 loads) in flight per lane
+    float a[4][VEC], d[4][VEC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ldv_nt<T, VEC>(y + (v + u * st) * ldy + c0, a[u]);
+      ldv_nt<T, VEC>(dout + (v + u * st) * ldd + c0, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v + u * st, a[u], d[u]);
+  }
+  for (; v < voxels; v += st) {
+    float a[VEC], d[VEC];
+    ldv_nt<T, VEC>(y + v * ldy + c0, a);
+    ldv_nt<T, VEC>(dout + v * ldd + c0, d);
+    one(v, a, d);
+  }
+}
+
 // stage 1 of backward: per-channel sums of dz and dz*xhat, and the slope gradient
 template <typename T, int VEC>
 __global__ void __launch_bounds__(EW_THREADS)
@@ -479,6 +568,11 @@ bool vec_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* 
 
 }  // namespace
 
+static inline bool ew_group_form() {     // A/B knob (benchmarks only): FPLX_EW_GROUP=0 selects the flat-index kernels
+  static const bool on = [] { const char* e = getenv("FPLX_EW_GROUP"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 #define DISPATCH_VEC(T, OK, KERNEL, ...)                         \
   do {                                                           \
     if (OK) KERNEL<T, Vec<T>::N> __VA_ARGS__;                    \
@@ -535,8 +629,12 @@ int fplx_bn_act_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, const fl
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(y, ldy, out, ldo, nullptr, 0, c);
     const int g = ew_grid(voxels * (ok ? c / 8 : c));
-    DISPATCH_VEC(bf16_t, ok, bn_act_fwd_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (bf16_t*)out, ldo, scale,
-                                                                      shift, slope, dc, voxels, c));
+    if (ok && c / 8 <= EW_THREADS && EW_THREADS % (c / 8) == 0 && ew_group_form())
+      bn_act_fwd_g_k<bf16_t, 8><<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (bf16_t*)out, ldo, scale, shift, slope, dc,
+                                                          voxels, c);
+    else
+      DISPATCH_VEC(bf16_t, ok, bn_act_fwd_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (bf16_t*)out, ldo, scale,
+                                                                        shift, slope, dc, voxels, c));
   } else
     return fplx_fail(FPLX_E_BADDTYPE, "bn_act_fwd: dtype %d", dt);
   return fplx_check_launch("bn_act_fwd");
@@ -597,9 +695,13 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, dy, ldo, c);
     const int g = ew_grid(voxels * (ok ? c / 8 : c));
-    DISPATCH_VEC(bf16_t, ok, bn_act_bwd_apply_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout,
-                                                                            ldd, (bf16_t*)dy, ldo, mean, rstd, scale,
-                                                                            shift, slope, coef, dc, voxels, c));
+    if (ok && c / 8 <= EW_THREADS && EW_THREADS % (c / 8) == 0 && ew_group_form())
+      bn_act_bwd_apply_g_k<bf16_t, 8><<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, ldd, (bf16_t*)dy,
+                                                                ldo, mean, rstd, scale, shift, slope, coef, dc, voxels, c);
+    else
+      DISPATCH_VEC(bf16_t, ok, bn_act_bwd_apply_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout,
+                                                                              ldd, (bf16_t*)dy, ldo, mean, rstd, scale,
+                                                                              shift, slope, coef, dc, voxels, c));
   } else
     return fplx_fail(FPLX_E_BADDTYPE, "bn_act_bwd_apply: dtype %d", dt);
   return fplx_check_launch("bn_act_bwd_apply");
