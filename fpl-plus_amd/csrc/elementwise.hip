@@ -444,12 +444,24 @@ maxpool2_fwd_k(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t 
   const int G = C / VEC, Do = D / pd, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int c0 = (int)(i % G) * VEC;
-    int64_t r = i / G;
-    const int64_t vo = r;
-    const int wo = r % Wo; r /= Wo;
-    const int ho = r % Ho; r /= Ho;
-    const int d_o = r % Do; r /= Do;
+    int c0, wo, ho, d_o;
+    int64_t vo, r;
+    if (total < ((int64_t)1 << 31)) {          // 32-bit index math: a 64-bit division is a ~100-instruction sequence
+      unsigned q = (unsigned)i;
+      c0 = (int)(q % (unsigned)G) * VEC; q /= (unsigned)G;
+      vo = q;
+      wo = (int)(q % (unsigned)Wo); q /= (unsigned)Wo;
+      ho = (int)(q % (unsigned)Ho); q /= (unsigned)Ho;
+      d_o = (int)(q % (unsigned)Do); q /= (unsigned)Do;
+      r = q;
+    } else {
+      c0 = (int)(i % G) * VEC;
+      r = i / G;
+      vo = r;
+      wo = r % Wo; r /= Wo;
+      ho = r % Ho; r /= Ho;
+      d_o = r % Do; r /= Do;
+    }
     float best[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
@@ -473,12 +485,24 @@ maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, i
   const int G = C / VEC, Do = D / pd, Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Do * Ho * Wo * G;
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
-    const int c0 = (int)(i % G) * VEC;
-    int64_t r = i / G;
-    const int64_t vo = r;
-    const int wo = r % Wo; r /= Wo;
-    const int ho = r % Ho; r /= Ho;
-    const int d_o = r % Do; r /= Do;
+    int c0, wo, ho, d_o;
+    int64_t vo, r;
+    if (total < ((int64_t)1 << 31)) {          // 32-bit index math: a 64-bit division is a ~100-instruction sequence
+      unsigned q = (unsigned)i;
+      c0 = (int)(q % (unsigned)G) * VEC; q /= (unsigned)G;
+      vo = q;
+      wo = (int)(q % (unsigned)Wo); q /= (unsigned)Wo;
+      ho = (int)(q % (unsigned)Ho); q /= (unsigned)Ho;
+      d_o = (int)(q % (unsigned)Do); q /= (unsigned)Do;
+      r = q;
+    } else {
+      c0 = (int)(i % G) * VEC;
+      r = i / G;
+      vo = r;
+      wo = r % Wo; r /= Wo;
+      ho = r % Ho; r /= Ho;
+      d_o = r % Do; r /= Do;
+    }
     float g[VEC], best[VEC];
     int arg[VEC];
     ldv<T, VEC>(dy + vo * ldy + c0, g);
