@@ -44,10 +44,11 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
     int64_t v = m0 + t * 32 + r;
     vok[t] = v < V;
     if (!vok[t]) v = 0;
-    vw[t] = (int)(v % W); v /= W;
-    vh[t] = (int)(v % H); v /= H;
-    vd[t] = (int)(v % D); v /= D;
-    vn[t] = (int)v;
+    unsigned q = (unsigned)v;                    // V < 2^31 (checked by the launchers)
+    vw[t] = (int)(q % (unsigned)W); q /= (unsigned)W;
+    vh[t] = (int)(q % (unsigned)H); q /= (unsigned)H;
+    vd[t] = (int)(q % (unsigned)D); q /= (unsigned)D;
+    vn[t] = (int)q;
   }
   f32x16 acc[MT][NTL];
 #pragma unroll
@@ -979,9 +980,10 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     const bool ok = v < V;
     if (!ok) v = 0;
     abase[u] = x + v * ldx + c16 * 8;
-    const int ww0 = (int)(v % W); v /= W;
-    const int hh0 = (int)(v % H); v /= H;
-    const int dd0 = (int)(v % D);
+    unsigned q = (unsigned)v;                    // V < 2^31 (mfma_applicable): 32-bit divisions, not 64-bit sequences
+    const int ww0 = (int)(q % (unsigned)W); q /= (unsigned)W;
+    const int hh0 = (int)(q % (unsigned)H); q /= (unsigned)H;
+    const int dd0 = (int)(q % (unsigned)D);
     uint32_t m = 0;
     for (int t = 0; t < 27; ++t) {
       const int dd = dd0 + t / 9 - 1, hh = hh0 + (t / 3) % 3 - 1, ww = ww0 + t % 3 - 1;
@@ -1311,7 +1313,7 @@ extern "C" size_t fplx_mfma_conv3d_mid_fwd_ws_bytes(int n, int d, int h, int w, 
 static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy, int n, int d,
                          int h, int w, int cin, int cout, float* stats, void* ws, size_t ws_bytes, int mid,
                          hipStream_t st) {
-  if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp)) return 0;
+  if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
   if (fplx_march_ok(n, d, h, w, cin, cout))
@@ -1445,6 +1447,7 @@ extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* 
   // GEMM view: K = 8 (or 4) taps x Cout (channels of dy), columns = Cin
   if (cout % 16 != 0 || cin % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16) || ((uintptr_t)wb % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
+  if (V * 8 >= ((int64_t)1 << 31)) return 0;                 // the kernel decodes voxel indices in 32 bits
 #define LAUNCH_DD(MT_, NTL_, MODE_, GRID_)                                                                          \
   conv_fwd_direct<MT_, NTL_, MODE_><<<GRID_, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr, \
                                                                       (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr)
