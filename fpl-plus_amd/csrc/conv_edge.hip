@@ -515,11 +515,16 @@ inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   *tw = (w + TW - 1) / TW;
   return (int64_t)n * d * (*th) * (*tw);                  // < 2^31 for anything that fits in memory (256 voxels per tile)
 }
-inline int edge_blocks(int64_t ntiles) {
+inline int edge_blocks(int64_t ntiles, int mult = 1) {
   static int cap = -1;
   if (cap < 0) { const char* e = getenv("FPLX_EDGE_BLOCKS"); cap = e ? atoi(e) : 1024; }   // tuning knob (benchmarks only)
-  return (int)(ntiles < cap ? ntiles : cap);
+  const int64_t c = (int64_t)cap * mult;
+  return (int)(ntiles < c ? ntiles : c);
 }
+// the stem weight gradient keeps few bytes per block (27 x 32 partial sums): twice the blocks hide more of its per-tile
+// load latency (98 -> 75 us at level 0) and the extra partial rows are negligible; for out_conv (9 x 1024 floats per
+// block and ci tile) the reduction would eat the gain
+constexpr int STEM_WGRAD_MULT = 2;
 
 }  // namespace
 
@@ -550,7 +555,7 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
 extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
   int th, tw;
-  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw), STEM_WGRAD_MULT);
   return (size_t)nb * ((27 * cin + 31) / 32) * 1024 * sizeof(float);
 }
 
@@ -559,7 +564,7 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
   if (!(cin == 1 || cin == 4) || cout % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16)) return 0;
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
-  const int nb = edge_blocks(nt);
+  const int nb = edge_blocks(nt, STEM_WGRAD_MULT);
   const int rt = (27 * cin + 31) / 32;
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
