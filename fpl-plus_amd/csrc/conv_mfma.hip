@@ -1453,7 +1453,11 @@ extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* 
                                                                       (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr)
   if (cin % 64 == 0) {
     dim3 grid((unsigned)((V + 255) / 256), cin / 64);
-    if (sd == 2) LAUNCH_DD(2, 2, 1, grid); else LAUNCH_DD(2, 2, 2, grid);
+    if ((int64_t)grid.x * grid.y < 192) {                     // deep levels: 128-voxel blocks, twice as many of them
+      dim3 g1((unsigned)((V + 127) / 128), cin / 64);
+      if (sd == 2) LAUNCH_DD(1, 2, 1, g1); else LAUNCH_DD(1, 2, 2, g1);
+    } else if (sd == 2) LAUNCH_DD(2, 2, 1, grid);
+    else LAUNCH_DD(2, 2, 2, grid);
   } else {
     dim3 grid((unsigned)((V + 511) / 512), cin / 32);
     if (sd == 2) LAUNCH_DD(4, 1, 1, grid); else LAUNCH_DD(4, 1, 2, grid);
