@@ -384,8 +384,10 @@ outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
   const int64_t Vs = (int64_t)D * H * W, V = (int64_t)N * Vs;
   const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (v >= V) return;
-  const int w = (int)(v % W), h = (int)((v / W) % H);
-  const int64_t n = v / Vs, vs = v % Vs;
+  // 32-bit index math (the launcher refuses V >= 2^31): four 64-bit divisions cost as much as half of the FMAs below
+  const unsigned vu = (unsigned)v, Vsu = (unsigned)Vs;
+  const int w = (int)(vu % (unsigned)W), h = (int)((vu / (unsigned)W) % (unsigned)H);
+  const int64_t n = vu / Vsu, vs = vu % Vsu;
   float acc[C0];
 #pragma unroll
   for (int j = 0; j < C0; ++j) acc[j] = 0.f;
@@ -398,7 +400,7 @@ outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
       const float g = ok ? dl[(n * ncls + co) * Vs + vs + kh * W + kw] : 0.f;
       const float* wr = wsh + (tap * 4 + co) * C0;
 #pragma unroll
-      for (int j = 0; j < C0; ++j) acc[j] = fmaf(g, wr[j], acc[j]);
+      for (int j = 0; j < C0; ++j) acc[j] = fmaf(g, wr[j], acc[j]);     // (v_pk_fma_f32 pairs were tried: slower)
     }
   }
 #pragma unroll
@@ -592,6 +594,7 @@ extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx
                                        int c0, int ncls, hipStream_t st) {
   if (!(c0 == 16 || c0 == 32 || c0 == 64) || ncls > 4 || ldx % 8 != 0 || ((uintptr_t)dx % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
+  if (V >= ((int64_t)1 << 31)) return 0;                      // 32-bit voxel decode in the kernel
   const unsigned nb = (unsigned)((V + 255) / 256);
   if (c0 == 16) outconv_dgrad_valu<16><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
   else if (c0 == 32) outconv_dgrad_valu<32><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
