@@ -93,8 +93,11 @@ inline DropCfg make_drop(float p, uint64_t seed, uint32_t sid) {
 }
 
 // ------------------------------------------------------------------------------------------
-// one wave per channel: lanes stride over the partial rows, fixed-order (per lane, then butterfly) sum
-__global__ void __launch_bounds__(64)
+// one block of four waves per channel: threads stride over the partial rows (two rows each at 512 rows instead of
+// eight on one wave - the kernel is a latency chain between a convolution and its BN-apply pass), fixed-order sum
+// (per thread, wave butterfly, four wave totals)
+constexpr int FIN_THREADS = 256;
+__global__ void __launch_bounds__(FIN_THREADS)
 bn_train_finalize_k(const float* __restrict__ stats, int rows, int C, double count,
                     const float* __restrict__ gamma, const float* __restrict__ beta,
                     float* __restrict__ rm, float* __restrict__ rv, int64_t* __restrict__ nbt,
@@ -102,13 +105,18 @@ bn_train_finalize_k(const float* __restrict__ stats, int rows, int C, double cou
                     float* __restrict__ scale, float* __restrict__ shift) {
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = threadIdx.x; r < rows; r += 64) {
+  for (int r = threadIdx.x; r < rows; r += FIN_THREADS) {
     s1 += (double)stats[((int64_t)r * 2 + 0) * C + c];
     s2 += (double)stats[((int64_t)r * 2 + 1) * C + c];
   }
   s1 = wave_sum_d(s1);
   s2 = wave_sum_d(s2);
+  __shared__ double wred[FIN_THREADS / 64][2];
+  if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = s1; wred[threadIdx.x >> 6][1] = s2; }
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  s1 = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
+  s2 = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
   if (c == 0 && nbt) *nbt += 1;
   const double m = s1 / count;
   double var = s2 / count - m * m;
@@ -392,21 +400,26 @@ bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ 
   }
 }
 
-// one wave per channel (+ one for the PReLU slope)
-__global__ void __launch_bounds__(64)
+// one block of four waves per channel (+ one for the PReLU slope); same summation scheme as bn_train_finalize_k
+__global__ void __launch_bounds__(FIN_THREADS)
 bn_act_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double count, int train,
                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
                       float* __restrict__ coef) {
   const int c = blockIdx.x;
   const int stride = 2 * C + 1;
+  __shared__ double wred[FIN_THREADS / 64][2];
   if (c < C) {
     double s0 = 0.0, s1 = 0.0;
-    for (int r = threadIdx.x; r < rows; r += 64) {
+    for (int r = threadIdx.x; r < rows; r += FIN_THREADS) {
       s0 += (double)part[(int64_t)r * stride + c];
       s1 += (double)part[(int64_t)r * stride + C + c];
     }
     s0 = wave_sum_d(s0);
     s1 = wave_sum_d(s1);
+    if ((threadIdx.x & 63) == 0) { wred[threadIdx.x >> 6][0] = s0; wred[threadIdx.x >> 6][1] = s1; }
+    __syncthreads();
+    s0 = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
+    s1 = (wred[0][1] + wred[1][1]) + (wred[2][1] + wred[3][1]);
     if (threadIdx.x == 0) {
       if (dbeta) dbeta[c] += (float)s0;
       if (dgamma) dgamma[c] += (float)s1;
@@ -415,8 +428,11 @@ bn_act_bwd_finalize_k(const float* __restrict__ part, int rows, int C, double co
     }
   } else {
     double s = 0.0;
-    for (int r = threadIdx.x; r < rows; r += 64) s += (double)part[(int64_t)r * stride + 2 * C];
+    for (int r = threadIdx.x; r < rows; r += FIN_THREADS) s += (double)part[(int64_t)r * stride + 2 * C];
     s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6][0] = s;
+    __syncthreads();
+    s = (wred[0][0] + wred[1][0]) + (wred[2][0] + wred[3][0]);
     if (threadIdx.x == 0 && dslope) dslope[0] += (float)s;
   }
 }
@@ -643,7 +659,7 @@ int fplx_bn_train_finalize(const float* stats, int rows, int c, int64_t count, c
                            float* mean, float* rstd, float* scale, float* shift, fplx_stream_t stream) {
   FPLX_REQUIRE(stats && gamma && beta && mean && rstd && scale && shift, FPLX_E_NULL, "bn_train_finalize: null pointer");
   FPLX_REQUIRE(rows > 0 && c > 0 && count > 0, FPLX_E_BADSHAPE, "bn_train_finalize: bad shape");
-  bn_train_finalize_k<<<c, 64, 0, (hipStream_t)stream>>>(stats, rows, c, (double)count, gamma, beta,
+  bn_train_finalize_k<<<c, FIN_THREADS, 0, (hipStream_t)stream>>>(stats, rows, c, (double)count, gamma, beta,
                                                                      running_mean, running_var, nbt, momentum, eps,
                                                                      mean, rstd, scale, shift);
   return fplx_check_launch("bn_train_finalize");
@@ -729,7 +745,7 @@ int fplx_bn_act_bwd_finalize(const float* part, int rows, int c, int64_t count, 
                              float* dslope, float* coef, fplx_stream_t stream) {
   FPLX_REQUIRE(part && coef, FPLX_E_NULL, "bn_act_bwd_finalize: null pointer");
   FPLX_REQUIRE(rows > 0 && c > 0 && count > 0, FPLX_E_BADSHAPE, "bn_act_bwd_finalize: bad shape");
-  bn_act_bwd_finalize_k<<<c + 1, 64, 0, (hipStream_t)stream>>>(part, rows, c, (double)count, train, dgamma,
+  bn_act_bwd_finalize_k<<<c + 1, FIN_THREADS, 0, (hipStream_t)stream>>>(part, rows, c, (double)count, train, dgamma,
                                                                        dbeta, dslope, coef);
   return fplx_check_launch("bn_act_bwd_finalize");
 }
