@@ -193,6 +193,58 @@ overlap_counts_k(const unsigned char* __restrict__ s, const unsigned char* __res
   }
 }
 
+// evaluation, surface metrics (binary_assd / binary_hd95): get_edge_points = img minus its erosion with the 6- (2D: 4-)
+// neighbour cross, outside the volume counting as background (scipy's binary_erosion, border_value 0)
+__global__ void __launch_bounds__(SP_THREADS)
+edge_points_k(const unsigned char* __restrict__ img, int D, int H, int W, unsigned char* __restrict__ edge) {
+  const int64_t n = (int64_t)D * H * W;
+  const int64_t hw = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    unsigned char e = 0;
+    if (img[i]) {
+      const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)(i / hw);
+      bool inner = x > 0 && x < W - 1 && y > 0 && y < H - 1 && img[i - 1] && img[i + 1] && img[i - W] && img[i + W];
+      if (D > 1) inner = inner && z > 0 && z < D - 1 && img[i - hw] && img[i + hw];
+      e = inner ? 0 : 1;
+    }
+    edge[i] = e;
+  }
+}
+
+// Distance from every query voxel to the nearest seed voxel in the metric GeodisTK's raster scan converges to on a
+// constant image (lambda = 0): shortest 26-neighbour lattice path with step lengths sqrt(sum (d_axis * spacing_axis)^2).
+// For a displacement with per-axis voxel counts a >= b >= c (axes A, B, C) that path is c body diagonals, b - c
+// diagonals in the A-B plane and a - b steps along A (replacing two moves by a more diagonal pair never lengthens the
+// path: norms are sub-additive and sqrt(s^2 + x) is concave in x).  One thread per query, seeds tiled through LDS.
+constexpr int SD_TILE = 1024;
+__global__ void __launch_bounds__(SP_THREADS)
+surface_min_dist_k(const int* __restrict__ q, int64_t nq, const int* __restrict__ s, int64_t ns, float sz, float sy,
+                   float sx, float* __restrict__ out) {
+  __shared__ int tile[SD_TILE * 3];
+  const int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x;
+  const bool live = i < nq;
+  const int qz = live ? q[i * 3] : 0, qy = live ? q[i * 3 + 1] : 0, qx = live ? q[i * 3 + 2] : 0;
+  const float w3 = sqrtf(sz * sz + sy * sy + sx * sx);
+  float best = 1.0e10f;                                      // the raster scan's initial distance (no seed reached)
+  for (int64_t t0 = 0; t0 < ns; t0 += SD_TILE) {
+    const int cnt = (int)(ns - t0 < SD_TILE ? ns - t0 : SD_TILE);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt * 3; k += SP_THREADS) tile[k] = s[t0 * 3 + k];
+    __syncthreads();
+    if (!live) continue;
+    for (int k = 0; k < cnt; ++k) {
+      int a = abs(qz - tile[3 * k]), b = abs(qy - tile[3 * k + 1]), c = abs(qx - tile[3 * k + 2]);
+      float sa = sz, sb = sy, sc = sx;
+      if (a < b) { const int t = a; a = b; b = t; const float u = sa; sa = sb; sb = u; }
+      if (b < c) { const int t = b; b = c; c = t; const float u = sb; sb = sc; sc = u; }
+      if (a < b) { const int t = a; a = b; b = t; const float u = sa; sa = sb; sb = u; }
+      const float d = (float)c * w3 + (float)(b - c) * sqrtf(sa * sa + sb * sb) + (float)(a - b) * sa;
+      best = fminf(best, d);
+    }
+  }
+  if (live) out[i] = best;
+}
+
 inline int sp_grid(int64_t total) {
   int64_t g = (total + SP_THREADS - 1) / SP_THREADS;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -291,6 +343,24 @@ int fplx_overlap_counts(const unsigned char* seg, const unsigned char* gt, int64
   // a thread sees at most n / (grid * 256) voxels: the 32-bit per-thread counters cannot overflow
   overlap_counts_k<<<sp_grid(n), SP_THREADS, 0, st>>>(seg, gt, n, labels, nlabels, fuse, out);
   return fplx_check_launch("overlap_counts");
+}
+
+int fplx_surface_edge_points(const unsigned char* img, int d, int h, int w, unsigned char* edge, fplx_stream_t stream) {
+  FPLX_REQUIRE(img && edge, FPLX_E_NULL, "edge_points: null pointer");
+  FPLX_REQUIRE(d > 0 && h > 0 && w > 0, FPLX_E_BADSHAPE, "edge_points: bad shape %dx%dx%d", d, h, w);
+  edge_points_k<<<sp_grid((int64_t)d * h * w), SP_THREADS, 0, (hipStream_t)stream>>>(img, d, h, w, edge);
+  return fplx_check_launch("edge_points");
+}
+
+int fplx_surface_min_dist(const int* query_zyx, int64_t nq, const int* seed_zyx, int64_t ns, float sz, float sy, float sx,
+                          float* out, fplx_stream_t stream) {
+  FPLX_REQUIRE(query_zyx && out && (seed_zyx || ns == 0), FPLX_E_NULL, "surface_min_dist: null pointer");
+  FPLX_REQUIRE(nq > 0 && ns >= 0 && nq < ((int64_t)1 << 31) * SP_THREADS, FPLX_E_BADSHAPE,
+               "surface_min_dist: %lld queries, %lld seeds", (long long)nq, (long long)ns);
+  FPLX_REQUIRE(sz > 0.f && sy > 0.f && sx > 0.f, FPLX_E_BADSHAPE, "surface_min_dist: spacing must be positive");
+  const unsigned grid = (unsigned)((nq + SP_THREADS - 1) / SP_THREADS);
+  surface_min_dist_k<<<grid, SP_THREADS, 0, (hipStream_t)stream>>>(query_zyx, nq, seed_zyx, ns, sz, sy, sx, out);
+  return fplx_check_launch("surface_min_dist");
 }
 
 }  // extern "C"

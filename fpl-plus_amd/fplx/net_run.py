@@ -1,8 +1,8 @@
 """`python -m fplx.net_run train|test config.cfg` - the reference's `pymic_run` entry for the DSBN agent
 (PyMIC/pymic/net_run_dsbn/net_run.py:11-40): parse + synchronize the .cfg, log to <ckpt_save_dir>/log_<stage>.txt,
 SegmentationAgent(config, stage).run(); after a training stage the test stage runs with the best checkpoint, then the
-evaluation reports are written (util/evaluation_seg_train.py:577-582: evaluation_1 with metric_1; evaluation_2's
-metric_2 = assd needs GeodisTK and is skipped with a log line)."""
+evaluation reports are written (util/evaluation_seg_train.py:577-582: evaluation_1 with metric_1, evaluation_2 with
+metric_2 - assd in every shipped cfg)."""
 import logging
 import os
 import sys
@@ -16,14 +16,8 @@ def eva_main(config):
     if 'evaluation' not in config:
         return None
     res = evaluation.evaluation_1(config)
-    m2 = config['evaluation'].get('metric_2', None)
-    if m2 is not None:
-        try:
-            cfg2 = dict(config)
-            cfg2['evaluation'] = dict(config['evaluation'], metric_1=m2)
-            evaluation.evaluation_1(cfg2)
-        except ValueError as e:
-            logging.info("evaluation_2 skipped: {0:}".format(e))
+    if config['evaluation'].get('metric_2', None) is not None:
+        evaluation.evaluation_2(config)
     return res
 
 

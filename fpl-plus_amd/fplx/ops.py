@@ -398,3 +398,29 @@ def overlap_counts(seg, gt, labels, fuse=False):
     out = torch.empty((rows, 3), dtype=torch.int64, device=s.device)
     call("fplx_overlap_counts", ptr(s), ptr(g), s.numel(), ptr(lab), lab.numel(), 1 if fuse else 0, ptr(out), stream())
     return out.tolist()
+
+
+def edge_points(mask):
+    """get_edge_points of a binary uint8 device volume [D, H, W] ([H, W]: the 2D form) -> uint8 edge map"""
+    require_gpu(mask)
+    assert mask.dtype == torch.uint8 and mask.dim() in (2, 3)
+    m = mask.contiguous()
+    d, h, w = (1,) + tuple(m.shape) if m.dim() == 2 else tuple(m.shape)
+    edge = torch.empty_like(m)
+    call("fplx_surface_edge_points", ptr(m), d, h, w, ptr(edge), stream())
+    return edge
+
+
+def surface_min_dist(query_zyx, seed_zyx, spacing):
+    """distance (GeodisTK raster-scan metric on a constant image) from each int32 (z, y, x) query row to the nearest
+    seed row -> fp32 [nq]; 1e10 everywhere when there is no seed"""
+    require_gpu(query_zyx)
+    assert query_zyx.dtype == torch.int32 and query_zyx.dim() == 2 and query_zyx.shape[1] == 3
+    assert seed_zyx.dtype == torch.int32 and seed_zyx.dim() == 2 and seed_zyx.shape[1] == 3
+    q, sd = query_zyx.contiguous(), seed_zyx.contiguous()
+    out = torch.empty((q.shape[0],), dtype=torch.float32, device=q.device)
+    if q.shape[0] == 0:
+        return out
+    call("fplx_surface_min_dist", ptr(q), q.shape[0], ptr(sd) if sd.shape[0] else 0, sd.shape[0], float(spacing[0]),
+         float(spacing[1]), float(spacing[2]), ptr(out), stream())
+    return out

@@ -299,6 +299,18 @@ int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_str
 int fplx_overlap_counts(const unsigned char* seg, const unsigned char* gt, int64_t n, const int* labels, int nlabels,
                         int fuse, unsigned long long* out, fplx_stream_t stream);
 
+/* Surface metrics behind binary_assd / binary_hd95 (PyMIC/pymic/util/evaluation_seg_train.py:84-99, 101-135, 137-171).
+ * fplx_surface_edge_points: get_edge_points - edge = img - binary_erosion(img, cross) of a binary [d][h][w] volume (d = 1: the
+ * 2D form, no depth neighbours); outside the volume is background.
+ * fplx_surface_min_dist replaces the reference's GeodisTK.geodesic3d_raster_scan(zeros, seeds, spacing, 0.0, 2) (a
+ * third-party C++ extension the reference imports, version unpinned, absent here) sampled at the query voxels:
+ * out[i] = length of the shortest 26-neighbour lattice path from query i to the nearest seed with Euclidean step
+ * lengths under spacing (sz, sy, sx) - the fixed point of that raster scan on a constant image; 1e10 when ns = 0.
+ * Coordinates are int32 (z, y, x) triples.  PARITY UNPINNED against GeodisTK itself (see oracle/np_ref.py ev_raster_scan). */
+int fplx_surface_edge_points(const unsigned char* img, int d, int h, int w, unsigned char* edge, fplx_stream_t stream);
+int fplx_surface_min_dist(const int* query_zyx, int64_t nq, const int* seed_zyx, int64_t ns, float sz, float sy, float sx,
+                          float* out, fplx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

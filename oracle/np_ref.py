@@ -6,6 +6,8 @@ Pinned by tests/test_oracle_golden.py against fixtures produced by running the r
 (tests/golden/fpl_filter.npz, pixel_weight.npz) and against the reference's own
 known-answer data pair (tests/golden/image_weight_kat.json).
 Reference paths are relative to /root/reference.
+PARITY UNPINNED for ev_raster_scan / ev_binary_assd / ev_binary_hd95 only: they restate GeodisTK (third-party, absent,
+version unpinned by the reference) from its published algorithm; everything else here is pinned as above.
 """
 import numpy as np
 
@@ -275,7 +277,7 @@ def ev_binary_rve(s, g):
 
 
 def ev_multi_class(s_volume, g_volume, label_list, fuse_label, spacing, metric):
-    """evaluation_seg_train.py:188-262 for dice / iou / rve / volume"""
+    """evaluation_seg_train.py:188-262"""
     if fuse_label:
         s_sub, g_sub = np.zeros_like(s_volume), np.zeros_like(g_volume)
         for lab in label_list:
@@ -298,6 +300,92 @@ def ev_multi_class(s_volume, g_volume, label_list, fuse_label, spacing, metric):
             for dim in range(len(spacing)):
                 voxel_size = voxel_size * spacing[dim]
             out.append(g.sum() * voxel_size)
+        elif m == "assd":
+            out.append(ev_binary_assd(_ev_squeeze(s), _ev_squeeze(g), spacing))
+        elif m == "hd95":
+            out.append(ev_binary_hd95(_ev_squeeze(s), _ev_squeeze(g), spacing))
         else:
             raise ValueError("unsupported evaluation metric: {0:}".format(metric))
     return out
+
+
+def _ev_squeeze(v):
+    """get_binary_evaluation_score, evaluation_seg_train.py:203-209"""
+    if v.ndim == 4:
+        assert v.shape[0] == 1
+        v = v.reshape(v.shape[1:])
+    if v.shape[0] == 1:
+        v = v.reshape(v.shape[1:])
+    return v
+
+
+def ev_edge_points(img):
+    """evaluation_seg_train.py:84-99 (scipy's binary_erosion with the cross structuring element, border_value 0)"""
+    from scipy import ndimage
+    strt = ndimage.generate_binary_structure(img.ndim, 1)
+    ero = ndimage.binary_erosion(img, strt)
+    return np.asarray(img, np.uint8) - np.asarray(ero, np.uint8)
+
+
+def ev_raster_scan(seeds, spacing, iterations=2):
+    """What the reference calls as GeodisTK.geodesic3d_raster_scan(zeros, seeds, spacing, 0.0, iterations)
+    (geodesic2d_raster_scan for 2D, unit spacing; evaluation_seg_train.py:121-126, 157-162).
+
+    PARITY UNPINNED: GeodisTK (github.com/taigw/GeodisTK, a C++ extension; the reference imports it without pinning a
+    version) is not in /root/reference and not installed, so this restates the published algorithm it implements -
+    the raster-scan geodesic distance transform of Toivanen (1996) / Criminisi et al. (2008): distances start at 0 on
+    the seeds and 1e10 elsewhere; a forward sweep relaxes every voxel against its already-visited half of the 26
+    (2D: 8) neighbourhood, a backward sweep against the other half; the step cost is sqrt(l_euc^2 + lambda^2 * dI^2),
+    here with lambda = 0 and a constant image simply the Euclidean step length under `spacing`.  Pure-Python loops:
+    small volumes only.  float32 like GeodisTK's buffers."""
+    seeds = np.asarray(seeds)
+    if seeds.ndim == 2:
+        seeds, spacing = seeds[None], (1.0, 1.0, 1.0)
+        return ev_raster_scan(seeds, spacing, iterations)[0]
+    D, H, W = seeds.shape
+    dis = np.where(seeds > 0, np.float32(0.0), np.float32(1.0e10)).astype(np.float32)
+    fwd = [(dd, dh, dw) for dd in (-1, 0) for dh in (-1, 0, 1) for dw in (-1, 0, 1)
+           if (dd, dh, dw) < (0, 0, 0)]                        # the 13 neighbours a forward raster has already visited
+    cost = {o: np.float32(np.sqrt((o[0] * spacing[0]) ** 2 + (o[1] * spacing[1]) ** 2 + (o[2] * spacing[2]) ** 2))
+            for o in fwd}
+    for _ in range(iterations):
+        for sign in (1, -1):
+            zs = range(D) if sign > 0 else range(D - 1, -1, -1)
+            ys = range(H) if sign > 0 else range(H - 1, -1, -1)
+            xs = range(W) if sign > 0 else range(W - 1, -1, -1)
+            for z in zs:
+                for y in ys:
+                    for x in xs:
+                        best = dis[z, y, x]
+                        for o in fwd:
+                            zz, yy, xx = z + sign * o[0], y + sign * o[1], x + sign * o[2]
+                            if 0 <= zz < D and 0 <= yy < H and 0 <= xx < W:
+                                v = np.float32(dis[zz, yy, xx] + cost[o])
+                                if v < best:
+                                    best = v
+                        dis[z, y, x] = best
+    return dis
+
+
+def ev_binary_assd(s, g, spacing=None):
+    """evaluation_seg_train.py:137-171"""
+    s_edge, g_edge = ev_edge_points(s), ev_edge_points(g)
+    dim = s.ndim
+    assert dim == g.ndim
+    if spacing is None:
+        spacing = [1.0] * dim
+    s_dis, g_dis = ev_raster_scan(s_edge, spacing, 2), ev_raster_scan(g_edge, spacing, 2)
+    ns, ng = s_edge.sum(), g_edge.sum()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assd = ((s_dis * g_edge).sum() + (g_dis * s_edge).sum()) / (ns + ng)
+    return 50 if assd > 50 else assd
+
+
+def ev_binary_hd95(s, g, spacing=None):
+    """evaluation_seg_train.py:101-135"""
+    s_edge, g_edge = ev_edge_points(s), ev_edge_points(g)
+    if spacing is None:
+        spacing = [1.0] * s.ndim
+    s_dis, g_dis = ev_raster_scan(s_edge, spacing, 2), ev_raster_scan(g_edge, spacing, 2)
+    l1, l2 = sorted(s_dis[g_edge > 0]), sorted(g_dis[s_edge > 0])
+    return max(l1[int(len(l1) * 0.95)], l2[int(len(l2) * 0.95)])
