@@ -381,7 +381,12 @@ __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const 
   }
 }
 
-template <class G, bool TWOD>          // TWOD: see conv_fwd_march32
+// NQ = Cin / 32 channel quarters per slab.  NQ = 2: the resident form above.  NQ = 4 (Cin = 128, the level-1 decoder
+// conv1 on its 64 | 64 concatenation): 27 x 32 x 128 weights do not fit, so the two weight slots become a ring like
+// the slab slots - quarter-step hf computes from slab slot hf & 1 and weight slot hf & 1 while the DMA fills the other
+// two with quarter hf + 1 (55 KB of weights + 21 KB of slab per 108 MFMAs per wave, all L2 hits: the pack is shared by
+// every block).  The tile kernel this replaces re-gathers its A tile from L2 for each of the 27 taps.
+template <class G, bool TWOD, int NQ>          // TWOD: see conv_fwd_march32
 __global__ void __launch_bounds__(256)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
@@ -428,12 +433,20 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
   // channel half 1: the next 32 channels of x, or a second tensor (torch.cat([x, x1], 1) never materialised)
   const char* xn1 = reinterpret_cast<const char*>(x1 ? x1 : x + 32) + (int64_t)n * D * xslice;
-  auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel half hf of slab s -> slot hf
+  auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel part hf of slab s -> slot hf & 1
     if (wave + 4 * k < G::SLAB_DMA && soff[k] != -2) {
-      const char* xs = (hf ? xn1 : xn) + s * xslice;        // uniform
+      const char* xs = (NQ == 2 ? (hf ? xn1 : xn) : xn + hf * 64) + s * xslice;        // uniform
       const void* src = soff[k] >= 0 ? (const void*)(xs + (unsigned)soff[k]) : (const void*)fplx_zero16;
-      lds_dma(src, slabs + hf * G::SLAB_BYTES + (wave + 4 * k) * 1024);
+      lds_dma(src, slabs + (hf & 1) * G::SLAB_BYTES + (wave + 4 * k) * 1024);
     }
+  };
+  // NQ = 4: 1-KiB piece j (0..53: 16 rows [tap j / 2][co (j & 1) * 16 ..] x 4 chunks) of weight quarter qt -> slot qt & 1
+  constexpr int CIN = NQ * 32;
+  const char* wlane = reinterpret_cast<const char*>(wp) + ((int64_t)(n0 + (lane >> 2)) * CIN) * 2 +
+                      (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  auto w_piece = [&](int qt, int j) {
+    const int64_t row0 = (int64_t)(j >> 1) * Cout + (j & 1) * 16;      // uniform
+    lds_dma(wlane + row0 * (CIN * 2) + qt * 64, wbuf + (qt & 1) * G::WH_BYTES + j * 1024);
   };
 
   f32x16 K0a, K0b, K1a, K1b, K2a, K2b, Ra, Rb;
@@ -446,11 +459,15 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) { slab_piece(sbase, 0, k); }
   }
-  for (int j = wave; j < 2 * 27 * 32 * G::CH / 64; j += 4) {
-    const int i = j * 64 + lane;                             // chunk index over [half][tap][co][4 chunks]
-    const int hf = i / (27 * 32 * G::CH), ii = i % (27 * 32 * G::CH);
-    const int row = ii >> 2, c = (ii & 3) ^ G::swz(row);
-    lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * 64 + hf * 32 + c * 8, wbuf + j * 1024);
+  if constexpr (NQ == 2) {
+    for (int j = wave; j < 2 * 27 * 32 * G::CH / 64; j += 4) {
+      const int i = j * 64 + lane;                           // chunk index over [half][tap][co][4 chunks]
+      const int hf = i / (27 * 32 * G::CH), ii = i % (27 * 32 * G::CH);
+      const int row = ii >> 2, c = (ii & 3) ^ G::swz(row);
+      lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * 64 + hf * 32 + c * 8, wbuf + j * 1024);
+    }
+  } else {
+    for (int j = wave; j < 54; j += 4) w_piece(0, j);
   }
   if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
   dma_wait();
@@ -520,13 +537,19 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     const bool wout = t >= (TWOD ? 2 : 3);
     const int o = s - 2;
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      // next half-slab: (s, 1) after (s, 0); (s + 1, 0) after (s, 1)
-      const int ns = hf == 0 ? s : s + 1, nh = hf ^ 1;
-      const bool fetch = TWOD ? (hf == 0 ? live : ns < d1)
-                              : (ns >= 0 && ns < D && ns <= d1 && (hf == 0 ? live : true));
+    for (int hf = 0; hf < NQ; ++hf) {
+      // next part-slab: (s, hf + 1) after (s, hf); (s + 1, 0) after the last part of s
+      const int ns = hf < NQ - 1 ? s : s + 1, nh = (hf + 1) % NQ;
+      const bool fetch = hf < NQ - 1 ? live : (TWOD ? ns < d1 : (ns >= 0 && ns < D && ns <= d1));
+      const bool wfetch = NQ > 2 && !(t == nsteps - 1 && hf == NQ - 1);     // weight quarter nh for the next part-step
       auto side = [&](int q, int g) {
         if (g == 5 && q < NPIECE && fetch) slab_piece(ns, nh, q < NPIECE ? q : 0);
+        if constexpr (NQ > 2) {                              // 14 (TWOD: 5) pieces per wave in the flush-free g = 4 gaps
+          if (g == 4 && q != 3 && q != 7 && wfetch) {
+            const int j = (TWOD ? 18 : 0) + wave + 4 * (q - (q > 3) - (q > 7));
+            if (j < (TWOD ? 36 : 54)) w_piece(nh, j);
+          }
+        }
         if (hf == 0 && wout && q < 8) {
           if (g < 4) {
             if (q < 4) retire_elem(Ra, 0, 4 * q + g);
@@ -536,8 +559,8 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
           if (g == 4 && q == 7) retire_flush(1, o);
         }
       };
-      const char* sl = slabs + hf * G::SLAB_BYTES;
-      const char* wh = wbuf + hf * G::WH_BYTES;
+      const char* sl = slabs + (hf & 1) * G::SLAB_BYTES;
+      const char* wh = wbuf + (hf & 1) * G::WH_BYTES;
 #define M64_STEP(MASK)                                                                                              \
   do {                                                                                                              \
     if (hf == 0) march64_half<MASK, true, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);           \
@@ -606,9 +629,9 @@ inline int march_enabled() {
 
 inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
   MarchCfg c;
-  int fh = cin == 64 ? MG64::FH : MG::FH;
+  int fh = cin >= 64 ? MG64::FH : MG::FH;
   c.fw = 32;
-  if (cin == 64) {                                           // 16 x 16 footprint when it wastes less area than 8 x 32
+  if (cin >= 64) {                                           // 16 x 16 footprint when it wastes less area than 8 x 32
     static const int kfw = [] { const char* e = getenv("FPLX_MARCH64_FW"); return e ? atoi(e) : 0; }();
     const int64_t a32 = (int64_t)((h + 7) / 8) * 8 * ((w + 31) / 32) * 32;
     const int64_t a16 = (int64_t)((h + 15) / 16) * 16 * ((w + 15) / 16) * 16;
@@ -646,6 +669,10 @@ extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout) {
   if (!en || cout % 32 != 0 || d < 4 || w < 64) return 0;
   if (cin == 32) return h >= 16;
   if (cin == 64) return en == 1 && h >= 8 && (int64_t)h * w * 64 * 2 < (int64_t)1 << 31;
+  if (cin == 128) {                                          // streamed-weight form of the Cin = 64 kernel
+    static const int k128 = [] { const char* e = getenv("FPLX_MARCH128"); return e ? atoi(e) : 1; }();   // A/B knob
+    return k128 && en == 1 && h >= 8 && (int64_t)h * w * 128 * 2 < (int64_t)1 << 31;
+  }
   return 0;
 }
 
@@ -664,19 +691,21 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
     return 0;
   const MarchCfg c = march_cfg(n, d, h, w, cin, cout);
   dim3 grid(c.nblk, cout / 32);
-  if (cin == 64) {
-    if (y1) return 0;
-#define LAUNCH_M64(G_, TWOD_)                                                                                       \
+  if (cin >= 64) {
+    if (y1 || (cin == 128 && x1)) return 0;
+#define LAUNCH_M64Q(G_, TWOD_, NQ_)                                                                                 \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
-    conv_fwd_march64<G_, TWOD_><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias,    \
-                                                                    (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
-                                                                    c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1);   \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_fwd_march64<G_, TWOD_, NQ_><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+                                                                         (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
+                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
   } while (0)
+#define LAUNCH_M64(G_, TWOD_) do { if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2); } while (0)
     using G16 = MG64T<16>;
     if (c.fw == 16) { if (twod) LAUNCH_M64(G16, true); else LAUNCH_M64(G16, false); }
     else { if (twod) LAUNCH_M64(MG64, true); else LAUNCH_M64(MG64, false); }
 #undef LAUNCH_M64
+#undef LAUNCH_M64Q
     const int rc64 = fplx_check_launch("march64_conv3d_fwd");
     return rc64 < 0 ? rc64 : 1;
   }

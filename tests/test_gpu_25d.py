@@ -84,7 +84,9 @@ def test_maxpool122_and_deconv122_match_torch(dtype, chans):
                                          (torch.bfloat16, (1, 128, 64, 3, 8, 9)), (torch.bfloat16, (2, 64, 128, 2, 5, 6)),
                                          # the march kernels' middle-plane mode: Cin 32 / 64, ragged tiles, depth segments
                                          (torch.bfloat16, (1, 32, 32, 5, 16, 64)), (torch.bfloat16, (2, 32, 64, 21, 20, 70)),
-                                         (torch.bfloat16, (1, 64, 96, 9, 24, 64)), (torch.bfloat16, (1, 64, 32, 4, 9, 70))])
+                                         (torch.bfloat16, (1, 64, 96, 9, 24, 64)), (torch.bfloat16, (1, 64, 32, 4, 9, 70)),
+                                         # Cin = 128 march (streamed weights: only the nine live taps are fetched)
+                                         (torch.bfloat16, (1, 128, 64, 5, 16, 64)), (torch.bfloat16, (2, 128, 32, 9, 20, 70))])
 def test_conv2d_through_the_3d_kernels(dtype, shape):
     """Conv2d(3x3) per depth slice = the 3x3x3 kernels on weights packed into the middle depth plane: forward, data
     gradient, and the weight gradient as the middle plane of the 27-tap gradient."""
@@ -370,7 +372,12 @@ def test_shipped_style_cfg_runs_train_test_evaluate(tmp_path):
     rep = (out / "test_tumor_dice_all.csv").read_text().strip().splitlines()
     assert rep[0] == "image,class_1" and rep[-2].startswith("mean,") and rep[-1].startswith("std,")
     assert res["test"][0].shape == (1,) and 0.0 <= float(res["test"][0][0]) <= 1.0
-    assert "evaluation_2 skipped" in (ck / "log_train.txt").read_text()          # metric_2 = assd needs GeodisTK
+    rep2 = (out / "test_tumor_assd_all.csv").read_text().strip().splitlines()    # evaluation_2: metric_2 = assd
+    assert rep2[0] == "image,class_1" and len(rep2) == len(rep) and rep2[-2].startswith("mean,")
+    for line in rep2[1:-2]:
+        v = float(line.split(",")[1])
+        assert np.isnan(v) or 0.0 <= v <= 50.0               # nan: neither volume has foreground (the reference's 0 / 0)
+    assert (out / "valid_tumor_assd_all.csv").exists()
 
 
 def test_25d_split_concat_path_agrees_with_the_single_buffer_path():

@@ -92,7 +92,9 @@ def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
     # Cin = 64, 16 x 16 footprint (less padded area than 8 x 32): exact fit, ragged in h and w, several depth segments
     (1, 64, 64, 6, 16, 80), (2, 64, 32, 5, 9, 70), (1, 64, 96, 21, 48, 80), (1, 64, 32, 4, 17, 65),
     # Cin = 64, 8 x 32 footprint; Cin = 32
-    (1, 64, 32, 7, 24, 64), (1, 32, 64, 9, 20, 96)])
+    (1, 64, 32, 7, 24, 64), (1, 32, 64, 9, 20, 96),
+    # Cin = 128: the streamed-weight form (four channel quarters per slab), both footprints, ragged, depth segments
+    (1, 128, 64, 6, 16, 80), (2, 128, 32, 5, 9, 70), (1, 128, 96, 21, 24, 64), (1, 128, 64, 4, 17, 65)])
 def test_conv3d_march_kernels_aligned_output(shape):
     """the depth-marching kernels need 16-byte aligned rows (the generic test writes into an odd channel slice and so
     exercises them only through the data gradient): forward + BN statistics on a dense output, bf16, against torch"""
