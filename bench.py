@@ -149,8 +149,10 @@ def pmc_traffic(key):
     dsegs = (d + dlen - 1) // dlen
     grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * threads
     tab = json.load(open(path))
-    e = tab.get("conv_fwd_march%d|grid=%d" % (cin, grid))
-    return None if e is None else e["hbm_bytes_per_launch"]
+    for k, e in tab.items():                       # "conv_fwd_march32<false>|grid=256000" (template arguments vary)
+        if k.startswith("conv_fwd_march%d" % cin) and k.endswith("|grid=%d" % grid):
+            return e["hbm_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline():

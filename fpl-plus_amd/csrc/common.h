@@ -79,3 +79,32 @@ static inline int fplx_rows_for(int64_t voxels) {
   if (r < 1) r = 1;
   return (int)r;
 }
+
+#ifdef __HIPCC__
+// XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
+// 4-MB L2, so blocks that share data (the cout blocks / tap splits of one voxel footprint, neighbouring footprints and
+// their halos) land on eight different L2s and the shared bytes are fetched eight times.  fplx_xcd_block re-labels the
+// hardware id L = (z * gy + y) * gx + x: XCD L % 8 takes the L / 8-th block of ITS contiguous eighth of the logical
+// order, and the logical order runs y fastest, then z, then x - all blocks of one footprint are consecutive, resident
+// at the same time and on the same L2.  on = 0 returns the hardware ids (A/B knob FPLX_XCD=0).
+struct FplxBlock { int x, y, z; };
+__device__ __forceinline__ FplxBlock fplx_xcd_block(int on) {
+  FplxBlock b = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (!on) return b;
+  const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, t = gx * gy * gz;
+  const unsigned l = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  const unsigned xcd = l & 7u, q = t >> 3, r = t & 7u;       // XCD j owns q + (j < r) blocks
+  const unsigned lp = xcd * q + (xcd < r ? xcd : r) + (l >> 3);
+  const unsigned per = gy * gz, xq = lp / per, rem = lp - xq * per;
+  b.x = __builtin_amdgcn_readfirstlane((int)xq);
+  b.z = __builtin_amdgcn_readfirstlane((int)(rem / gy));
+  b.y = __builtin_amdgcn_readfirstlane((int)(rem % gy));
+  return b;
+}
+#endif
+static inline int fplx_xcd_on() {
+  static const int v = [] { const char* e = getenv("FPLX_XCD"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+

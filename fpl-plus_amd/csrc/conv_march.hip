@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(MG::THREADS)
 conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
-                 bf16_t* __restrict__ y1, int ysplit) {
+                 bf16_t* __restrict__ y1, int ysplit, int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;
   char* wbuf = smem + 2 * MG::SLAB_BYTES;
@@ -109,7 +109,8 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // block-uniform values live in SGPRs
   const int r = lane & 31, khalf = lane >> 5;
-  int b = blockIdx.x;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
   const int seg = b % dsegs; b /= dsegs;
   const int tw = b % tilesW; b /= tilesW;
   const int th = b % tilesH; b /= tilesH;
@@ -117,7 +118,7 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int h0 = __builtin_amdgcn_readfirstlane(th * MG::FH), w0 = __builtin_amdgcn_readfirstlane(tw * MG::FW);
   const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
-  const int n0 = blockIdx.y * 32;
+  const int n0 = bid.y * 32;
 
   // global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass).  A wave-instruction
   // fills 1 KiB = 16 voxel rows linearly, so the XOR swizzle is applied to each lane's SOURCE chunk; halo voxels
@@ -199,7 +200,7 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const bool hok0 = h0 + wave * 2 < H, hok1 = h0 + wave * 2 + 1 < H;
   const unsigned ldy2 = (unsigned)ldy * 2u;
   // split output (the data gradient of a conv on concatenated inputs): channel blocks >= ysplit go to y1
-  bf16_t* ysel = (int)blockIdx.y >= ysplit ? y1 + ((int)blockIdx.y - ysplit) * 32 : y + n0;
+  bf16_t* ysel = bid.y >= ysplit ? y1 + (bid.y - ysplit) * 32 : y + n0;
   char* yn = reinterpret_cast<char*>(ysel) + (((int64_t)n * D * H + (h0 + wave * 2)) * W + w0) * ldy * 2;
   const int64_t yslice = (int64_t)H * W * ldy * 2;        // bytes per output depth
   const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
@@ -299,7 +300,7 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       float t = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 8; ++wv) t += red[(wv * 2 + which) * 32 + c];
-      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = t;
     }
   }
 }
@@ -391,7 +392,7 @@ __global__ void __launch_bounds__(256)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
-                 const bf16_t* __restrict__ x1) {
+                 const bf16_t* __restrict__ x1, int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;                                        // [2 channel halves][SLAB][32]
   char* wbuf = smem + 2 * G::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
@@ -399,7 +400,8 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, khalf = lane >> 5;
-  int b = blockIdx.x;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
   const int seg = b % dsegs; b /= dsegs;
   const int tw = b % tilesW; b /= tilesW;
   const int th = b % tilesH; b /= tilesH;
@@ -407,7 +409,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int h0 = __builtin_amdgcn_readfirstlane(th * G::FH), w0 = __builtin_amdgcn_readfirstlane(tw * G::FW);
   const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
-  const int n0 = blockIdx.y * 32;
+  const int n0 = bid.y * 32;
 
   auto lds_dma = [&](const void* g, const char* l) {         // see conv_fwd_march32
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((const __attribute__((address_space(3))) char*)l));
@@ -611,7 +613,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       float tt = 0.f;
 #pragma unroll
       for (int wv = 0; wv < 4; ++wv) tt += red[(wv * 2 + which) * 32 + c];
-      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = tt;
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = tt;
     }
   }
 }
@@ -698,7 +700,7 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
     (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
     conv_fwd_march64<G_, TWOD_, NQ_><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
                                                                          (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
-                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
+                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
   } while (0)
 #define LAUNCH_M64(G_, TWOD_) do { if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2); } while (0)
     using G16 = MG64T<16>;
@@ -715,7 +717,7 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
     (void)hipFuncSetAttribute((const void*)conv_fwd_march32<TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS); \
     conv_fwd_march32<TWOD_><<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
                                                                 ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
-                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32);    \
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
   } while (0)
   if (twod) LAUNCH_M32(true); else LAUNCH_M32(false);
 #undef LAUNCH_M32

@@ -244,7 +244,7 @@ template <int TW, int WV, int CIT, bool TWOD>
 __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                             int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
                                             int Cout, int tilesH, int tilesW, int dsegs, int dlen,
-                                            const bf16_t* __restrict__ x1) {
+                                            const bf16_t* __restrict__ x1, const FplxBlock bid) {
   constexpr int TH = WG_TH, SW = TW + 2, SH = TH + 2, SLAB = SH * SW;   // voxels per x slab
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PLANE = SLAB * 64, XSLOT = CIT * PLANE;
@@ -252,13 +252,13 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   char* dys = smem + 3 * XSLOT;                      // [TH*TW][32] bf16
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int wave = WV;
-  int b = blockIdx.x;
+  int b = bid.x;
   const int seg = b % dsegs; b /= dsegs;
   const int tw = b % tilesW; b /= tilesW;
   const int th = b % tilesH; b /= tilesH;
   const int n = b;
   const int ncg = Cin / (32 * CIT);                  // groups of CIT ci tiles: one block reads whole CIT*64-byte rows
-  const int cot = blockIdx.y / ncg, cg = blockIdx.y % ncg;
+  const int cot = bid.y / ncg, cg = bid.y % ncg;
   const int h0 = th * TH, w0 = tw * TW, d0 = seg * dlen;
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
   const bf16_t* xb = x + cg * (32 * CIT);
@@ -354,7 +354,7 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   for (int c = 0; c < CIT; ++c) {
     // pair index of (cot, ci tile cg * CIT + c) in the [Cout/32][Cin/32] enumeration the reduction kernel uses
     const int pair = cot * (Cin / 32) + cg * CIT + c;
-    float* out = part + ((int64_t)blockIdx.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
+    float* out = part + ((int64_t)bid.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int tap = (TWOD ? 9 : 0) + wave + 4 * i;        // TWOD: only taps 9..17 are written (and later reduced)
@@ -373,12 +373,13 @@ template <int TW, int CIT, bool TWOD>
 __global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
-                  int dsegs, int dlen, const bf16_t* __restrict__ x1) {
+                  int dsegs, int dlen, const bf16_t* __restrict__ x1, int xcd) {
+  const FplxBlock bid = fplx_xcd_block(xcd);
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
-    case 0: wgrad_march<TW, 0, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    case 1: wgrad_march<TW, 1, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    case 2: wgrad_march<TW, 2, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
-    default: wgrad_march<TW, 3, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1); break;
+    case 0: wgrad_march<TW, 0, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 1: wgrad_march<TW, 1, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 2: wgrad_march<TW, 2, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    default: wgrad_march<TW, 3, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
   }
 }
 
@@ -953,7 +954,7 @@ template <int NT, int KC, int MTL>
 __global__ void __launch_bounds__(MTL * 2, MTL == 128 ? 2 : 1)
 conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-              float* __restrict__ stats, float* __restrict__ partial, int tap_lo, int tap_cnt) {
+              float* __restrict__ stats, float* __restrict__ partial, int tap_lo, int tap_cnt, int xcd) {
   // tap_lo / tap_cnt: the taps to run - 0 / 27, or 9 / 9 for the 2.5D levels whose 27-tap packs are zero outside the
   // middle depth plane (a third of the work, the same result)
   constexpr int THREADS = MTL * 2, NTW = NT / 64;            // N tiles (32 wide) per wave
@@ -966,8 +967,9 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   const int r = lane & 31, khalf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t V = (int64_t)N * D * H * W;
-  const int64_t m0 = (int64_t)blockIdx.x * MTL;
-  const int n0 = blockIdx.y * NT;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  const int64_t m0 = (int64_t)bid.x * MTL;
+  const int n0 = bid.y * NT;
   // staging geometry: thread -> 16-byte chunk c16 of rows row0 + RP * u
   const int c16 = tid % CH, row0 = tid / CH;
   // per staged row: pointer to its centre-tap voxel and a 27-bit mask of the taps that stay inside the volume,
@@ -992,7 +994,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
     amask[u] = m;
   }
   const int nkc = Cin / KC;
-  const int ntaps = (tap_cnt - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int ntaps = (tap_cnt - bid.z + (int)gridDim.z - 1) / (int)gridDim.z;
   const int niter = ntaps * nkc;
   auto swz = [](int row) { return (row / (16 / CH)) % CH; };
   // named staging registers (runtime-indexed arrays would go to scratch).  The A loads are UNCONDITIONAL: a row
@@ -1018,7 +1020,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   if (PB > (U)) breg##S##U = *reinterpret_cast<const uint4*>(wp + ((int64_t)tap_ * Cout + n0 + row0 + RP * (U)) * Cin + kc_ + c16 * 8);
 #define TILE_FETCH(IT, S)                                                                                           \
   do {                                                                                                              \
-    const int tap_ = tap_lo + blockIdx.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                       \
+    const int tap_ = tap_lo + bid.z + ((IT) / nkc) * gridDim.z, kc_ = ((IT) % nkc) * KC;                       \
     const int kd_ = tap_ / 9 - 1, kh_ = (tap_ / 3) % 3 - 1, kw_ = tap_ % 3 - 1;                                     \
     const int64_t aoff_ = (((int64_t)kd_ * H + kh_) * W + kw_) * ldx + kc_;     /* wave-uniform */                  \
     zmask##S = 0;                                                                                                   \
@@ -1102,7 +1104,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
   if (partial) {
     // fp32 partial tiles [voxel][Cout]: transposed through a 4-KB per-wave LDS tile, 16-byte stores (the operand tiles
     // are dead after the loop's last barrier)
-    float* pz = partial + (int64_t)blockIdx.z * V * Cout;
+    float* pz = partial + (int64_t)bid.z * V * Cout;
     float* stf = reinterpret_cast<float*>(smem + 4096 + wave * 4096);
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -1169,7 +1171,7 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
       float t = 0.f;
 #pragma unroll
       for (int m = 0; m < MTL / 64; ++m) t += red[(m * 2 + which) * NT + c];
-      stats[((int64_t)blockIdx.x * 2 + which) * Cout + n0 + c] = t;
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = t;
     }
   }
 }
@@ -1353,7 +1355,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     constexpr int LDS = 2 * (MT_ + NT_) * KC_ * 2;                                                                  \
     (void)hipFuncSetAttribute((const void*)conv_fwd_tile<NT_, KC_, MT_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
     conv_fwd_tile<NT_, KC_, MT_><<<tg, MT_ * 2, LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, \
-                                                           n, d, h, w, cin, cout, stats, partial, tap_lo, tap_cnt);  \
+                                                           n, d, h, w, cin, cout, stats, partial, tap_lo, tap_cnt, fplx_xcd_on()); \
   } while (0)
     const bool k64 = cin % 64 == 0;
     if (c.tile_mt == 256) { if (c.tile_nt == 128) LAUNCH_TILE(128, 64, 256); else LAUNCH_TILE(64, 64, 256); }
@@ -1415,7 +1417,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
     const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + WG_TH * TW_) * 64;                             \
     (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     conv_wgrad_stream<TW_, CIT_, TWOD_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
-                                                                h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1); \
+                                                                h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
   } while (0)
 #define LAUNCH_WG(TW_, CIT_) do { if (mid) LAUNCH_WG2(TW_, CIT_, true); else LAUNCH_WG2(TW_, CIT_, false); } while (0)
   if (c.tw == 32) { if (c.cit == 2) LAUNCH_WG(32, 2); else LAUNCH_WG(32, 1); }
