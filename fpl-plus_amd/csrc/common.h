@@ -101,6 +101,20 @@ __device__ __forceinline__ FplxBlock fplx_xcd_block(int on) {
   b.y = __builtin_amdgcn_readfirstlane((int)(rem % gy));
   return b;
 }
+// The same for persistent kernels that stride a block over a list of tiles (grid.x blocks, tile += grid.x): XCD j sweeps
+// its contiguous eighth of the tile list with its own blocks, so neighbouring tiles (shared halos) run on one L2.
+struct FplxTileRange { int64_t first, end, step; };
+__device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) {
+  FplxTileRange t = {(int64_t)blockIdx.x, ntiles, (int64_t)gridDim.x};
+  if (!on || gridDim.x < 16) return t;
+  const unsigned c = blockIdx.x & 7u, xcd = (blockIdx.y * gridDim.x + blockIdx.x) & 7u;
+  const int64_t q = ntiles >> 3, r = ntiles & 7;
+  const int64_t start = xcd * q + ((int64_t)xcd < r ? xcd : r);
+  t.first = start + (blockIdx.x >> 3);
+  t.end = start + q + ((int64_t)xcd < r ? 1 : 0);
+  t.step = (gridDim.x - c + 7u) >> 3;
+  return t;
+}
 #endif
 static inline int fplx_xcd_on() {
   static const int v = [] { const char* e = getenv("FPLX_XCD"); return e ? atoi(e) : 1; }();

@@ -89,7 +89,7 @@ template <int CIN>
 __global__ void __launch_bounds__(256)
 stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
-              float* __restrict__ stats, int64_t ntiles, int tilesH, int tilesW, int vec_ok) {
+              float* __restrict__ stats, int64_t ntiles, int tilesH, int tilesW, int vec_ok, int xcd) {
   constexpr int KTOT = 27 * CIN, KS = (KTOT + 15) / 16;
   __shared__ bf16_t xs[CIN * 3 * SH * SW];
   __shared__ float red[4][2][32];
@@ -115,16 +115,17 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   float ssum = 0.f, qsum = 0.f;
   char* stg = stg_all[wave];
   PlanarFetch<CIN> pf;
-  int64_t tt = blockIdx.x;
-  Tile tn = tile_of(tt < ntiles ? tt : 0, D, tilesH, tilesW);
-  if (tt < ntiles) pf.fetch(x, tn, D, H, W);
-  for (; tt < ntiles; tt += gridDim.x) {
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  int64_t tt = tr.first;
+  Tile tn = tile_of(tt < tr.end ? tt : 0, D, tilesH, tilesW);
+  if (tt < tr.end) pf.fetch(x, tn, D, H, W);
+  for (; tt < tr.end; tt += tr.step) {
     const Tile t = tn;
     __syncthreads();
     pf.commit(xs);
     __syncthreads();
-    if (tt + gridDim.x < ntiles) {
-      tn = tile_of(tt + gridDim.x, D, tilesH, tilesW);
+    if (tt + tr.step < tr.end) {
+      tn = tile_of(tt + tr.step, D, tilesH, tilesW);
       pf.fetch(x, tn, D, H, W);
     }
 #pragma unroll
@@ -188,7 +189,7 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
 template <int CIN>
 __global__ void __launch_bounds__(256)
 stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int64_t ldy, float* __restrict__ part,
-                int N, int D, int H, int W, int co0, int64_t ntiles, int tilesH, int tilesW) {
+                int N, int D, int H, int W, int co0, int64_t ntiles, int tilesH, int tilesW, int xcd) {
   constexpr int KTOT = 27 * CIN, RT = (KTOT + 31) / 32;
   __shared__ bf16_t xs[CIN * 3 * SH * SW + 16];
   __shared__ __attribute__((aligned(16))) char dys[TH * TW * 64];
@@ -209,7 +210,8 @@ stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int6
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[rt][i] = 0.f;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
     const Tile t = tile_of(tt, D, tilesH, tilesW);
     __syncthreads();
     stage_x_planar<CIN>(x, xs, t, D, H, W);
@@ -301,7 +303,7 @@ stem_wgrad_reduce(const float* __restrict__ part, int nparts, int rt, int cin, i
 template <int KSTEPS>      // Cin / 16
 __global__ void __launch_bounds__(256)
 outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
-                 float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW) {
+                 float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
   constexpr int CIN = KSTEPS * 16, ROWB = CIN * 2, CH = ROWB / 16;
   __shared__ __attribute__((aligned(16))) char xs[SH * SW * ROWB];
   __shared__ bf16x8 bsh[9 * KSTEPS][64];            // B fragments, lane-linear
@@ -318,7 +320,8 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
   }
   const float bv = (r < ncls && bias) ? bias[r] : 0.f;
   auto swz = [](int vox) { return (vox / (16 / CH)) % CH; };
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
     const Tile t = tile_of(tt, D, tilesH, tilesW);
     __syncthreads();
     for (int i = threadIdx.x; i < SH * SW * CH; i += 256) {
@@ -418,7 +421,7 @@ outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 // fp32 planes; the 9 taps are dealt to the 4 waves (3/2/2/2).
 __global__ void __launch_bounds__(256)
 outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ dl, float* __restrict__ part,
-                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW) {
+                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
   __shared__ __attribute__((aligned(16))) char xs[SH * SW * 64];
   __shared__ __attribute__((aligned(16))) bf16_t dls[32][TH * TW];   // dlogits tile per class, bf16
   const int lane = threadIdx.x & 63;
@@ -433,7 +436,8 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
     const Tile t = tile_of(tt, D, tilesH, tilesW);
     __syncthreads();
     for (int i = threadIdx.x; i < SH * SW * 4; i += 256) {
@@ -546,9 +550,9 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   const int nb = edge_blocks(nt);
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1)
-      stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok);
+      stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok, fplx_xcd_on());
     else
-      stem_fwd_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok);
+      stem_fwd_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok, fplx_xcd_on());
   }
   int rc = fplx_check_launch("edge_stem_fwd");
   return rc < 0 ? rc : 1;
@@ -569,8 +573,8 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
   const int nb = edge_blocks(nt, STEM_WGRAD_MULT);
   const int rt = (27 * cin + 31) / 32;
   for (int co0 = 0; co0 < cout; co0 += 32) {
-    if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
-    else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw);
+    if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on());
+    else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on());
     stem_wgrad_reduce<<<(rt * 1024 + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nb, rt, cin, co0, dw);
   }
   int rc = fplx_check_launch("edge_stem_wgrad");
@@ -583,9 +587,9 @@ extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = (int)(nt < 2048 ? nt : 2048);
-  if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
-  else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
-  else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw);
+  if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+  else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+  else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
   int rc = fplx_check_launch("edge_outconv_fwd");
   return rc < 0 ? rc : 1;
 }
@@ -617,7 +621,7 @@ extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* 
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
   dim3 grid(nb, c0 / 32);
-  outconv_wgrad_mfma<<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, dl, (float*)ws, n, d, h, w, ncls, nt, th, tw);
+  outconv_wgrad_mfma<<<grid, 256, 0, st>>>((const bf16_t*)x, ldx, dl, (float*)ws, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
   const int total = (c0 / 32) * 9 * 1024;
   outconv_wgrad_reduce<<<(total + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nb, c0 / 32, c0, ncls, dw);
   int rc = fplx_check_launch("edge_outconv_wgrad");

@@ -462,12 +462,13 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
 __global__ void __launch_bounds__(DIRECT_THREADS)
 deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wf,
                 const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
-                int Cin, int Cout, int sd, int vec_ok) {
+                int Cin, int Cout, int sd, int vec_ok, int xcd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, kh8 = (lane >> 5) * 8;
   const int64_t V = (int64_t)N * D * H * W;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  const int n0 = blockIdx.y * 32, tap0 = blockIdx.z * 4;
+  const FplxBlock bid = fplx_xcd_block(xcd);               // the cout blocks / depth taps of one voxel tile share an L2
+  const int64_t m0 = ((int64_t)bid.x * 4 + wave) * 32;
+  const int n0 = bid.y * 32, tap0 = bid.z * 4;
   const int64_t v = m0 + r;
   const bool ok = v < V;
   const bf16_t* ap = x + (ok ? v : 0) * ldx + kh8;
@@ -1439,7 +1440,7 @@ extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf,
   dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
   const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
   deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
-                                                   h, w, cin, cout, sd, vec_ok);
+                                                   h, w, cin, cout, sd, vec_ok, fplx_xcd_on());
   int rc = fplx_check_launch("mfma_deconv2_fwd");
   return rc < 0 ? rc : 1;
 }
