@@ -294,11 +294,11 @@ __global__ void pack_conv_w(const float* __restrict__ w, T* __restrict__ wf, T* 
 // wb[26-tap][ci][co] in 32-byte runs - instead of one scattered 2-byte store per element and layout (the element-wise
 // kernel above is store-issue-bound: 0.7 TB/s on the 512x512 layers).
 constexpr int PK_CO = 16, PK_CI = 32, PK_ROW = PK_CI * 27 + 2;     // +2 bf16: odd dword stride between co rows
-__global__ void __launch_bounds__(256)
-pack_conv_w27_tiled(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb, int Cout, int Cin) {
+__device__ __forceinline__ void pack27_tile(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb,
+                                            int Cout, int Cin, int blk) {
   __shared__ bf16_t lds[PK_CO * PK_ROW];
   const int ci_tiles = Cin / PK_CI;
-  const int co0 = (blockIdx.x / ci_tiles) * PK_CO, ci0 = (blockIdx.x % ci_tiles) * PK_CI;
+  const int co0 = (blk / ci_tiles) * PK_CO, ci0 = (blk % ci_tiles) * PK_CI;
   constexpr int SEG4 = PK_CI * 27 / 4;                               // float4 per co run (216)
   for (int i = threadIdx.x; i < PK_CO * SEG4; i += 256) {
     const int co_l = i / SEG4, q = i % SEG4;
@@ -323,6 +323,25 @@ pack_conv_w27_tiled(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t
       for (int j = 0; j < 8; ++j) p.h[j] = lds[(8 * half + j) * PK_ROW + ci_l * 27 + tap];
       *reinterpret_cast<uint4*>(wb + ((int64_t)(26 - tap) * Cin + ci0 + ci_l) * Cout + co0 + 8 * half) = p.u;
     }
+}
+__global__ void __launch_bounds__(256)
+pack_conv_w27_tiled(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb, int Cout, int Cin) {
+  pack27_tile(w, wf, wb, Cout, Cin, blockIdx.x);
+}
+// every 3x3x3 layer of the network in ONE launch (the per-layer launches are 5-18 us each, mostly latency: 17 of them
+// cost a training step 0.17 ms right after Adam, where nothing can overlap them): block -> (layer, tile) by a table
+constexpr int PK_MAX = 32;
+struct PackTable {
+  const float* w[PK_MAX];
+  bf16_t* wf[PK_MAX];
+  bf16_t* wb[PK_MAX];
+  int cout[PK_MAX], cin[PK_MAX], first[PK_MAX + 1], n;
+};
+__global__ void __launch_bounds__(256)
+pack_conv_w27_tiled_multi(const PackTable t) {
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
+  pack27_tile(t.w[e], t.wf[e], t.wb[e], t.cout[e], t.cin[e], (int)blockIdx.x - t.first[e]);
 }
 
 template <typename T>
@@ -467,6 +486,33 @@ int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin,
   else
     return fplx_fail(FPLX_E_BADDTYPE, "pack_conv_weight: dtype %d", dt);
   return fplx_check_launch("pack_conv_weight");
+}
+
+int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf, void* const* wb, const int* cout,
+                                   const int* cin, int dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(w && wf && wb && cout && cin, FPLX_E_NULL, "pack_conv_weights_batched: null pointer");
+  FPLX_REQUIRE(n > 0 && n <= PK_MAX, FPLX_E_BADSHAPE, "pack_conv_weights_batched: %d layers (1..%d)", n, PK_MAX);
+  static const bool tiled = [] { const char* e = getenv("FPLX_PACK_TILED"); return !e || atoi(e) != 0; }();
+  static const bool multi = [] { const char* e = getenv("FPLX_PACK_MULTI"); return !e || atoi(e) != 0; }();   // A/B knob
+  PackTable t;
+  t.n = 0;
+  t.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    FPLX_REQUIRE(w[i] && wf[i] && cout[i] > 0 && cin[i] > 0, FPLX_E_NULL, "pack_conv_weights_batched: layer %d", i);
+    const bool ok = multi && tiled && dt == FPLX_BF16 && cin[i] % PK_CI == 0 && cout[i] % PK_CO == 0 &&
+                    ((uintptr_t)w[i] % 16 == 0) && ((uintptr_t)wf[i] % 16 == 0) && ((uintptr_t)wb[i] % 16 == 0);
+    if (!ok) {                                                // layers the tiled kernel does not take: one by one
+      const int rc = fplx_pack_conv_weight(w[i], wf[i], wb[i], cout[i], cin[i], 3, 3, 3, dt, stream);
+      if (rc != FPLX_OK) return rc;
+      continue;
+    }
+    const int k = t.n++;
+    t.w[k] = w[i]; t.wf[k] = (bf16_t*)wf[i]; t.wb[k] = (bf16_t*)wb[i]; t.cout[k] = cout[i]; t.cin[k] = cin[i];
+    t.first[k + 1] = t.first[k] + (cout[i] / PK_CO) * (cin[i] / PK_CI);
+  }
+  if (t.n == 0) return FPLX_OK;
+  pack_conv_w27_tiled_multi<<<t.first[t.n], 256, 0, (hipStream_t)stream>>>(t);
+  return fplx_check_launch("pack_conv_weights_batched");
 }
 
 int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt, fplx_stream_t stream) {

@@ -51,12 +51,18 @@ class Engine(object):
         net = self.net
         packs = {}
         first = next(iter(net.conv_sites()))[0]
+        batch = []                                       # the 3x3x3 layers: one launch for all of them
         for name, conv in net.conv_sites():
             want_wb = name != first                      # no data gradient w.r.t. the network input
             if conv.weight.dim() == 4:                   # Conv2d of a 2.5D level
                 packs[name] = ops.pack_conv2d_weight(conv.weight, act_dtype, want_wb)
             else:
-                packs[name] = ops.pack_conv_weight(conv.weight, act_dtype, want_wb)
+                batch.append((name, conv.weight, want_wb))
+        for i in range(0, len(batch), 32):
+            part = batch[i:i + 32]
+            res = ops.pack_conv_weights_batched([b[1] for b in part], act_dtype, [b[2] for b in part])
+            for b, r in zip(part, res):
+                packs[b[0]] = r
         for name, tr in net.deconv_sites():
             packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
         oc = net.out_conv

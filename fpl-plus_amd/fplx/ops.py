@@ -53,6 +53,25 @@ def pack_conv_weight(w, act_dtype, want_wb=True):
     return wf, wb
 
 
+def pack_conv_weights_batched(ws, act_dtype, want_wb):
+    """pack_conv_weight for a list of 3x3x3 weights in one launch -> list of (wf, wb)"""
+    import ctypes
+    n = len(ws)
+    outs = []
+    for w, wantb in zip(ws, want_wb):
+        co, ci = w.shape[0], w.shape[1]
+        assert tuple(w.shape[2:]) == (3, 3, 3) and w.dtype == torch.float32 and w.is_contiguous()
+        wf = torch.empty((27, co, ci), dtype=act_dtype, device=w.device)
+        wb = torch.empty((27, ci, co), dtype=act_dtype, device=w.device) if wantb else None
+        outs.append((wf, wb))
+    vp = ctypes.c_void_p * n
+    ip = ctypes.c_int * n
+    call("fplx_pack_conv_weights_batched", n, vp(*[ptr(w) for w in ws]), vp(*[ptr(o[0]) for o in outs]),
+         vp(*[ptr(o[1]) or None for o in outs]), ip(*[w.shape[0] for w in ws]), ip(*[w.shape[1] for w in ws]),
+         _DT[act_dtype], stream())
+    return outs
+
+
 def pack_deconv_weight(w, act_dtype):
     """ConvTranspose3d weight [Cin,Cout,2,2,2] (8 taps) or ConvTranspose2d weight [Cin,Cout,2,2] (4 taps)"""
     ci, co = w.shape[0], w.shape[1]

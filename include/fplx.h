@@ -56,6 +56,10 @@ int fplx_num_partials(int64_t voxels);
  * both in dtype dt.  tap = (kd*KH + kh)*KW + kw. */
 int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin, int kd, int kh, int kw,
                           int dt, fplx_stream_t stream);
+/* the same for n (<= 32) 3x3x3 layers in one launch: host arrays of per-layer pointers / channel counts (what the train
+ * step does after every optimizer step for all ConvBlockND convolutions, unet2d5_dsbn.py:54-55).  wb[i] may be NULL. */
+int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf, void* const* wb, const int* cout,
+                                   const int* cin, int dt, fplx_stream_t stream);
 /* nn.ConvTranspose3d weight [Cin][Cout][2][2][2] fp32 (unet2d5_dsbn.py:152)
  *   -> wf[tap][Cout][Cin] and wb[tap][Cin][Cout] (dtype dt), tap = (i*2+j)*2+k */
 int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt,

@@ -321,3 +321,21 @@ def test_outconv_kernels_bf16(shape):
                      dw, db, dims, c0, ncls, (1, 3, 3), ws)
     assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
     assert float((db.cpu() - br.grad).abs().max()) < 1e-4 * float(br.grad.abs().max())
+
+
+def test_pack_conv_weights_batched_equals_per_layer_packs():
+    """fplx_pack_conv_weights_batched (every 3x3x3 layer in one launch) against fplx_pack_conv_weight layer by layer:
+    bit-identical packs, including a layer the tiled kernel does not take (Cin = 1), a missing data-gradient pack and
+    the fp32 mode (which falls back to the per-layer kernel inside)."""
+    from fplx import ops
+    shapes = [(32, 1), (32, 32), (64, 32), (64, 64), (128, 64), (48, 96), (512, 256)]
+    ws = [torch.from_numpy(detdata.normal("pk.%d.%d" % s, s + (3, 3, 3), 0.3)).cuda() for s in shapes]
+    want = [i != 0 for i in range(len(ws))]
+    for dtype in (torch.bfloat16, torch.float32):
+        got = ops.pack_conv_weights_batched(ws, dtype, want)
+        for w, wb_wanted, (wf, wb) in zip(ws, want, got):
+            rf, rb = ops.pack_conv_weight(w, dtype, wb_wanted)
+            assert torch.equal(wf, rf)
+            assert (wb is None and rb is None) or torch.equal(wb, rb)
+    with pytest.raises(ValueError):
+        ops.pack_conv_weights_batched(ws * 5, torch.bfloat16, want * 5)          # more than 32 layers in one call
