@@ -478,13 +478,21 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  for (int kc = 0; kc < Cin; kc += 16) {
-    const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(ap + kc) : zero;
+  // Cin % 32 == 0 (fplx_mfma_deconv2_fwd): two k-steps per trip, all ten loads issued before the eight MFMAs
+  const bf16_t* bp = wf + ((int64_t)tap0 * Cout + n0 + r) * Cin + kh8;
+  const int64_t tstride = (int64_t)Cout * Cin;
+  for (int kc = 0; kc < Cin; kc += 32) {
+    bf16x8 a[2], b[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(tap0 + t) * Cout + n0 + r) * Cin + kc + kh8);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+    for (int u = 0; u < 2; ++u) {
+      a[u] = ok ? *reinterpret_cast<const bf16x8*>(ap + kc + 16 * u) : zero;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[u][t] = *reinterpret_cast<const bf16x8*>(bp + t * tstride + kc + 16 * u);
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u][t], acc[t], 0, 0, 0);
   }
   const int co = n0 + r, rh = (lane >> 5) * 4;
   const float bv = bias[co];
@@ -501,10 +509,11 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
       int64_t vv = m0 + (lane >> 2) + 16 * half;
       ook[half] = vv < V;
       if (!ook[half]) vv = 0;
-      const int w0 = (int)(vv % W); vv /= W;
-      const int h0 = (int)(vv % H); vv /= H;
-      const int d0 = (int)(vv % D); vv /= D;
-      obase[half] = ((vv * sd * D + sd * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
+      unsigned q = (unsigned)vv;                             // V < 2^31 (host check): 32-bit divisions
+      const int w0 = (int)(q % (unsigned)W); q /= (unsigned)W;
+      const int h0 = (int)(q % (unsigned)H); q /= (unsigned)H;
+      const int d0 = (int)(q % (unsigned)D); q /= (unsigned)D;
+      obase[half] = (((int64_t)q * sd * D + sd * d0) * 2 * H + 2 * h0) * 2 * W + 2 * w0;
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1435,8 +1444,9 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
 // sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (4 taps, packs [4][..][..])
 extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, int sd, hipStream_t st) {
-  if (cin % 16 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
+  if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
+  if (V >= ((int64_t)1 << 31)) return 0;
   dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
   const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
   deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
