@@ -31,6 +31,10 @@ class GradAllReducer(object):
     def begin(self, gflat):
         self._works, self._next, self._gflat = [], 0, gflat
 
+    def pending(self, end):
+        """would ready(end) launch a collective?  (the engine joins its weight-gradient stream only then)"""
+        return self.enabled and self._next < len(self.buckets) and self.buckets[self._next][1] <= end
+
     def ready(self, end):
         """gradients of flat elements [0, end) are final: launch every bucket that is complete"""
         if not self.enabled:

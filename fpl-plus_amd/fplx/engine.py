@@ -280,9 +280,27 @@ class Engine(object):
 
         def ready(last_name):
             if on_ready is not None:
-                join_side()                # the bucket's weight gradients were produced on the side stream
                 o, n, _ = net._layout[last_name]
-                on_ready((o + n + 3) // 4 * 4)             # parameters start on 4-float boundaries (net._ensure_flat)
+                end = (o + n + 3) // 4 * 4                 # parameters start on 4-float boundaries (net._ensure_flat)
+                # a reducer that would launch nothing here (single rank, bucket not complete) must not cost a join:
+                # the main stream would wait for the weight gradients ten times per step
+                pending = getattr(getattr(on_ready, "__self__", None), "pending", None)
+                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1":          # A/B knob (benchmarks only): the former order
+                    pending = None
+                if pending is not None and not pending(end):
+                    return
+                if side_on and pending is not None:
+                    # the bucket's weight gradients were produced on the side stream, its BN / bias gradients on this
+                    # one: launch the collective FROM the side stream once that has caught up with this stream's
+                    # position - the communication stream then depends on both and the data-gradient chain never waits
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        on_ready(end)
+                    return
+                join_side()                # generic callback: make everything visible on the current stream first
+                on_ready(end)
 
         ready("out_conv.bias")
         d_cur = empty(vox[0], ft[0])

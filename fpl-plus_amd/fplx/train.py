@@ -7,6 +7,8 @@ backward + optimizer.step the published loop forgot (it exists in training_all, 
 the vanilla agent, net_run/agent_seg.py:153-159).  `step_all()` = one iteration of training_all
 (agent_seg.py:459-495): every domain forward, loss (l0 + l1)/2, ONE Adam step.
 """
+import os
+
 import torch
 
 from . import ops
@@ -28,6 +30,7 @@ class TrainStep(object):
         self.gflat = torch.zeros_like(net.flat_params)
         self.gacc = None
         shared, doms = net.segments()
+        bucket_elems = int(os.environ.get("FPLX_BUCKET_ELEMS", bucket_elems))      # tuning knob (benchmarks only)
         self.reducer = GradAllReducer(net.bucket_ranges(bucket_elems), doms, group)
         self.opt.grad_scale = 1.0 / self.reducer.world
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
