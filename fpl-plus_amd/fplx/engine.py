@@ -285,7 +285,10 @@ class Engine(object):
                 # a reducer that would launch nothing here (single rank, bucket not complete) must not cost a join:
                 # the main stream would wait for the weight gradients ten times per step
                 pending = getattr(getattr(on_ready, "__self__", None), "pending", None)
-                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1":          # A/B knob (benchmarks only): the former order
+                # Nets with 2D levels keep the join at every block boundary: without it the 2.5D soak trajectory
+                # (tools/soak.py) differs from run to run in the 4th digit, while the all-3D one stays bit-identical -
+                # an ordering hazard in one of the 2D-level weight-gradient launches that is not located yet.
+                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1" or any(d != 3 for d in net.dims):
                     pending = None
                 if pending is not None and not pending(end):
                     return
