@@ -261,6 +261,11 @@ class Engine(object):
             keep.extend(tensors)
             with torch.cuda.stream(side):
                 fn()
+            dbg = os.environ.get("FPLX_JOIN_KIND", "")          # bisect knob: join right after the named launches
+            if dbg:
+                kind = [n for n in fn.__code__.co_names if "wgrad" in n]
+                if kind and kind[0] in dbg.split(","):
+                    join_side()
 
         def join_side():
             if side_on:
@@ -288,7 +293,8 @@ class Engine(object):
                 # Nets with 2D levels keep the join at every block boundary: without it the 2.5D soak trajectory
                 # (tools/soak.py) differs from run to run in the 4th digit, while the all-3D one stays bit-identical -
                 # an ordering hazard in one of the 2D-level weight-gradient launches that is not located yet.
-                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1" or any(d != 3 for d in net.dims):
+                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1" or (any(d != 3 for d in net.dims) and
+                                                                       os.environ.get("FPLX_FAST_READY", "0") != "1"):
                     pending = None
                 if pending is not None and not pending(end):
                     return
