@@ -206,11 +206,13 @@ seg_loss_bwd_k(const float* __restrict__ logits, const float* __restrict__ label
 // ------------------------------------------------------------------------------------------
 // MC / TTA uncertainty filter (agent_seg.py:911-931) for one volume
 constexpr int MAXT = 16;
+constexpr uint32_t FPL_CUT_LO = 0x3ACA8577u, FPL_CUT_HI = 0x3F7D6D40u;   // m1 in [0.00154511526, 0.989948273]
 
 template <int C>
 __global__ void __launch_bounds__(LT)
 mc_filter_k(const float* __restrict__ logits, int T, int64_t V, float thr, uint8_t* __restrict__ hards,
             float* __restrict__ mean_out, float* __restrict__ unc_out, double* __restrict__ part) {
+  const bool exact_cut = thr == 0.01f;
   double var_acc = 0.0;
   long long bnd = 0;
   for (int64_t v = (int64_t)blockIdx.x * LT + threadIdx.x; v < V; v += (int64_t)gridDim.x * LT) {
@@ -247,7 +249,12 @@ mc_filter_k(const float* __restrict__ logits, int T, int64_t V, float thr, uint8
     const float u = -1.0f * (m1 * logf(m1 + 1e-6f));
     if (mean_out) mean_out[v] = m1;
     if (unc_out) unc_out[v] = u;
-    bnd += (u > thr) ? 1 : 0;
+    // `u > 0.01` (the reference's hard-coded threshold) is decided on m1 itself: numpy's float32 u(m) crosses 0.01
+    // exactly twice on [0, 1] (tools/filter_cutpoints.py: bisection + exhaustive check of 2^17 patterns around each
+    // crossing), so the count does not depend on this device's logf.  Any other threshold uses u.
+    const uint32_t mb = __float_as_uint(m1);
+    const bool over = exact_cut ? (mb >= FPL_CUT_LO && mb <= FPL_CUT_HI) : (u > thr);
+    bnd += over ? 1 : 0;
   }
   __shared__ double red[LT / 64][2];
   const double a = wave_sum_d(var_acc), b = wave_sum_d((double)bnd);

@@ -39,6 +39,9 @@ class Engine(object):
         # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
         self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
         self.use_split_cat = os.environ.get("FPLX_SPLIT_CAT", "1") != "0"     # A/B knob (benchmarks only)
+        # block_joins: the main stream waits for the weight-gradient stream at every block boundary of backward.
+        # None = decide per network (see backward()); tools/race25.py sets it to bisect.
+        self.block_joins = None
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
@@ -70,6 +73,11 @@ class Engine(object):
         _, wb = ops.pack_conv_weight(oc.weight, act_dtype, True)
         packs["out_conv"] = (wf, wb)
         return packs
+
+    def default_block_joins(self):
+        """Networks with 2D levels join the weight-gradient stream at every block boundary of backward, whoever
+        calls backward (train step, autograd, with or without a reducer): see DESIGN section 7, stream order."""
+        return any(d != 3 for d in self.net.dims)
 
     def invalidate(self):
         self._pack_cache = None
@@ -249,6 +257,9 @@ class Engine(object):
             self._side = torch.cuda.Stream(device=dev)
         side = self._side if side_on else None
         keep = []                          # tensors the side stream still reads: kept alive until the join
+        block_joins = self.block_joins
+        if block_joins is None:
+            block_joins = self.default_block_joins()
         ws_w = self.ws_side if side_on else ws
 
         def on_side(fn, *tensors):
@@ -261,11 +272,6 @@ class Engine(object):
             keep.extend(tensors)
             with torch.cuda.stream(side):
                 fn()
-            dbg = os.environ.get("FPLX_JOIN_KIND", "")          # bisect knob: join right after the named launches
-            if dbg:
-                kind = [n for n in fn.__code__.co_names if "wgrad" in n]
-                if kind and kind[0] in dbg.split(","):
-                    join_side()
 
         def join_side():
             if side_on:
@@ -284,32 +290,30 @@ class Engine(object):
                                          gv["out_conv.bias"], dims[0], ft[0], ncls, (1, 3, 3), ws_w), dlogits)
 
         def ready(last_name):
-            if on_ready is not None:
-                o, n, _ = net._layout[last_name]
-                end = (o + n + 3) // 4 * 4                 # parameters start on 4-float boundaries (net._ensure_flat)
-                # a reducer that would launch nothing here (single rank, bucket not complete) must not cost a join:
-                # the main stream would wait for the weight gradients ten times per step
-                pending = getattr(getattr(on_ready, "__self__", None), "pending", None)
-                # Nets with 2D levels keep the join at every block boundary: without it the 2.5D soak trajectory
-                # (tools/soak.py) differs from run to run in the 4th digit, while the all-3D one stays bit-identical -
-                # an ordering hazard in one of the 2D-level weight-gradient launches that is not located yet.
-                if os.environ.get("FPLX_JOIN_ALWAYS", "0") == "1" or (any(d != 3 for d in net.dims) and
-                                                                       os.environ.get("FPLX_FAST_READY", "0") != "1"):
-                    pending = None
-                if pending is not None and not pending(end):
-                    return
-                if side_on and pending is not None:
-                    # the bucket's weight gradients were produced on the side stream, its BN / bias gradients on this
-                    # one: launch the collective FROM the side stream once that has caught up with this stream's
-                    # position - the communication stream then depends on both and the data-gradient chain never waits
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        on_ready(end)
-                    return
-                join_side()                # generic callback: make everything visible on the current stream first
-                on_ready(end)
+            """block boundary: the gradients of flat elements [0, end of last_name) have been enqueued"""
+            if block_joins:
+                join_side()
+            if on_ready is None:
+                return
+            o, n, _ = net._layout[last_name]
+            end = (o + n + 3) // 4 * 4                 # parameters start on 4-float boundaries (net._ensure_flat)
+            # a reducer that would launch nothing here (single rank, bucket not complete) must not cost a join:
+            # the main stream would wait for the weight gradients ten times per step
+            pending = getattr(getattr(on_ready, "__self__", None), "pending", None)
+            if pending is not None and not pending(end):
+                return
+            if side_on and pending is not None and not block_joins:
+                # the bucket's weight gradients were produced on the side stream, its BN / bias gradients on this
+                # one: launch the collective FROM the side stream once that has caught up with this stream's
+                # position - the communication stream then depends on both and the data-gradient chain never waits
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    on_ready(end)
+                return
+            join_side()                # generic callback: make everything visible on the current stream first
+            on_ready(end)
 
         ready("out_conv.bias")
         d_cur = empty(vox[0], ft[0])

@@ -76,10 +76,23 @@ def test_full_volume_filter_matches_numpy_oracle():
     stack = (rng.standard_normal((6, 2, 48, 160, 272)) * 1.5).astype(np.float32)
     stack[:, 1, :, :80] -= 6.0                                # confident background half
     ref = N.fpl_filter(stack)
-    r = fplx.filter.fpl_filter(torch.from_numpy(stack).cuda())
+    r = fplx.ops.mc_filter(torch.from_numpy(stack).cuda(), want_maps=True)
     assert np.array_equal(r["hards"].cpu().numpy(), ref["hards"])            # masks: bit exact
     st = r["stats"].cpu().numpy()
-    assert abs(int(st[1]) - ref["boundary"]) <= 2            # voxels within 1 ulp of the 0.01 threshold
+    # boundary = #(u > 0.01): decided on the float32 mean m itself (two cut points of numpy's float32 u(m), found by
+    # tools/filter_cutpoints.py), so given m the count is numpy's exactly ...
+    m_gpu = r["means"].cpu().numpy()
+    with np.errstate(divide="ignore"):
+        pred_gpu = (-1.0 * (m_gpu * np.log(m_gpu + 1e-6))) > 0.01
+    assert int(st[1]) == int(pred_gpu.sum())
+    # ... and m is numpy's mean up to the last bits of exp (numpy's float32 exp is not correctly rounded either): a voxel
+    # may only be counted differently if its two means straddle a cut point
+    flipped = pred_gpu != (ref["uncertainty"] > 0.01)
+    assert int(st[1]) - ref["boundary"] == int(pred_gpu.sum()) - int((ref["uncertainty"] > 0.01).sum())
+    assert flipped.sum() <= 2
+    if flipped.any():
+        assert np.abs(m_gpu[flipped] - ref["means"][flipped]).max() <= 4 * np.spacing(ref["means"][flipped]).max()
+    assert np.abs(m_gpu - ref["means"]).max() <= 2.5e-7
     assert abs(st[0] - float(ref["vars"])) <= 2e-5 * float(ref["vars"])
     assert abs(st[2] - float(ref["uncer_one"])) <= 2e-5 * float(ref["uncer_one"])
     a = (rng.random((48, 160, 272)) > 0.5).astype(np.uint8)

@@ -176,3 +176,23 @@ def test_reference_key_order_rule_matches_reference_dump(golden_dir):
     k = json.load(open(os.path.join(golden_dir, "ref_state_keys.json")))
     assert C.reference_state_keys(2) == k["state_dict"] and len(k["state_dict"]) == 484
     assert C.reference_param_names(2) == k["named_parameters"] and len(k["named_parameters"]) == 268
+
+
+def test_filter_cut_points_are_numpys():
+    """The FPL boundary count (agent_seg.py:922-924) is decided on the float32 mean with two cut points compiled into
+    csrc/loss_filter.hip: they must be exactly where numpy's float32 u(m) = -m*log(m+1e-6) crosses 0.01."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "fpl-plus_amd", "csrc", "loss_filter.hip")).read()
+    m = re.search(r"FPL_CUT_LO = (0x[0-9A-Fa-f]+)u, FPL_CUT_HI = (0x[0-9A-Fa-f]+)u", src)
+    lo, hi = int(m.group(1), 16), int(m.group(2), 16)
+
+    def pred(bits):
+        v = np.asarray(bits, np.uint32).view(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return (-1.0 * (v * np.log(v + 1e-6))) > 0.01
+    for cut in (lo, hi):
+        w = np.arange(cut - 4096, cut + 4097, dtype=np.uint32)
+        assert np.array_equal(pred(w), (w >= lo) & (w <= hi))
+    coarse = np.arange(0, int(np.float32(1.0).view(np.uint32)) + 1, 4099, dtype=np.uint32)
+    assert np.array_equal(pred(coarse), (coarse >= lo) & (coarse <= hi))
