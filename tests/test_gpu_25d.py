@@ -423,3 +423,51 @@ def test_25d_split_concat_path_agrees_with_the_single_buffer_path():
         r, g = prm[k].grad.numpy().reshape(-1).astype(np.float64), ga[k].reshape(-1)
         cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r)))
         assert cos > 0.9, (k, cos)
+
+
+@pytest.mark.parametrize("path", ["step_all", "autograd"])
+def test_25d_32base_backward_is_bitwise_reproducible_with_the_side_stream(path):
+    """The shipped-style network (32-base, conv_dims = [2,2,3,3,3], bf16, 4 x 1 x 28 x 128 x 128) with the weight-gradient
+    stream ON: repeated runs of the same iteration give the same bits, through TrainStep.step_all (no reducer hook) and
+    through net(x) / loss.backward() (what SegmentationAgent runs)."""
+    import fplx
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0.0, 0.0, 0.3, 0.4, 0.5], conv_dims=[2, 2, 3, 3, 3],
+             class_num=2, bilinear=False, num_domains=2, precision="bf16")
+    shape = (4, 1, 28, 128, 128)
+    g = torch.Generator().manual_seed(0)
+    bs = []
+    for dmn in range(2):
+        x = torch.randn(*shape, generator=g)
+        lab = torch.zeros(4, 2, *shape[2:])
+        lab[:, 0] = 1.0
+        lab[:, 0, 7:14, 32:64, 42:84] = 0.0
+        lab[:, 1, 7:14, 32:64, 42:84] = 1.0
+        x[:, 0] += 2.0 * lab[:, 1]
+        bs.append({"image": x.cuda(), "label_prob": lab.cuda()})
+
+    def run():
+        torch.manual_seed(1)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        assert net.engine.use_side_stream
+        if path == "step_all":
+            ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+            for _ in range(4):
+                ts.step_all(bs)
+            torch.cuda.synchronize()
+            return net.flat_params.clone()
+        net.train()
+        net._ensure_flat()
+        grads = []
+        for it in range(4):
+            b = bs[it % 2]
+            for q in net.parameters():
+                q.grad = None
+            out = net(b["image"], domain_label=(it % 2) * torch.ones(4, dtype=torch.long))
+            fplx.DiceLoss()({"prediction": out, "ground_truth": b["label_prob"]}).backward()
+            grads.append(torch.cat([q.grad.reshape(-1) for q in net.parameters() if q.grad is not None]))
+        torch.cuda.synchronize()
+        return torch.cat(grads)
+
+    a = run()
+    for _ in range(3):
+        assert torch.equal(run(), a)

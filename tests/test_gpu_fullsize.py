@@ -158,3 +158,48 @@ def test_bench_under_torchrun_exercises_the_rccl_path():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 10 and np.isfinite(d["final_loss"])
+
+
+def test_config5_full_size_weighted_dual_domain_step():
+    """BASELINE config 5 at its full size on one GPU: dual-domain UNet3D-DSBN, in_chns 4, 32-base bf16, 2 x 4 x 128^3 crops
+    per domain, weighted Dice + CE with pixel_weight in {0, w_img} (= NiftyDataset.set_weight_ of a {1, 0.5} map,
+    nifty_dataset.py:165-168) - `training_all` iterations (both domains, one Adam step each): two runs bit-identical,
+    finite, the loss falls.  Timing of the same step: tools/cfg5_bench.py."""
+    import fplx
+    net_cfg = dict(NET, in_chns=4)
+    shape = (2, 4, 128, 128, 128)
+
+    def batches():
+        out = []
+        for dmn in range(2):
+            g = torch.Generator().manual_seed(20 + dmn)
+            x = torch.randn(shape, generator=g)
+            lab = torch.zeros((2, 2) + shape[2:])
+            lab[:, 0] = 1.0
+            lab[:, 0, 40:90, 30:100, 50:110] = 0.0
+            lab[:, 1, 40:90, 30:100, 50:110] = 1.0
+            x[:, :2] += 1.5 * lab[:, 1:2]
+            w_img = torch.rand(2, generator=g) + 0.01                                   # U(0.01, 1.01)
+            agree = (torch.rand((2, 1) + shape[2:], generator=g) > 0.1).float()          # 10 % of the voxels filtered out
+            pw = agree * w_img.view(2, 1, 1, 1, 1)
+            out.append({"image": x.cuda(), "label_prob": lab.cuda(), "pixel_weight": pw.cuda(), "image_weight": w_img.cuda()})
+        return out
+
+    def run(steps):
+        torch.manual_seed(3)
+        net = fplx.UNet2D5_dsbn(dict(net_cfg)).cuda()
+        loss = fplx.make_loss({"loss_type": ["DiceLoss", "CrossEntropyLoss"], "loss_weight": [0.5, 0.5]})
+        ts = fplx.TrainStep(net, loss.terms, True, lr=1e-3, weight_decay=1e-5)
+        bs = batches()
+        ls = []
+        for _ in range(steps):
+            outs = ts.step_all(bs)
+            ls.append(0.5 * (outs[0][0] + outs[1][0]))
+        torch.cuda.synchronize()
+        return net, [float(v.item()) for v in ls]
+
+    net_a, la = run(5)
+    net_b, lb = run(5)
+    assert la == lb and torch.equal(net_a.flat_params, net_b.flat_params)
+    assert all(np.isfinite(la)) and bool(torch.isfinite(net_a.flat_params).all())
+    assert la[-1] < la[0]

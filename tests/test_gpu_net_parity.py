@@ -177,3 +177,79 @@ def test_standalone_dsbn_layer_matches_torch_batchnorm():
     layer.eval(); ref.eval()
     y, _ = layer(x.cuda(), torch.ones(2, dtype=torch.long))
     assert np.abs(y.cpu().numpy() - ref(x).detach().numpy()).max() < 1e-4
+
+
+# 32-base networks on shapes where the benchmarked MFMA kernels run (fplx_march_ok needs H >= 16, W >= 64 at Cin = 32 and
+# H >= 8, W >= 64 at Cin = 64 / 128): "m1" = level-0 AND level-1 depth marches (the Cin = 128 march on up3's concat too),
+# "m4" = 4-channel stem (config 5 style), level-0 marches, the LDS-tiled kernel from level 1 down.
+MARCH_CASES = {
+    "m1": (dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0, 0, 0], conv_dims=[3] * 5, class_num=2,
+                bilinear=False, num_domains=2, net_type="UNet2D5_dsbn"), (1, 1, 32, 64, 128)),
+    "m4": (dict(in_chns=4, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0, 0, 0], conv_dims=[3] * 5, class_num=2,
+                bilinear=False, num_domains=2, net_type="UNet2D5_dsbn"), (2, 4, 16, 64, 64)),
+}
+
+
+@pytest.mark.parametrize("case", ["m1", "m4"])
+def test_bf16_march_kernels_end_to_end_against_oracle(case):
+    """The bf16 bench path end to end (march / tile / stream-wgrad MFMA kernels, split concat, bf16 activations) against the
+    oracle that rounds to bf16 at the same points: logits <= 2e-2 of their range, every weight gradient within 0.1
+    relative L2, BN affine / PReLU gradients likewise, then three `training_all`-style Adam steps."""
+    import fplx
+    from fplx import _lib
+    from oracle import torch_ref as R
+    p, shape = MARCH_CASES[case]
+    p = dict(p, precision="bf16")
+    n, cin, D, H, W = shape
+    lib = _lib.lib()
+    assert lib.fplx_conv3d_cat2_ok(n, D, H, W, 64, 32) == 1                 # the level-0 split concat + march path is taken
+    x = torch.from_numpy(detdata.normal("x." + case, shape))
+    y = torch.from_numpy(detdata.ball_label((D, H, W), min(D, H, W) / 3.0, n=n, offsets=[(0, 1, -2), (1, -3, 2)][:n]))
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    net.train()
+    dom = 1
+    lt = net(x.cuda(), domain_label=dom * torch.ones(n, dtype=torch.long))
+    loss = fplx.DiceLoss()({"prediction": lt, "ground_truth": y.cuda()})
+    loss.backward()
+    sd, prm = R.split_state(detdata.state_dict_3d(p))
+    ref = R.unet_forward(sd, p, x, dom, True, act_dtype=torch.bfloat16)
+    rl = R.dice_loss(ref, y)
+    rl.backward()
+    rng = float(ref.detach().abs().max())
+    err = float(np.abs(lt.detach().cpu().numpy() - ref.detach().numpy()).max())
+    assert err < 2e-2 * rng, (err, rng)
+    assert abs(loss.item() - rl.item()) < 1e-3
+    named = dict(net.named_parameters())
+    worst = {}
+    for k, t in prm.items():
+        if t.grad is None:
+            continue
+        r = t.grad.numpy().reshape(-1).astype(np.float64)
+        g = named[k].grad.cpu().numpy().reshape(-1).astype(np.float64)
+        if k.endswith("bias") and "conv3d_" in k:          # bias before train-mode BN: exactly 0 here, fp32 noise there
+            assert np.abs(g).max() == 0.0
+            continue
+        rel = float(np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30))
+        worst[k] = rel
+    bad = {k: v for k, v in worst.items() if v > 0.1}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "parity_bf16_%s.txt" % case), "w") as f:
+        f.write("logits err %.4g of range %.4g; loss %.6f vs %.6f\n" % (err, rng, loss.item(), rl.item()))
+        for k, v in sorted(worst.items(), key=lambda kv: -kv[1]):
+            f.write("%-44s rel L2 %.4f\n" % (k, v))
+    assert not bad, bad
+    # three optimisation steps (one domain per step, as bench.py runs them): loss trajectory against the oracle's
+    net2 = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net2, p, "cuda")
+    ts = fplx.TrainStep(net2, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+    sd2, prm2 = R.split_state(detdata.state_dict_3d(p))
+    opt = R.AdamRef(prm2, 1e-3, 1e-5)
+    xs, ys = x.cuda(), y.cuda()
+    for it in range(3):
+        out = ts.step(xs, ys, it % 2)
+        opt.zero_grad()
+        lr_ = R.dice_loss(R.unet_forward(sd2, p, x, it % 2, True, act_dtype=torch.bfloat16), y)
+        lr_.backward()
+        opt.step()
+        assert abs(float(out[0].item()) - float(lr_.item())) < 3e-3, (it, float(out[0].item()), float(lr_.item()))
