@@ -356,11 +356,16 @@ class SegmentationAgent(object):
     # ---- inference (agent_seg.py:834-964)
     def infer(self, mc_passes=6, return_outputs=False):
         cfg = self.config['testing']
+        ckpt_names = None
         if 'ckpt_mode' in cfg and self.checkpoint is None:                  # agent_seg.py:854-866
             ckpt_name = self.get_checkpoint_name()
-            if isinstance(ckpt_name, (tuple, list)):
-                raise ValueError("fplx: ckpt_mode 3 (ensemble of checkpoints) is not built")
-            self.checkpoint = torch.load(ckpt_name, map_location=self.device, weights_only=False)
+            if cfg['ckpt_mode'] == 3:
+                assert (isinstance(ckpt_name, (tuple, list)))
+                ckpt_names = list(ckpt_name)                                  # ensemble of checkpoints (966-1019)
+            elif isinstance(ckpt_name, (tuple, list)):
+                raise ValueError("ckpt_mode should be 3 if ckpt_name is a list")
+            else:
+                self.checkpoint = torch.load(ckpt_name, map_location=self.device, weights_only=False)
         domian_label = cfg['domian_label']
         self.FPL = cfg.get('fpl', False)
         self.net.to(self.device)
@@ -378,37 +383,71 @@ class SegmentationAgent(object):
             infer_cfg['class_num'] = self.config['network']['class_num']
             self.inferer = Inferer(infer_cfg)
         uncertainty_list, outputs = {}, {}
+        if ckpt_names is not None:
+            return self.infer_with_multiple_checkpoints(ckpt_names, domian_label)
+        # an injected inferer that overrides run() is called pass by pass, as the reference does
+        batched_mc = isinstance(self.inferer, Inferer) and type(self.inferer).run is Inferer.run
         with torch.no_grad():
             for data in self.test_loader:
                 images = self.convert_tensor_type(data['image']).to(self.device)
                 names = data['names']
                 dl = domian_label * torch.ones(images.shape[0], dtype=torch.long)
                 if self.FPL:
-                    stack = torch.empty((mc_passes, self.config['network']['class_num']) + tuple(images.shape[2:]),
-                                        dtype=torch.float32, device=self.device)
-                    for i in range(mc_passes):                               # agent_seg.py:898-899 (6 passes)
-                        stack[i] = self.inferer.run(self.net, images, dl)[0]
+                    if batched_mc:                                           # all passes x flips x tiles in one batch
+                        stack = self.inferer.run_mc(self.net, images, dl, mc_passes)[:, 0]
+                    else:
+                        stack = torch.empty((mc_passes, self.config['network']['class_num']) + tuple(images.shape[2:]),
+                                            dtype=torch.float32, device=self.device)
+                        for i in range(mc_passes):                           # agent_seg.py:898-899 (6 passes)
+                            stack[i] = self.inferer.run(self.net, images, dl)[0]
                     r = fpl_filter_mod.fpl_uncertainty(stack)
                     uncertainty_list[names[0]] = r['uncer_one']
                     if return_outputs:
                         outputs[names[0]] = r
                 else:
                     pred = self.inferer.run(self.net, images, dl)
-                    data['predict'] = pred
-                    for transform in self.transform_list[::-1]:              # agent_seg.py:944-947
-                        if transform.inverse:
-                            data = transform.inverse_transform_for_prediction(data)
-                    hard = fpl_filter_mod.hard_label(data['predict'])        # save_outputs, 1049-1050
-                    for i, name in enumerate(names):
-                        outputs[name] = hard[i]
-                    if cfg.get('output_dir', None) is not None:
-                        self.save_outputs(data, hard)
+                    outputs.update(self._finish_prediction(data, pred, names))
         if self.FPL:
             srt = fpl_filter_mod.sort_uncertainty(uncertainty_list)
             path = cfg.get('fpl_uncertainty_sorted', None)
             if path:
                 np.save(path, np.array(srt, dtype=object), allow_pickle=True)
             return (srt, outputs) if return_outputs else srt
+        return outputs
+
+    def _finish_prediction(self, data, pred, names):
+        """agent_seg.py:944-953: inverse transforms of the prediction, hard labels, optional files"""
+        cfg = self.config['testing']
+        data['predict'] = pred
+        for transform in self.transform_list[::-1]:                          # agent_seg.py:944-947
+            if transform.inverse:
+                data = transform.inverse_transform_for_prediction(data)
+        pr = data['predict']
+        hard = fpl_filter_mod.hard_label(pr[0] if isinstance(pr, (list, tuple)) else pr)   # save_outputs, 1049-1050
+        if cfg.get('output_dir', None) is not None:
+            self.save_outputs(data, hard)
+        return {name: hard[i] for i, name in enumerate(names)}
+
+    def infer_with_multiple_checkpoints(self, ckpt_names, domian_label):
+        """agent_seg.py:966-1019 (ckpt_mode = 3): the prediction is the mean over the checkpoints' logits - numpy's float32
+        mean over the list axis = additions in list order, one division - formed on the device."""
+        states = [torch.load(n, map_location=self.device, weights_only=False)['model_state_dict'] for n in ckpt_names]
+        outputs = {}
+        with torch.no_grad():
+            for data in self.test_loader:
+                images = self.convert_tensor_type(data['image']).to(self.device)
+                dl = domian_label * torch.ones(images.shape[0], dtype=torch.long)
+                acc = None
+                for sd in states:
+                    self.net.load_state_dict(sd)
+                    pred = self.inferer.run(self.net, images, dl)
+                    if isinstance(pred, (tuple, list)):
+                        acc = [p.clone() for p in pred] if acc is None else [a + p for a, p in zip(acc, pred)]
+                    else:
+                        acc = pred.clone() if acc is None else acc + pred
+                k = float(len(states))
+                pred = [a / k for a in acc] if isinstance(acc, list) else acc / k
+                outputs.update(self._finish_prediction(data, pred, data['names']))
         return outputs
 
     def save_outputs(self, data, hard=None):

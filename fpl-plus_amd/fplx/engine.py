@@ -42,6 +42,7 @@ class Engine(object):
         # block_joins: the main stream waits for the weight-gradient stream at every block boundary of backward.
         # None = decide per network (see backward()); tools/race25.py sets it to bisect.
         self.block_joins = None
+        self.debug_tap = None              # tools/race25.py: callable(name, tensor) on intermediate gradients of backward
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
@@ -258,6 +259,7 @@ class Engine(object):
         side = self._side if side_on else None
         keep = []                          # tensors the side stream still reads: kept alive until the join
         block_joins = self.block_joins
+        tap = self.debug_tap
         if block_joins is None:
             block_joins = self.default_block_joins()
         ws_w = self.ws_side if side_on else ws
@@ -326,6 +328,8 @@ class Engine(object):
             gkey = "%s.bns.%d" % (bnkey, domain)
             ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
                            gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
+            if tap is not None:
+                tap(key + ".dy", d_out)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
             db = None if sv.train else gv[key + ".bias"]
             gw = gv[key + ".weight"]
@@ -335,6 +339,9 @@ class Engine(object):
                         d_out, xin[0], xin[1])
                 if want_dx:
                     ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c, two_d)
+                    if tap is not None:
+                        tap(key + ".dx0", dx_view[0])
+                        tap(key + ".dx1", dx_view[1])
                 return
             if two_d:
                 on_side(lambda: ops.conv2d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
@@ -346,6 +353,8 @@ class Engine(object):
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None,
                                mid=two_d)
+                if tap is not None:
+                    tap(key + ".dx", dx_view)
 
         def block_bwd(b, d_out, want_dx):
             """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""
@@ -382,6 +391,8 @@ class Engine(object):
             ready(name + ".bias")
             d_cur = empty(vox[l + 1], ft[l + 1])
             ops.deconv2_dgrad(d_up, packs[name][1], d_cur, dims[l + 1], ft[l + 1], ft[l], pds[l])
+            if tap is not None:
+                tap(name + ".dx", d_cur)
         # ---- encoder, block4 .. block0
         d_pool = block_bwd(4, d_cur, True)                            # grad w.r.t. pooled3 [V_4, ft_3]
         ready("block4.conv.relu_1.weight")

@@ -295,6 +295,24 @@ int fplx_label_to_probability(const unsigned char* label, float* prob, int class
                               fplx_stream_t stream);
 int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_stream_t stream);
 
+/* ------------------------------------------------------------------ Inferer: sliding window + flip TTA
+ * PyMIC/pymic/net_run_dsbn/infer_func.py:50-112 (tiling, overlap averaging), 188-222 (tta_mode 1).
+ * The tile grid is the Cartesian product of per-axis start lists (HOST arrays, at most 64 entries each, non-decreasing,
+ * first 0, last start + window == size; a clamped duplicate start is a separate tile, as in the reference's list);
+ * tile index = (iw * nh + ih) * nd + id, the reference's enumeration order.  flips: HOST array of 1..4 masks,
+ * bit0 = W axis flipped, bit1 = H axis flipped (reference order: 0, 2, 1, 3).
+ *  fplx_sw_extract: image fp32 [n][c][d][h][w] -> patches [nflips][tiles][n][c][wd][wh][ww]: tile t of flip f is cut from
+ *                   the flipped image.
+ *  fplx_sw_merge:   predictions [nflips][tiles][n][c][wd][wh][ww] (c = classes) -> out [n][c][d][h][w]: per flip the
+ *                   sum over the covering tiles IN TILE ORDER divided by their number (no division when there is one
+ *                   tile), flipped back, then ((o1 + o2) + o3 + o4) / nflips - the reference's additions in its order. */
+int fplx_sw_extract(const float* image, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
+                    int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* patches,
+                    fplx_stream_t stream);
+int fplx_sw_merge(const float* patches, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
+                  int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* out,
+                  fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ evaluation
  * Exact voxel counts behind binary_dice / binary_iou / rve / volume (PyMIC/pymic/util/evaluation_seg_train.py:21-50,
  * 68-81, 171-186, 220-225): out[row][3] = {|seg==l & gt==l|, |seg==l|, |gt==l|} (uint64) for each of the nlabels labels

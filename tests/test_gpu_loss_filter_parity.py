@@ -212,3 +212,74 @@ def test_image_weight_known_answer(golden_dir):
     d = json.load(open(os.path.join(golden_dir, "image_weight_kat.json")))
     got = fplx.filter.image_weights([(u, p) for u, p in d["input"]])
     assert [str(w) for w in got] == [r[3] for r in d["csv_rows"]]
+
+
+def test_batched_inferer_equals_the_tile_by_tile_loop():
+    """fplx.Inferer gathers all tiles x flips (x MC passes) into one batch and merges them with the reference's additions
+    in the reference's order; the literal loop of forwards (`_run_generic`, infer_func.py:96-112, 199-219) must agree."""
+    import fplx
+    p = dict(NETS["tiny"], dropout=[0, 0, 0.3, 0.4, 0.5])
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    x = torch.from_numpy(detdata.normal("inf.x", (1, 1, 40, 72, 72))).cuda()
+    dl = torch.ones(1, dtype=torch.long)
+    c = dict(sliding_window_enable=True, sliding_window_size=[16, 32, 32], sliding_window_stride=[8, 24, 16], tta_mode=1, class_num=2)
+    with torch.no_grad():
+        for train_bn in (False, True):                     # eval: tiles batched; train-mode BatchNorm: one tile per forward
+            net.train(train_bn)
+            for m in net.modules():
+                if type(m) == torch.nn.Dropout:
+                    m.eval()
+            inf = fplx.Inferer(c)
+            a = inf.run(net, x, dl)
+            inf.model = net
+            b = inf._run_generic(x, dl)
+            assert float((a - b).abs().max()) <= 1e-5, train_bn
+        # Monte-Carlo passes (test-time dropout) in one batch: right shape, passes differ, every pass a valid prediction
+        net.eval()
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.train()
+        mc = fplx.Inferer(c).run_mc(net, x, dl, 3)
+        assert tuple(mc.shape) == (3, 1, 2, 40, 72, 72) and bool(torch.isfinite(mc).all())
+        assert not torch.equal(mc[0], mc[1]) and not torch.equal(mc[1], mc[2])
+        # a small forward budget cuts the batch differently; the merge does not care
+        small = fplx.Inferer(dict(c, infer_batch_voxels=16 * 32 * 32 * 3))
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.eval()
+        assert torch.equal(small.run(net, x, dl), fplx.Inferer(c).run(net, x, dl))
+
+
+def test_ckpt_mode_3_ensemble_is_the_mean_of_the_checkpoints_logits(tmp_path):
+    """agent_seg.py:966-1019: np.mean over the checkpoints' predictions, then the usual hard labels."""
+    import fplx
+    p = dict(NETS["tiny"])
+    names = []
+    x = torch.from_numpy(detdata.normal("ens.x", (1, 1, 16, 32, 32)))
+    preds = []
+    for k in range(3):
+        net = fplx.UNet2D5_dsbn(dict(p))
+        sd = {kk: torch.from_numpy(v) for kk, v in detdata.state_dict_3d(p, prefix="ens%d" % k).items()}
+        net.load_state_dict(sd)
+        net.cuda().eval()
+        with torch.no_grad():
+            preds.append(net(x.cuda(), domain_label=torch.ones(1, dtype=torch.long)))
+        f = str(tmp_path / ("m_%d.pt" % k))
+        torch.save({"model_state_dict": net.state_dict()}, f)
+        names.append(f)
+    cfg = {"dataset": {"tensor_type": "float"}, "network": dict(p), "training": {},
+           "testing": {"domian_label": 1, "gpus": [0], "fpl": False, "evaluation_mode": True, "tta_mode": 0, "ckpt_mode": 3,
+                       "ckpt_name": names, "sliding_window_enable": False}}
+    agent = fplx.SegmentationAgent(cfg, "test")
+    agent.create_network()
+    agent.set_loaders(test_loader=[{"image": x, "names": ["case0.nii.gz"]}])
+    out = agent.infer()
+    mean = ((preds[0] + preds[1]) + preds[2]) / 3.0
+    assert torch.equal(out["case0.nii.gz"], fplx.filter.hard_label(mean)[0])
+    cfg["testing"]["ckpt_mode"] = 2
+    agent2 = fplx.SegmentationAgent(cfg, "test")
+    agent2.create_network()
+    agent2.set_loaders(test_loader=[{"image": x, "names": ["case0.nii.gz"]}])
+    with pytest.raises(ValueError):
+        agent2.infer()

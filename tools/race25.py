@@ -44,12 +44,14 @@ ops.seg_loss_bwd(logits, lab, None, coef, one, terms, True, dlogits)
 torch.cuda.synchronize()
 
 
-def bwd(side, joins):
+def bwd(side, joins, taps=None):
     eng.use_side_stream = side
     eng.block_joins = joins
+    eng.debug_tap = None if taps is None else (lambda name, t: taps.append((name, t.clone())))
     gf = torch.empty_like(net.flat_params)
     eng.backward(sv, dlogits.clone(), gf)
     torch.cuda.synchronize()
+    eng.debug_tap = None
     return gf
 
 
@@ -72,3 +74,56 @@ for side, joins in ((True, True), (True, False)):
     print("side=%d joins=%d: %d parameter tensors differ in some of %d runs" % (side, joins, len(bad), reps))
     for k, e in sorted(bad.items(), key=lambda kv: -kv[1][0]):
         print("   %-40s runs %3d  max|diff| %.3e  (max|ref| %.3e)" % (k, e[0], e[1], e[2]))
+
+# intermediate data gradients (main stream): first tensor that differs from the single-stream run
+t_ref, t_run = [], []
+bwd(False, False, t_ref)
+for r in range(5):
+    t_run = []
+    bwd(True, False, t_run)
+    diffs = [(a[0], int((a[1].float() != b[1].float()).sum()), float((a[1].float() - b[1].float()).abs().max()))
+             for a, b in zip(t_ref, t_run) if not torch.equal(a[1], b[1])]
+    print("run %d with taps: %d of %d intermediate tensors differ; first: %s" % (r, len(diffs), len(t_ref), diffs[:3]))
+
+# discriminator: same schedule, same kernels, but nothing allocated during backward is freed before the final sync
+_orig_empty, hold = torch.empty, []
+
+
+def _empty_hold(*a, **k):
+    t = _orig_empty(*a, **k)
+    hold.append(t)
+    return t
+
+
+torch.empty = _empty_hold
+nbad = 0
+for r in range(10):
+    hold.clear()
+    nbad += int(not torch.equal(bwd(True, False), ref))
+torch.empty = _orig_empty
+print("side=1 joins=0 with every backward allocation held until the sync: %d of 10 runs differ" % nbad)
+
+# bisect by position: ONE join of the weight-gradient stream, at tap i only.  If kernel S (enqueued on the side stream at
+# position a) must not run beside main-stream kernel M (launched at position b), exactly the joins with a < i <= b help.
+names = [n for n, _ in t_ref]
+main_s = torch.cuda.current_stream()
+
+
+def bwd_join_at(i):
+    cnt = [0]
+
+    def tap(name, t):
+        if cnt[0] == i:
+            main_s.wait_stream(eng._side)
+        cnt[0] += 1
+    eng.use_side_stream, eng.block_joins, eng.debug_tap = True, False, tap
+    gf = torch.empty_like(net.flat_params)
+    eng.backward(sv, dlogits.clone(), gf)
+    torch.cuda.synchronize()
+    eng.debug_tap = None
+    return gf
+
+
+for i, nm in enumerate(names):
+    bad = sum(int(not torch.equal(bwd_join_at(i), ref)) for _ in range(3))
+    print("join only at tap %2d (%-28s): %d of 3 runs differ" % (i, nm, bad))
