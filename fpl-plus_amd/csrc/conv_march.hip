@@ -222,9 +222,14 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
       const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
       // inline asm: a store hipcc knows about makes it guard later register reuse with vmcnt(N) waits, and since it
-      // does not know about the DMA pieces in flight, those waits end up waiting for the DMA
-      if (sok0) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
-      if (sok1) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+      // does not know about the DMA pieces in flight, those waits end up waiting for the DMA.
+      // s_nop 1: a VMEM store of more than 8 bytes reads its data VGPRs for two more cycles ("12-dword store" hazard:
+      // a VALU write of those registers needs 2 wait states on gfx940+); hipcc's hazard recognizer does not look inside
+      // inline asm, and the register allocator reuses v0 / v1 at once.  Without the nop the first dword of the store's
+      // last lanes picked up the next instruction's result whenever another kernel's waves shared the SIMD
+      // (tools/race25c.py: the 2.5D stream-order hazard of round 1)
+      if (sok0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
     }
   };
 
@@ -522,8 +527,8 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       char* rowp = yn + o * yslice + (unsigned)(m * G::HPM * W) * l2;
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
       const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
-      if (sok[m][0]) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + soffb), "v"(v0) : "memory");
-      if (sok[m][1]) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(rowp + step1 * l2 + soffb), "v"(v1) : "memory");
+      if (sok[m][0]) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok[m][1]) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + step1 * l2 + soffb), "v"(v1) : "memory");
     }
   };
 

@@ -76,9 +76,10 @@ class Engine(object):
         return packs
 
     def default_block_joins(self):
-        """Networks with 2D levels join the weight-gradient stream at every block boundary of backward, whoever
-        calls backward (train step, autograd, with or without a reducer): see DESIGN section 7, stream order."""
-        return any(d != 3 for d in self.net.dims)
+        """No joins at block boundaries: backward's main stream never waits for the weight-gradient stream until the end.
+        (Round 1 needed them for networks with 2D levels; the cause was a store-data hazard inside the march kernels'
+        inline-asm 16-byte stores, fixed there - DESIGN section 7, tools/race25.py / race25c.py.)"""
+        return False
 
     def invalidate(self):
         self._pack_cache = None
