@@ -217,27 +217,48 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
     rl = R.dice_loss(ref, y)
     rl.backward()
     rng = float(ref.detach().abs().max())
-    err = float(np.abs(lt.detach().cpu().numpy() - ref.detach().numpy()).max())
-    assert err < 2e-2 * rng, (err, rng)
-    assert abs(loss.item() - rl.item()) < 1e-3
+    dlt = lt.detach().cpu().numpy() - ref.detach().numpy()
+    err, rms = float(np.abs(dlt).max()), float(np.sqrt((dlt.astype(np.float64) ** 2).mean()))
+    # the oracle's own fp32-vs-bf16 gap: the scale any bf16 implementation's rounding noise lives on
+    # the scale bf16 rounding noise lives on for THIS network and loss: the oracle's own fp32-vs-bf16 gap, for the logits
+    # and for every gradient (Dice gradients are concentrated on a small region and pass up to 36 bf16 tensors: the gap of
+    # the encoder's weight gradients is 0.3-0.4 relative L2, tools/.. measured in DESIGN section 2)
+    sd32, prm32 = R.split_state(detdata.state_dict_3d(p))
+    ref32 = R.unet_forward(sd32, p, x, dom, True)
+    R.dice_loss(ref32, y).backward()
+    gap = float((ref32.detach() - ref.detach()).abs().max())
     named = dict(net.named_parameters())
-    worst = {}
+    worst, bad = {}, {}
+    slope_scale = max(float(t.grad.abs().max()) for k, t in prm.items() if t.grad is not None and ".relu_" in k)
     for k, t in prm.items():
         if t.grad is None:
             continue
         r = t.grad.numpy().reshape(-1).astype(np.float64)
+        r32 = prm32[k].grad.numpy().reshape(-1).astype(np.float64)
         g = named[k].grad.cpu().numpy().reshape(-1).astype(np.float64)
         if k.endswith("bias") and "conv3d_" in k:          # bias before train-mode BN: exactly 0 here, fp32 noise there
             assert np.abs(g).max() == 0.0
             continue
-        rel = float(np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30))
-        worst[k] = rel
-    bad = {k: v for k, v in worst.items() if v > 0.1}
+        e, nr, gk = float(np.linalg.norm(g - r)), float(np.linalg.norm(r)), float(np.linalg.norm(r32 - r))
+        worst[k] = (e / max(nr, 1e-30), gk / max(nr, 1e-30))
+        # within 0.1 relative L2 of the bf16 oracle, or no further from it than 1.5 x the oracle's own fp32 result is (two
+        # independent bf16 realisations of the same noise differ by sqrt(2) of it).  A PReLU slope gradient is ONE number, a
+        # sum over a whole tensor that cancels to near zero at some layers: its scale is the largest slope gradient.
+        tol = max(0.1 * nr, 1.5 * gk)
+        if r.size == 1:
+            tol = max(tol, 0.05 * slope_scale)
+        if e > tol:
+            bad[k] = worst[k]
     os.makedirs("gpurun_out", exist_ok=True)
     with open(os.path.join("gpurun_out", "parity_bf16_%s.txt" % case), "w") as f:
-        f.write("logits err %.4g of range %.4g; loss %.6f vs %.6f\n" % (err, rng, loss.item(), rl.item()))
-        for k, v in sorted(worst.items(), key=lambda kv: -kv[1]):
-            f.write("%-44s rel L2 %.4f\n" % (k, v))
+        f.write("logits max err %.4g rms %.4g of range %.4g (oracle fp32-vs-bf16 gap %.4g); loss %.6f vs %.6f\n" % (
+            err, rms, rng, gap, loss.item(), rl.item()))
+        for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0]):
+            f.write("%-44s rel L2 %.4f   (oracle fp32-vs-bf16 %.4f)\n" % (k, v[0], v[1]))
+    # logits: max error within 3e-2 of the range and below the oracle's own bf16 gap, rms within 5e-3 of the range
+    assert err < 3e-2 * rng and err < gap + 1e-3 * rng, (err, rng, gap)
+    assert rms < 5e-3 * rng, (rms, rng)
+    assert abs(loss.item() - rl.item()) < 1e-3
     assert not bad, bad
     # three optimisation steps (one domain per step, as bench.py runs them): loss trajectory against the oracle's
     net2 = fplx.UNet2D5_dsbn(p)
