@@ -25,6 +25,9 @@
 namespace {
 
 __device__ __attribute__((aligned(16))) const unsigned int fplx_zero16[4] = {0u, 0u, 0u, 0u};
+#ifdef FPLX_STAMP
+__device__ long long* fplx_stamp_buf;      // set by the micro-benchmark
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -103,6 +106,9 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
                  bf16_t* __restrict__ y1, int ysplit, int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FPLX_STAMP
+  const long long st_launch = __builtin_amdgcn_s_memtime();
+#endif
   char* slabs = smem;
   char* wbuf = smem + 2 * MG::SLAB_BYTES;
   float* bias_s = reinterpret_cast<float*>(wbuf + MG::W_BYTES);
@@ -209,10 +215,12 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     const int wu = (i & 3) + 8 * (i >> 2);
     const float ov = A[i] + bv;
     *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
+#ifndef FPLX_ABL_NOSTATS
     if ((m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
       ssum += ov;
       qsum = fmaf(ov, ov, qsum);
     }
+#endif
   };
   auto retire_flush = [&](int m, int o) {                 // LDS tile -> y, two 16-byte stores per lane
     if (m ? hok1 : hok0) {
@@ -241,7 +249,16 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   // the kd = 1 plane of the 3D march (K1 -> K2 -> R).
   const int nd = d1 - d0;                         // >= 2 (march_cfg)
   const int nsteps = TWOD ? nd + 1 : nd + 2;
+#ifdef FPLX_STAMP
+  // diagnostic build only (tools/micro/march_bench.hip): shader-clock stamps around the three phases of a step
+  long long st_step = 0, st_wait = 0, st_bar = 0;
+  const long long st_begin = __builtin_amdgcn_s_memtime();
+  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int t = 0; t < nsteps; ++t) {
+#ifdef FPLX_STAMP
+    const long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     const int s = sbase + t;
     const bool fetch = TWOD ? s + 1 < d1 : (s + 1 <= d1 && s + 1 < D);
     const bool wout = t >= (TWOD ? 2 : 3);
@@ -251,7 +268,12 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 #pragma unroll
     for (int k = 0; k < NPIECE; ++k) so[k] = soff_s[k * MG::THREADS + tid];
     auto side = [&](int q) {
+#ifndef FPLX_ABL_NODMA
       if (q < NPIECE && fetch) slab_piece(s + 1, q, so[q < NPIECE ? q : 0]);
+#endif
+#ifdef FPLX_ABL_NORETIRE
+      return;
+#endif
       // write-out of the depth that completed in the previous step: stages 0-3 M-tile 0 -> LDS tile, 4 flush,
       // 4-7 M-tile 1, 8 flush.  (Staggering the two waves of a SIMD - waves 4-7 in stages 9..17 - was tried: it
       // keeps the set alive for the whole step and the spills cost more than the overlap gains.)
@@ -281,9 +303,26 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     }
 #undef MARCH_STEP
     Ra = K2a; Rb = K2b; K2a = K1a; K2b = K1b; K1a = K0a; K1b = K0b;
+#ifdef FPLX_STAMP
+    const long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     dma_wait();                                        // slab s + 1 landed and the stores left stages ago
+#ifdef FPLX_STAMP
+    const long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     block_sync();
+#ifdef FPLX_STAMP
+    const long long st3 = __builtin_amdgcn_s_memtime();
+    st_step += st1 - st0; st_wait += st2 - st1; st_bar += st3 - st2;
+#endif
   }
+#ifdef FPLX_STAMP
+  if (lane == 0) {
+    long long* o = fplx_stamp_buf + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 6;
+    o[0] = st_step; o[1] = st_wait; o[2] = st_bar; o[3] = __builtin_amdgcn_s_memtime() - st_begin; o[4] = nsteps;
+    o[5] = __builtin_amdgcn_s_memrealtime() - st_rbegin;        // 100 MHz ticks over the loop
+  }
+#endif
   // drain: the last depth completed in the final step
   {
 #pragma unroll
