@@ -99,11 +99,9 @@ seg_loss_fwd_k(const float* __restrict__ logits, const float* __restrict__ label
   }
 }
 
-// one block: reduce rows (double), evaluate the loss terms and the backward coefficient table
-__global__ void seg_loss_finalize_k(const float* __restrict__ part, int rows, int N, int C, double V, int has_pw,
-                                    const float* __restrict__ image_weight, float w_dice, float w_ce, float w_img,
-                                    float w_ent, float* __restrict__ out, float* __restrict__ coef) {
-  extern __shared__ double sums[];   // [N][K]
+// one block: reduce the partial rows (double) to per-sample sums [N][K] and their total over the local samples [K]
+__global__ void seg_loss_sums_k(const float* __restrict__ part, int rows, int N, int C, double* __restrict__ sums,
+                                double* __restrict__ totals) {
   const int K = 6 * C + 3;
   // one wave per (n, k) sum: lanes stride over rows
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -115,30 +113,41 @@ __global__ void seg_loss_finalize_k(const float* __restrict__ part, int rows, in
     if (lane == 0) sums[i] = s;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  if ((int)threadIdx.x < K) {
+    double t = 0.0;
+    for (int n = 0; n < N; ++n) t += sums[n * K + threadIdx.x];      // fixed order
+    totals[threadIdx.x] = t;
+  }
+}
+
+// one thread: the loss terms and the backward coefficient table from the per-sample sums of the LOCAL samples and the
+// totals over the WHOLE batch (= the local totals in one process; all-reduced over the ranks under data parallelism, where
+// the reference's nn.DataParallel gathers the logits and evaluates ONE loss over the full batch, agent_seg.py:692-698)
+__global__ void seg_loss_coef_k(const double* __restrict__ sums, const double* __restrict__ tot, int N, int NG, int C,
+                                double V, int has_pw, const float* __restrict__ image_weight, float w_dice, float w_ce,
+                                float w_img, float w_ent, float* __restrict__ out, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int K = 6 * C + 3;
   double Ld = 0.0, Limg = 0.0, Lce = 0.0, Lent = 0.0;
   for (int i = 0; i < N * C * 2; ++i) coef[i] = 0.f;
   // global Dice over all voxels of the batch (dice.py:20-57)
   for (int c = 0; c < C; ++c) {
-    double Y = 0, P = 0, I = 0, Yh = 0, Ph = 0, Ih = 0;
-    for (int n = 0; n < N; ++n) {
-      const double* s = sums + n * K + 6 * c;
-      Y += s[0]; P += s[1]; I += s[2]; Yh += s[3]; Ph += s[4]; Ih += s[5];
-    }
-    const double den = Y + P + 1e-5, num = 2.0 * I + 1e-5;
+    const double* t = tot + 6 * c;
+    const double den = t[0] + t[1] + 1e-5, num = 2.0 * t[2] + 1e-5;
     Ld += num / den;
-    out[4 + c] = (float)((2.0 * Ih + 1e-5) / (Yh + Ph + 1e-5));
+    out[4 + c] = (float)((2.0 * t[5] + 1e-5) / (t[3] + t[4] + 1e-5));
     for (int n = 0; n < N; ++n) {
       coef[(n * C + c) * 2 + 0] += (float)(w_dice * (-2.0 / (C * den)));
       coef[(n * C + c) * 2 + 1] += (float)(w_dice * (num / (C * den * den)));
     }
   }
   Ld = 1.0 - Ld / C;
-  // per-sample Dice times image weight (dice.py:106-128)
+  // per-sample Dice times image weight, mean over the batch (dice.py:106-128): this rank's samples only; the terms of the
+  // other ranks' samples are theirs (the value is completed by the caller's all-reduce when it wants the number)
   if (w_img != 0.f && image_weight) {
     for (int n = 0; n < N; ++n) {
       double dn = 0.0;
-      const double f = (double)image_weight[n] / N;
+      const double f = (double)image_weight[n] / NG;
       for (int c = 0; c < C; ++c) {
         const double* s = sums + n * K + 6 * c;
         const double den = s[0] + s[1] + 1e-5, num = 2.0 * s[2] + 1e-5;
@@ -149,17 +158,12 @@ __global__ void seg_loss_finalize_k(const float* __restrict__ part, int rows, in
       Limg += f * (1.0 - dn / C);
     }
   }
-  double cenum = 0, wsum = 0, ent = 0;
-  for (int n = 0; n < N; ++n) {
-    cenum += sums[n * K + 6 * C + 0];
-    wsum += sums[n * K + 6 * C + 1];
-    ent += sums[n * K + 6 * C + 2];
-  }
-  const double ce_norm = has_pw ? 1.0 / (wsum + 1e-5) : 1.0 / (N * V);   // ce.py:39-43
+  const double cenum = tot[6 * C + 0], wsum = tot[6 * C + 1], ent = tot[6 * C + 2];
+  const double ce_norm = has_pw ? 1.0 / (wsum + 1e-5) : 1.0 / (NG * V);   // ce.py:39-43
   Lce = cenum * ce_norm;
-  Lent = ent / (N * V);                                                  // agent_seg.py:352-353
+  Lent = ent / (NG * V);                                                  // agent_seg.py:352-353
   coef[N * C * 2 + 0] = (float)(w_ce * ce_norm);
-  coef[N * C * 2 + 1] = (float)(w_ent / (N * V));
+  coef[N * C * 2 + 1] = (float)(w_ent / (NG * V));
   out[0] = (float)(w_dice * Ld + w_img * Limg + w_ce * Lce + w_ent * Lent);
   out[1] = (float)(w_dice * Ld + w_img * Limg);
   out[2] = (float)Lce;
@@ -332,23 +336,58 @@ inline int grid1(int64_t v, int cap) {
 
 extern "C" {
 
-int fplx_loss_rows(int64_t voxels_per_sample) { return loss_rows(voxels_per_sample); }
+// rows to ALLOCATE per sample: the partial rows the kernels use plus 4 spare ones - behind the N x rows x K partials of a call
+// the spare N x 4 x K floats hold the per-sample sums and the batch totals as doubles ((N + 1) x K)
+int fplx_loss_rows(int64_t voxels_per_sample) { return loss_rows(voxels_per_sample) + 4; }
 
-int fplx_seg_loss_fwd(const float* logits, const float* label, const float* pixel_weight, const float* image_weight,
-                      int n, int c, int64_t v, float w_dice, float w_ce, float w_dice_img, float w_entropy, int softmax,
-                      float* part, float* out, float* coef, fplx_stream_t stream) {
-  FPLX_REQUIRE(logits && label && part && out && coef, FPLX_E_NULL, "seg_loss_fwd: null pointer");
-  FPLX_REQUIRE(n > 0 && n <= 64 && c >= 1 && c <= MAXC && v > 0, FPLX_E_BADSHAPE,
-               "seg_loss_fwd: n=%d (<=64) c=%d (<=%d) v=%lld", n, c, MAXC, (long long)v);
-  FPLX_REQUIRE(w_dice_img == 0.f || (image_weight && pixel_weight), FPLX_E_NULL,
-               "seg_loss_fwd: image-weighted Dice needs image_weight and pixel_weight");
+static int seg_loss_check(const char* what, const float* logits, const float* label, int n, int c, int64_t v) {
+  FPLX_REQUIRE(logits && label, FPLX_E_NULL, "%s: null pointer", what);
+  FPLX_REQUIRE(n > 0 && n <= 64 && c >= 1 && c <= MAXC && v > 0, FPLX_E_BADSHAPE, "%s: n=%d (<=64) c=%d (<=%d) v=%lld", what, n,
+               c, MAXC, (long long)v);
+  return FPLX_OK;
+}
+
+int fplx_seg_loss_sums(const float* logits, const float* label, const float* pixel_weight, int n, int c, int64_t v,
+                       int softmax, float* part, double* sums, double* totals, fplx_stream_t stream) {
+  const int rc = seg_loss_check("seg_loss_sums", logits, label, n, c, v);
+  if (rc != FPLX_OK) return rc;
+  FPLX_REQUIRE(part && sums && totals, FPLX_E_NULL, "seg_loss_sums: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int rows = loss_rows(v);
   dim3 grid(rows, n);
   DISPATCH_C(c, seg_loss_fwd_k, <<<grid, LT, 0, st>>>(logits, label, pixel_weight, v, softmax, part));
-  seg_loss_finalize_k<<<1, 1024, (size_t)n * (6 * c + 3) * sizeof(double), st>>>(
-      part, rows, n, c, (double)v, pixel_weight != nullptr, image_weight, w_dice, w_ce, w_dice_img, w_entropy, out, coef);
-  return fplx_check_launch("seg_loss_fwd");
+  seg_loss_sums_k<<<1, 1024, 0, st>>>(part, rows, n, c, sums, totals);
+  return fplx_check_launch("seg_loss_sums");
+}
+
+int fplx_seg_loss_from_sums(const double* sums, const double* totals, const float* image_weight, int n, int n_global, int c,
+                            int64_t v, int has_pixel_weight, float w_dice, float w_ce, float w_dice_img, float w_entropy,
+                            float* out, float* coef, fplx_stream_t stream) {
+  FPLX_REQUIRE(sums && totals && out && coef, FPLX_E_NULL, "seg_loss_from_sums: null pointer");
+  FPLX_REQUIRE(n > 0 && n <= 64 && n_global >= n && c >= 1 && c <= MAXC && v > 0, FPLX_E_BADSHAPE, "seg_loss_from_sums: bad shape");
+  FPLX_REQUIRE(w_dice_img == 0.f || (image_weight && has_pixel_weight), FPLX_E_NULL,
+               "seg_loss_from_sums: image-weighted Dice needs image_weight and pixel_weight");
+  seg_loss_coef_k<<<1, 64, 0, (hipStream_t)stream>>>(sums, totals, n, n_global, c, (double)v, has_pixel_weight, image_weight,
+                                                     w_dice, w_ce, w_dice_img, w_entropy, out, coef);
+  return fplx_check_launch("seg_loss_from_sums");
+}
+
+int fplx_seg_loss_fwd(const float* logits, const float* label, const float* pixel_weight, const float* image_weight,
+                      int n, int c, int64_t v, float w_dice, float w_ce, float w_dice_img, float w_entropy, int softmax,
+                      float* part, float* out, float* coef, fplx_stream_t stream) {
+  FPLX_REQUIRE(part && out && coef, FPLX_E_NULL, "seg_loss_fwd: null pointer");
+  FPLX_REQUIRE(w_dice_img == 0.f || (image_weight && pixel_weight), FPLX_E_NULL,
+               "seg_loss_fwd: image-weighted Dice needs image_weight and pixel_weight");
+  // the per-sample sums live in the spare rows of the caller's `part` buffer (fplx_loss_rows)
+  const int rows = loss_rows(v), K = 6 * c + 3;
+  int rc = seg_loss_check("seg_loss_fwd", logits, label, n, c, v);
+  if (rc != FPLX_OK) return rc;
+  double* sums = reinterpret_cast<double*>(part + (((size_t)n * rows * K + 1) / 2) * 2);
+  double* totals = sums + (size_t)n * K;
+  rc = fplx_seg_loss_sums(logits, label, pixel_weight, n, c, v, softmax, part, sums, totals, stream);
+  if (rc != FPLX_OK) return rc;
+  return fplx_seg_loss_from_sums(sums, totals, image_weight, n, n, c, v, pixel_weight != nullptr, w_dice, w_ce, w_dice_img,
+                                 w_entropy, out, coef, stream);
 }
 
 int fplx_seg_loss_bwd(const float* logits, const float* label, const float* pixel_weight, const float* coef,

@@ -8,7 +8,13 @@ get_loss_value, training_all (dual=True), training (dual=False), infer with its 
 get_stage_dataset_from_config / create_dataset over device-resident NiftyDatasets with GPU transforms, the inverse
 transforms of the prediction and save_outputs (uint8 masks as .nii.gz with the input's geometry), and (8f #4) validation,
 train_valid with the reference's checkpoint files (`<prefix>_<it>.pt`, `_latest.txt`, `_best.txt`), get_checkpoint_name, run.
-Not here (out of the hot-path tier): tensorboard, the `dis` adversarial branch, nn.DataParallel (one process per GPU instead).
+Not here (out of the hot-path tier): tensorboard, the `dis` adversarial branch.
+Several GPUs: the reference wraps the network in nn.DataParallel over config[...]['gpus'] (agent_seg.py:692-698); here the
+agent runs as ONE PROCESS PER GPU under `python -m torch.distributed.run` (fplx.ddp.init_from_env, RCCL): every rank
+collates its chunk of each global batch (DataParallel's scatter), BatchNorm statistics stay per rank (per replica there),
+the loss is evaluated over the full batch of all ranks (DataParallel's gather + one loss), gradients are all-reduced
+before the optimizer step (its reduce_add), rank 0's running statistics and checkpoints win (replica 0's there), and
+pseudo-label inference shards the volumes over the ranks with one gather of the (uncertainty, name) pairs to rank 0.
 Loaders are any iterables of batch dicts ('image', 'label_prob', optional 'pixel_weight',
 'image_weight', 'names'); create_dataset builds them from the config, set_loaders injects them.
 """
@@ -21,6 +27,7 @@ import torch.nn as nn
 from torch.optim import lr_scheduler
 
 from . import checkpoint as ckpt_mod
+from . import ddp
 from . import filter as fpl_filter_mod
 from . import ops
 from .dataset import NiftyDataset, BatchLoader
@@ -52,7 +59,12 @@ class SegmentationAgent(object):
         self.train_loader_1 = self.train_loader_2 = self.test_loader = None
         self.tensor_type = config['dataset'].get('tensor_type', 'float')
         self.fpl_uda = config['training'].get('train_fpl_uda', False) if 'training' in config else False
-        self.device = torch.device("cuda:{0:}".format(self._gpus()[0]))
+        # one process per GPU: the process group comes up BEFORE anything touches the device
+        self.distributed = ddp.init_from_env()
+        self.rank, self.world = ddp.rank(), (ddp.world_size() if self.distributed else 1)
+        gpus = self._gpus()
+        lr_ = ddp.local_rank()
+        self.device = torch.device("cuda:{0:}".format((gpus[lr_] if lr_ < len(gpus) else lr_) if self.distributed else gpus[0]))
         self.transform_list = []
         self.transform_dict = TransformDict
         self.test_set = None
@@ -123,10 +135,10 @@ class SegmentationAgent(object):
             g_train = torch.Generator()
             g_train.manual_seed(self.random_seed)
             self.train_set_1 = self.get_stage_dataset_from_config('1_train')
-            self.train_loader_1 = BatchLoader(self.train_set_1, bn_train, True, g_train)
+            self.train_loader_1 = BatchLoader(self.train_set_1, bn_train, True, g_train, self.rank, self.world)
             if self.config['network']['num_domains'] == 2:
                 self.train_set_2 = self.get_stage_dataset_from_config('2_train')
-                self.train_loader_2 = BatchLoader(self.train_set_2, bn_train, True, g_train)
+                self.train_loader_2 = BatchLoader(self.train_set_2, bn_train, True, g_train, self.rank, self.world)
             bn_valid = ds.get('valid_batch_size', 1)
             self.valid_loader_1 = self.valid_loader_2 = None
             if ds.get('1_valid_csv', None) is not None:
@@ -151,6 +163,8 @@ class SegmentationAgent(object):
         self.net.to(self.device)
         n = sum(p.numel() for p in self.net.parameters() if p.requires_grad)
         logging.info('parameter number {0:}'.format(n))
+        if self.distributed and isinstance(self.net, UNet2D5_dsbn):
+            ddp.broadcast_params_from_rank0(self.net)            # DataParallel replicates the master module every forward
 
     def get_parameters_to_update(self):
         return self.net.parameters()
@@ -166,11 +180,15 @@ class SegmentationAgent(object):
         if self.scheduler is None:
             opt_params["last_iter"] = last_iter
             self.scheduler = get_lr_scheduler(self.optimizer, opt_params)
+        if self.distributed and hasattr(self.optimizer, 'dist_sync'):
+            self.optimizer.dist_sync = True                       # all-reduce(sum) of the gradients inside step()
 
     def create_loss_calculator(self, entropy_weight=0.0):
         if self.loss_dict is None:
             self.loss_dict = SegLossDict
         self.loss_calculator = make_loss(self.config['training'], self.loss_dict, entropy_weight)
+        if self.distributed:
+            self.loss_calculator.dist_sync = True                 # ONE loss over the full batch of all ranks
 
     def convert_tensor_type(self, t):
         return t.float()
@@ -268,11 +286,15 @@ class SegmentationAgent(object):
             infer_cfg = dict(self.config.get('testing', {}))
             infer_cfg['class_num'] = class_num
             self.inferer = Inferer(infer_cfg)
-        with torch.no_grad():
+        if self.distributed and isinstance(self.net, UNet2D5_dsbn):
+            ddp.broadcast_buffers_from_rank0(self.net)           # replica 0's running statistics are the module's
+        sync, self.loss_calculator.dist_sync = getattr(self.loss_calculator, 'dist_sync', False), False
+        with torch.no_grad():                                    # every rank validates the whole set: same numbers everywhere
             self.net.eval()
             loss_0, cls_0 = self._valid_domain(self.valid_loader_1, 0, class_num)
             if nd == 2:
                 loss_1, cls_1 = self._valid_domain(self.valid_loader_2, 1, class_num)
+        self.loss_calculator.dist_sync = sync
         avg_0 = cls_0.mean()
         if nd == 2:
             avg_1 = cls_1.mean()
@@ -334,7 +356,7 @@ class SegmentationAgent(object):
                 self.max_val_it = self.glob_it
                 self.best_model_wts = copy.deepcopy(ckpt_mod.reference_model_state_dict(self.net))
             stop_now = early_stop_it is not None and self.glob_it - self.max_val_it > early_stop_it
-            if (self.glob_it in iter_save_list) or stop_now:
+            if ((self.glob_it in iter_save_list) or stop_now) and self.rank == 0:
                 ckpt_mod.save_checkpoint(self.config, self.glob_it, valid_scalars['avg_dice'],
                                          ckpt_mod.reference_model_state_dict(self.net), self.optimizer, "latest")
             if stop_now:
@@ -343,7 +365,8 @@ class SegmentationAgent(object):
         # the best performing checkpoint (agent_seg.py:806-826)
         if self.best_model_wts is None:
             self.best_model_wts = ckpt_mod.reference_model_state_dict(self.net)
-        ckpt_mod.save_checkpoint(self.config, self.max_val_it, self.max_val_dice, self.best_model_wts, self.optimizer, "best")
+        if self.rank == 0:
+            ckpt_mod.save_checkpoint(self.config, self.max_val_it, self.max_val_dice, self.best_model_wts, self.optimizer, "best")
         logging.info('The best performing iter is {0:}, valid dice {1:}'.format(self.max_val_it, self.max_val_dice))
         return history
 
@@ -388,7 +411,9 @@ class SegmentationAgent(object):
         # an injected inferer that overrides run() is called pass by pass, as the reference does
         batched_mc = isinstance(self.inferer, Inferer) and type(self.inferer).run is Inferer.run
         with torch.no_grad():
-            for data in self.test_loader:
+            for case_no, data in enumerate(self.test_loader):
+                if self.distributed and case_no % self.world != self.rank:
+                    continue                                             # volumes are sharded over the ranks
                 images = self.convert_tensor_type(data['image']).to(self.device)
                 names = data['names']
                 dl = domian_label * torch.ones(images.shape[0], dtype=torch.long)
@@ -408,9 +433,15 @@ class SegmentationAgent(object):
                     pred = self.inferer.run(self.net, images, dl)
                     outputs.update(self._finish_prediction(data, pred, names))
         if self.FPL:
-            srt = fpl_filter_mod.sort_uncertainty(uncertainty_list)
+            if self.distributed:                                         # the only exchange: (uncertainty, name) pairs to rank 0
+                parts = ddp.gather_objects_to_rank0(uncertainty_list)
+                if self.rank == 0:
+                    uncertainty_list = {}
+                    for part in parts:
+                        uncertainty_list.update(part)
+            srt = fpl_filter_mod.sort_uncertainty(uncertainty_list)     # agent_seg.py:957-959
             path = cfg.get('fpl_uncertainty_sorted', None)
-            if path:
+            if path and self.rank == 0:
                 np.save(path, np.array(srt, dtype=object), allow_pickle=True)
             return (srt, outputs) if return_outputs else srt
         return outputs

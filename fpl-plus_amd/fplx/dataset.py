@@ -115,10 +115,16 @@ def collate(samples):
 
 
 class BatchLoader(object):
-    """iterable of collated batches over a dataset (agent_abstract.py:263-281: batch_size, shuffle, seeded generator)"""
+    """iterable of collated batches over a dataset (agent_abstract.py:263-281: batch_size, shuffle, seeded generator).
+    rank / world: data parallelism with one process per GPU - `batch_size` stays the GLOBAL batch of the config and every
+    rank collates its chunk of each batch, chunk r of `world` along the batch axis: what nn.DataParallel's scatter hands to
+    replica r (agent_seg.py:692-698).  All ranks draw the same permutation (same seeded generator)."""
 
-    def __init__(self, dataset, batch_size=1, shuffle=False, generator=None):
+    def __init__(self, dataset, batch_size=1, shuffle=False, generator=None, rank=0, world=1):
         self.dataset, self.batch_size, self.shuffle, self.generator = dataset, int(batch_size), shuffle, generator
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1 and self.batch_size % self.world:
+            raise ValueError("fplx BatchLoader: batch size {0:} is not a multiple of the {1:} ranks".format(batch_size, world))
 
     def __len__(self):
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
@@ -126,5 +132,11 @@ class BatchLoader(object):
     def __iter__(self):
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        per = self.batch_size // self.world
         for i in range(0, n, self.batch_size):
-            yield collate([self.dataset[j] for j in order[i:i + self.batch_size]])
+            full = order[i:i + self.batch_size]
+            if self.world > 1:
+                if len(full) < self.batch_size:          # a ragged last batch cannot be split evenly: dropped on all ranks
+                    return
+                full = full[self.rank * per:(self.rank + 1) * per]
+            yield collate([self.dataset[j] for j in full])

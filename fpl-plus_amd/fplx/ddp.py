@@ -59,6 +59,62 @@ class GradAllReducer(object):
         self._works = []
 
 
+def init_from_env(backend=None):
+    """One process per GPU, launched by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment): select the GPU and create the process group - BEFORE anything else touches the device.  Returns True
+    when a group with more than one rank (or FPLX_DDP_FORCE=1) is up.  Backend: nccl (= RCCL over xGMI); FPLX_DDP_BACKEND
+    overrides it (the 2-rank tests on one GPU use gloo)."""
+    if not dist.is_available():
+        return False
+    if dist.is_initialized():
+        return dist.get_world_size() > 1 or os.environ.get("FPLX_DDP_FORCE", "0") == "1"
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return False
+    world = int(os.environ["WORLD_SIZE"])
+    if world == 1 and os.environ.get("FPLX_DDP_FORCE", "0") != "1":
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = backend or os.environ.get("FPLX_DDP_BACKEND", "nccl")
+    local = local_rank()
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend)
+    return True
+
+
+def local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def active(group=None):
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size(group) > 1 or os.environ.get("FPLX_DDP_FORCE", "0") == "1")
+
+
+def rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def barrier(group=None):
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier(group=group)
+
+
+def gather_objects_to_rank0(obj, group=None):
+    """-> list of every rank's object on rank 0 (None elsewhere); [obj] without a process group"""
+    if not active(group):
+        return [obj]
+    out = [None] * world_size(group) if rank(group) == 0 else None
+    dist.gather_object(obj, out, dst=0, group=group)
+    return out
+
+
 def broadcast_buffers_from_rank0(net, group=None):
     """running_mean / running_var of rank 0 win, as replica 0's do under nn.DataParallel."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

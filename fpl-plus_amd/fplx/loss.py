@@ -37,7 +37,11 @@ class _FusedSegLoss(torch.autograd.Function):
         part = torch.empty((n, ops.loss_rows(v), ops.loss_k(c)), dtype=torch.float32, device=dev)
         out = torch.empty(4 + c, dtype=torch.float32, device=dev)
         coef = torch.empty(n * c * 2 + 2, dtype=torch.float32, device=dev)
-        ops.seg_loss_fwd(logits, label, pw, iw, weights, softmax, part, out, coef)
+        group = getattr(holder, "dist_group", None) if holder is not None else None
+        if holder is not None and getattr(holder, "dist_sync", False):
+            ops.seg_loss_fwd_dist(logits, label, pw, iw, weights, softmax, part, out, coef, group)
+        else:
+            ops.seg_loss_fwd(logits, label, pw, iw, weights, softmax, part, out, coef)
         ctx.save_for_backward(logits, label, pw, coef)
         ctx.weights, ctx.softmax = weights, softmax
         if holder is not None:
@@ -61,6 +65,9 @@ class AbstractSegLoss(nn.Module):
         super(AbstractSegLoss, self).__init__()
         self.softmax = True if params is None else params.get('loss_softmax', True)
         self.last_out = None      # device tensor [4 + C]: total, dice, ce, entropy, hard class Dice[C]
+        # data parallelism (fplx.ddp.attach): evaluate the loss over the FULL batch of all ranks, as the reference's
+        # nn.DataParallel does on its gathered logits; the ranks' gradients then add up to the full-batch gradient
+        self.dist_sync, self.dist_group = False, None
 
     def _run(self, loss_input_dict, terms):
         predict = loss_input_dict['prediction']

@@ -36,12 +36,15 @@ def main(argv=None):
     task = config['dataset'].get('task_type', 'seg')
     if task != 'seg':
         raise ValueError("fplx.net_run: only task_type = seg is built (got {0:})".format(task))
+    from . import ddp
     agent = SegmentationAgent(config, stage)
     agent.run()
     if stage != 'test':
+        ddp.barrier()                      # rank 0 has written the best checkpoint
         agent2 = SegmentationAgent(config, 'test')
         agent2.run()
-    return eva_main(config)
+    ddp.barrier()                          # every rank has written its share of the predictions
+    return eva_main(config) if ddp.rank() == 0 else None
 
 
 if __name__ == "__main__":

@@ -278,6 +278,24 @@ def seg_loss_fwd(logits, label, pw, iw, weights, softmax, part, out, coef):
          weights[3], 1 if softmax else 0, ptr(part), ptr(out), ptr(coef), stream())
 
 
+def seg_loss_fwd_dist(logits, label, pw, iw, weights, softmax, part, out, coef, group):
+    """seg_loss_fwd under data parallelism: the sums over the local samples are all-reduced over `group` between the
+    reduction and the evaluation, so loss, metric and backward coefficients are those of the FULL batch (what the
+    reference's nn.DataParallel computes on its gathered logits, agent_seg.py:692-698).  All ranks must hold the same
+    number of samples."""
+    import torch.distributed as dist
+    n, c = logits.shape[0], logits.shape[1]
+    v = logits[0, 0].numel()
+    k = loss_k(c)
+    sums = torch.empty((n + 1, k), dtype=torch.float64, device=logits.device)
+    call("fplx_seg_loss_sums", ptr(logits), ptr(label), ptr(pw), n, c, v, 1 if softmax else 0, ptr(part), ptr(sums[:n]),
+         ptr(sums[n]), stream())
+    dist.all_reduce(sums[n], op=dist.ReduceOp.SUM, group=group)
+    world = dist.get_world_size(group)
+    call("fplx_seg_loss_from_sums", ptr(sums[:n]), ptr(sums[n]), ptr(iw), n, n * world, c, v, 0 if pw is None else 1,
+         weights[0], weights[1], weights[2], weights[3], ptr(out), ptr(coef), stream())
+
+
 def seg_loss_bwd(logits, label, pw, coef, gscale, weights, softmax, dlogits):
     n, c = logits.shape[0], logits.shape[1]
     v = logits[0, 0].numel()

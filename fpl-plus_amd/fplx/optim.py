@@ -30,6 +30,9 @@ class FusedAdam(Optimizer):
         self.seg_ranges = [shared] + doms
         self.seg_steps = [0] * len(self.seg_ranges)
         self.grad_scale = 1.0            # e.g. 1/world_size after an all-reduce(sum)
+        # data parallelism in autograd mode (SegmentationAgent): step() all-reduces (sum) the gradients first - the loss was
+        # evaluated over the full batch of all ranks (fplx.loss dist_sync), so the sum IS its gradient
+        self.dist_sync, self.dist_group = False, None
 
     def _segment_grad(self, start, end):
         """flat gradient tensor covering [start, end) if every parameter's .grad is the matching
@@ -79,6 +82,16 @@ class FusedAdam(Optimizer):
             if isinstance(g, str):
                 continue                                        # whole segment has no gradient: skipped
             self.seg_steps[si] += 1
+            if self.dist_sync:
+                import torch.distributed as dist
+                if g is not None:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.dist_group)
+                else:
+                    for k in net._order:
+                        o, n, _ = net._layout[k]
+                        p = net.get_param(k)
+                        if start <= o < end and p.grad is not None:
+                            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.dist_group)
             if g is not None:
                 ops.adam_step(net.flat_params[start:end], g, self.exp_avg[start:end], self.exp_avg_sq[start:end],
                               lr, self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps)

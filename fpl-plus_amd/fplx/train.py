@@ -32,7 +32,10 @@ class TrainStep(object):
         shared, doms = net.segments()
         bucket_elems = int(os.environ.get("FPLX_BUCKET_ELEMS", bucket_elems))      # tuning knob (benchmarks only)
         self.reducer = GradAllReducer(net.bucket_ranges(bucket_elems), doms, group)
-        self.opt.grad_scale = 1.0 / self.reducer.world
+        # the loss is evaluated over the FULL batch of all ranks (reference: nn.DataParallel gathers the logits, one loss):
+        # the ranks' gradients add up to its gradient, nothing is divided by the world size
+        self.group = group
+        self.opt.grad_scale = 1.0
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
         self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
         self._loss_bufs = {}
@@ -57,7 +60,10 @@ class TrainStep(object):
         v = logits[0, 0].numel()
         part, coef = self._loss_buffers(n, c, v, logits.device)
         out = torch.empty(4 + c, dtype=torch.float32, device=logits.device)
-        ops.seg_loss_fwd(logits, label, pw, iw, self.terms, self.softmax, part, out, coef)
+        if self.reducer.enabled:
+            ops.seg_loss_fwd_dist(logits, label, pw, iw, self.terms, self.softmax, part, out, coef, self.group)
+        else:
+            ops.seg_loss_fwd(logits, label, pw, iw, self.terms, self.softmax, part, out, coef)
         dlogits = torch.empty_like(logits)
         ops.seg_loss_bwd(logits, label, pw, coef, gscale, self.terms, self.softmax, dlogits)
         net.engine.backward(sv, dlogits, gflat, reduce_hook)

@@ -228,17 +228,31 @@ int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, c
  * regulariser (net_run_dsbn/agent_seg.py:352-354) + hard-Dice train metric
  * (agent_seg.py:472-476).  logits / label: fp32 [N,C,D,H,W] contiguous (C <= 8);
  * pixel_weight fp32 [N,1,D,H,W] or NULL.
- *   part   fp32 workspace [N][rows][FPLX_LOSS_K(C)], rows = fplx_loss_rows(D*H*W)
+ *   part   fp32 workspace [N][rows][FPLX_LOSS_K(C)], rows = fplx_loss_rows(D*H*W) (partial rows + spare rows that hold the
+ *          per-sample sums as doubles)
  *   cfg    host floats: w_dice, w_ce, w_dice_img (per-sample Dice x image_weight), w_entropy
  *   image_weight fp32 [N] device or NULL (needed iff w_dice_img != 0)
  *   out    fp32 device [4 + C]: total loss, dice term, ce term, entropy term, hard class Dice[C]
- *   coef   fp32 device [N][C][2] + [2]: backward coefficients (written by the finalize kernel) */
+ *   coef   fp32 device [N][C][2] + [2]: backward coefficients (written by the finalize kernel)
+ * Data parallelism (one process per GPU): the reference's nn.DataParallel gathers the replicas' logits and evaluates ONE
+ * loss over the full batch (agent_seg.py:692-698 with get_loss_value 134-142); Dice and the weighted CE are not sums of
+ * per-shard losses.  fplx_seg_loss_fwd = fplx_seg_loss_sums + fplx_seg_loss_from_sums; between the two a caller
+ * all-reduces `totals` (double [FPLX_LOSS_K(C)], the sums over the local samples) over the ranks and passes the global
+ * sample count: loss value, metric and coefficients are then those of the full batch, and the ranks' gradients ADD UP to
+ * the full-batch gradient (no division by the world size).
+ *   sums   double device [N][FPLX_LOSS_K(C)] per-sample sums;  totals double device [FPLX_LOSS_K(C)] */
 #define FPLX_LOSS_K(C) (6 * (C) + 3)
 int fplx_loss_rows(int64_t voxels_per_sample);
 int fplx_seg_loss_fwd(const float* logits, const float* label, const float* pixel_weight,
                       const float* image_weight, int n, int c, int64_t voxels_per_sample,
                       float w_dice, float w_ce, float w_dice_img, float w_entropy, int softmax,
                       float* part, float* out, float* coef, fplx_stream_t stream);
+int fplx_seg_loss_sums(const float* logits, const float* label, const float* pixel_weight, int n, int c,
+                       int64_t voxels_per_sample, int softmax, float* part, double* sums, double* totals,
+                       fplx_stream_t stream);
+int fplx_seg_loss_from_sums(const double* sums, const double* totals, const float* image_weight, int n, int n_global, int c,
+                            int64_t voxels_per_sample, int has_pixel_weight, float w_dice, float w_ce, float w_dice_img,
+                            float w_entropy, float* out, float* coef, fplx_stream_t stream);
 /* dlogits = gscale[0] * dLoss/dlogits ; gscale: device fp32 scalar (upstream gradient) */
 int fplx_seg_loss_bwd(const float* logits, const float* label, const float* pixel_weight,
                       const float* coef, const float* gscale, int n, int c, int64_t voxels_per_sample,

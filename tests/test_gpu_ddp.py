@@ -1,0 +1,180 @@
+"""Data parallelism through the HIP path with TWO ranks: this box has one GPU, so both processes use cuda:0 and talk over
+gloo (FPLX_DDP_BACKEND=gloo; RCCL refuses two ranks on one device) - the collectives, bucketing, full-batch loss and the
+agent's sharding are the code that runs over RCCL on a node.  The 2-rank results are compared with a single-process
+emulation of the reference's nn.DataParallel (per-chunk BatchNorm, one loss over the gathered batch, gradients added)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import detdata
+from make_golden_cfg import NETS
+from util import load_det_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, "fpl-plus_amd"), os.path.join(root, "tests", "golden"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import fplx, detdata
+from fplx import ddp
+from make_golden_cfg import NETS
+from util import load_det_weights
+assert ddp.init_from_env()
+rank, world = ddp.rank(), ddp.world_size()
+torch.cuda.set_device(0)
+p = dict(NETS["tiny"])
+net = fplx.UNet2D5_dsbn(p)
+load_det_weights(net, p, "cuda")
+net._ensure_flat()
+ddp.broadcast_params_from_rank0(net)
+ts = fplx.TrainStep(net, (1.0, 0.5, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5, bucket_elems=1 << 14)
+assert ts.reducer.enabled and ts.reducer.world == 2 and len(ts.reducer.buckets) > 2
+N = 4
+xs = torch.from_numpy(detdata.normal("ddp.x", (N, 1, 16, 32, 32)))
+ys = torch.from_numpy(detdata.ball_label((16, 32, 32), 6.0, n=N, offsets=[(0, 1, -2), (1, -3, 2), (-2, 0, 3), (2, 2, -1)]))
+per = N // world
+x, y = xs[rank * per:(rank + 1) * per].cuda(), ys[rank * per:(rank + 1) * per].cuda()
+losses = []
+for it in range(2):
+    out = ts.step(x, y, it % 2)
+    losses.append(float(out[0].item()))
+torch.cuda.synchronize()
+np.savez(sys.argv[2] + ".%d.npz" % rank, flat=net.flat_params.cpu().numpy(), losses=np.array(losses))
+ddp.barrier()
+print("OK", rank)
+'''
+
+
+def _launch(tmp_path, script_text, extra=(), nproc=2, timeout=900):
+    script = tmp_path / "worker.py"
+    script.write_text(script_text)
+    env = dict(os.environ, FPLX_DDP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = str(24500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", port, str(script), ROOT] + list(extra)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    return r
+
+
+def test_two_rank_train_step_equals_dataparallel_emulation(tmp_path):
+    import fplx
+    from fplx import ops
+    out = str(tmp_path / "res")
+    _launch(tmp_path, _WORKER, [out])
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"])                       # replicas stay identical
+    assert np.array_equal(r0["losses"], r1["losses"])                   # every rank reports the full-batch loss
+    # ---- single process: chunk forwards (per-chunk BN statistics), ONE loss over both chunks, gradients added, Adam
+    p = dict(NETS["tiny"])
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    net._ensure_flat()
+    net.train()
+    opt = fplx.FusedAdam(net, 1e-3, weight_decay=1e-5)
+    N = 4
+    xs = torch.from_numpy(detdata.normal("ddp.x", (N, 1, 16, 32, 32))).cuda()
+    ys = torch.from_numpy(detdata.ball_label((16, 32, 32), 6.0, n=N, offsets=[(0, 1, -2), (1, -3, 2), (-2, 0, 3), (2, 2, -1)])).cuda()
+    terms, one = (1.0, 0.5, 0.0, 0.0), torch.ones(1, device="cuda")
+    losses = []
+    for it in range(2):
+        dom = it % 2
+        fw = []
+        for c in range(2):
+            x, y = xs[2 * c:2 * c + 2].contiguous(), ys[2 * c:2 * c + 2].contiguous()
+            logits, sv = net.engine.forward(x, dom, True, net.dropout_active(), net.dropout_seed, 10 * it + c, keep=True)
+            n, cc = logits.shape[0], logits.shape[1]
+            v = logits[0, 0].numel()
+            part = torch.empty((n, ops.loss_rows(v), ops.loss_k(cc)), device="cuda")
+            sums = torch.empty((n + 1, ops.loss_k(cc)), dtype=torch.float64, device="cuda")
+            ops.call("fplx_seg_loss_sums", ops.ptr(logits), ops.ptr(y), 0, n, cc, v, 1, ops.ptr(part), ops.ptr(sums[:n]),
+                     ops.ptr(sums[n]), ops.stream())
+            fw.append((logits, sv, y, sums))
+        tot = fw[0][3][2] + fw[1][3][2]
+        g = torch.zeros_like(net.flat_params)
+        for logits, sv, y, sums in fw:
+            outv = torch.empty(4 + 2, device="cuda")
+            coef = torch.empty(2 * 2 * 2 + 2, device="cuda")
+            ops.call("fplx_seg_loss_from_sums", ops.ptr(sums[:2]), ops.ptr(tot), 0, 2, 4, 2, logits[0, 0].numel(), 0, terms[0],
+                     terms[1], terms[2], terms[3], ops.ptr(outv), ops.ptr(coef), ops.stream())
+            dl = torch.empty_like(logits)
+            ops.seg_loss_bwd(logits, y, None, coef, one, terms, True, dl)
+            gi = torch.empty_like(net.flat_params)
+            net.engine.backward(sv, dl, gi)
+            g += gi
+        losses.append(float(outv[0].item()))
+        opt.step_flat(g, [dom])
+        net.engine.invalidate()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(r0["losses"], losses, rtol=0, atol=2e-6)
+    ref = net.flat_params.cpu().numpy()
+    # Adam normalises the step: compare the update itself, scaled by lr (2 steps of at most lr each)
+    assert np.abs(r0["flat"] - ref).max() <= 0.05 * 2e-3
+
+
+_AGENT_WORKER = r'''
+import os, sys
+root, cfg = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(root, "fpl-plus_amd"))
+import random, numpy as np, torch
+random.seed(3)
+from fplx import net_run, ddp
+res = net_run.main(["fplx.net_run", sys.argv[3], cfg])
+from fplx import ddp
+print("OK", ddp.rank(), ddp.world_size())
+'''
+
+
+def test_agent_train_and_sharded_fpl_inference_with_two_ranks(tmp_path):
+    """`python -m torch.distributed.run ... fplx.net_run train cfg` with two ranks: global batch 2 = one crop per rank, rank 0
+    writes the checkpoints, both ranks test; then the FPL stage (testing.fpl) shards the volumes over the ranks and rank 0
+    writes the sorted (uncertainty, name) list with every volume in it."""
+    from fplx import nifti
+    from test_gpu_25d import SHIPPED_STYLE_CFG
+    root = tmp_path
+    rs = np.random.RandomState(9)
+    (root / "img").mkdir()
+    (root / "lab").mkdir()
+    names = []
+    for i in range(5):
+        shp = (12, 30 + 2 * (i % 2), 44)
+        lab = np.zeros(shp, np.uint8)
+        lab[3:9, 8 + i:20 + i, 10:30] = 1
+        img = rs.randn(*shp) * 15 + 90 + 70.0 * lab
+        nifti.write_nifti(str(root / "img" / ("c%d.nii.gz" % i)), img.astype(np.float32), (0.5, 0.5, 1.5))
+        nifti.write_nifti(str(root / "lab" / ("c%d.nii.gz" % i)), lab, (0.5, 0.5, 1.5))
+        names.append("c%d.nii.gz" % i)
+    rows = ["img/%s,lab/%s" % (n, n) for n in names]
+    (root / "train_1.csv").write_text("image,label\n" + "\n".join(rows[:4]) + "\n")
+    (root / "train_2.csv").write_text("image,label\n" + "\n".join(rows[1:5]) + "\n")
+    (root / "valid_1.csv").write_text("image,label\n" + rows[0] + "\n")
+    (root / "valid_2.csv").write_text("image,label\n" + rows[4] + "\n")
+    (root / "test.csv").write_text("image\n" + "\n".join("img/" + n for n in names[2:]) + "\n")
+    (root / "pair.csv").write_text("ground_truth,segmentation\n" + "\n".join("%s,%s" % (n, n) for n in names[2:]) + "\n")
+    text = SHIPPED_STYLE_CFG.format(root=str(root)).replace("gpus       = [0]", "gpus       = [0, 0]")
+    cfg = root / "vs_like.cfg"
+    cfg.write_text(text)
+    _launch(tmp_path, _AGENT_WORKER, [str(cfg), "train"], timeout=1500)
+    ck = root / "model_dual" / "vs_t1s_g"
+    files = sorted(os.listdir(str(ck)))
+    assert "vs_t1s_g_latest.txt" in files and "vs_t1s_g_best.txt" in files and any(f.endswith(".pt") for f in files)
+    out = root / "results_dual" / "vs_t1s_g_test"
+    for n in names[2:]:                                     # predictions of BOTH ranks' shares are there
+        assert (out / n).exists(), n
+    assert (out / "test_tumor_dice_all.csv").exists()
+    # ---- FPL stage, sharded over the ranks
+    srt = root / "uncertainty_sorted.npy"
+    cfg.write_text(text.replace("fpl = False", "fpl = True\nfpl_uncertainty_sorted = %s" % str(srt)))
+    _launch(tmp_path, _AGENT_WORKER, [str(cfg), "test"], timeout=1500)
+    lst = np.load(str(srt), allow_pickle=True)
+    assert sorted(str(e[1]) for e in lst) == sorted("img/" + n for n in names[2:])
+    u = [float(e[0][0]) for e in lst]
+    assert u == sorted(u)
