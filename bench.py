@@ -117,13 +117,23 @@ def roofline_of(key, n_avg_ms):
     return flops, nbytes, flops / sec / 1e12, nbytes / sec / 1e9
 
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+
+
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (profiles/r01_pmc_hbm_traffic.json, made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE passes with the gfx950 x2 FETCH correction).  None if no matching entry."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r02_pmc_hbm_traffic.json,
+    made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of THIS command with the gfx950
+    x2 FETCH correction).  The summary records the sha256 of the kernel sources it was measured on: if conv_march.hip or
+    common.h have changed since, the figure is stale and None is reported.  None also if there is no matching entry."""
+    import hashlib
+    path = PMC_FILE
     if not os.path.exists(path):
         return None
+    meta = json.load(open(path)).get("_meta", {}).get("sources_sha256", {})
+    for f in ("conv_march.hip", "common.h"):
+        src = os.path.join(ROOT, "fpl-plus_amd", "csrc", f)
+        if not os.path.exists(src) or hashlib.sha256(open(src, "rb").read()).hexdigest() != meta.get(f):
+            return None
     name, dims, cin, cout, k = key
     n, d, h, w = dims
     if not (name == "conv3d_fwd" and k == (3, 3, 3) and cin in (32, 64) and cout % 32 == 0 and h >= 16 and w >= 64):
@@ -149,17 +159,30 @@ def pmc_traffic(key):
     dsegs = (d + dlen - 1) // dlen
     grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * threads
     tab = json.load(open(path))
-    for k, e in tab.items():                       # "conv_fwd_march32<false>|grid=256000" (template arguments vary)
+    for k, e in tab.items():
+        if k == "_meta":
+            continue                       # "conv_fwd_march32<false>|grid=256000" (template arguments vary)
         if k.startswith("conv_fwd_march%d" % cin) and k.endswith("|grid=%d" % grid):
             return e["hbm_bytes_per_launch"]
     return None
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline():
-    """The oracle (PyTorch-CPU restatement of the reference modules, oracle/torch_ref.py) timed on the
-    host cores on a bounded sample of the same workload: fp32 train steps (forward, Dice loss, backward,
-    Adam) of the 32-base network on a 1x1x32x80x80 crop = 1/10 of one 80x160x160 volume (about 10-15 s of work on
-    the GPU box's 64 host cores; the loop stops early after 25 s on slower hosts)."""
+    """The oracle (PyTorch-CPU restatement of the reference modules, oracle/torch_ref.py; `kind: port`) timed on the host
+    cores on a bounded sample of the SAME workload, fp32 as the reference runs it: a few train steps (forward, Dice loss,
+    backward, Adam) on a 1 x 1 x 32 x 80 x 80 crop (1/10 volume) to size the run, then ONE full step at the benchmark
+    shape 2 x 1 x 80 x 160 x 160 (about 20 s on the GPU box's 64 host cores; skipped, and the crop figure extrapolated,
+    when the crop says it would take more than 90 s)."""
     from oracle import torch_ref as R
     import detdata
     try:
@@ -170,23 +193,36 @@ def cpu_baseline():
     torch.set_num_threads(cores)
     p = dict(NET)
     p["dropout"] = [0, 0, 0, 0, 0]
-    sd, prm = R.split_state(detdata.state_dict_3d(p))
-    opt = R.AdamRef(prm, 1e-4, 1e-5)
-    shape = (1, 1, 32, 80, 80)
-    x = torch.randn(shape)
-    lab = torch.from_numpy(detdata.ball_label(shape[2:], 6.0, n=1))
     loss_fn = R.loss_from_config({"loss_type": "DiceLoss"})
-    times, t_start = [], time.time()
-    for it in range(13):
-        t0 = time.time()
-        R.training_all_step(sd, prm, opt, p, [{"image": x, "label_prob": lab}], loss_fn)
-        times.append(time.time() - t0)
-        if time.time() - t_start > 25.0:
-            break
-    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return {"value": (1.0 / 10.0) / t, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": "fp32 train step on a 1x1x32x80x80 crop (1/10 volume), 32-base UNet-DSBN, oracle/torch_ref.py, "
-                      "%d threads; median of %d step(s) after 1 warm-up, %.2f s/step" % (cores, max(1, len(times) - 1), t)}
+
+    def steps(shape, count, budget):
+        sd, prm = R.split_state(detdata.state_dict_3d(p))
+        opt = R.AdamRef(prm, 1e-4, 1e-5)
+        x = torch.randn(shape)
+        lab = torch.from_numpy(detdata.ball_label(shape[2:], 6.0 if shape[2] < 80 else 10.0, n=shape[0]))
+        times, t_start = [], time.time()
+        for it in range(count):
+            t0 = time.time()
+            R.training_all_step(sd, prm, opt, p, [{"image": x, "label_prob": lab}], loss_fn)
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget:
+                break
+        return times
+
+    crop = steps((1, 1, 32, 80, 80), 5, 12.0)
+    t_crop = float(np.median(crop[1:])) if len(crop) > 1 else crop[0]
+    est_full = t_crop * 10.0 * SHAPE[0]
+    note = "crop 1x1x32x80x80 (1/10 volume): %.2f s/step" % t_crop
+    if est_full <= 90.0:
+        t_full = steps(SHAPE, 1, 0.0)[0]
+        value = SHAPE[0] / t_full
+        sample = ("ONE full fp32 train step at the benchmark shape %dx1x80x160x160 (no warm-up), %.1f s; %s" % (
+            SHAPE[0], t_full, note))
+    else:
+        value = (1.0 / 10.0) / t_crop
+        sample = "extrapolated from the " + note + " (a full step would take about %.0f s here)" % est_full
+    return {"value": value, "unit": "volumes/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+            "sample": "32-base UNet-DSBN, DiceLoss + Adam, oracle/torch_ref.py, %d threads: %s" % (cores, sample)}
 
 
 def main():

@@ -70,10 +70,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // so that producer and consumer agree without extra plumbing.  One row per 64 voxels, at most 512: the deep levels
 // (8000 / 1000 voxels x 256 / 512 channels) still spread over the chip - with one row per 2048 voxels they ran on 1-32
 // CUs and cost as much as level 0 - and the finalize kernels read at most 512 rows (measured: +4% on the train step).
-// FPLX_ROWS_DIV / FPLX_ROWS_CAP override both for tuning.
+// (Part of the ABI's contract - callers size their buffers from fplx_num_partials / fplx_*_stats_rows - so a constant,
+// not an environment knob.)
 static inline int fplx_rows_for(int64_t voxels) {
-  static const int div = [] { const char* e = getenv("FPLX_ROWS_DIV"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
-  static const int cap = [] { const char* e = getenv("FPLX_ROWS_CAP"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+  constexpr int div = 64, cap = 512;
   int64_t r = (voxels + div - 1) / div;
   if (r > cap) r = cap;
   if (r < 1) r = 1;

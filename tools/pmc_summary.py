@@ -7,9 +7,20 @@ of a wide coalesced streaming read on gfx950 -> doubled; WRITE_SIZE is exact for
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 """
 import csv
+import hashlib
 import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_hashes():
+    """sha256 of every kernel source: bench.py reports `roofline.traffic` from this file only while they still match"""
+    d = os.path.join(ROOT, "fpl-plus_amd", "csrc")
+    return {f: hashlib.sha256(open(os.path.join(d, f), "rb").read()).hexdigest() for f in sorted(os.listdir(d))
+            if f.endswith((".hip", ".h"))}
 
 
 def per_kernel(path, counter):
@@ -38,8 +49,11 @@ def main():
         write = w.get(k, (0.0, 0))[0] * 1024.0
         out[short(k)] = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                          "hbm_bytes_per_launch": fetch + write, "launches": max(f.get(k, (0, 0))[1], w.get(k, (0, 0))[1])}
+    listing = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])
+    out["_meta"] = {"sources_sha256": source_hashes(), "command": os.environ.get("PMC_COMMAND", ""),
+                    "total_hbm_bytes": sum(v["hbm_bytes_per_launch"] * v["launches"] for _, v in listing)}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
+    for k, v in listing[:12]:
         print("%-80s %4d launches  %8.1f MB fetch  %8.1f MB write" % (k[:80], v["launches"], v["fetch_bytes_per_launch"] / 1e6,
                                                                       v["write_bytes_per_launch"] / 1e6))
 
