@@ -71,8 +71,14 @@ def _dead_default(key, live):
     up = key.split(".")[0]
     t = live.get(up + ".trans3d.weight")
     if t is None:
-        t = live[up + ".trans2d.weight"]
-    ci, co = t.shape[0], t.shape[1]
+        t = live.get(up + ".trans2d.weight")
+    if t is not None:
+        ci, co = t.shape[0], t.shape[1]
+    else:                                                      # bilinear = True: the live member is the kernel-1 convolution
+        c1 = live.get(up + ".conv3d.weight")
+        if c1 is None:
+            c1 = live[up + ".conv2d.weight"]
+        co, ci = c1.shape[0], c1.shape[1]
     if key.endswith("bias"):
         return torch.zeros(co)
     if ".trans2d." in key:

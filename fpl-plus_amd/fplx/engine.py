@@ -68,7 +68,11 @@ class Engine(object):
             for b, r in zip(part, res):
                 packs[b[0]] = r
         for name, tr in net.deconv_sites():
-            packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
+            if net.bilinear:                             # kernel-1 convolution in front of the (tri / bi)linear upsampling
+                w5 = tr.weight.reshape(tr.weight.shape[0], tr.weight.shape[1], 1, 1, 1)
+                packs[name] = ops.pack_conv_weight(w5, act_dtype, True)
+            else:
+                packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
         oc = net.out_conv
         wf, _ = ops.pack_conv_weight(oc.weight, torch.float32, False)       # fp32 planar logits
         _, wb = ops.pack_conv_weight(oc.weight, act_dtype, True)
@@ -203,8 +207,15 @@ class Engine(object):
             up = net.up_modules[j]
             tr = up.trans()
             sv.deconv_in.append(cur)
-            ops.deconv2_fwd(cur, packs["up%d.%s" % (j + 1, up.tname())][0], tr.bias, ups[l], dims[l + 1], ft[l + 1], ft[l],
-                            pds[l])
+            if net.bilinear:                             # unet2d5_dsbn.py:172-176: conv(kernel 1) -> Upsample(align_corners)
+                low = empty(vox[l + 1], ft[l])
+                ops.conv3d_fwd(cur, ops.cl_strides(*dims[l + 1][1:], ft[l + 1]), a_dt, packs["up%d.%s" % (j + 1, up.tname())][0],
+                               tr.bias, low, ops.cl_strides(*dims[l + 1][1:], ft[l]), a_dt, dims[l + 1], ft[l + 1], ft[l],
+                               (1, 1, 1), None)
+                ops.upsample2_fwd(low, ups[l], dims[l + 1], ft[l], pds[l])
+            else:
+                ops.deconv2_fwd(cur, packs["up%d.%s" % (j + 1, up.tname())][0], tr.bias, ups[l], dims[l + 1], ft[l + 1],
+                                ft[l], pds[l])
             out = empty(vox[l], ft[l])
             xin = (skips[l], ups[l]) if split[l] else cats[l]
             conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
@@ -249,7 +260,10 @@ class Engine(object):
         pds = [2 if net.dims[l] == 3 else 1 for l in range(4)]
         for j in range(4):
             l = 3 - j
-            need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l], pds[l]))
+            if net.bilinear:
+                need = max(need, ops.conv3d_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l], (1, 1, 1)))
+            else:
+                need = max(need, ops.deconv2_wgrad_ws_bytes(dims[l + 1], ft[l + 1], ft[l], pds[l]))
         ws = self._workspace(need, dev)
         # Weight-gradient kernels hang off the dependency chain (dgrad -> bn backward -> dgrad ...): they run
         # on a second stream with their own workspace, overlapping the HBM-bound BN/pool passes with MFMA work.
@@ -386,6 +400,20 @@ class Engine(object):
                 d_up = d_cat[:, ft[l]:]
             name = "up%d.%s" % (j + 1, net.up_modules[j].tname())
             xin = sv.deconv_in[j]
+            if net.bilinear:
+                d_low = empty(vox[l + 1], ft[l])
+                ops.upsample2_bwd(d_up, d_low, dims[l + 1], ft[l], pds[l])
+                lows, highs = ops.cl_strides(*dims[l + 1][1:], ft[l]), ops.cl_strides(*dims[l + 1][1:], ft[l + 1])
+                on_side(lambda xin=xin, d_low=d_low, name=name, l=l, lows=lows, highs=highs: ops.conv3d_wgrad(
+                    xin, highs, a_dt, d_low, lows, a_dt, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1],
+                    ft[l], (1, 1, 1), ws_w), d_low, d_up, d_cat, xin)
+                ready(name + ".bias")
+                d_cur = empty(vox[l + 1], ft[l + 1])
+                ops.conv3d_fwd(d_low, lows, a_dt, packs[name][1], None, d_cur, highs, a_dt, dims[l + 1], ft[l], ft[l + 1],
+                               (1, 1, 1), None)
+                if tap is not None:
+                    tap(name + ".dx", d_cur)
+                continue
             on_side(lambda xin=xin, d_up=d_up, name=name, l=l: ops.deconv2_wgrad(
                 xin, d_up, gv[name + ".weight"], gv[name + ".bias"], dims[l + 1], ft[l + 1], ft[l], ws_w, pds[l]),
                 d_up, d_cat, xin)

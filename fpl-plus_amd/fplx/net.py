@@ -9,7 +9,7 @@ dropout switch, net_run_dsbn/agent_seg.py:843-852, behave identically); all arit
 the HIP kernels of libfplx.so through fplx.engine.  There is no CPU path.
 
 Differences, on purpose:
-  * bilinear = False only.  conv_dims[l] = 3 (the benchmark configuration) or 2 (the 2.5D levels of the shipped
+  * conv_dims[l] = 3 (the benchmark configuration) or 2 (the 2.5D levels of the shipped
     configs, config_dual/data_vs/vs_t1s_g.cfg:58 conv_dims = [2, 2, 3, 3, 3]): a dim-2 level holds conv2d_* / bn2d* /
     trans2d members (same state_dict keys and shapes as the reference's) and runs Conv2d / MaxPool2d / ConvTranspose2d
     on every depth slice, which is what the reference's fold of the depth axis into the batch computes
@@ -70,17 +70,27 @@ class DownBlock(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, in_channels1, in_channels2, out_channels, num_domains, dropout_p, dim=3):
+    """parameter container of reference UpBlock (unet2d5_dsbn.py:131-188): the up-sampling member its configuration uses -
+    `trans{2,3}d` (bilinear = False: transposed convolution) or `conv{2,3}d` (bilinear = True: the kernel-1 convolution in
+    front of nn.Upsample(scale 2, bi / trilinear, align_corners=True))"""
+
+    def __init__(self, in_channels1, in_channels2, out_channels, num_domains, dropout_p, dim=3, bilinear=False):
         super(UpBlock, self).__init__()
         self.dim = dim
-        if dim == 3:
+        self.bilinear = bool(bilinear)
+        if self.bilinear:
+            if dim == 3:
+                self.conv3d = nn.Conv3d(in_channels1, in_channels2, kernel_size=1)
+            else:
+                self.conv2d = nn.Conv2d(in_channels1, in_channels2, kernel_size=1)
+        elif dim == 3:
             self.trans3d = nn.ConvTranspose3d(in_channels1, in_channels2, kernel_size=2, stride=2)
         else:
             self.trans2d = nn.ConvTranspose2d(in_channels1, in_channels2, kernel_size=2, stride=2)
         self.conv = ConvBlockND(in_channels2 * 2, out_channels, num_domains, dropout_p, dim)
 
     def tname(self):
-        return "trans%dd" % self.dim
+        return ("conv%dd" if self.bilinear else "trans%dd") % self.dim
 
     def trans(self):
         return getattr(self, self.tname())
@@ -122,8 +132,6 @@ class UNet2D5_dsbn(nn.Module):
         assert (len(self.ft_chns) == 5)                                    # unet2d5_dsbn.py:277
         if len(self.dims) != 5 or any(d not in (2, 3) for d in self.dims):
             raise ValueError("fplx UNet2D5_dsbn: conv_dims must be five values out of {{2, 3}} (got {0:})".format(self.dims))
-        if self.bilinear:
-            raise ValueError("fplx UNet2D5_dsbn: only bilinear = False (transposed convolution) is built")
         prec = params.get('precision', 'fp32')
         if prec not in ('fp32', 'bf16'):
             raise ValueError("fplx UNet2D5_dsbn: precision must be fp32 or bf16 (got {0:})".format(prec))
@@ -134,10 +142,10 @@ class UNet2D5_dsbn(nn.Module):
         self.block2 = DownBlock(ft[1], ft[2], nd, dp[2], dm[2])
         self.block3 = DownBlock(ft[2], ft[3], nd, dp[3], dm[3])
         self.block4 = DownBlock(ft[3], ft[4], nd, dp[4], dm[4])
-        self.up1 = UpBlock(ft[4], ft[3], ft[3], nd, dp[3], dm[3])          # unet2d5_dsbn.py:284-291: dims[3] .. dims[0]
-        self.up2 = UpBlock(ft[3], ft[2], ft[2], nd, dp[2], dm[2])
-        self.up3 = UpBlock(ft[2], ft[1], ft[1], nd, dp[1], dm[1])
-        self.up4 = UpBlock(ft[1], ft[0], ft[0], nd, dp[0], dm[0])
+        self.up1 = UpBlock(ft[4], ft[3], ft[3], nd, dp[3], dm[3], self.bilinear)          # unet2d5_dsbn.py:284-291: dims[3] .. dims[0]
+        self.up2 = UpBlock(ft[3], ft[2], ft[2], nd, dp[2], dm[2], self.bilinear)
+        self.up3 = UpBlock(ft[2], ft[1], ft[1], nd, dp[1], dm[1], self.bilinear)
+        self.up4 = UpBlock(ft[1], ft[0], ft[0], nd, dp[0], dm[0], self.bilinear)
         self.out_conv = nn.Conv3d(ft[0], self.n_class, kernel_size=(1, 3, 3), padding=(0, 1, 1))
 
         self.block_keys = ["block0.conv", "block1.conv", "block2.conv", "block3.conv", "block4.conv",

@@ -217,6 +217,17 @@ def deconv2_wgrad(x, dy, dw, db, dims, cin, cout, ws, sd=2):
          dt_of(x), ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
+def upsample2_fwd(x, y, dims, c, sd=2):
+    """(tri / bi)linear x2 upsampling, align_corners = True; dims = INPUT dims, sd = 1: H and W only (2.5D levels)"""
+    n, d, h, w = dims
+    call("fplx_upsample2_fwd", ptr(x), ld_of(x), ptr(y), ld_of(y), n, d, h, w, c, dt_of(x), sd, stream())
+
+
+def upsample2_bwd(dy, dx, dims, c, sd=2):
+    n, d, h, w = dims
+    call("fplx_upsample2_bwd", ptr(dy), ld_of(dy), ptr(dx), ld_of(dx), n, d, h, w, c, dt_of(dy), sd, stream())
+
+
 def bn_train_finalize(stats, rows, c, count, gamma, beta, rm, rv, nbt, bnbuf, momentum=0.1, eps=1e-5):
     """bnbuf: fp32 [4, C] -> rows mean, rstd, scale, shift"""
     call("fplx_bn_train_finalize", ptr(stats), rows, c, count, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt),

@@ -222,6 +222,15 @@ int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, i
 int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
                       void* dx, int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream);
 
+/* (Tri / bi)linear x2 upsampling, align_corners = True - UpBlock with bilinear = True (unet2d5_dsbn.py:148-150, 172-176:
+ * nn.Upsample(scale_factor=2, mode='trilinear' | 'bilinear', align_corners=True) behind a kernel-1 convolution, which runs
+ * through fplx_conv3d_fwd / _wgrad with kd = kh = kw = 1).  x [n][d][h][w][ldx] -> y [n][sd*d][2h][2w][ldy]; sd = 2:
+ * trilinear, sd = 1: bilinear on every depth slice (2.5D levels).  bwd: dx = the transpose applied to dy (gather, no atomics). */
+int fplx_upsample2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt, int sd,
+                       fplx_stream_t stream);
+int fplx_upsample2_bwd(const void* dy, int64_t ldy, void* dx, int64_t ldx, int n, int d, int h, int w, int c, int dt, int sd,
+                       fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ segmentation loss
  * Fused softmax + Dice (loss/seg/dice.py:20-57, util.py:85-107) + cross entropy
  * (loss/seg/ce.py:23-44) + per-sample image-weighted Dice (dice.py:106-128) + entropy

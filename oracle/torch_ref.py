@@ -159,7 +159,7 @@ def block_dropout_p(net_params):
 
 def unet_forward(sd, net_params, x, domain, train=True, dropout_masks=None, act_dtype=None,
                  dropout_on=None):
-    """UNet2D5_dsbn.forward with bilinear=False (unet2d5_dsbn.py:296-309); conv_dims[l] = 2 levels fold the depth axis
+    """UNet2D5_dsbn.forward (unet2d5_dsbn.py:296-309), both UpBlock forms (bilinear False / True); conv_dims[l] = 2 levels fold the depth axis
     into the batch and use the 2D members, exactly like DownBlock / UpBlock (108-129, 156-188).
 
     sd: dict key -> tensor (reference state_dict names, live members only).
@@ -186,8 +186,26 @@ def unet_forward(sd, net_params, x, domain, train=True, dropout_masks=None, act_
             if i < 4:
                 skips.append(h)
                 h = F.max_pool3d(h, 2, 2)                               # DownBlock, line 106/117
+    bilinear = bool(net_params.get("bilinear", False))
     for j in range(4):
         key = "up%d" % (j + 1)
+        if bilinear:
+            # UpBlock with bilinear = True (unet2d5_dsbn.py:148-150, 172-176): Conv(kernel 1) then nn.Upsample(scale 2,
+            # 'bilinear' / 'trilinear', align_corners=True)
+            if dims[3 - j] == 2:
+                up = F.conv2d(fold_depth(h), quant(sd[key + ".conv2d.weight"], act_dtype), sd[key + ".conv2d.bias"])
+                up = quant(up, act_dtype)
+                up = quant(F.interpolate(up, scale_factor=2, mode="bilinear", align_corners=True), act_dtype)
+                hc = torch.cat([fold_depth(skips[3 - j]), up], dim=1)
+                h = unfold_depth(conv_block2d(hc, sd, BLOCK_KEYS[5 + j], domain, train, ps[5 + j], masks[5 + j], act_dtype,
+                                              dropout_on), n)
+            else:
+                up = F.conv3d(h, quant(sd[key + ".conv3d.weight"], act_dtype), sd[key + ".conv3d.bias"])
+                up = quant(up, act_dtype)
+                up = quant(F.interpolate(up, scale_factor=2, mode="trilinear", align_corners=True), act_dtype)
+                h = torch.cat([skips[3 - j], up], dim=1)
+                h = conv_block(h, sd, BLOCK_KEYS[5 + j], domain, train, ps[5 + j], masks[5 + j], act_dtype, dropout_on)
+            continue
         if dims[3 - j] == 2:
             up = F.conv_transpose2d(fold_depth(h), quant(sd[key + ".trans2d.weight"], act_dtype),
                                     sd[key + ".trans2d.bias"], stride=2)   # line 179

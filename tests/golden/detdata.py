@@ -78,9 +78,14 @@ def state_dict_3d(net_params, prefix="w"):
     for i, (c1, c2) in enumerate([(ft[4], ft[3]), (ft[3], ft[2]), (ft[2], ft[1]), (ft[1], ft[0])]):
         key = "up%d" % (i + 1)
         dim = dims[3 - i]
-        # ConvTranspose{2,3}d weight is [Cin, Cout, 2, 2(, 2)]
-        sd[key + ".trans%dd.weight" % dim] = normal(prefix + key + ".t.w", (c1, c2) + (2,) * dim, scale=(1.0 / c1) ** 0.5)
-        sd[key + ".trans%dd.bias" % dim] = normal(prefix + key + ".t.b", (c2,), scale=0.1)
+        if net_params.get("bilinear", False):
+            # bilinear = True: 1x1(x1) convolution `conv{2,3}d` + (tri/bi)linear upsampling (unet2d5_dsbn.py:148-149, 175-176)
+            sd[key + ".conv%dd.weight" % dim] = normal(prefix + key + ".c1.w", (c2, c1) + (1,) * dim, scale=(1.0 / c1) ** 0.5)
+            sd[key + ".conv%dd.bias" % dim] = normal(prefix + key + ".c1.b", (c2,), scale=0.1)
+        else:
+            # ConvTranspose{2,3}d weight is [Cin, Cout, 2, 2(, 2)]
+            sd[key + ".trans%dd.weight" % dim] = normal(prefix + key + ".t.w", (c1, c2) + (2,) * dim, scale=(1.0 / c1) ** 0.5)
+            sd[key + ".trans%dd.bias" % dim] = normal(prefix + key + ".t.b", (c2,), scale=0.1)
         block(key + ".conv", 2 * c2, c2, dim)
     conv("out_conv", ncls, ft[0], (1, 3, 3))
     return sd

@@ -15,7 +15,10 @@ NETS = {
 }
 # the shipped configs' dimensionality pattern (config_dual/data_vs/vs_t1s_g.cfg:58): 2D convolutions at levels 0-1
 NETS["tiny25"] = dict(NETS["tiny"], conv_dims=[2, 2, 3, 3, 3])
-SHAPES = {"tiny25": (2, 1, 16, 32, 32), "tiny": (2, 1, 16, 32, 32), "cfg1": (1, 1, 32, 64, 64), "c4": (2, 4, 16, 32, 32)}
+# bilinear = True: UpBlock = 1x1(x1) convolution + (tri / bi)linear upsampling with align_corners (unet2d5_dsbn.py:148-149, 175-176)
+NETS["tinybl"] = dict(NETS["tiny"], bilinear=True)
+NETS["tinybl25"] = dict(NETS["tiny"], bilinear=True, conv_dims=[2, 2, 3, 3, 3])
+SHAPES = {"tinybl": (2, 1, 16, 32, 32), "tinybl25": (2, 1, 16, 32, 32), "tiny25": (2, 1, 16, 32, 32), "tiny": (2, 1, 16, 32, 32), "cfg1": (1, 1, 32, 64, 64), "c4": (2, 4, 16, 32, 32)}
 
 
 def label_for(name):
@@ -43,4 +46,4 @@ def key_for(name, params):
     lvl = _LEVEL_OF.get(name.split(".")[0])
     if lvl is None or params["conv_dims"][lvl] == 3:
         return name
-    return name.replace("conv3d_", "conv2d_").replace("bn3d", "bn2d").replace("trans3d", "trans2d")
+    return name.replace("conv3d_", "conv2d_").replace("bn3d", "bn2d").replace("trans3d", "trans2d").replace(".conv3d.", ".conv2d.")

@@ -13,7 +13,7 @@ from util import load_det_weights, max_rel
 pytestmark = pytest.mark.gpu
 
 # max-normalised gradient tolerance: see tests/test_oracle_golden.py (reference's own fp32 noise) x2
-GRAD_TOL = {"tiny": 1e-3, "tiny25": 1e-2, "c4": 1e-3, "cfg1": 1e-2}
+GRAD_TOL = {"tiny": 1e-3, "tiny25": 1e-2, "c4": 1e-3, "cfg1": 1e-2, "tinybl": 1e-3, "tinybl25": 4e-2}
 LOGIT_TOL = 1e-3            # north_star: logits within 1e-3 in fp32
 
 
@@ -28,7 +28,8 @@ def _net(name, precision="fp32", dropout=None):
     return net, p
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny25", "c4", "cfg1"])     # tiny25: conv_dims = [2, 2, 3, 3, 3] (shipped cfgs)
+# tiny25: conv_dims = [2, 2, 3, 3, 3] (shipped cfgs); tinybl / tinybl25: bilinear = True (kernel-1 convolution + upsampling)
+@pytest.mark.parametrize("name", ["tiny", "tiny25", "c4", "cfg1", "tinybl", "tinybl25"])
 def test_fp32_forward_backward_matches_reference(golden_dir, name):
     import fplx
     g = np.load(os.path.join(golden_dir, "net_%s.npz" % name))
@@ -153,10 +154,8 @@ def test_error_behaviour_mirrors_reference():
         net(torch.zeros(1, 1, 16, 32, 40).cuda(), domain_label=torch.zeros(1, dtype=torch.long))
     with pytest.raises(IndexError):
         net(torch.zeros(1, 1, 16, 32, 32).cuda(), domain_label=5 * torch.ones(1, dtype=torch.long))
-    bad = dict(p)
-    bad["bilinear"] = True
-    with pytest.raises(ValueError):
-        fplx.UNet2D5_dsbn(bad)
+    bl = fplx.UNet2D5_dsbn(dict(p, bilinear=True))                    # bilinear = True: conv{3}d members instead of trans3d
+    assert "up1.conv3d.weight" in bl.state_dict() and "up1.trans3d.weight" not in bl.state_dict()
     layer = fplx.DomainSpecificBatchNorm3d(8, 2).cuda()
     with pytest.raises(ValueError):
         layer(torch.zeros(2, 8, 4, 4).cuda(), torch.zeros(2, dtype=torch.long))
@@ -274,3 +273,31 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
         lr_.backward()
         opt.step()
         assert abs(float(out[0].item()) - float(lr_.item())) < 3e-3, (it, float(out[0].item()), float(lr_.item()))
+
+
+@pytest.mark.parametrize("dtype,sd", [(torch.float32, 2), (torch.float32, 1), (torch.bfloat16, 2)])
+def test_upsample2_matches_torch_interpolate(dtype, sd):
+    """fplx_upsample2_fwd / _bwd against nn.Upsample(scale 2, trilinear | bilinear per slice, align_corners=True)"""
+    from fplx import ops
+    n, d, h, w, c = 2, 3, 5, 4, 6
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, d, h, w, generator=g)
+    if sd == 2:
+        xr = x.clone().requires_grad_(True)
+        yr = torch.nn.functional.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True)
+    else:
+        xr = x.clone().requires_grad_(True)
+        y2 = torch.nn.functional.interpolate(xr.transpose(1, 2).reshape(n * d, c, h, w), scale_factor=2, mode="bilinear",
+                                             align_corners=True)
+        yr = y2.reshape(n, d, c, 2 * h, 2 * w).transpose(1, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1]).contiguous()
+    xg = cl(x).to(dtype).cuda()
+    yg = torch.empty((n * d * sd * 4 * h * w, c), dtype=dtype, device="cuda")
+    ops.upsample2_fwd(xg, yg, (n, d, h, w), c, sd)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((yg.float().cpu() - cl(yr.detach())).abs().max()) < tol * float(yr.abs().max())
+    dx = torch.empty_like(xg)
+    ops.upsample2_bwd(cl(gy).to(dtype).cuda(), dx, (n, d, h, w), c, sd)
+    assert float((dx.float().cpu() - cl(xr.grad)).abs().max()) < tol * float(xr.grad.abs().max())

@@ -61,7 +61,7 @@ def test_net_module_surface():
     ref_like["up1.conv3d.weight"] = torch.zeros(64, 128, 1, 1, 1)
     net.load_state_dict(ref_like)
     np.testing.assert_array_equal(net.out_conv.weight.detach().numpy(), want["out_conv.weight"])
-    for bad in ({"conv_dims": [2, 2, 3, 3]}, {"conv_dims": [1, 2, 3, 3, 3]}, {"bilinear": True}, {"precision": "fp8"}):
+    for bad in ({"conv_dims": [2, 2, 3, 3]}, {"conv_dims": [1, 2, 3, 3, 3]}, {"precision": "fp8"}):
         q = dict(p)
         q.update(bad)
         with pytest.raises(ValueError):
