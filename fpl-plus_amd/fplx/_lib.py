@@ -10,6 +10,13 @@ import ctypes
 import os
 import re
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin.  fplx runs backward on two streams (data
+# gradients | weight gradients); once a process group exists RCCL adds streams of its own, and with 4 queues the two fplx
+# streams end up sharing one - serialised, the whole overlap (about 1 ms of the 10 ms train step) is lost
+# (profiles/r02_rccl_single_rank.txt).  Must be in the environment before the HIP runtime initialises, i.e. before the
+# first GPU call of the process; an explicit setting of the user wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 # torch first: libfplx.so must bind to the SAME HIP runtime (libamdhip64.so.7) the process uses
 # for its device memory and streams.  PyTorch-ROCm ships its own copy; whichever copy is loaded
 # first serves both, and the ROCm-7.2 system copy does not see the devices torch opened.

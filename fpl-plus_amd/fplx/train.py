@@ -36,6 +36,12 @@ class TrainStep(object):
         # the ranks' gradients add up to its gradient, nothing is divided by the world size
         self.group = group
         self.opt.grad_scale = 1.0
+        self.dist_loss = self.reducer.enabled
+        dbg = os.environ.get("FPLX_DDP_DEBUG", "")        # measurement knob (tools/gpu_job6.sh): which part costs what
+        if "noloss" in dbg:
+            self.dist_loss = False
+        if "nogr" in dbg:
+            self.reducer.enabled = False
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
         self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
         self._loss_bufs = {}
@@ -60,7 +66,7 @@ class TrainStep(object):
         v = logits[0, 0].numel()
         part, coef = self._loss_buffers(n, c, v, logits.device)
         out = torch.empty(4 + c, dtype=torch.float32, device=logits.device)
-        if self.reducer.enabled:
+        if self.dist_loss:
             ops.seg_loss_fwd_dist(logits, label, pw, iw, self.terms, self.softmax, part, out, coef, self.group)
         else:
             ops.seg_loss_fwd(logits, label, pw, iw, self.terms, self.softmax, part, out, coef)
