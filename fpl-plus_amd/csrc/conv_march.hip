@@ -21,6 +21,7 @@
 // torch.cat of unet2d5_dsbn.py:182 when the input / output is given as two tensors (x1 / y1).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -345,6 +346,332 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 #pragma unroll
       for (int wv = 0; wv < 8; ++wv) t += red[(wv * 2 + which) * 32 + c];
       stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv_fwd_march32v2: the Cin = 32 depth march re-cut for ONE wave per SIMD (4 waves, up to 512 registers each), for
+// footprints that lie entirely inside the volume (H % 16 == 0, W % 32 == 0) - the benchmark's level 0.
+// What the stamps of round 2 showed about the 8-wave kernel above (tools/micro/march_bench.hip): the matrix pipe is busy
+// 52 % of a block's cycles; a depth step costs 9650 cycles against 6144 of MFMA issue, and the difference is vector work
+// of the wave pair sharing a SIMD - about 7 VALU + 5 SALU instructions per MFMA: write-out with masked statistics (1600
+// cycles), 96 register moves for the accumulator role shift, per-stage fragment addresses, the DMA's address selects.
+// Here a wave owns FOUR M-tiles (rows 4 wave .. 4 wave + 3 of the 16 x 32 footprint):
+//   * a group = one (kw, k-half): the 6 slab rows the four M-tiles touch are read ONCE (6 A fragments) and serve the 12
+//     (M-tile, kh) pairs x 3 kd = 36 MFMAs with 9 weight fragments: 0.42 ds_read_b128 per MFMA (0.83 above);
+//   * the accumulator roles rotate by NAME (four unrolled copies of the step), no register moves;
+//   * the slab DMA goes through a buffer descriptor: halo and padding come out of the hardware's range check as zeros,
+//     a piece costs a handful of scalar instructions and no vector one;
+//   * statistics are unmasked (interior footprints only); segment borders are handled by data, not by flags (below).
+// LDS: two 39-KB slab slots, the 27 x 32 x 32 weights (54 KB), two 2-KiB store-transpose tiles per wave, the DMA offsets.
+struct MG2 {
+  static constexpr int CIN = 32, ROWB = 64, CH = 4;
+  static constexpr int FH = 16, FW = 32, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
+  static constexpr int THREADS = 256, WAVES = 4;
+  static constexpr int SLAB_CHUNKS = SLAB * CH, SLAB_DMA = (SLAB_CHUNKS + 63) / 64;
+  static constexpr int SLAB_BYTES = SLAB_DMA * 1024, W_BYTES = 27 * 32 * ROWB;
+  static constexpr int NPIECE = (SLAB_DMA + WAVES - 1) / WAVES;       // DMA wave-instructions per wave and slab (10)
+  static constexpr int STAGE_BYTES = 32 * 32 * 2;
+  static constexpr int LDS = 2 * SLAB_BYTES + W_BYTES + 32 * 4 + WAVES * 2 * STAGE_BYTES + NPIECE * THREADS * 4;
+  static __device__ __forceinline__ int swz(int row) { return (row >> 2) & 3; }
+};
+
+template <bool STATS>
+__global__ void __launch_bounds__(MG2::THREADS)
+conv_fwd_march32v2(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                   const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                   int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
+                   bf16_t* __restrict__ y1, int ysplit, int xcd) {
+  using G = MG2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;
+  char* wbuf = smem + 2 * G::SLAB_BYTES;
+  float* bias_s = reinterpret_cast<float*>(wbuf + G::W_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * G::FH), w0 = __builtin_amdgcn_readfirstlane(tw * G::FW);
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = bid.y * 32;
+
+  auto lds_dma = [&](const void* g, char* l) {          // see conv_fwd_march32 (the resident weights come this way)
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int NPIECE = G::NPIECE;
+  // Slab DMA through a buffer descriptor over this sample's volume (base x[n], num_records = D slices): `buffer_load_dwordx4
+  // ... offen lds` with a per-lane byte offset inside the depth slice (a constant of the whole march), the depth as the
+  // scalar offset, and 0x40000000 for halo voxels outside the volume and the tail of the last 1-KiB piece - out of range
+  // (the launcher keeps a sample below 1 GiB), and the hardware writes ZEROS into LDS for such lanes
+  // (tools/micro/bufload_lds_test.hip; the scalar offset takes part in the range check on gfx950).  A depth slice outside
+  // the volume gets the scalar offset 0x40000000: every lane out of range, no 32-bit wrap, a slab of zeros = the padding.
+  // The ten offsets of a lane are parked in LDS and read back a group ahead of their use: as registers they push the step
+  // into spills, and a scratch reload waits on vmcnt, i.e. on the DMA in flight.
+  unsigned* voff_s = reinterpret_cast<unsigned*>(smem + 2 * G::SLAB_BYTES + G::W_BYTES + 32 * 4 + G::WAVES * 2 * G::STAGE_BYTES);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) {
+    int piece = wave + G::WAVES * k;
+    if (piece > G::SLAB_DMA - 1) piece = G::SLAB_DMA - 1;      // wave 3's tenth piece repeats wave 2's (same bytes, same place)
+    const int i = piece * 64 + lane;
+    const int vox = i >> 2, c = (i & 3) ^ G::swz(vox);
+    const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
+    const bool in = i < G::SLAB_CHUNKS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    voff_s[k * G::THREADS + tid] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2;
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  u32x4 rsrc;
+  rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * xslice));
+  rsrc[3] = 0x00020000u;
+  const unsigned xslice32 = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+  auto slab_piece = [&](int s, int k, unsigned vo) {    // piece k of slab s -> slot (s + 1) & 1; vo = voff_s[k][tid]
+    int piece = wave + G::WAVES * k;
+    if (piece > G::SLAB_DMA - 1) piece = G::SLAB_DMA - 1;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)((__attribute__((address_space(3))) char*)(slabs + ((s + 1) & 1) * G::SLAB_BYTES + piece * 1024)));
+    const unsigned so = __builtin_amdgcn_readfirstlane((s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so), "s"(dst) : "memory");
+  };
+
+  // accumulator sets: at step t role j (K0 = depth s + 1, K1 = s, K2 = s - 1, R = being written out) is set (j - t) & 3
+  f32x16 S[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[a][m][i] = 0.f;
+
+  __syncthreads();                                       // voff_s is complete
+  const int sbase = d0 - 1;
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) slab_piece(sbase, k, voff_s[k * G::THREADS + tid]);
+  for (int j = wave; j < 27 * 32 * G::CH / 64; j += G::WAVES) {
+    const int i = j * 64 + lane;
+    const int row = i >> 2, c = (i & 3) ^ G::swz(row);
+    lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * G::CIN + c * 8, wbuf + j * 1024);
+  }
+  if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  dma_wait();
+  block_sync();
+
+  const float bv = bias_s[r];
+  float ssum = 0.f, qsum = 0.f;
+  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * 2 * G::STAGE_BYTES;       // two tiles per wave, used alternately
+  const unsigned ldy2 = (unsigned)ldy * 2u;
+  bf16_t* ysel = bid.y >= ysplit ? y1 + (bid.y - ysplit) * 32 : y + n0;
+  char* yn = reinterpret_cast<char*>(ysel) + (((int64_t)n * D * H + (h0 + wave * 4)) * W + w0) * ldy * 2;
+  const int64_t yslice = (int64_t)H * W * ldy * 2;
+  const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
+  // M-tile m of set A: bias, statistics, bf16 -> LDS tile (m & 1) -> two 16-byte stores per lane
+  auto retire_elems = [&](const f32x16& A, int m, int i0, int cnt) {
+    char* w_ = stg + (m & 1) * G::STAGE_BYTES + (4 * khalf) * 64 + r * 2;
+#pragma unroll
+    for (int i = i0; i < i0 + cnt; ++i) {
+      const int wu = (i & 3) + 8 * (i >> 2);
+      const float ov = A[i] + bv;
+      *reinterpret_cast<bf16_t*>(w_ + wu * 64) = (bf16_t)ov;
+      if (STATS) { ssum += ov; qsum = fmaf(ov, ov, qsum); }
+    }
+  };
+  auto retire_flush = [&](int m, int o) {
+    const char* r_ = stg + (m & 1) * G::STAGE_BYTES + lane * 16;
+    unsigned l2 = ldy2;
+    asm volatile("" : "+s"(l2));
+    char* rowp = yn + o * yslice + (unsigned)(m * W) * l2;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(r_);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(r_ + 1024);
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+  };
+
+  const int nd = d1 - d0;                         // >= 2 (march_cfg)
+  const int nsteps = nd + 2;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // One depth step, the same code for EVERY step of the segment; ROT = t & 3 names the accumulator sets.
+  // Segment borders are handled by data, not by special steps:
+  //   * a slab outside the volume (s = -1, s = D) is fetched like any other - its scalar offset is out of the descriptor's
+  //     range, so the DMA fills the slot with zeros (= the padding) and the MFMAs add nothing;
+  //   * depth taps whose output depth lies outside [d0, d1) are skipped by block-uniform branches around 12 MFMAs each;
+  //   * every step writes out its R set: before step 3 that set holds no finished depth - the stores go to depth d0, which
+  //     step 3 overwrites (the block's vmcnt(0) in between retires them first), and the statistics restart at step 3.
+  // A step = 6 groups (kw, k-half) x 3 depth taps x 12 MFMAs.  Per group: the tile written in the previous group is read
+  // back, M-tile g of R goes to the other tile (8 elements beside the kd = 0 MFMAs, 8 beside the kd = 2 ones), the previous
+  // tile's two 16-byte stores, the slab DMA and next group's A fragments go beside the kd = 1 MFMAs; the three weight
+  // fragments of a depth tap are reloaded for the next group right behind their 12 MFMAs.
+  // The fragments of a step's FIRST group are loaded by the step before it: the block's vmcnt(0) + barrier sits behind
+  // group 4 (the last group that reads this slab's A fragments; by then the next slab's ten DMA pieces, issued in groups
+  // 0-3, have had time to land), so group 5 already reads the next slab and no step begins with an empty pipe.
+  bf16x8 fa[2][6], fb[9];
+  auto load_a = [&](const char* sl, int g, int buf) {    // g = kw * 2 + ks
+    const int kw = g >> 1, ks = g & 1, c = 2 * ks + khalf;
+    int vb = wave * 4 * G::SW + r;
+    asm volatile("" : "+v"(vb));                         // lane bases re-derived at the point of use (no hoisted address zoo)
+#pragma unroll
+    for (int rho = 0; rho < 6; ++rho) {
+      const int vox = vb + rho * G::SW + kw;
+      fa[buf][rho] = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((c ^ G::swz(vox)) << 4));
+    }
+  };
+  auto load_b = [&](int g, int kd) {
+    const int kw = g >> 1, ks = g & 1;
+    int rb = r;
+    asm volatile("" : "+v"(rb));
+    const char* wl = wbuf + rb * G::ROWB + (((2 * ks + khalf) ^ G::swz(rb)) << 4);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+      fb[kd * 3 + kh] = *reinterpret_cast<const bf16x8*>(wl + ((kd * 9 + kh * 3 + kw) * 32) * G::ROWB);
+  };
+  load_a(slabs + ((sbase + 1) & 1) * G::SLAB_BYTES, 0, 0);
+  load_b(0, 0); load_b(0, 1); load_b(0, 2);
+  auto step = [&](auto rot_c, int t) {
+    constexpr int ROT = decltype(rot_c)::value;
+    const int s = sbase + t;
+    const int o = (s - 2 > d0) ? s - 2 : d0;
+    const char* sl = slabs + ((s + 1) & 1) * G::SLAB_BYTES;
+    const char* sl_next = slabs + (s & 1) * G::SLAB_BYTES;
+    const bool on0 = t < nd, on1 = t >= 1 && t <= nd, on2 = t >= 2;
+    f32x16 (&K0)[4] = S[(0 - ROT) & 3];
+    f32x16 (&K1)[4] = S[(1 - ROT) & 3];
+    f32x16 (&K2)[4] = S[(2 - ROT) & 3];
+    f32x16 (&R)[4] = S[(3 - ROT) & 3];
+    u32x4 fl0, fl1;
+    unsigned vo0 = 0, vo1 = 0, vo2 = 0;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int bf = g & 1;
+      const int p0 = g < 2 ? 3 * g : 2 * g + 2, np = g < 2 ? 3 : (g < 4 ? 2 : 0);     // DMA pieces of this group: 3, 3, 2, 2
+      // ---- kd = 0: read back the previous tile (and this group's DMA offsets), first half of M-tile g of R
+      if (np > 0) {
+        vo0 = voff_s[p0 * G::THREADS + tid];
+        vo1 = voff_s[(p0 + 1) * G::THREADS + tid];
+        if (np > 2) vo2 = voff_s[(p0 + 2) * G::THREADS + tid];
+      }
+      if (g >= 1 && g <= 4) {
+        const char* r_ = stg + ((g - 1) & 1) * G::STAGE_BYTES + lane * 16;
+        fl0 = *reinterpret_cast<const u32x4*>(r_);
+        fl1 = *reinterpret_cast<const u32x4*>(r_ + 1024);
+      }
+      if (g < 4) retire_elems(R[g], g, 0, 8);
+      if (on0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+            K0[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bf][m + kh], fb[0 + kh], (g == 0 && kh == 0) ? zero : K0[m], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- kd = 1: next group's A fragments and kd = 0 weights, the previous tile's stores, the slab DMA
+      if (g < 5) load_a(sl, g + 1, bf ^ 1); else load_a(sl_next, 0, 0);
+      load_b((g + 1) % 6, 0);
+      if (g >= 1 && g <= 4) {
+        unsigned l2 = ldy2;
+        asm volatile("" : "+s"(l2));
+        char* rowp = yn + o * yslice + (unsigned)((g - 1) * W) * l2;
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(fl0) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(fl1) : "memory");
+      }
+      if (np > 0) {
+        slab_piece(s + 1, p0, vo0);
+        slab_piece(s + 1, p0 + 1, vo1);
+        if (np > 2) slab_piece(s + 1, p0 + 2, vo2);
+      }
+      if (on1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+            K1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bf][m + kh], fb[3 + kh], K1[m], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- kd = 2: second half of M-tile g, next group's kd = 1 weights; its kd = 2 weights behind the MFMAs
+      load_b((g + 1) % 6, 1);
+      if (g < 4) retire_elems(R[g], g, 8, 8);
+      if (on2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+            K2[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bf][m + kh], fb[6 + kh], K2[m], 0, 0, 0);
+      }
+      load_b((g + 1) % 6, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 4) {                                      // the next slab has landed; nobody reads this one any more
+        dma_wait();
+        block_sync();
+      }
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+#ifdef FPLX_STAMP
+  const long long st_begin = __builtin_amdgcn_s_memtime();
+  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+  int t = 0;
+  for (;;) {
+    step(C0{}, t); ++t;
+    if (t >= nsteps) break;
+    step(C1{}, t); ++t;
+    if (t >= nsteps) break;
+    step(C2{}, t); ++t;
+    if (t >= nsteps) break;
+    if (STATS && t == 3) { ssum = 0.f; qsum = 0.f; }      // what steps 0-2 wrote out (and counted) was no finished depth
+    step(C3{}, t); ++t;
+    if (t >= nsteps) break;
+  }
+#ifdef FPLX_STAMP
+  if (lane == 0) {
+    long long* o_ = fplx_stamp_buf + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 6;
+    o_[0] = 0; o_[1] = 0; o_[2] = 0; o_[3] = __builtin_amdgcn_s_memtime() - st_begin; o_[4] = nsteps;
+    o_[5] = __builtin_amdgcn_s_memrealtime() - st_rbegin;
+  }
+#endif
+  // ---- drain: the depth completed in the final step sits in the set that would be R of step nsteps
+  auto drain = [&](auto rot_c) {
+    constexpr int ROT = decltype(rot_c)::value;
+    f32x16 (&R)[4] = S[(3 - ROT) & 3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { retire_elems(R[m], m, 0, 16); retire_flush(m, d1 - 1); }
+  };
+  switch (nsteps & 3) {
+    case 0: drain(C0{}); break;
+    case 1: drain(C1{}); break;
+    case 2: drain(C2{}); break;
+    default: drain(C3{}); break;
+  }
+
+  if (STATS && stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
+    const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float tt = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) tt += red[(wv * 2 + which) * 32 + c];
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = tt;
     }
   }
 }
@@ -756,6 +1083,22 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
     return rc64 < 0 ? rc64 : 1;
   }
   if (x1) return 0;
+  {
+    static const int kv2 = [] { const char* e = getenv("FPLX_MARCH32_V2"); return e ? atoi(e) : 1; }();   // A/B knob
+    if (kv2 && !twod && h % MG2::FH == 0 && w % MG2::FW == 0 && (int64_t)d * h * w * ldx * 2 <= ((int64_t)1 << 30)) {
+#define LAUNCH_M32V2(STATS_)                                                                                        \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march32v2<STATS_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG2::LDS); \
+    conv_fwd_march32v2<STATS_><<<grid, MG2::THREADS, MG2::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+                                                                ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
+  } while (0)
+      if (stats) LAUNCH_M32V2(true); else LAUNCH_M32V2(false);
+#undef LAUNCH_M32V2
+      const int rc2 = fplx_check_launch("march32v2_conv3d_fwd");
+      return rc2 < 0 ? rc2 : 1;
+    }
+  }
 #define LAUNCH_M32(TWOD_)                                                                                           \
   do {                                                                                                              \
     (void)hipFuncSetAttribute((const void*)conv_fwd_march32<TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS); \

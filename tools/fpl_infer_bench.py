@@ -29,11 +29,10 @@ def main():
     dl = torch.ones(1, dtype=torch.long)
 
     def mc(T, tta):
-        inf = Inferer(dict(class_num=2, tta_mode=tta))
-        stack = torch.empty((T, 2, d, h, w), dtype=torch.float32, device=dev)
+        # all T passes x flips gathered into one batch, forwards in chunks of `infer_batch_voxels`, ordered merge (fplx/infer.py)
+        inf = Inferer(dict(class_num=2, tta_mode=tta, infer_batch_voxels=int(os.environ.get("INFER_BATCH_VOXELS", 1 << 23))))
         with torch.no_grad():
-            for i in range(T):
-                stack[i] = inf.run(net, x, dl)[0]
+            stack = inf.run_mc(net, x, dl, T)[:, 0]
         return stack, ops.mc_filter(stack, 0.01)
 
     for T, tta in ((4, 0), (6, 1)):

@@ -7,6 +7,7 @@
 #include <vector>
 #include <algorithm>
 #include <random>
+#include <string>
 
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
@@ -52,6 +53,9 @@ int main(int argc, char** argv) {
   hipMemcpy(hy.data(), y, hy.size() * 2, hipMemcpyDeviceToHost);
   unsigned long long cs = 0; for (size_t i = 0; i < hy.size(); i += 7) cs = cs * 1315423911ull + hy[i];
   printf("checksum %llx\n", cs);
+  if (const char* f = getenv("MB_DUMP")) { FILE* fp = fopen(f, "wb"); fwrite(hy.data(), 2, hy.size(), fp); fclose(fp);
+    std::vector<float> hst((size_t)rows * 2 * cout); hipMemcpy(hst.data(), stats, hst.size() * 4, hipMemcpyDeviceToHost);
+    std::string g = std::string(f) + ".stats"; fp = fopen(g.c_str(), "wb"); fwrite(hst.data(), 4, hst.size(), fp); fclose(fp); }
 #ifdef FPLX_STAMP
   std::vector<long long> hs(nst);
   hipMemcpy(hs.data(), sb, nst * 8, hipMemcpyDeviceToHost);
@@ -59,6 +63,10 @@ int main(int argc, char** argv) {
   std::vector<long long> tot;
   for (size_t i = 0; i < nst; i += 6) { if (hs[i + 4] == 0) continue; for (int k = 0; k < 6; ++k) s[k] += hs[i + k]; tot.push_back(hs[i + 3]); ++cnt; }
   std::sort(tot.begin(), tot.end());
+  if (getenv("FPLX_MARCH32_V2") == nullptr || atoi(getenv("FPLX_MARCH32_V2")) != 0)
+    printf("v2 stamps per wave (avg over %zu waves): fast steps %.1f at %.0f cycles each | flagged steps total %.0f | rotations total %.0f | loop total %.0f | clock %.3f GHz\n",
+           cnt, s[4] / cnt, s[0] / s[4], s[1] / cnt, s[2] / cnt, s[3] / cnt, s[3] / s[5] * 0.1);
+  else
   printf("per wave (avg over %zu waves): steps %.1f | cycles per step: compute %.0f  vmcnt-wait %.0f  barrier %.0f | loop total %.0f (median %lld, max %lld)  in-kernel clock %.3f GHz\n",
          cnt, s[4] / cnt, s[0] / s[4], s[1] / s[4], s[2] / s[4], s[3] / cnt, tot[tot.size() / 2], tot.back(), s[3] / s[5] * 0.1);
 #endif
