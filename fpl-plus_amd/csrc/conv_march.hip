@@ -33,6 +33,7 @@ __device__ long long* fplx_stamp_buf;      // set by the micro-benchmark
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct MG {
@@ -676,6 +677,338 @@ conv_fwd_march32v2(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
   }
 }
 
+// conv_fwd_march32v3: conv_fwd_march32v2 on v_mfma_f32_16x16x32_bf16.  The kernels of this file run against the chip's power
+// limit, not its issue rate (in-kernel clock 1.4-1.6 GHz on random data, 1.8-1.9 GHz on zeros, profiles/r02_march_bench_*):
+// cycles saved come back as a lower clock, energy saved does not, and the 16 x 16 x 32 shape moves the same FLOPs for less
+// (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15 x the FLOP/s of the 32 x 32 x 16 loop at equal cycles per FLOP).
+// Same tiling, LDS image, DMA, rotation and write-out as v2; what changes is the fragment geometry - a lane is (row or
+// column r16 = lane & 15, k-group kg = lane >> 4), one MFMA spans all 32 input channels, an accumulator tile is four
+// 16 x 16 blocks (voxel half x cout half) - and the weight image's swizzle (wswz).
+template <bool STATS>
+__global__ void __launch_bounds__(MG2::THREADS)
+conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                   const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                   int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
+                   bf16_t* __restrict__ y1, int ysplit, int xcd) {
+  using G = MG2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;
+  char* wbuf = smem + 2 * G::SLAB_BYTES;
+  float* bias_s = reinterpret_cast<float*>(wbuf + G::W_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kg = lane >> 4;          // v_mfma_f32_16x16x32_bf16: lane = (row | column, k-group of 8)
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * G::FH), w0 = __builtin_amdgcn_readfirstlane(tw * G::FW);
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = bid.y * 32;
+
+  // weight rows are read 16 at a time from a 16-aligned row (one cout half): a ds_read_b128 lane group then holds rows
+  // {0-3, 12-15} of one k-group and rows {4-11} of the next, and the chunk swizzle [0, 3, 2, 1] by row quad keeps its 16
+  // lanes on 16 different bank quads (the slab keeps the (row >> 2) & 3 swizzle: its fragments start at any voxel, a
+  // fixed function cannot serve every alignment, and a 2-way conflict on a third of the reads is far from the LDS limit)
+  auto wswz = [](int row) { const int q = (row >> 2) & 3; return (4 - q) & 3; };
+  auto lds_dma = [&](const void* g, char* l) {          // see conv_fwd_march32 (the resident weights come this way)
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int NPIECE = G::NPIECE;
+  // Slab DMA through a buffer descriptor over this sample's volume (base x[n], num_records = D slices): `buffer_load_dwordx4
+  // ... offen lds` with a per-lane byte offset inside the depth slice (a constant of the whole march), the depth as the
+  // scalar offset, and 0x40000000 for halo voxels outside the volume and the tail of the last 1-KiB piece - out of range
+  // (the launcher keeps a sample below 1 GiB), and the hardware writes ZEROS into LDS for such lanes
+  // (tools/micro/bufload_lds_test.hip; the scalar offset takes part in the range check on gfx950).  A depth slice outside
+  // the volume gets the scalar offset 0x40000000: every lane out of range, no 32-bit wrap, a slab of zeros = the padding.
+  // The ten offsets of a lane are parked in LDS and read back a group ahead of their use: as registers they push the step
+  // into spills, and a scratch reload waits on vmcnt, i.e. on the DMA in flight.
+  unsigned* voff_s = reinterpret_cast<unsigned*>(smem + 2 * G::SLAB_BYTES + G::W_BYTES + 32 * 4 + G::WAVES * 2 * G::STAGE_BYTES);
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) {
+    int piece = wave + G::WAVES * k;
+    if (piece > G::SLAB_DMA - 1) piece = G::SLAB_DMA - 1;      // wave 3's tenth piece repeats wave 2's (same bytes, same place)
+    const int i = piece * 64 + lane;
+    const int vox = i >> 2, c = (i & 3) ^ G::swz(vox);
+    const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
+    const bool in = i < G::SLAB_CHUNKS && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    voff_s[k * G::THREADS + tid] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2;
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  u32x4 rsrc;
+  rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * xslice));
+  rsrc[3] = 0x00020000u;
+  const unsigned xslice32 = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+  auto slab_piece = [&](int s, int k, unsigned vo) {    // piece k of slab s -> slot (s + 1) & 1; vo = voff_s[k][tid]
+    int piece = wave + G::WAVES * k;
+    if (piece > G::SLAB_DMA - 1) piece = G::SLAB_DMA - 1;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)((__attribute__((address_space(3))) char*)(slabs + ((s + 1) & 1) * G::SLAB_BYTES + piece * 1024)));
+    const unsigned so = __builtin_amdgcn_readfirstlane((s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so), "s"(dst) : "memory");
+  };
+
+  // accumulator sets: at step t role j (K0 = depth s + 1, K1 = s, K2 = s - 1, R = being written out) is set (j - t) & 3
+  f32x4 S[4][4][4];                                      // [set][M-tile][voxel half * 2 + cout half]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S[a][m][q][i] = 0.f;
+
+  __syncthreads();                                       // voff_s is complete
+  const int sbase = d0 - 1;
+#pragma unroll
+  for (int k = 0; k < NPIECE; ++k) slab_piece(sbase, k, voff_s[k * G::THREADS + tid]);
+  for (int j = wave; j < 27 * 32 * G::CH / 64; j += G::WAVES) {
+    const int i = j * 64 + lane;
+    const int row = i >> 2, c = (i & 3) ^ wswz(row);
+    lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * G::CIN + c * 8, wbuf + j * 1024);
+  }
+  if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  dma_wait();
+  block_sync();
+
+  const float bv0 = bias_s[r16], bv1 = bias_s[16 + r16];
+  float ssum0 = 0.f, qsum0 = 0.f, ssum1 = 0.f, qsum1 = 0.f;
+  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * 2 * G::STAGE_BYTES;       // two tiles per wave, used alternately
+  const unsigned ldy2 = (unsigned)ldy * 2u;
+  bf16_t* ysel = bid.y >= ysplit ? y1 + (bid.y - ysplit) * 32 : y + n0;
+  char* yn = reinterpret_cast<char*>(ysel) + (((int64_t)n * D * H + (h0 + wave * 4)) * W + w0) * ldy * 2;
+  const int64_t yslice = (int64_t)H * W * ldy * 2;
+  const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
+  // M-tile m of set A: bias, statistics, bf16 -> LDS tile (m & 1) -> two 16-byte stores per lane.  A lane holds, for its
+  // two channels r16 and 16 + r16, the voxels 4 kg + i of either 16-voxel half: half mh is written by retire_half(.., mh)
+  auto retire_half = [&](const f32x4 (&A)[4], int m, int mh) {
+    char* w_ = stg + (m & 1) * G::STAGE_BYTES + (mh * 16 + 4 * kg) * 64 + r16 * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float o0 = A[mh * 2 + 0][i] + bv0, o1 = A[mh * 2 + 1][i] + bv1;
+      *reinterpret_cast<bf16_t*>(w_ + i * 64) = (bf16_t)o0;
+      *reinterpret_cast<bf16_t*>(w_ + i * 64 + 32) = (bf16_t)o1;
+      if (STATS) { ssum0 += o0; qsum0 = fmaf(o0, o0, qsum0); ssum1 += o1; qsum1 = fmaf(o1, o1, qsum1); }
+    }
+  };
+  auto retire_flush = [&](int m, int o) {
+    const char* r_ = stg + (m & 1) * G::STAGE_BYTES + lane * 16;
+    unsigned l2 = ldy2;
+    asm volatile("" : "+s"(l2));
+    char* rowp = yn + o * yslice + (unsigned)(m * W) * l2;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(r_);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(r_ + 1024);
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
+  };
+
+  const int nd = d1 - d0;                         // >= 2 (march_cfg)
+  const int nsteps = nd + 2;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  // One depth step (see conv_fwd_march32v2, whose schedule this kernel keeps), the same code for EVERY step of the segment.
+  // Segment borders are handled by data, not by special steps:
+  //   * a slab outside the volume (s = -1, s = D) is fetched like any other - its scalar offset is out of the descriptor's
+  //     range, so the DMA fills the slot with zeros (= the padding) and the MFMAs add nothing;
+  //   * depth taps whose output depth lies outside [d0, d1) are skipped by block-uniform branches around 12 MFMAs each;
+  //   * every step writes out its R set: before step 3 that set holds no finished depth - the stores go to depth d0, which
+  //     step 3 overwrites (the block's vmcnt(0) in between retires them first), and the statistics restart at step 3.
+  // A step = 6 groups (kw, k-half) x 3 depth taps x 12 MFMAs.  Per group: the tile written in the previous group is read
+  // back, M-tile g of R goes to the other tile (8 elements beside the kd = 0 MFMAs, 8 beside the kd = 2 ones), the previous
+  // tile's two 16-byte stores, the slab DMA and next group's A fragments go beside the kd = 1 MFMAs; the three weight
+  // fragments of a depth tap are reloaded for the next group right behind their 12 MFMAs.
+  // The fragments of a step's FIRST group are loaded by the step before it: the block's vmcnt(0) + barrier sits behind
+  // group 4 (the last group that reads this slab's A fragments; by then the next slab's ten DMA pieces, issued in groups
+  // 0-3, have had time to land), so group 5 already reads the next slab and no step begins with an empty pipe.
+  // v_mfma_f32_16x16x32_bf16 covers all 32 input channels at once: a group is (kw, 16-voxel half mh) - 6 A fragments (the
+  // half's six slab rows) x the 18 weight fragments (kd, kh, cout half) of the kw, which stay in registers for both halves
+  // and are reloaded for the next kw behind their MFMAs of the second half: the same 0.42 reads per 32 cycles of MFMA.
+  bf16x8 fa[2][6], fb[18];
+  auto load_a = [&](const char* sl, int g, int buf) {    // g = kw * 2 + mh
+    const int kw = g >> 1, mh = g & 1;
+    int vb = wave * 4 * G::SW + r16;
+    asm volatile("" : "+v"(vb));
+#pragma unroll
+    for (int rho = 0; rho < 6; ++rho) {
+      const int vox = vb + rho * G::SW + kw + mh * 16;
+      fa[buf][rho] = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((kg ^ G::swz(vox)) << 4));
+    }
+  };
+  auto load_b = [&](int kw, int kd) {                    // the six fragments (kh, cout half) of depth tap kd
+    int rb = r16;
+    asm volatile("" : "+v"(rb));
+    const char* wl = wbuf + rb * G::ROWB + ((kg ^ wswz(rb)) << 4);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+        fb[kd * 6 + kh * 2 + nh] = *reinterpret_cast<const bf16x8*>(wl + (((kd * 9 + kh * 3 + kw) * 32) + nh * 16) * G::ROWB);
+  };
+  load_a(slabs + ((sbase + 1) & 1) * G::SLAB_BYTES, 0, 0);
+  load_b(0, 0); load_b(0, 1); load_b(0, 2);
+  auto step = [&](auto rot_c, int t) {
+    constexpr int ROT = decltype(rot_c)::value;
+    const int s = sbase + t;
+    const int o = (s - 2 > d0) ? s - 2 : d0;
+    const char* sl = slabs + ((s + 1) & 1) * G::SLAB_BYTES;
+    const char* sl_next = slabs + (s & 1) * G::SLAB_BYTES;
+    const bool on0 = t < nd, on1 = t >= 1 && t <= nd, on2 = t >= 2;
+    f32x4 (&K0)[4][4] = S[(0 - ROT) & 3];
+    f32x4 (&K1)[4][4] = S[(1 - ROT) & 3];
+    f32x4 (&K2)[4][4] = S[(2 - ROT) & 3];
+    f32x4 (&R)[4][4] = S[(3 - ROT) & 3];
+    u32x4 fl0, fl1;
+    unsigned vo0 = 0, vo1 = 0, vo2 = 0;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int bf = g & 1, kw = g >> 1, mh = g & 1;
+      const int p0 = g < 2 ? 3 * g : 2 * g + 2, np = g < 2 ? 3 : (g < 4 ? 2 : 0);     // DMA pieces of this group: 3, 3, 2, 2
+      // ---- kd = 0: read back the previous tile (and this group's DMA offsets), first half of M-tile g of R
+      if (np > 0) {
+        vo0 = voff_s[p0 * G::THREADS + tid];
+        vo1 = voff_s[(p0 + 1) * G::THREADS + tid];
+        if (np > 2) vo2 = voff_s[(p0 + 2) * G::THREADS + tid];
+      }
+      if (g >= 1 && g <= 4) {
+        const char* r_ = stg + ((g - 1) & 1) * G::STAGE_BYTES + lane * 16;
+        fl0 = *reinterpret_cast<const u32x4*>(r_);
+        fl1 = *reinterpret_cast<const u32x4*>(r_ + 1024);
+      }
+      if (g < 4) retire_half(R[g], g, 0);
+      if (on0) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+              K0[m][mh * 2 + nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[bf][m + kh], fb[0 + kh * 2 + nh],
+                                                                          (kw == 0 && kh == 0) ? zero : K0[m][mh * 2 + nh], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- kd = 1: next group's A fragments and kd = 0 weights, the previous tile's stores, the slab DMA
+      if (g < 5) load_a(sl, g + 1, bf ^ 1); else load_a(sl_next, 0, 0);
+      if (mh == 1) load_b((kw + 1) % 3, 0);
+      if (g >= 1 && g <= 4) {
+        unsigned l2 = ldy2;
+        asm volatile("" : "+s"(l2));
+        char* rowp = yn + o * yslice + (unsigned)((g - 1) * W) * l2;
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(fl0) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(fl1) : "memory");
+      }
+      if (np > 0) {
+        slab_piece(s + 1, p0, vo0);
+        slab_piece(s + 1, p0 + 1, vo1);
+        if (np > 2) slab_piece(s + 1, p0 + 2, vo2);
+      }
+      if (on1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+              K1[m][mh * 2 + nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[bf][m + kh], fb[6 + kh * 2 + nh], K1[m][mh * 2 + nh], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- kd = 2: second half of M-tile g, next group's kd = 1 weights; its kd = 2 weights behind the MFMAs
+      if (mh == 1) load_b((kw + 1) % 3, 1);
+      if (g < 4) retire_half(R[g], g, 1);
+      if (on2) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+              K2[m][mh * 2 + nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[bf][m + kh], fb[12 + kh * 2 + nh], K2[m][mh * 2 + nh], 0, 0, 0);
+      }
+      if (mh == 1) load_b((kw + 1) % 3, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 4) {                                      // the next slab has landed; nobody reads this one any more
+        dma_wait();
+        block_sync();
+      }
+    }
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  using C2 = std::integral_constant<int, 2>;
+  using C3 = std::integral_constant<int, 3>;
+#ifdef FPLX_STAMP
+  const long long st_begin = __builtin_amdgcn_s_memtime();
+  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
+  int t = 0;
+  for (;;) {
+    step(C0{}, t); ++t;
+    if (t >= nsteps) break;
+    step(C1{}, t); ++t;
+    if (t >= nsteps) break;
+    step(C2{}, t); ++t;
+    if (t >= nsteps) break;
+    if (STATS && t == 3) { ssum0 = qsum0 = ssum1 = qsum1 = 0.f; }      // what steps 0-2 wrote out (and counted) was no finished depth
+    step(C3{}, t); ++t;
+    if (t >= nsteps) break;
+  }
+#ifdef FPLX_STAMP
+  if (lane == 0) {
+    long long* o_ = fplx_stamp_buf + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 6;
+    o_[0] = 0; o_[1] = 0; o_[2] = 0; o_[3] = __builtin_amdgcn_s_memtime() - st_begin; o_[4] = nsteps;
+    o_[5] = __builtin_amdgcn_s_memrealtime() - st_rbegin;
+  }
+#endif
+  // ---- drain: the depth completed in the final step sits in the set that would be R of step nsteps
+  auto drain = [&](auto rot_c) {
+    constexpr int ROT = decltype(rot_c)::value;
+    f32x4 (&R)[4][4] = S[(3 - ROT) & 3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { retire_half(R[m], m, 0); retire_half(R[m], m, 1); retire_flush(m, d1 - 1); }
+  };
+  switch (nsteps & 3) {
+    case 0: drain(C0{}); break;
+    case 1: drain(C1{}); break;
+    case 2: drain(C2{}); break;
+    default: drain(C3{}); break;
+  }
+
+  if (STATS && stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
+    float a0 = ssum0, a1 = ssum1, q0 = qsum0, q1 = qsum1;   // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same two channels
+    a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
+    a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+    q0 += __shfl_xor(q0, 16, 64); q0 += __shfl_xor(q0, 32, 64);
+    q1 += __shfl_xor(q1, 16, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (lane < 16) {
+      red[(wave * 2 + 0) * 32 + r16] = a0; red[(wave * 2 + 0) * 32 + 16 + r16] = a1;
+      red[(wave * 2 + 1) * 32 + r16] = q0; red[(wave * 2 + 1) * 32 + 16 + r16] = q1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float tt = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) tt += red[(wv * 2 + which) * 32 + c];
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = tt;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // conv_fwd_march64: the same input-stationary depth march for Cin = 64 (level-0 decoder conv1 on the skip | up
 // concatenation, level-1 convs).  All 27 x 32 x 64 weights of the block's 32 output channels stay resident in LDS
@@ -1084,7 +1417,7 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   }
   if (x1) return 0;
   {
-    static const int kv2 = [] { const char* e = getenv("FPLX_MARCH32_V2"); return e ? atoi(e) : 1; }();   // A/B knob
+    static const int kv2 = [] { const char* e = getenv("FPLX_MARCH32_V2"); return e ? atoi(e) : 4; }();   // A/B knob
     if (kv2 && !twod && h % MG2::FH == 0 && w % MG2::FW == 0 && (int64_t)d * h * w * ldx * 2 <= ((int64_t)1 << 30)) {
 #define LAUNCH_M32V2(STATS_)                                                                                        \
   do {                                                                                                              \
@@ -1093,7 +1426,17 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                                                 ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
                                                                 c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
   } while (0)
-      if (stats) LAUNCH_M32V2(true); else LAUNCH_M32V2(false);
+#define LAUNCH_M32V3(STATS_)                                                                                        \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march32v3<STATS_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG2::LDS); \
+    conv_fwd_march32v3<STATS_><<<grid, MG2::THREADS, MG2::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+                                                                ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
+  } while (0)
+      // 1: v2 everywhere; 3: v3 everywhere; 4: v3 where no statistics are wanted (its STATS form spills), v2 otherwise
+      if (stats) { if (kv2 == 3) LAUNCH_M32V3(true); else LAUNCH_M32V2(true); }
+      else { if (kv2 >= 3) LAUNCH_M32V3(false); else LAUNCH_M32V2(false); }
+#undef LAUNCH_M32V3
 #undef LAUNCH_M32V2
       const int rc2 = fplx_check_launch("march32v2_conv3d_fwd");
       return rc2 < 0 ? rc2 : 1;

@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
   hipMalloc(&bias, cout * 4); hipMemset(bias, 0, cout * 4);
   const int rows = fplx_march_rows(n, d, h, w, cin, cout);
   hipMalloc(&stats, (size_t)rows * 2 * cout * 4);
+  float* stats_arg = getenv("MB_NOSTATS") ? nullptr : stats;
   hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(wp, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
   if (!fplx_march_ok(n, d, h, w, cin, cout)) { printf("shape not march-eligible\n"); return 1; }
@@ -36,12 +37,12 @@ int main(int argc, char** argv) {
   hipMemcpyToSymbol(HIP_SYMBOL(fplx_stamp_buf), &sb, sizeof(sb));
 #endif
   hipStream_t st; hipStreamCreate(&st);
-  for (int i = 0; i < 3; ++i) fplx_march_conv3d_fwd(x, cin, wp, bias, y, cout, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, twod);
+  for (int i = 0; i < 3; ++i) fplx_march_conv3d_fwd(x, cin, wp, bias, y, cout, n, d, h, w, cin, cout, stats_arg, st, nullptr, nullptr, twod);
   hipStreamSynchronize(st);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20;
   hipEventRecord(e0, st);
-  for (int i = 0; i < iters; ++i) fplx_march_conv3d_fwd(x, cin, wp, bias, y, cout, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, twod);
+  for (int i = 0; i < iters; ++i) fplx_march_conv3d_fwd(x, cin, wp, bias, y, cout, n, d, h, w, cin, cout, stats_arg, st, nullptr, nullptr, twod);
   hipEventRecord(e1, st);
   hipStreamSynchronize(st);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= iters;
