@@ -585,6 +585,160 @@ maxpool2_bwd_k(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy, i
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused forms at the end of a DownBlock (second ConvBlockND site, no dropout there: unet2d5_dsbn.py:79-81 then 117):
+//   bn_act_pool_fwd_k  y2 -> a2 = PReLU(BN(y2)) (the skip tensor) AND MaxPool(a2) in one pass: the pooling pass no longer
+//                      re-reads the activation it was just handed (6.25 -> 4.25 bytes per element);
+//   pool_bwd_bn_reduce_k  the pooling gradient + skip gradient -> d(a2) AND the two per-channel sums of the BatchNorm
+//                      backward over that d(a2) in one pass; a2 itself is recomputed from y2 (same arithmetic, same bf16
+//                      rounding, same first-maximum rule) instead of read: 10.25 -> 6.25 bytes per element.
+// A thread owns one group of VEC channels (constants in registers) and strides over POOLED voxels.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_pool_fwd_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t ldo, T* __restrict__ pooled, int64_t ldp,
+                  const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ slope_p, int N,
+                  int D, int H, int W, int C, int pd) {
+  const int G = C / VEC, VL = EW_THREADS / G;            // host: EW_THREADS % G == 0
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const int Do = D / pd, Ho = H / 2, Wo = W / 2;
+  const int64_t vout = (int64_t)N * Do * Ho * Wo;
+  const float slope = *slope_p;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  for (int64_t vo = (int64_t)blockIdx.x * VL + vl; vo < vout; vo += (int64_t)gridDim.x * VL) {
+    int64_t q = vo;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho); q /= Ho;
+    const int d_o = (int)(q % Do);
+    const int64_t n = q / Do;
+    float a[8][VEC], best[VEC];
+    int64_t vis[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
+      vis[t] = ((n * D + pd * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      ldv_nt<T, VEC>(y + vis[t] * ldy + c0, a[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z = fmaf(a[t][j], sc[j], sh[j]);
+        z = z > 0.f ? z : z * slope;
+        z = (float)(T)z;                                 // what the skip tensor stores and the pooling compares
+        a[t][j] = z;
+        best[j] = z > best[j] ? z : best[j];
+      }
+      stv<T, VEC>(out + vis[t] * ldo + c0, a[t]);
+    }
+    stv<T, VEC>(pooled + vo * ldp + c0, best);
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+pool_bwd_bn_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dy, int64_t lddy, const T* __restrict__ dskip,
+                     int64_t lds, T* __restrict__ dx, int64_t ldo, const float* __restrict__ mean,
+                     const float* __restrict__ rstd, const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ slope_p, int N, int D, int H, int W, int C, int pd, float* __restrict__ part) {
+  const int G = C / VEC, VL = EW_THREADS / G;            // host: G a power of two <= 64 dividing EW_THREADS
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const int Do = D / pd, Ho = H / 2, Wo = W / 2;
+  const int64_t vout = (int64_t)N * Do * Ho * Wo;
+  const float slope = *slope_p;
+  float sdz[VEC], sdx[VEC], sds = 0.f, m[VEC], rs[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sdz[j] = sdx[j] = 0.f;
+    m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+  }
+  for (int64_t vo = (int64_t)blockIdx.x * VL + vl; vo < vout; vo += (int64_t)gridDim.x * VL) {
+    int64_t q = vo;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho); q /= Ho;
+    const int d_o = (int)(q % Do);
+    const int64_t n = q / Do;
+    float gr[VEC], best[VEC], a[8][VEC], o[8][VEC];
+    int arg[VEC];
+    int64_t vis[8];
+    ldv<T, VEC>(dy + vo * lddy + c0, gr);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
+      vis[t] = ((n * D + pd * d_o + (t >> 2)) * H + 2 * ho + ((t >> 1) & 1)) * W + 2 * wo + (t & 1);
+      ldv<T, VEC>(y + vis[t] * ldy + c0, a[t]);
+      if (dskip) ldv<T, VEC>(dskip + vis[t] * lds + c0, o[t]);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[t][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; arg[j] = 0; }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z = fmaf(a[t][j], sc[j], sh[j]);
+        z = z > 0.f ? z : z * slope;
+        z = (float)(T)z;                                 // the stored activation the forward pooling compared
+        if (z > best[j]) { best[j] = z; arg[j] = t; }    // first maximum wins (ATen max_pool3d)
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t >= 4 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float dv = (float)(T)(o[t][j] + ((arg[j] == t) ? gr[j] : 0.f));     // d(a2) as stored; the sums use the stored value
+        o[t][j] = dv;
+        const float z = fmaf(a[t][j], sc[j], sh[j]);
+        const float dz = z > 0.f ? dv : dv * slope;
+        sds += z > 0.f ? 0.f : dv * z;
+        sdz[j] += dz;
+        sdx[j] = fmaf(dz, (a[t][j] - m[j]) * rs[j], sdx[j]);
+      }
+      stv<T, VEC>(dx + vis[t] * ldo + c0, o[t]);
+    }
+  }
+  // per-block partial row, as bn_act_bwd_reduce_k writes it (butterfly over the lanes of a channel group, 4 waves via LDS)
+  __shared__ float red[EW_THREADS / 64 * 64][2 * VEC + 1];
+  float* row = part + (int64_t)blockIdx.x * (2 * C + 1);
+  for (int ofs = G; ofs < 64; ofs <<= 1) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sdz[j] += __shfl_xor(sdz[j], ofs, 64); sdx[j] += __shfl_xor(sdx[j], ofs, 64); }
+    sds += __shfl_xor(sds, ofs, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[wave * 64 + lane][j] = sdz[j]; red[wave * 64 + lane][VEC + j] = sdx[j]; }
+    red[wave * 64 + lane][2 * VEC] = sds;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < EW_THREADS / 64; ++wv) { t0 += red[wv * 64 + threadIdx.x][j]; t1 += red[wv * 64 + threadIdx.x][VEC + j]; }
+      row[c0 + j] = t0;
+      row[C + c0 + j] = t1;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int wv = 0; wv < EW_THREADS / 64; ++wv)
+      for (int k = 0; k < G; ++k) t += red[wv * 64 + k][2 * VEC];
+    row[2 * C] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EW_THREADS)
 adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
        float step_size, float b1, float b2, float eps, float wd, float inv_sqrt_bc2, float gscale) {
@@ -837,6 +991,48 @@ int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n,
 int fplx_maxpool122_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds, void* dx,
                         int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream) {
   return maxpool_bwd_impl(x, ldx, dy, ldy, dskip, lds, dx, ldo, n, d, h, w, c, dt, 1, stream);
+}
+
+// 1 if the fused DownBlock-tail kernels take this shape (bf16, 16-byte channel groups that tile a block), else 0
+int fplx_bn_pool_fused_ok(int c, int dt) {
+  const int g = c / 8;
+  return dt == FPLX_BF16 && c % 8 == 0 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 ? 1 : 0;
+}
+
+static int bn_pool_args_ok(const char* what, int n, int d, int h, int w, int c, int dt, int pd) {
+  FPLX_REQUIRE(n > 0 && c > 0 && d >= pd && h >= 2 && w >= 2 && !(d % pd) && !(h & 1) && !(w & 1) && (pd == 1 || pd == 2),
+               FPLX_E_BADSHAPE, "%s: bad shape", what);
+  FPLX_REQUIRE(fplx_bn_pool_fused_ok(c, dt), FPLX_E_BADSHAPE, "%s: C=%d dtype %d not supported (fplx_bn_pool_fused_ok)", what, c, dt);
+  return FPLX_OK;
+}
+
+int fplx_bn_act_pool_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, void* pooled, int64_t ldp, const float* scale,
+                         const float* shift, const float* slope, int n, int d, int h, int w, int c, int dt, int pd,
+                         fplx_stream_t stream) {
+  FPLX_REQUIRE(y && out && pooled && scale && shift && slope, FPLX_E_NULL, "bn_act_pool_fwd: null pointer");
+  const int rc = bn_pool_args_ok("bn_act_pool_fwd", n, d, h, w, c, dt, pd);
+  if (rc != FPLX_OK) return rc;
+  FPLX_REQUIRE(vec_ok<bf16_t>(y, ldy, out, ldo, pooled, ldp, c), FPLX_E_BADSHAPE, "bn_act_pool_fwd: pointers / leading dimensions not 16-byte aligned");
+  const int64_t vo = (int64_t)n * (d / pd) * (h / 2) * (w / 2);
+  bn_act_pool_fwd_k<bf16_t, 8><<<ew_grid(vo * (c / 8)), EW_THREADS, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)y, ldy, (bf16_t*)out, ldo, (bf16_t*)pooled, ldp, scale, shift, slope, n, d, h, w, c, pd);
+  return fplx_check_launch("bn_act_pool_fwd");
+}
+
+int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t lddy, const void* dskip, int64_t lds, void* dx,
+                            int64_t ldo, const float* mean, const float* rstd, const float* scale, const float* shift,
+                            const float* slope, int n, int d, int h, int w, int c, int dt, int pd, float* part,
+                            fplx_stream_t stream) {
+  FPLX_REQUIRE(y && dy && dx && mean && rstd && scale && shift && slope && part, FPLX_E_NULL, "pool_bwd_bn_reduce: null pointer");
+  const int rc = bn_pool_args_ok("pool_bwd_bn_reduce", n, d, h, w, c, dt, pd);
+  if (rc != FPLX_OK) return rc;
+  FPLX_REQUIRE(vec_ok<bf16_t>(y, ldy, dy, lddy, dx, ldo, c) && vec_ok<bf16_t>(dskip, lds, nullptr, 0, nullptr, 0, c), FPLX_E_BADSHAPE,
+               "pool_bwd_bn_reduce: pointers / leading dimensions not 16-byte aligned");
+  const int rows = fplx_rows_for((int64_t)n * d * h * w);          // the partial rows bn_act_bwd_finalize expects for this tensor
+  pool_bwd_bn_reduce_k<bf16_t, 8><<<rows, EW_THREADS, 0, (hipStream_t)stream>>>(
+      (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (const bf16_t*)dskip, lds, (bf16_t*)dx, ldo, mean, rstd, scale, shift, slope, n,
+      d, h, w, c, pd, part);
+  return fplx_check_launch("pool_bwd_bn_reduce");
 }
 
 int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -39,6 +39,7 @@ class Engine(object):
         # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
         self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
         self.use_split_cat = os.environ.get("FPLX_SPLIT_CAT", "1") != "0"     # A/B knob (benchmarks only)
+        self.use_fused_pool = os.environ.get("FPLX_FUSED_POOL", "1") != "0"   # A/B knob (benchmarks only)
         # block_joins: the main stream waits for the weight-gradient stream at every block boundary of backward.
         # None = decide per network (see backward()); tools/race25.py sets it to bisect.
         self.block_joins = None
@@ -149,8 +150,9 @@ class Engine(object):
                 ups.append(cats[l][:, ft[l]:])
         sv.cats, sv.skips, sv.split = cats, skips, split
 
-        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active):
-            """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view"""
+        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None):
+            """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view; pool = (pooled, pd): the
+            MaxPool of out_view is produced by the same pass (tail of a DownBlock)"""
             conv, bn, prelu = site
             cout = conv.weight.shape[0]
             mid = conv.weight.dim() == 4           # Conv2d of a 2.5D level: its pack lives in the middle depth plane
@@ -173,10 +175,13 @@ class Engine(object):
             else:
                 ops.bn_eval_prepare(bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var, bnbuf, bnm.eps)
             pp = p if dropout_active else 0.0
-            ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
+            if pool is not None:
+                ops.bn_act_pool_fwd(y, out_view, pool[0], bnbuf, prelu.weight, dims[l], cout, pool[1])
+            else:
+                ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
             return y, bnbuf, pp
 
-        def conv_block(b, xin, xs, x_dt, cin, l, out_view):
+        def conv_block(b, xin, xs, x_dt, cin, l, out_view, pool=None):
             blk = net.block_modules[b]
             key = net.block_keys[b]
             c = ft[l]
@@ -185,7 +190,7 @@ class Engine(object):
             y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + "." + blk.cname(1),
                                     (blk.conv_of(1), blk.bn_of(1), blk.relu_1), l, a1, blk.dropout_p, sid, drop_on[b])
             y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + "." + blk.cname(2),
-                                   (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False)
+                                   (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False, pool)
             sv.blocks.append(dict(xin=xin, xs=xs, x_dt=x_dt, cin=cin, l=l, y1=y1, bn1=bn1, p1=p1, sid=sid, a1=a1,
                                   y2=y2, bn2=bn2, out=out_view))
 
@@ -193,10 +198,12 @@ class Engine(object):
         cur, cur_s, cur_dt, cur_c = x, ops.planar_strides(Cin, D, H, W), F32, Cin
         for i in range(5):
             out_view = skips[i] if i < 4 else empty(vox[4], ft[4])
-            conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view)
+            fused = i < 4 and self.use_fused_pool and ops.bn_pool_fused_ok(ft[i], adt)
+            pooled = empty(vox[i + 1], ft[i]) if i < 4 else None
+            conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view, (pooled, pds[i]) if fused else None)
             if i < 4:
-                pooled = empty(vox[i + 1], ft[i])
-                ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i], pds[i])
+                if not fused:
+                    ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i], pds[i])
                 sv.pooled.append(pooled)
                 cur, cur_s, cur_dt, cur_c = pooled, ops.cl_strides(*dims[i + 1][1:], ft[i]), a_dt, ft[i]
             else:
@@ -337,12 +344,13 @@ class Engine(object):
         ops.conv3d_fwd(dlogits, ops.planar_strides(ncls, D, H, W), F32, packs["out_conv"][1], None, d_cur,
                        ops.cl_strides(D, H, W, ft[0]), a_dt, dims[0], ncls, ft[0], (1, 3, 3), None)
 
-        def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view):
-            """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy."""
+        def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view, reduced=False):
+            """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy.
+            reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)"""
             c = ft[l]
             gkey = "%s.bns.%d" % (bnkey, domain)
             ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
-                           gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef)
+                           gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced)
             if tap is not None:
                 tap(key + ".dy", d_out)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
@@ -371,7 +379,7 @@ class Engine(object):
                 if tap is not None:
                     tap(key + ".dx", dx_view)
 
-        def block_bwd(b, d_out, want_dx):
+        def block_bwd(b, d_out, want_dx, reduced=False):
             """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""
             blk = sv.blocks[b]
             key = net.block_keys[b]
@@ -379,7 +387,7 @@ class Engine(object):
             l, c, cin = blk["l"], ft[blk["l"]], blk["cin"]
             d_a1 = empty(vox[l], c)
             site_bwd(key + "." + mod.cname(2), key + "." + mod.bname(2), key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0,
-                     d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1)
+                     d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1, reduced)
             if isinstance(blk["xin"], tuple):
                 d_in = (empty(vox[l], cin // 2), empty(vox[l], cin // 2)) if want_dx else None
             else:
@@ -427,8 +435,14 @@ class Engine(object):
         ready("block4.conv.relu_1.weight")
         for i in range(3, -1, -1):
             d_a2 = empty(vox[i], ft[i])
-            ops.maxpool2_bwd(sv.skips[i], d_pool, d_skips[i], d_a2, dims[i], ft[i], pds[i])
-            d_pool = block_bwd(i, d_a2, i > 0)
+            fused = self.use_fused_pool and ops.bn_pool_fused_ok(ft[i], adt)
+            if fused:      # pooling gradient + skip gradient AND the BatchNorm reduction over the result, in one pass
+                blk = sv.blocks[i]
+                ops.pool_bwd_bn_reduce(blk["y2"], d_pool, d_skips[i], d_a2, blk["bn2"],
+                                       net.get_param(net.block_keys[i] + ".relu_2.weight"), dims[i], ft[i], part, pds[i])
+            else:
+                ops.maxpool2_bwd(sv.skips[i], d_pool, d_skips[i], d_a2, dims[i], ft[i], pds[i])
+            d_pool = block_bwd(i, d_a2, i > 0, fused)
             ready("block%d.conv.relu_1.weight" % i)
         join_side()
         del keep

@@ -249,12 +249,33 @@ def num_partials(voxels):
     return _lib.lib().fplx_num_partials(voxels)
 
 
-def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope, part, coef):
-    """three-stage backward of the fused BN-apply + PReLU + dropout pass; dy may alias dout"""
+def bn_pool_fused_ok(c, dtype):
+    return _lib.lib().fplx_bn_pool_fused_ok(int(c), _DT[dtype]) == 1
+
+
+def bn_act_pool_fwd(y, out, pooled, bnbuf, slope, dims, c, pd=2):
+    """tail of a DownBlock in one pass: out = PReLU(BN(y)) (the skip tensor) and pooled = MaxPool(out)"""
+    n, d, h, w = dims
+    call("fplx_bn_act_pool_fwd", ptr(y), ld_of(y), ptr(out), ld_of(out), ptr(pooled), ld_of(pooled), ptr(bnbuf[2]), ptr(bnbuf[3]),
+         ptr(slope), n, d, h, w, c, dt_of(y), pd, stream())
+
+
+def pool_bwd_bn_reduce(y, dy, dskip, dx, bnbuf, slope, dims, c, part, pd=2):
+    """dx = dskip + unpooled(dy) (= d of the DownBlock's output) and the partial rows of bn_act_bwd's reduction over it"""
+    n, d, h, w = dims
+    call("fplx_pool_bwd_bn_reduce", ptr(y), ld_of(y), ptr(dy), ld_of(dy), ptr(dskip), 0 if dskip is None else ld_of(dskip), ptr(dx),
+         ld_of(dx), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), n, d, h, w, c, dt_of(y), pd, ptr(part),
+         stream())
+
+
+def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope, part, coef, reduced=False):
+    """three-stage backward of the fused BN-apply + PReLU + dropout pass; dy may alias dout.
+    reduced: `part` already holds the partial rows (pool_bwd_bn_reduce wrote them while it formed dout)"""
     v = y.shape[0]
     rows = num_partials(v)
-    call("fplx_bn_act_bwd_reduce", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(bnbuf[0]), ptr(bnbuf[1]),
-         ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), v, c, dt_of(y), ptr(part), stream())
+    if not reduced:
+        call("fplx_bn_act_bwd_reduce", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(bnbuf[0]), ptr(bnbuf[1]),
+             ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), v, c, dt_of(y), ptr(part), stream())
     call("fplx_bn_act_bwd_finalize", ptr(part), rows, c, v, 1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope),
          ptr(coef), stream())
     call("fplx_bn_act_bwd_apply", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]),

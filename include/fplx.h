@@ -222,6 +222,21 @@ int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, i
 int fplx_maxpool2_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
                       void* dx, int64_t ldo, int n, int d, int h, int w, int c, int dt, fplx_stream_t stream);
 
+/* Fused tail of a DownBlock (second ConvBlockND site - no dropout there - then the pooling, unet2d5_dsbn.py:79-81, 117):
+ *  fplx_bn_act_pool_fwd:   a2 = PReLU(BN(y2)) written to `out` (the skip tensor) and MaxPool(a2) to `pooled` in one pass.
+ *  fplx_pool_bwd_bn_reduce: dx = dskip + unpooled(dy) = d(a2) (first-maximum rule on a2 recomputed from y2) and, over that
+ *                          dx, the partial rows of fplx_bn_act_bwd_reduce for this site (same layout: fplx_num_partials(voxels)
+ *                          rows of 2C+1 floats) - the caller then runs fplx_bn_act_bwd_finalize / _apply as usual.
+ * pd = 2: MaxPool3d(2), pd = 1: MaxPool2d(2) per depth slice; dims = the UNPOOLED tensor's; bf16 only, see fplx_bn_pool_fused_ok. */
+int fplx_bn_pool_fused_ok(int c, int dt);
+int fplx_bn_act_pool_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, void* pooled, int64_t ldp, const float* scale,
+                         const float* shift, const float* slope, int n, int d, int h, int w, int c, int dt, int pd,
+                         fplx_stream_t stream);
+int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t lddy, const void* dskip, int64_t lds, void* dx,
+                            int64_t ldo, const float* mean, const float* rstd, const float* scale, const float* shift,
+                            const float* slope, int n, int d, int h, int w, int c, int dt, int pd, float* part,
+                            fplx_stream_t stream);
+
 /* (Tri / bi)linear x2 upsampling, align_corners = True - UpBlock with bilinear = True (unet2d5_dsbn.py:148-150, 172-176:
  * nn.Upsample(scale_factor=2, mode='trilinear' | 'bilinear', align_corners=True) behind a kernel-1 convolution, which runs
  * through fplx_conv3d_fwd / _wgrad with kd = kh = kw = 1).  x [n][d][h][w][ldx] -> y [n][sd*d][2h][2w][ldy]; sd = 2:

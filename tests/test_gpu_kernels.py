@@ -339,3 +339,39 @@ def test_pack_conv_weights_batched_equals_per_layer_packs():
             assert (wb is None and rb is None) or torch.equal(wb, rb)
     with pytest.raises(ValueError):
         ops.pack_conv_weights_batched(ws * 5, torch.bfloat16, want * 5)          # more than 32 layers in one call
+
+
+def test_fused_downblock_tail_equals_the_separate_passes():
+    """fplx_bn_act_pool_fwd == bn_act_fwd then maxpool, and fplx_pool_bwd_bn_reduce == maxpool_bwd then the BatchNorm
+    reduction, bit for bit (same arithmetic, same bf16 rounding points, same first-maximum rule)"""
+    from fplx import ops
+    g = torch.Generator().manual_seed(5)
+    for (n, d, h, w, c, pd) in ((2, 4, 8, 12, 32, 2), (1, 3, 6, 8, 64, 1), (1, 2, 4, 4, 16, 2)):
+        v, vo = n * d * h * w, n * (d // pd) * (h // 2) * (w // 2)
+        y = torch.randn(v, c, generator=g).bfloat16().cuda()
+        # repeated values make ties: the first maximum must win in both forms
+        y[::3] = y[1::3][: y[::3].shape[0]]
+        bnbuf = torch.stack([torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) + 0.5,
+                             torch.randn(c, generator=g) * 0.1]).cuda()
+        slope = torch.full((1,), 0.25, device="cuda")
+        a_ref = torch.empty_like(y)
+        ops.bn_act_fwd(y, a_ref, bnbuf, slope, 0.0, 1, 0, c)
+        p_ref = torch.empty((vo, c), dtype=torch.bfloat16, device="cuda")
+        ops.maxpool2_fwd(a_ref, p_ref, (n, d, h, w), c, pd)
+        a_f, p_f = torch.empty_like(y), torch.empty_like(p_ref)
+        ops.bn_act_pool_fwd(y, a_f, p_f, bnbuf, slope, (n, d, h, w), c, pd)
+        assert torch.equal(a_f, a_ref) and torch.equal(p_f, p_ref)
+        dy = (torch.randn(vo, c, generator=g) * 0.01).bfloat16().cuda()
+        dskip = (torch.randn(v, c, generator=g) * 0.01).bfloat16().cuda()
+        dx_ref = torch.empty_like(y)
+        ops.maxpool2_bwd(a_ref, dy, dskip, dx_ref, (n, d, h, w), c, pd)
+        rows = ops.num_partials(v)
+        part_ref = torch.zeros((rows, 2 * c + 1), device="cuda")
+        ops.call("fplx_bn_act_bwd_reduce", ops.ptr(y), c, ops.ptr(dx_ref), c, ops.ptr(bnbuf[0]), ops.ptr(bnbuf[1]), ops.ptr(bnbuf[2]),
+                 ops.ptr(bnbuf[3]), ops.ptr(slope), 0.0, 1, 0, v, c, ops.dt_of(y), ops.ptr(part_ref), ops.stream())
+        dx_f = torch.empty_like(y)
+        part_f = torch.zeros((rows, 2 * c + 1), device="cuda")
+        ops.pool_bwd_bn_reduce(y, dy, dskip, dx_f, bnbuf, slope, (n, d, h, w), c, part_f, pd)
+        assert torch.equal(dx_f, dx_ref)
+        tot_ref, tot_f = part_ref.double().sum(0), part_f.double().sum(0)          # the rows partition the voxels differently
+        assert float((tot_ref - tot_f).abs().max()) <= 1e-5 * float(tot_ref.abs().max()) + 1e-9
