@@ -140,8 +140,10 @@ def pmc_traffic(key):
     n, d, h, w = dims
     if not (name == "conv3d_fwd" and k == (3, 3, 3) and cin in (32, 64) and cout % 32 == 0 and h >= 16 and w >= 64):
         return None
-    # launch geometry of conv_fwd_march32 / conv_fwd_march64 (fpl-plus_amd/csrc/conv_march.hip: march_cfg)
-    fh, threads = (16, 512) if cin == 32 else (8, 256)
+    # launch geometry of the depth-march kernels (fpl-plus_amd/csrc/conv_march.hip: march_cfg): Cin = 32 interior shapes run
+    # conv_fwd_march32v2 / v3 (4 waves), ragged ones conv_fwd_march32 (8 waves); Cin = 64 conv_fwd_march64 (4 waves)
+    interior = cin == 32 and h % 16 == 0 and w % 32 == 0
+    fh, threads = (16, 256 if interior else 512) if cin == 32 else (8, 256)
     if h < fh:
         return None
     tiles_h, tiles_w = (h + fh - 1) // fh, (w + 31) // 32
@@ -161,12 +163,11 @@ def pmc_traffic(key):
     dsegs = (d + dlen - 1) // dlen
     grid = n * tiles_h * tiles_w * dsegs * (cout // 32) * threads
     tab = json.load(open(path))
-    for k, e in tab.items():
-        if k == "_meta":
-            continue                       # "conv_fwd_march32<false>|grid=256000" (template arguments vary)
-        if k.startswith("conv_fwd_march%d" % cin) and k.endswith("|grid=%d" % grid):
-            return e["hbm_bytes_per_launch"]
-    return None
+    hits = [e for k, e in tab.items() if k != "_meta" and k.startswith("conv_fwd_march%d" % cin) and k.endswith("|grid=%d" % grid)]
+    if not hits:
+        return None
+    # forward (statistics) and data-gradient launches of one shape are different instantiations: launch-weighted mean
+    return sum(e["hbm_bytes_per_launch"] * e["launches"] for e in hits) / sum(e["launches"] for e in hits)
 
 
 def _cpu_model():
