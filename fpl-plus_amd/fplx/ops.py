@@ -120,8 +120,9 @@ def conv3d_fwd(x, xs, x_dt, wp, bias, y, ys, y_dt, dims, cin, cout, k, stats=Non
     if ws is None:
         need = conv3d_fwd_ws_bytes(dims, cin, cout, k, x_dt, y_dt, mid)
         if need:
-            # per-device scratch for the split-K kernels; consecutive launches on one stream may share it
-            key = y.device
+            # scratch for the split-K kernels, per (device, stream): launches on one stream are ordered and may share it,
+            # launches on different streams (the engine runs two) may not
+            key = (y.device, torch.cuda.current_stream(y.device).cuda_stream)
             if key not in _fwd_ws or _fwd_ws[key].numel() < need:
                 _fwd_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=y.device)
             ws = _fwd_ws[key]
