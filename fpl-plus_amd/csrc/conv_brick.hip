@@ -1,0 +1,296 @@
+// conv_fwd_brick: 3x3x3 convolution (forward and, with the mirrored pack, data gradient) for the levels whose planes are too
+// small for the depth march (W < 64) and whose channel counts are too large for resident weights: Cin % 32 == 0,
+// Cout % 128 == 0 - levels 2.. of the 32-base network (128 / 256 channels on 20 x 40 x 40 at the benchmark shape).
+// (reference op: PyMIC/pymic/net/net3d/unet2d5_dsbn.py:66-81 ConvBlockND's nn.Conv3d(k=3, padding=1))
+//
+// What it replaces there is conv_fwd_tile (conv_mfma.hip), an LDS-tiled implicit GEMM that re-stages the shifted voxel rows
+// for every one of the 27 taps: 32 KB of L2 -> registers -> LDS traffic per 64 MFMAs, 1.5 KB of LDS traffic per MFMA - it
+// runs at 0.27-0.31 of the MFMA peak, bound by the fill path.  Here the INPUT is stationary:
+//   * a block owns a brick of 4 x 8 x 8 output voxels x 128 output channels; the brick's halo (6 x 10 x 10 voxels) of one
+//     32-channel chunk is staged ONCE by LDS-DMA through a buffer descriptor (padding = the hardware's out-of-range zeros,
+//     see conv_fwd_march32v2) and serves all 27 taps: 46 KB per 1728 MFMAs instead of 16 KB per 64;
+//   * the weights stream through a two-slot ring, one stage = the three depth taps of one (kh, kw) for the chunk (24 KB,
+//     L2 hits: every block reads the same pack), DMA'd a stage ahead;
+//   * ONE wave per SIMD, a wave = 4 depth planes x (4 x 8 voxels) x 64 channels: an A fragment (input plane q) feeds the
+//     up to three output planes q - kd, so a half-stage (16 input channels) reads 6 A + 6 B fragments for 24 MFMAs
+//     (0.5 ds_read_b128 per MFMA); fragments are prefetched a half-stage ahead, one barrier per stage (between its halves);
+//   * LDS image: voxel rows of 64 B, voxel index L = plane * 128 + row * 12 + col, 16-byte chunks XOR-swizzled with
+//     (L >> 2) & 3; the lane -> voxel map of an M-tile follows ds_read_b128's lane groups so that each group touches
+//     16 distinct 16-byte slots for every tap shift (rows 0, 2 in one group, rows 1, 3 in the other).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct BK {
+  static constexpr int TD = 4, TH = 8, TW = 8, NT = 128, KC = 32, ROWB = 64;
+  static constexpr int SWP = 12, PL = 128, SD = TD + 2;
+  static constexpr int BRICK_BYTES = SD * PL * ROWB;          // 49152
+  static constexpr int NPB = BRICK_BYTES / 1024 / 4;          // DMA wave-instructions per wave and brick chunk (12)
+  static constexpr int WST_BYTES = 3 * NT * ROWB;             // 24576: one weight stage
+  static constexpr int NPW = WST_BYTES / 1024 / 4;            // 6
+  static constexpr int LDS = 2 * BRICK_BYTES + 2 * WST_BYTES + NT * 4;
+  static constexpr int THREADS = 256;
+};
+
+// M-tile row m (0..31, = lane & 31 of an A fragment) -> (row 0..3, col 0..7) of the wave's 4 x 8 patch
+__device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) ^ (m >> 3) ^ (m >> 2)) & 1); }
+__device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
+
+template <bool STATS>
+__global__ void __launch_bounds__(BK::THREADS)
+conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
+               float* __restrict__ stats, int bD, int bH, int bW, int xcd) {
+  using G = BK;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bricks = smem;
+  char* wring = smem + 2 * G::BRICK_BYTES;
+  float* bias_s = reinterpret_cast<float*>(wring + 2 * G::WST_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  const int hhalf = wave >> 1, wn = wave & 1;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
+  const int bw = b % bW; b /= bW;
+  const int bh = b % bH; b /= bH;
+  const int bd = b % bD; b /= bD;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int d0 = __builtin_amdgcn_readfirstlane(bd * G::TD), h0 = __builtin_amdgcn_readfirstlane(bh * G::TH),
+            w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
+  const int n0 = bid.y * G::NT;
+
+  // ---- DMA plumbing (see conv_fwd_march32v2): out-of-range lanes of a buffer load to LDS write zeros
+  const int64_t xsample = (int64_t)D * H * W * ldx * 2;
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * xsample;
+  u32x4 rx, rw;
+  rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
+  rx[3] = 0x00020000u;
+  rw[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wp);
+  rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
+  rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
+  rw[3] = 0x00020000u;
+  auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, char* l) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
+    const unsigned so_ = __builtin_amdgcn_readfirstlane(so);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so_), "s"(dst) : "memory");
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  // brick pieces: piece p = wave + 4 k covers LDS bytes [p * 1024, +1024) of the slot; lane -> 16-byte chunk
+  unsigned bvo[G::NPB];
+#pragma unroll
+  for (int k = 0; k < G::NPB; ++k) {
+    const int ci = (wave + 4 * k) * 64 + lane;
+    const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
+    const int q = L >> 7, rem = L & 127, hh = rem / G::SWP, ww = rem % G::SWP;
+    const int gd = d0 - 1 + q, gh = h0 - 1 + hh, gw = w0 - 1 + ww;
+    const bool in = rem < 10 * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    bvo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
+  }
+  // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][128 couts], swizzle (lane >> 4) & 3
+  const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
+  const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
+  auto brick_piece = [&](int ch, int k) {
+    buf_dma(rx, bvo[k], (unsigned)(ch * G::KC * 2), bricks + (ch & 1) * G::BRICK_BYTES + (wave + 4 * k) * 1024);
+  };
+  auto weight_stage = [&](int ch, int t9) {                 // all six pieces of stage ch * 9 + t9 -> slot (ch + t9) & 1
+#pragma unroll
+    for (int k = 0; k < G::NPW; ++k) {
+      const int j = wave + 4 * k, kd = j >> 3;
+      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j & 7) * 16 * Cin + ch * G::KC) * 2);
+      buf_dma(rw, wvo, so, wring + ((ch + t9) & 1) * G::WST_BYTES + j * 1024);
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
+
+  const int nch = Cin / G::KC, nst = nch * 9;
+  // prologue: brick chunk 0, weight stages 0 and 1
+#pragma unroll
+  for (int k = 0; k < G::NPB; ++k) brick_piece(0, k);
+  weight_stage(0, 0);
+  weight_stage(0, 1);
+  if (tid < G::NT) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  dma_wait();
+  block_sync();
+
+  // fragment addresses: A lane base (voxel index of the patch's tap (0, 0, 0) corner voxel), B lane base
+  const int L0 = (hhalf * 4 + bk_row(r)) * G::SWP + bk_col(r);
+  const int bb = (wn * 64 + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
+  bf16x8 fa[2][6], fb[2][6];
+  auto load_a = [&](const char* brick, int kh, int kw, int ks, int buf) {
+    int a0 = L0 + kh * G::SWP + kw;
+    asm volatile("" : "+v"(a0));
+    const char* p = brick + a0 * G::ROWB + (((2 * ks + khalf) ^ ((a0 >> 2) & 3)) << 4);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) fa[buf][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
+  };
+  auto load_b = [&](const char* wslot, int ks, int buf) {
+    int b0 = bb;
+    asm volatile("" : "+v"(b0));
+    const char* p = wslot + (b0 ^ (ks << 5));
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[buf][kd * 2 + j] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + j * 32) * G::ROWB);
+  };
+  auto mfmas = [&](int buf, int kd) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * 2 + j], acc[p][j], 0, 0, 0);
+  };
+
+  load_a(bricks, 0, 0, 0, 0);
+  load_b(wring, 0, 0);
+  for (int ch = 0; ch < nch; ++ch) {
+    const char* brick = bricks + (ch & 1) * G::BRICK_BYTES;
+    const char* brick_nx = bricks + ((ch + 1) & 1) * G::BRICK_BYTES;
+    const bool more = ch + 1 < nch;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const int kh = t9 / 3, kw = t9 % 3;
+      const int st = ch * 9 + t9;
+      const char* wslot = wring + ((ch + t9) & 1) * G::WST_BYTES;
+      const char* wslot_nx = wring + ((ch + t9 + 1) & 1) * G::WST_BYTES;
+      // ---- first half (input channels 0-15 of the chunk): prefetch the second half's fragments
+      load_a(brick, kh, kw, 1, 1);
+      mfmas(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(wslot, 1, 1);
+      mfmas(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      // stage st + 1's weights (issued in the second half of stage st - 1) and, at t9 == 8, the next brick have landed;
+      // nobody reads stage st's slot / (at t9 == 8) this brick any more once past this barrier
+      dma_wait();
+      block_sync();
+      // ---- second half: stage st + 2's weights -> this stage's slot, two pieces of the next brick, next stage's fragments
+      if (st + 2 < nst) { if (t9 < 7) weight_stage(ch, t9 + 2); else weight_stage(ch + 1, t9 - 7); }
+      if (t9 < 6 && more) { brick_piece(ch + 1, 2 * t9); brick_piece(ch + 1, 2 * t9 + 1); }
+      if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
+      mfmas(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_b(wslot_nx, 0, 0);
+      mfmas(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(1, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- write-out: bias, statistics, bf16 through a 2-KiB per-wave LDS tile, 16-byte stores (the operands are dead)
+  __syncthreads();
+  char* stg = smem + wave * 2048;
+  const int rh = khalf * 4;
+  // validity of the 16 accumulator rows of this lane / of the two rows it stores (ragged bricks at the volume's far faces)
+  unsigned vmask = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i & 3) + 8 * (i >> 2) + rh;
+    if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+  }
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int dd = d0 + p;
+    if (dd >= D) break;                                        // uniform
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bv = bias_s[wn * 64 + j * 32 + r];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + rh;
+        const float o = acc[p][j][i] + bv;
+        *reinterpret_cast<bf16_t*>(stg + m * 64 + r * 2) = (bf16_t)o;
+        if (STATS && ((vmask >> i) & 1u)) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int m = (lane >> 2) + 16 * half;
+        const int hh = h0 + hhalf * 4 + bk_row(m), ww = w0 + bk_col(m);
+        const uint4 pk = *reinterpret_cast<const uint4*>(stg + m * 64 + (lane & 3) * 16);
+        if (hh < H && ww < W)
+          *reinterpret_cast<uint4*>(y + ((((int64_t)n * D + dd) * H + hh) * W + ww) * ldy + n0 + wn * 64 + j * 32 +
+                                    (lane & 3) * 8) = pk;
+      }
+    }
+  }
+  if (STATS && stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem + 8192);       // [2 (hhalf)][2][128]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float a = s1[j] + __shfl_xor(s1[j], 32, 64), q2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      if (lane < 32) {
+        red[(hhalf * 2 + 0) * G::NT + wn * 64 + j * 32 + r] = a;
+        red[(hhalf * 2 + 1) * G::NT + wn * 64 + j * 32 + r] = q2;
+      }
+    }
+    __syncthreads();
+    {
+      const int which = tid >> 7, c = tid & 127;
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * G::NT + c] + red[(1 * 2 + which) * G::NT + c];
+    }
+  }
+}
+
+inline int brick_enabled() {
+  static const int v = [] { const char* e = getenv("FPLX_BRICK"); return e ? atoi(e) : 1; }();   // A/B knob (benchmarks only)
+  return v;
+}
+
+}  // namespace
+
+// 1 if the brick kernel takes this 3x3x3 layer (after the march kernels have declined it)
+extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout) {
+  if (!brick_enabled() || cin % BK::KC != 0 || cin < 64 || cout % BK::NT != 0) return 0;
+  if ((int64_t)d * h * w * cin * 2 >= ((int64_t)1 << 30)) return 0;
+  const int64_t bricks = (int64_t)n * ((d + BK::TD - 1) / BK::TD) * ((h + BK::TH - 1) / BK::TH) * ((w + BK::TW - 1) / BK::TW);
+  // padding waste of ragged bricks and chip fill: the tile kernel (voxel-linear M tiles, split-K) keeps the rest
+  const int64_t padded = bricks * BK::TD * BK::TH * BK::TW, V = (int64_t)n * d * h * w;
+  return padded * 4 <= V * 5 && bricks * (cout / BK::NT) >= 192 && bricks < ((int64_t)1 << 24);
+}
+
+extern "C" int fplx_brick_rows(int n, int d, int h, int w) {
+  return n * ((d + BK::TD - 1) / BK::TD) * ((h + BK::TH - 1) / BK::TH) * ((w + BK::TW - 1) / BK::TW);
+}
+
+// returns 1 if launched, 0 if the operands do not allow it (alignment), <0 on error
+extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+  if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
+    return 0;
+  if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30)) return 0;
+  const int bD = (d + BK::TD - 1) / BK::TD, bH = (h + BK::TH - 1) / BK::TH, bW = (w + BK::TW - 1) / BK::TW;
+  dim3 grid(n * bD * bH * bW, cout / BK::NT);
+#define LAUNCH_BRICK(STATS_)                                                                                         \
+  do {                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_>, hipFuncAttributeMaxDynamicSharedMemorySize, BK::LDS); \
+    conv_fwd_brick<STATS_><<<grid, BK::THREADS, BK::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+                                                               ldy, n, d, h, w, cin, cout, stats, bD, bH, bW, fplx_xcd_on()); \
+  } while (0)
+  if (stats) LAUNCH_BRICK(true); else LAUNCH_BRICK(false);
+#undef LAUNCH_BRICK
+  const int rc = fplx_check_launch("brick_conv3d_fwd");
+  return rc < 0 ? rc : 1;
+}

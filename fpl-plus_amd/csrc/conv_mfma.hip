@@ -1280,6 +1280,11 @@ extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
                                      const void* x1, void* y1, int twod);
+// conv_brick.hip
+extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_brick_rows(int n, int d, int h, int w);
+extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
 
 // mid != 0: the 27-tap pack is zero outside the middle depth plane (a Conv2d per depth slice, 2.5D levels).  Layers that
 // would go to the tile kernel run taps 9..17 only (measured 348 -> 155 us on the 128 -> 64 level-1 layer of the shipped
@@ -1296,6 +1301,7 @@ static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mi
   const int64_t V = (int64_t)n * d * h * w;
   if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cin, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return fplx_brick_rows(n, d, h, w);
   const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   if (c.ksplit > 1) return c.fin_blocks;
   return (int)c.mblocks;
@@ -1304,6 +1310,7 @@ static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mi
 static size_t fwd_ws_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
   if (fplx_march_ok(n, d, h, w, cin, cout) || stream_ok(d, h, w, cin, cout)) return 0;
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
@@ -1347,6 +1354,8 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     int rc0 = fplx_check_launch("mfma_conv3d_fwd_stream");
     return rc0 < 0 ? rc0 : 1;
   }
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout))
+    return fplx_brick_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout, tap_cnt);
   const int ks = c.ksplit;

@@ -1,0 +1,105 @@
+"""conv_fwd_brick: correctness against torch (CPU fp32 on bf16-rounded operands) and timing, forward (+statistics) and
+data gradient, through fplx.ops.  FPLX_BRICK=0 in the environment times the tile kernel on the same shapes.
+
+    python tools/brick_check.py [check]"""
+import os
+import sys
+import ctypes
+
+sys.path.insert(0, os.path.join(os.getcwd(), "fpl-plus_amd"))
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from fplx import ops  # noqa: E402
+
+bf = torch.bfloat16
+dt = ops._DT[bf]
+lib = ops._lib.lib()
+
+
+def cl(t):
+    return t.permute(0, 2, 3, 4, 1).contiguous().view(-1, t.shape[1])
+
+
+def run_direct(xg, wf, bias, y, dims, cin, cout, stats):
+    """straight into fplx_brick_conv3d_fwd (shapes fplx_brick_ok would leave to the tile kernel)"""
+    n, d, h, w = dims
+    lib.fplx_brick_conv3d_fwd.restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    rc = lib.fplx_brick_conv3d_fwd(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()),
+                                   vp(bias.data_ptr()) if bias is not None else None, vp(y.data_ptr()),
+                                   ctypes.c_int64(cout), n, d, h, w, cin, cout,
+                                   vp(stats.data_ptr()) if stats is not None else None,
+                                   vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 1, rc
+
+
+def check(shape, direct):
+    n, cin, cout, d, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.randn(n, cin, d, h, w, generator=g))
+    wt = q(torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05)
+    b = torch.randn(cout, generator=g)
+    yr = F.conv3d(x, wt, b, padding=1)
+    dims = (n, d, h, w)
+    xg = cl(x).to(bf).cuda()
+    wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
+    y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
+    if direct:
+        rows = lib.fplx_brick_rows(n, d, h, w)
+        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+        run_direct(xg, wf, b.cuda(), y, dims, cin, cout, stats)
+    else:
+        assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
+        rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+        assert rows == lib.fplx_brick_rows(n, d, h, w)
+        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+        ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin,
+                       cout, (3, 3, 3), stats)
+    torch.cuda.synchronize()
+    got = y.float().cpu().view(n, d, h, w, cout).permute(0, 4, 1, 2, 3)
+    scale = float(yr.abs().max())
+    err = float((got - yr).abs().max()) / scale
+    s = stats.sum(0).cpu()
+    yf = cl(yr)
+    e1 = float((s[0] - yf.sum(0)).abs().max()) / (scale * yf.shape[0] ** 0.5)
+    e2 = float(((s[1] - (yf * yf).sum(0)) / (yf * yf).sum(0)).abs().max())
+    print("shape %s direct=%d: max err %.4f of max, stats sum %.4f sumsq rel %.4f" % (shape, direct, err, e1, e2), flush=True)
+    assert err < 2e-2 and e1 < 2e-2 and e2 < 8e-2
+
+
+def timeit(shape, stats_on, reps=30):
+    n, cin, cout, d, h, w = shape
+    dims = (n, d, h, w)
+    V = n * d * h * w
+    xg = torch.randn(V, cin, device="cuda").to(bf)
+    wf = (torch.randn(27, cout, cin, device="cuda") * 0.05).to(bf)
+    y = torch.empty(V, cout, dtype=bf, device="cuda")
+    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+    stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda") if stats_on else None
+    f = lambda: ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, None, y, ops.cl_strides(d, h, w, cout), dt, dims,
+                               cin, cout, (3, 3, 3), stats)
+    for _ in range(5):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1000 / reps
+    fl = 2.0 * V * 27 * cin * cout
+    print("time %s stats=%d brick_ok=%d: %.1f us  %.3f PFLOP/s (%.3f of 2.5)" %
+          (shape, stats_on, lib.fplx_brick_ok(n, d, h, w, cin, cout), us, fl / us / 1e9, fl / us / 1e9 / 2.5), flush=True)
+
+
+if "check" in sys.argv:
+    check((1, 64, 128, 4, 8, 8), True)            # one brick
+    check((1, 64, 128, 6, 20, 20), True)          # ragged in d, h and w
+    check((2, 96, 256, 5, 9, 17), True)           # two couts tiles, three chunks, ragged, n = 2
+    check((2, 128, 128, 20, 40, 40), False)       # the benchmark's level-2 layer through the dispatcher
+for shp in ((2, 128, 128, 20, 40, 40), (2, 128, 256, 20, 40, 40), (2, 256, 128, 20, 40, 40)):
+    timeit(shp, True)
+    timeit(shp, False)
