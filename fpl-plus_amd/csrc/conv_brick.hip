@@ -26,26 +26,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 struct BK {
-  static constexpr int TD = 4, TH = 8, TW = 8, NT = 128, KC = 32, ROWB = 64;
+  static constexpr int TD = 4, TH = 8, TW = 8, KC = 32, ROWB = 64;
   static constexpr int SWP = 12, PL = 128, SD = TD + 2;
   static constexpr int BRICK_BYTES = SD * PL * ROWB;          // 49152
   static constexpr int NPB = BRICK_BYTES / 1024 / 4;          // DMA wave-instructions per wave and brick chunk (12)
-  static constexpr int WST_BYTES = 3 * NT * ROWB;             // 24576: one weight stage
-  static constexpr int NPW = WST_BYTES / 1024 / 4;            // 6
-  static constexpr int LDS = 2 * BRICK_BYTES + 2 * WST_BYTES + NT * 4;
   static constexpr int THREADS = 256;
+};
+// NTW = N-tiles (32 output channels) per wave: 2 -> 128 output channels per block, 1 -> 64 (0.75 fragment reads per MFMA)
+template <int NTW>
+struct BKN : BK {
+  static constexpr int NT = 64 * NTW;
+  static constexpr int WST_BYTES = 3 * NT * ROWB;             // one weight stage: 24576 / 12288
+  static constexpr int NPW = WST_BYTES / 1024 / 4;            // 6 / 3
+  static constexpr int LDS = 2 * BRICK_BYTES + 2 * WST_BYTES + NT * 4;
 };
 
 // M-tile row m (0..31, = lane & 31 of an A fragment) -> (row 0..3, col 0..7) of the wave's 4 x 8 patch
 __device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) ^ (m >> 3) ^ (m >> 2)) & 1); }
 __device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
 
-template <bool STATS>
+template <bool STATS, int NTW>
 __global__ void __launch_bounds__(BK::THREADS)
 conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
                bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
                float* __restrict__ stats, int bD, int bH, int bW, int xcd) {
-  using G = BK;
+  using G = BKN<NTW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bricks = smem;
   char* wring = smem + 2 * G::BRICK_BYTES;
@@ -97,7 +102,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     const bool in = rem < 10 * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
     bvo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
   }
-  // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][128 couts], swizzle (lane >> 4) & 3
+  // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][NT couts], swizzle (lane >> 4) & 3
   const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
   const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
   auto brick_piece = [&](int ch, int k) {
@@ -106,17 +111,17 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   auto weight_stage = [&](int ch, int t9) {                 // all six pieces of stage ch * 9 + t9 -> slot (ch + t9) & 1
 #pragma unroll
     for (int k = 0; k < G::NPW; ++k) {
-      const int j = wave + 4 * k, kd = j >> 3;
-      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j & 7) * 16 * Cin + ch * G::KC) * 2);
+      const int j = wave + 4 * k, kd = j / (G::NT / 16);
+      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + ch * G::KC) * 2);
       buf_dma(rw, wvo, so, wring + ((ch + t9) & 1) * G::WST_BYTES + j * 1024);
     }
   };
 
-  f32x16 acc[4][2];
+  f32x16 acc[4][NTW];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
 
@@ -132,8 +137,8 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 
   // fragment addresses: A lane base (voxel index of the patch's tap (0, 0, 0) corner voxel), B lane base
   const int L0 = (hhalf * 4 + bk_row(r)) * G::SWP + bk_col(r);
-  const int bb = (wn * 64 + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
-  bf16x8 fa[2][6], fb[2][6];
+  const int bb = (wn * (G::NT / 2) + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
+  bf16x8 fa[2][6], fb[2][3 * NTW];
   auto load_a = [&](const char* brick, int kh, int kw, int ks, int buf) {
     int a0 = L0 + kh * G::SWP + kw;
     asm volatile("" : "+v"(a0));
@@ -148,15 +153,15 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        fb[buf][kd * 2 + j] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + j * 32) * G::ROWB);
+      for (int j = 0; j < NTW; ++j)
+        fb[buf][kd * NTW + j] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + j * 32) * G::ROWB);
   };
   auto mfmas = [&](int buf, int kd) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * 2 + j], acc[p][j], 0, 0, 0);
+      for (int j = 0; j < NTW; ++j)
+        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * NTW + j], acc[p][j], 0, 0, 0);
   };
 
   load_a(bricks, 0, 0, 0, 0);
@@ -199,56 +204,68 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   }
 
   // ---- write-out: bias, statistics, bf16 through a 2-KiB per-wave LDS tile, 16-byte stores (the operands are dead)
-  __syncthreads();
-  char* stg = smem + wave * 2048;
+  block_sync();                                              // LDS only: no DMA is in flight past the last stage's barrier
+  char* stg = smem + wave * 4096;
   const int rh = khalf * 4;
-  // validity of the 16 accumulator rows of this lane / of the two rows it stores (ragged bricks at the volume's far faces)
-  unsigned vmask = 0;
+  // ragged bricks at the volume's far faces: validity of the 16 accumulator rows of this lane / of the rows it stores
+  const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
+  unsigned vmask = 0xFFFFu;
+  if (!full) {
+    vmask = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int m = (i & 3) + 8 * (i >> 2) + rh;
-    if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+    for (int i = 0; i < 16; ++i) {
+      const int m = (i & 3) + 8 * (i >> 2) + rh;
+      if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+    }
   }
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  float s1[NTW], s2[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) s1[j] = s2[j] = 0.f;
+  const int mrow = lane >> 2;                                  // this lane stores tile rows mrow and mrow + 16
+  const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
+  const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
+  const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
+  const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
+  bf16_t* ycol = y + n0 + wn * (G::NT / 2) + (lane & 3) * 8;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int dd = d0 + p;
     if (dd >= D) break;                                        // uniform
+    bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const float bv = bias_s[wn * 64 + j * 32 + r];
+    for (int j = 0; j < NTW; ++j) {
+      const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
+      char* tile = stg + ((p * NTW + j) & 1) * 2048;          // two tiles per wave, used alternately
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = (i & 3) + 8 * (i >> 2) + rh;
         const float o = acc[p][j][i] + bv;
-        *reinterpret_cast<bf16_t*>(stg + m * 64 + r * 2) = (bf16_t)o;
-        if (STATS && ((vmask >> i) & 1u)) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
+        *reinterpret_cast<bf16_t*>(tile + m * 64 + r * 2) = (bf16_t)o;
+        if (STATS) {
+          if (full) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
+          else if ((vmask >> i) & 1u) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
+        }
       }
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int m = (lane >> 2) + 16 * half;
-        const int hh = h0 + hhalf * 4 + bk_row(m), ww = w0 + bk_col(m);
-        const uint4 pk = *reinterpret_cast<const uint4*>(stg + m * 64 + (lane & 3) * 16);
-        if (hh < H && ww < W)
-          *reinterpret_cast<uint4*>(y + ((((int64_t)n * D + dd) * H + hh) * W + ww) * ldy + n0 + wn * 64 + j * 32 +
-                                    (lane & 3) * 8) = pk;
-      }
+      const uint4 pk0 = *reinterpret_cast<const uint4*>(tile + mrow * 64 + (lane & 3) * 16);
+      const uint4 pk1 = *reinterpret_cast<const uint4*>(tile + (mrow + 16) * 64 + (lane & 3) * 16);
+      if (ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
+      if (ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
     }
   }
   if (STATS && stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem + 8192);       // [2 (hhalf)][2][128]
+    block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
+    float* red = reinterpret_cast<float*>(smem + 16384);       // [2 (hhalf)][2][NT]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NTW; ++j) {
       const float a = s1[j] + __shfl_xor(s1[j], 32, 64), q2 = s2[j] + __shfl_xor(s2[j], 32, 64);
       if (lane < 32) {
-        red[(hhalf * 2 + 0) * G::NT + wn * 64 + j * 32 + r] = a;
-        red[(hhalf * 2 + 1) * G::NT + wn * 64 + j * 32 + r] = q2;
+        red[(hhalf * 2 + 0) * G::NT + wn * (G::NT / 2) + j * 32 + r] = a;
+        red[(hhalf * 2 + 1) * G::NT + wn * (G::NT / 2) + j * 32 + r] = q2;
       }
     }
-    __syncthreads();
-    {
-      const int which = tid >> 7, c = tid & 127;
+    block_sync();
+    if (tid < 2 * G::NT) {
+      const int which = tid / G::NT, c = tid % G::NT;
       stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * G::NT + c] + red[(1 * 2 + which) * G::NT + c];
     }
   }
@@ -263,12 +280,21 @@ inline int brick_enabled() {
 
 // 1 if the brick kernel takes this 3x3x3 layer (after the march kernels have declined it)
 extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout) {
-  if (!brick_enabled() || cin % BK::KC != 0 || cin < 64 || cout % BK::NT != 0) return 0;
+  if (!brick_enabled() || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
   if ((int64_t)d * h * w * cin * 2 >= ((int64_t)1 << 30)) return 0;
   const int64_t bricks = (int64_t)n * ((d + BK::TD - 1) / BK::TD) * ((h + BK::TH - 1) / BK::TH) * ((w + BK::TW - 1) / BK::TW);
   // padding waste of ragged bricks and chip fill: the tile kernel (voxel-linear M tiles, split-K) keeps the rest
   const int64_t padded = bricks * BK::TD * BK::TH * BK::TW, V = (int64_t)n * d * h * w;
-  return padded * 4 <= V * 5 && bricks * (cout / BK::NT) >= 192 && bricks < ((int64_t)1 << 24);
+  const int nt = cout % 128 == 0 ? 128 : 64;
+  return padded * 4 <= V * 5 && bricks * (cout / nt) >= 192 && bricks < ((int64_t)1 << 24);
+}
+// the layers a march kernel could take as well but the brick kernel runs faster (level 1 of the benchmark, 2 x 40 x 80 x 80:
+// 128 -> 64 305 -> 234 us against the streamed-weight march, 64 -> 128 255 -> 231 us; 64 -> 64 is a tie and stays).
+// A/B knob FPLX_BRICK: 2 = every eligible layer, 3 = only the layers no march kernel takes (benchmarks only)
+extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout) {
+  const int en = brick_enabled();
+  if (!en || en == 3 || !fplx_brick_ok(n, d, h, w, cin, cout)) return 0;
+  return en == 2 || cin == 128 || (cin == 64 && cout % 128 == 0);
 }
 
 extern "C" int fplx_brick_rows(int n, int d, int h, int w) {
@@ -280,16 +306,20 @@ extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
     return 0;
-  if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30)) return 0;
+  if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30) || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
   const int bD = (d + BK::TD - 1) / BK::TD, bH = (h + BK::TH - 1) / BK::TH, bW = (w + BK::TW - 1) / BK::TW;
-  dim3 grid(n * bD * bH * bW, cout / BK::NT);
-#define LAUNCH_BRICK(STATS_)                                                                                         \
+  const int ntw = cout % 128 == 0 ? 2 : 1;
+  dim3 grid(n * bD * bH * bW, cout / (64 * ntw));
+#define LAUNCH_BRICK(STATS_, NTW_)                                                                                   \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_>, hipFuncAttributeMaxDynamicSharedMemorySize, BK::LDS); \
-    conv_fwd_brick<STATS_><<<grid, BK::THREADS, BK::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
-                                                               ldy, n, d, h, w, cin, cout, stats, bD, bH, bW, fplx_xcd_on()); \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_, NTW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              BKN<NTW_>::LDS);                                                                       \
+    conv_fwd_brick<STATS_, NTW_><<<grid, BK::THREADS, BKN<NTW_>::LDS, st>>>(                                          \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, bD, bH, bW,    \
+        fplx_xcd_on());                                                                                              \
   } while (0)
-  if (stats) LAUNCH_BRICK(true); else LAUNCH_BRICK(false);
+  if (ntw == 2) { if (stats) LAUNCH_BRICK(true, 2); else LAUNCH_BRICK(false, 2); }
+  else { if (stats) LAUNCH_BRICK(true, 1); else LAUNCH_BRICK(false, 1); }
 #undef LAUNCH_BRICK
   const int rc = fplx_check_launch("brick_conv3d_fwd");
   return rc < 0 ? rc : 1;

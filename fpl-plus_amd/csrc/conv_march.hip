@@ -36,6 +36,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// Barrier for LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for the acknowledgement of every global store
+// the wave has in flight - at the end of a block that is the whole write-out of its last depth (2-3 us per block, 12-24 us
+// per launch measured on the statistics forms); the statistics tail only exchanges LDS data.  Callers guarantee that no
+// LDS-DMA is in flight (the march loops end with vmcnt(0) + barrier).
+#define FPLX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 struct MG {
   static constexpr int CIN = 32, ROWB = 64, CH = 4;
   static constexpr int FH = 16, FW = 32, SH = FH + 2, SW = FW + 2, SLAB = SH * SW;
@@ -336,11 +342,11 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   }
 
   if (stats) {
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     float* red = reinterpret_cast<float*>(smem);            // [8 waves][2][32]; the slabs are dead
     const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
     if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
       float t = 0.f;
@@ -662,11 +668,11 @@ conv_fwd_march32v2(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
   }
 
   if (STATS && stats) {
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
     const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
     if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
       float tt = 0.f;
@@ -987,7 +993,7 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
   }
 
   if (STATS && stats) {
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
     float a0 = ssum0, a1 = ssum1, q0 = qsum0, q1 = qsum1;   // lanes l, l ^ 16, l ^ 32, l ^ 48 hold the same two channels
     a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
@@ -998,7 +1004,7 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
       red[(wave * 2 + 0) * 32 + r16] = a0; red[(wave * 2 + 0) * 32 + 16 + r16] = a1;
       red[(wave * 2 + 1) * 32 + r16] = q0; red[(wave * 2 + 1) * 32 + 16 + r16] = q1;
     }
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
       float tt = 0.f;
@@ -1307,11 +1313,11 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   retire_flush(1, d1 - 1);
 
   if (stats) {
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
     const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
     if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
-    __syncthreads();
+    FPLX_LDS_BARRIER();
     if (tid < 64) {
       const int which = tid >> 5, c = tid & 31;
       float tt = 0.f;

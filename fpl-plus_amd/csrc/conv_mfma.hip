@@ -1282,6 +1282,7 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                      const void* x1, void* y1, int twod);
 // conv_brick.hip
 extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_brick_rows(int n, int d, int h, int w);
 extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
@@ -1299,6 +1300,7 @@ static inline bool mid_tile(int mid, int n, int d, int h, int w, int cin, int co
 static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
   const int64_t V = (int64_t)n * d * h * w;
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return fplx_brick_rows(n, d, h, w);
   if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cin, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
   if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return fplx_brick_rows(n, d, h, w);
@@ -1335,6 +1337,8 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout))
+    return fplx_brick_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
   if (fplx_march_ok(n, d, h, w, cin, cout))
     return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, mid);
   if (stream_ok(d, h, w, cin, cout)) {

@@ -122,6 +122,54 @@ def test_conv3d_march_kernels_aligned_output(shape):
     np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
 
 
+@pytest.mark.parametrize("shape,direct", [
+    ((1, 64, 128, 4, 8, 8), True),            # one brick
+    ((1, 64, 128, 6, 20, 20), True),          # ragged in d, h and w
+    ((2, 96, 256, 5, 9, 17), True),           # two 128-channel blocks, three channel chunks, ragged, n = 2
+    ((1, 64, 64, 5, 10, 17), True),           # 64 output channels per block
+    ((2, 96, 192, 4, 8, 16), True),
+    ((2, 128, 128, 20, 40, 40), False),       # through the dispatcher: a level-2 layer of the benchmark
+    ((2, 128, 64, 12, 32, 64), False)])       # ... and a layer a march kernel would take as well
+def test_conv3d_brick_kernel(shape, direct):
+    """conv_fwd_brick (input-stationary 4 x 8 x 8 bricks, conv_brick.hip): forward + BN statistics against torch, bf16;
+    direct = straight into fplx_brick_conv3d_fwd for shapes the dispatcher leaves to other kernels (few / ragged bricks)"""
+    import ctypes
+    from fplx import ops
+    lib = ops._lib.lib()
+    n, cin, cout, d, h, w = shape
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.from_numpy(detdata.normal("b.x%s" % (shape,), (n, cin, d, h, w))))
+    wt = q(torch.from_numpy(detdata.normal("b.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.05)))
+    b = torch.from_numpy(detdata.normal("b.b%s" % (shape,), (cout,)))
+    yr = F.conv3d(x, wt, b, padding=1)
+    bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
+    xg = cl(x).to(bf).cuda()
+    wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
+    y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
+    bg = b.cuda()
+    if direct:
+        rows = lib.fplx_brick_rows(n, d, h, w)
+        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+        vp = ctypes.c_void_p
+        rc = lib.fplx_brick_conv3d_fwd(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()), vp(bg.data_ptr()),
+                                       vp(y.data_ptr()), ctypes.c_int64(cout), n, d, h, w, cin, cout, vp(stats.data_ptr()),
+                                       vp(torch.cuda.current_stream().cuda_stream))
+        assert rc == 1
+    else:
+        assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
+        rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+        assert rows == lib.fplx_brick_rows(n, d, h, w)
+        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+        ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, bg, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
+                       (3, 3, 3), stats)
+    scale = float(yr.abs().max())
+    assert float((uncl(y.float().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
+    s = stats.sum(0).cpu()
+    yf = cl(yr)
+    np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
+    np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
+
+
 @pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70)])
 def test_conv3d_cat2_split_concat(shape):
     """conv3x3x3 on cat([x0, x1], channel) with the concatenation never built (reference unet2d5_dsbn.py:182-183):

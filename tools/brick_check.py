@@ -100,6 +100,10 @@ if "check" in sys.argv:
     check((1, 64, 128, 6, 20, 20), True)          # ragged in d, h and w
     check((2, 96, 256, 5, 9, 17), True)           # two couts tiles, three chunks, ragged, n = 2
     check((2, 128, 128, 20, 40, 40), False)       # the benchmark's level-2 layer through the dispatcher
-for shp in ((2, 128, 128, 20, 40, 40), (2, 128, 256, 20, 40, 40), (2, 256, 128, 20, 40, 40)):
+    check((1, 64, 64, 5, 10, 17), True)           # 64 output channels per block
+    check((2, 96, 192, 4, 8, 16), True)
+L1 = ((2, 64, 64, 40, 80, 80), (2, 128, 64, 40, 80, 80), (2, 64, 128, 40, 80, 80))
+L2 = ((2, 128, 128, 20, 40, 40), (2, 128, 256, 20, 40, 40), (2, 256, 128, 20, 40, 40))
+for shp in (L1 if "l1" in sys.argv else L2):
     timeit(shp, True)
     timeit(shp, False)
