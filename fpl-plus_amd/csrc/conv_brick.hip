@@ -18,12 +18,14 @@
 //     (L >> 2) & 3; the lane -> voxel map of an M-tile follows ds_read_b128's lane groups so that each group touches
 //     16 distinct 16-byte slots for every tap shift (rows 0, 2 in one group, rows 1, 3 in the other).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct BK {
   static constexpr int TD = 4, TH = 8, TW = 8, KC = 32, ROWB = 64;
@@ -218,46 +220,57 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
       if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
     }
   }
-  float s1[NTW], s2[NTW];
+  // statistics in packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32: accumulator elements i, i + 1 sit in consecutive registers)
+  f32x2 s1[NTW], s2[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) s1[j] = s2[j] = 0.f;
+  for (int j = 0; j < NTW; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
   const int mrow = lane >> 2;                                  // this lane stores tile rows mrow and mrow + 16
   const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
   const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
   const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
   const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
   bf16_t* ycol = y + n0 + wn * (G::NT / 2) + (lane & 3) * 8;
+  auto write_out = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int dd = d0 + p;
-    if (dd >= D) break;                                        // uniform
-    bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
+    for (int p = 0; p < 4; ++p) {
+      const int dd = d0 + p;
+      if (!FULL && dd >= D) break;                             // uniform
+      bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
-      char* tile = stg + ((p * NTW + j) & 1) * 2048;          // two tiles per wave, used alternately
+      for (int j = 0; j < NTW; ++j) {
+        const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
+        char* tile = stg + ((p * NTW + j) & 1) * 2048;        // two tiles per wave, used alternately
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = (i & 3) + 8 * (i >> 2) + rh;
-        const float o = acc[p][j][i] + bv;
-        *reinterpret_cast<bf16_t*>(tile + m * 64 + r * 2) = (bf16_t)o;
-        if (STATS) {
-          if (full) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
-          else if ((vmask >> i) & 1u) { s1[j] += o; s2[j] = fmaf(o, o, s2[j]); }
+        for (int i = 0; i < 16; i += 2) {
+          const int m = (i & 3) + 8 * (i >> 2) + rh;           // rows m, m + 1
+          f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
+          *reinterpret_cast<bf16_t*>(tile + m * 64 + r * 2) = (bf16_t)o[0];
+          *reinterpret_cast<bf16_t*>(tile + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
+          if (STATS) {
+            if (!FULL) {
+              if (!((vmask >> i) & 1u)) o[0] = 0.f;
+              if (!((vmask >> (i + 1)) & 1u)) o[1] = 0.f;
+            }
+            s1[j] += o;
+            s2[j] = __builtin_elementwise_fma(o, o, s2[j]);
+          }
         }
+        const uint4 pk0 = *reinterpret_cast<const uint4*>(tile + mrow * 64 + (lane & 3) * 16);
+        const uint4 pk1 = *reinterpret_cast<const uint4*>(tile + (mrow + 16) * 64 + (lane & 3) * 16);
+        if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
+        if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
       }
-      const uint4 pk0 = *reinterpret_cast<const uint4*>(tile + mrow * 64 + (lane & 3) * 16);
-      const uint4 pk1 = *reinterpret_cast<const uint4*>(tile + (mrow + 16) * 64 + (lane & 3) * 16);
-      if (ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
-      if (ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
     }
-  }
+  };
+  if (full) write_out(std::true_type{}); else write_out(std::false_type{});
   if (STATS && stats) {
     block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
     float* red = reinterpret_cast<float*>(smem + 16384);       // [2 (hhalf)][2][NT]
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-      const float a = s1[j] + __shfl_xor(s1[j], 32, 64), q2 = s2[j] + __shfl_xor(s2[j], 32, 64);
+      const float a_ = s1[j][0] + s1[j][1], q_ = s2[j][0] + s2[j][1];
+      const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
       if (lane < 32) {
         red[(hhalf * 2 + 0) * G::NT + wn * (G::NT / 2) + j * 32 + r] = a;
         red[(hhalf * 2 + 1) * G::NT + wn * (G::NT / 2) + j * 32 + r] = q2;
