@@ -61,24 +61,15 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, khalf = lane >> 5;
   const int hhalf = wave >> 1, wn = wave & 1;
-  const FplxBlock bid = fplx_xcd_block(xcd);
-  int b = bid.x;
-  const int bw = b % bW; b /= bW;
-  const int bh = b % bH; b /= bH;
-  const int bd = b % bD; b /= bD;
-  const int n = __builtin_amdgcn_readfirstlane(b);
-  const int d0 = __builtin_amdgcn_readfirstlane(bd * G::TD), h0 = __builtin_amdgcn_readfirstlane(bh * G::TH),
-            w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
-  const int n0 = bid.y * G::NT;
+  const int n0 = blockIdx.y * G::NT;
+  // persistent: the block walks its share of the brick list (XCD-contiguous: neighbouring bricks, shared halos, one L2);
+  // the next brick's first chunk is fetched during the current brick's last one, the weight ring never stops
+  const FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd);
+  if (tr.first >= tr.end) return;
 
   // ---- DMA plumbing (see conv_fwd_march32v2): out-of-range lanes of a buffer load to LDS write zeros
   const int64_t xsample = (int64_t)D * H * W * ldx * 2;
-  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * xsample;
-  u32x4 rx, rw;
-  rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
-  rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
-  rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
-  rx[3] = 0x00020000u;
+  u32x4 rw;
   rw[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wp);
   rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
   rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
@@ -93,29 +84,48 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  // brick pieces: piece p = wave + 4 k covers LDS bytes [p * 1024, +1024) of the slot; lane -> 16-byte chunk
-  unsigned bvo[G::NPB];
+  // a brick's coordinates, its descriptor (the sample's volume) and its DMA lane offsets: piece p = wave + 4 k covers LDS
+  // bytes [p * 1024, +1024) of the slot, lane -> 16-byte chunk
+  struct Brick { int n, d0, h0, w0; unsigned vo[BK::NPB]; };
+  auto setup = [&](int64_t tile, Brick& B) {
+    int b = (int)tile;
+    const int bw = b % bW; b /= bW;
+    const int bh = b % bH; b /= bH;
+    const int bd = b % bD; b /= bD;
+    B.n = __builtin_amdgcn_readfirstlane(b);
+    B.d0 = __builtin_amdgcn_readfirstlane(bd * G::TD);
+    B.h0 = __builtin_amdgcn_readfirstlane(bh * G::TH);
+    B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
 #pragma unroll
-  for (int k = 0; k < G::NPB; ++k) {
-    const int ci = (wave + 4 * k) * 64 + lane;
-    const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
-    const int q = L >> 7, rem = L & 127, hh = rem / G::SWP, ww = rem % G::SWP;
-    const int gd = d0 - 1 + q, gh = h0 - 1 + hh, gw = w0 - 1 + ww;
-    const bool in = rem < 10 * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-    bvo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
-  }
+    for (int k = 0; k < G::NPB; ++k) {
+      const int ci = (wave + 4 * k) * 64 + lane;
+      const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
+      const int q = L >> 7, rem = L & 127, hh = rem / G::SWP, ww = rem % G::SWP;
+      const int gd = B.d0 - 1 + q, gh = B.h0 - 1 + hh, gw = B.w0 - 1 + ww;
+      const bool in = rem < 10 * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      B.vo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
+    }
+  };
   // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][NT couts], swizzle (lane >> 4) & 3
   const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
   const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
-  auto brick_piece = [&](int ch, int k) {
-    buf_dma(rx, bvo[k], (unsigned)(ch * G::KC * 2), bricks + (ch & 1) * G::BRICK_BYTES + (wave + 4 * k) * 1024);
+  auto brick_pieces = [&](const Brick& B, int ch, int slot, int k0, int cnt) {     // pieces k0 .. k0 + cnt - 1 of chunk ch
+    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
+    u32x4 rx;
+    rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+    rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+    rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
+    rx[3] = 0x00020000u;
+#pragma unroll
+    for (int k = k0; k < k0 + cnt; ++k)
+      buf_dma(rx, B.vo[k], (unsigned)(ch * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
   };
-  auto weight_stage = [&](int ch, int t9) {                 // all six pieces of stage ch * 9 + t9 -> slot (ch + t9) & 1
+  auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
 #pragma unroll
     for (int k = 0; k < G::NPW; ++k) {
       const int j = wave + 4 * k, kd = j / (G::NT / 16);
       const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + ch * G::KC) * 2);
-      buf_dma(rw, wvo, so, wring + ((ch + t9) & 1) * G::WST_BYTES + j * 1024);
+      buf_dma(rw, wvo, so, wring + slot * G::WST_BYTES + j * 1024);
     }
   };
 
@@ -127,12 +137,14 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
 
-  const int nch = Cin / G::KC, nst = nch * 9;
-  // prologue: brick chunk 0, weight stages 0 and 1
-#pragma unroll
-  for (int k = 0; k < G::NPB; ++k) brick_piece(0, k);
-  weight_stage(0, 0);
-  weight_stage(0, 1);
+  const int nch = Cin / G::KC;
+  Brick cur, nxt;
+  int64_t tile = tr.first;
+  setup(tile, cur);
+  // prologue: brick chunk 0 -> brick slot 0, weight stages 0 and 1
+  brick_pieces(cur, 0, 0, 0, G::NPB);
+  weight_stage(0, 0, 0);
+  weight_stage(0, 1, 1);
   if (tid < G::NT) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
   dma_wait();
   block_sync();
@@ -165,122 +177,148 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
       for (int j = 0; j < NTW; ++j)
         acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * NTW + j], acc[p][j], 0, 0, 0);
   };
+  const int rh = khalf * 4;
 
   load_a(bricks, 0, 0, 0, 0);
   load_b(wring, 0, 0);
-  for (int ch = 0; ch < nch; ++ch) {
-    const char* brick = bricks + (ch & 1) * G::BRICK_BYTES;
-    const char* brick_nx = bricks + ((ch + 1) & 1) * G::BRICK_BYTES;
-    const bool more = ch + 1 < nch;
+  int cc = 0;                                               // chunks done so far (all bricks): brick slot = cc & 1
+  int gs = 0;                                               // stages done so far: weight slot = gs & 1
+  for (;;) {
+    const int64_t tile_nx = tile + tr.step;
+    const bool has_next = tile_nx < tr.end;                  // uniform
+    if (has_next) setup(tile_nx, nxt);
+    for (int ch = 0; ch < nch; ++ch, ++cc) {
+      const char* brick = bricks + (cc & 1) * G::BRICK_BYTES;
+      const char* brick_nx = bricks + ((cc + 1) & 1) * G::BRICK_BYTES;
+      const bool last_ch = ch + 1 == nch;
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) {
-      const int kh = t9 / 3, kw = t9 % 3;
-      const int st = ch * 9 + t9;
-      const char* wslot = wring + ((ch + t9) & 1) * G::WST_BYTES;
-      const char* wslot_nx = wring + ((ch + t9 + 1) & 1) * G::WST_BYTES;
-      // ---- first half (input channels 0-15 of the chunk): prefetch the second half's fragments
-      load_a(brick, kh, kw, 1, 1);
-      mfmas(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_b(wslot, 1, 1);
-      mfmas(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      // stage st + 1's weights (issued in the second half of stage st - 1) and, at t9 == 8, the next brick have landed;
-      // nobody reads stage st's slot / (at t9 == 8) this brick any more once past this barrier
-      dma_wait();
-      block_sync();
-      // ---- second half: stage st + 2's weights -> this stage's slot, two pieces of the next brick, next stage's fragments
-      if (st + 2 < nst) { if (t9 < 7) weight_stage(ch, t9 + 2); else weight_stage(ch + 1, t9 - 7); }
-      if (t9 < 6 && more) { brick_piece(ch + 1, 2 * t9); brick_piece(ch + 1, 2 * t9 + 1); }
-      if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
-      mfmas(1, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      load_b(wslot_nx, 0, 0);
-      mfmas(1, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(1, 2);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t9 = 0; t9 < 9; ++t9, ++gs) {
+        const int kh = t9 / 3, kw = t9 % 3;
+        const char* wslot = wring + (gs & 1) * G::WST_BYTES;
+        const char* wslot_nx = wring + ((gs + 1) & 1) * G::WST_BYTES;
+        // ---- first half (input channels 0-15 of the chunk): prefetch the second half's fragments
+        load_a(brick, kh, kw, 1, 1);
+        mfmas(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(wslot, 1, 1);
+        mfmas(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // the next stage's weights (issued in the second half of the stage before this one) and, at t9 == 8, the next
+        // chunk of the brick / the next brick's first chunk have landed; nobody reads this stage's weight slot / (at
+        // t9 == 8) this chunk's brick slot any more once past this barrier
+        dma_wait();
+        block_sync();
+        // ---- second half: the stage after next's weights -> this stage's slot, two pieces of the next chunk, next stage's
+        // fragments
+        {
+          int ch2 = ch, t92 = t9 + 2;
+          if (t92 >= 9) { t92 -= 9; ++ch2; }
+          if (ch2 < nch) weight_stage(ch2, t92, gs & 1);
+          else if (has_next) weight_stage(0, t92, gs & 1);
+        }
+        if (t9 < 6) {
+          if (!last_ch) brick_pieces(cur, ch + 1, (cc + 1) & 1, 2 * t9, 2);
+          else if (has_next) brick_pieces(nxt, 0, (cc + 1) & 1, 2 * t9, 2);
+        }
+        if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
+        mfmas(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(wslot_nx, 0, 0);
+        mfmas(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  }
 
-  // ---- write-out: bias, statistics, bf16 through a 2-KiB per-wave LDS tile, 16-byte stores (the operands are dead)
-  block_sync();                                              // LDS only: no DMA is in flight past the last stage's barrier
-  char* stg = smem + wave * 4096;
-  const int rh = khalf * 4;
-  // ragged bricks at the volume's far faces: validity of the 16 accumulator rows of this lane / of the rows it stores
-  const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
-  unsigned vmask = 0xFFFFu;
-  if (!full) {
-    vmask = 0;
+    // ---- write-out of this brick: bias, statistics, bf16 through 2-KiB per-wave LDS tiles, 16-byte stores.  The tiles
+    // live in the brick slot of the chunk just finished: nobody has read it since the last stage's barrier, and the next
+    // DMA into it is issued behind the next stage's barrier, i.e. after every wave has left this write-out
+    char* dead = bricks + ((cc - 1) & 1) * G::BRICK_BYTES;
+    char* stg = dead + wave * 4096;
+    const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
+    // ragged bricks at the volume's far faces: validity of the 16 accumulator rows of this lane / of the rows it stores
+    const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
+    unsigned vmask = 0xFFFFu;
+    if (!full) {
+      vmask = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = (i & 3) + 8 * (i >> 2) + rh;
-      if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + rh;
+        if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+      }
     }
-  }
-  // statistics in packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32: accumulator elements i, i + 1 sit in consecutive registers)
-  f32x2 s1[NTW], s2[NTW];
+    // statistics in packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32: accumulator elements i, i + 1 sit in consecutive registers)
+    f32x2 s1[NTW], s2[NTW];
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
-  const int mrow = lane >> 2;                                  // this lane stores tile rows mrow and mrow + 16
-  const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
-  const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
-  const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
-  const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
-  bf16_t* ycol = y + n0 + wn * (G::NT / 2) + (lane & 3) * 8;
-  auto write_out = [&](auto full_c) {
-    constexpr bool FULL = decltype(full_c)::value;
+    for (int j = 0; j < NTW; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+    const int mrow = lane >> 2;                                // this lane stores tile rows mrow and mrow + 16
+    const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
+    const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
+    const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
+    const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
+    bf16_t* ycol = y + n0 + wn * (G::NT / 2) + (lane & 3) * 8;
+    auto write_out = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int dd = d0 + p;
-      if (!FULL && dd >= D) break;                             // uniform
-      bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
+      for (int p = 0; p < 4; ++p) {
+        const int dd = d0 + p;
+        if (FULL || dd < D) {                                  // uniform
+          bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
-        char* tile = stg + ((p * NTW + j) & 1) * 2048;        // two tiles per wave, used alternately
+          for (int j = 0; j < NTW; ++j) {
+            const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
+            char* tile_ = stg + ((p * NTW + j) & 1) * 2048;    // two tiles per wave, used alternately
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const int m = (i & 3) + 8 * (i >> 2) + rh;           // rows m, m + 1
-          f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
-          *reinterpret_cast<bf16_t*>(tile + m * 64 + r * 2) = (bf16_t)o[0];
-          *reinterpret_cast<bf16_t*>(tile + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
-          if (STATS) {
-            if (!FULL) {
-              if (!((vmask >> i) & 1u)) o[0] = 0.f;
-              if (!((vmask >> (i + 1)) & 1u)) o[1] = 0.f;
+            for (int i = 0; i < 16; i += 2) {
+              const int m = (i & 3) + 8 * (i >> 2) + rh;       // rows m, m + 1
+              f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
+              *reinterpret_cast<bf16_t*>(tile_ + m * 64 + r * 2) = (bf16_t)o[0];
+              *reinterpret_cast<bf16_t*>(tile_ + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
+              if (STATS) {
+                if (!FULL) {
+                  if (!((vmask >> i) & 1u)) o[0] = 0.f;
+                  if (!((vmask >> (i + 1)) & 1u)) o[1] = 0.f;
+                }
+                s1[j] += o;
+                s2[j] = __builtin_elementwise_fma(o, o, s2[j]);
+              }
             }
-            s1[j] += o;
-            s2[j] = __builtin_elementwise_fma(o, o, s2[j]);
+            const uint4 pk0 = *reinterpret_cast<const uint4*>(tile_ + mrow * 64 + (lane & 3) * 16);
+            const uint4 pk1 = *reinterpret_cast<const uint4*>(tile_ + (mrow + 16) * 64 + (lane & 3) * 16);
+            if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
+            if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
           }
         }
-        const uint4 pk0 = *reinterpret_cast<const uint4*>(tile + mrow * 64 + (lane & 3) * 16);
-        const uint4 pk1 = *reinterpret_cast<const uint4*>(tile + (mrow + 16) * 64 + (lane & 3) * 16);
-        if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
-        if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
-      }
-    }
-  };
-  if (full) write_out(std::true_type{}); else write_out(std::false_type{});
-  if (STATS && stats) {
-    block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
-    float* red = reinterpret_cast<float*>(smem + 16384);       // [2 (hhalf)][2][NT]
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const float a_ = s1[j][0] + s1[j][1], q_ = s2[j][0] + s2[j][1];
-      const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
-      if (lane < 32) {
-        red[(hhalf * 2 + 0) * G::NT + wn * (G::NT / 2) + j * 32 + r] = a;
-        red[(hhalf * 2 + 1) * G::NT + wn * (G::NT / 2) + j * 32 + r] = q2;
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
+      }
+    };
+    if (full) write_out(std::true_type{}); else write_out(std::false_type{});
+    if (STATS && stats) {
+      float* red = reinterpret_cast<float*>(dead + 16384);     // [2 (hhalf)][2][NT]
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const float a_ = s1[j][0] + s1[j][1], q_ = s2[j][0] + s2[j][1];
+        const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
+        if (lane < 32) {
+          red[(hhalf * 2 + 0) * G::NT + wn * (G::NT / 2) + j * 32 + r] = a;
+          red[(hhalf * 2 + 1) * G::NT + wn * (G::NT / 2) + j * 32 + r] = q2;
+        }
+      }
+      block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
+      if (tid < 2 * G::NT) {
+        const int which = tid / G::NT, c = tid % G::NT;
+        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * G::NT + c] + red[(1 * 2 + which) * G::NT + c];
       }
     }
-    block_sync();
-    if (tid < 2 * G::NT) {
-      const int which = tid / G::NT, c = tid % G::NT;
-      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * G::NT + c] + red[(1 * 2 + which) * G::NT + c];
-    }
+    if (!has_next) break;
+    tile = tile_nx;
+    cur = nxt;
   }
 }
 
@@ -301,13 +339,12 @@ extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout) {
   const int nt = cout % 128 == 0 ? 128 : 64;
   return padded * 4 <= V * 5 && bricks * (cout / nt) >= 192 && bricks < ((int64_t)1 << 24);
 }
-// the layers a march kernel could take as well but the brick kernel runs faster (level 1 of the benchmark, 2 x 40 x 80 x 80:
-// 128 -> 64 305 -> 234 us against the streamed-weight march, 64 -> 128 255 -> 231 us; 64 -> 64 is a tie and stays).
-// A/B knob FPLX_BRICK: 2 = every eligible layer, 3 = only the layers no march kernel takes (benchmarks only)
+// the layers a march kernel could take as well: the brick kernel is the faster one on all of them (level 1 of the benchmark,
+// 2 x 40 x 80 x 80, with statistics: 128 -> 64 305 -> 219 us against the streamed-weight march, 64 -> 128 255 -> 213 us,
+// 64 -> 64 157 -> 142 us).  A/B knob FPLX_BRICK=3: only the layers no march kernel takes (benchmarks only)
 extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout) {
   const int en = brick_enabled();
-  if (!en || en == 3 || !fplx_brick_ok(n, d, h, w, cin, cout)) return 0;
-  return en == 2 || cin == 128 || (cin == 64 && cout % 128 == 0);
+  return en && en != 3 && fplx_brick_ok(n, d, h, w, cin, cout);
 }
 
 extern "C" int fplx_brick_rows(int n, int d, int h, int w) {
@@ -322,7 +359,12 @@ extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30) || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
   const int bD = (d + BK::TD - 1) / BK::TD, bH = (h + BK::TH - 1) / BK::TH, bW = (w + BK::TW - 1) / BK::TW;
   const int ntw = cout % 128 == 0 ? 2 : 1;
-  dim3 grid(n * bD * bH * bW, cout / (64 * ntw));
+  // persistent blocks: one per CU (LDS), each walking its share of the bricks
+  const int gy = cout / (64 * ntw);
+  int64_t gx = (int64_t)n * bD * bH * bW;
+  const int64_t per = (256 + gy - 1) / gy;
+  if (gx > per) gx = per;
+  dim3 grid((unsigned)gx, gy);
 #define LAUNCH_BRICK(STATS_, NTW_)                                                                                   \
   do {                                                                                                               \
     (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_, NTW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -1,5 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "brick" 2>&1 | tail -n 2
-timeout 300 python tools/brick_check.py l1 2>&1 | grep "time"
-timeout 300 python tools/brick_check.py 2>&1 | grep "time"
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -n 3
+echo "--- bench"
+for i in 1 2; do
+timeout 600 python bench.py 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}, d['roofline']['avg_ms'])"
+FPLX_BRICK=3 timeout 600 python bench.py 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('brick=3', {k:d[k] for k in ('value','ms_per_step')}, d['roofline']['avg_ms'])"
+done
+FPLX_BRICK=0 timeout 600 python bench.py 2>&1 | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('brick=0', {k:d[k] for k in ('value','ms_per_step')}, d['roofline']['avg_ms'])"
