@@ -321,18 +321,39 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
   const float bv = (r < ncls && bias) ? bias[r] : 0.f;
   auto swz = [](int vox) { return (vox / (16 / CH)) % CH; };
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
-  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
-    const Tile t = tile_of(tt, D, tilesH, tilesW);
-    __syncthreads();
-    for (int i = threadIdx.x; i < SH * SW * CH; i += 256) {
+  // the next tile's rows travel global -> registers while this tile computes (a synchronous fill left every block idle for
+  // a memory round trip per tile: 143 us at the benchmark shape, 2.1 TB/s)
+  constexpr int NLD = (SH * SW * CH + 255) / 256;
+  uint4 xreg[NLD];
+  auto fetch = [&](const Tile& t) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
       const int vox = i / CH, c = i % CH;
       const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (h >= 0 && h < H && w >= 0 && w < W)
+      if (i < SH * SW * CH && h >= 0 && h < H && w >= 0 && w < W)
         v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + c * 8);
-      *reinterpret_cast<uint4*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16)) = v;
+      xreg[k] = v;
+    }
+  };
+  int64_t tt = tr.first;
+  Tile tn = tile_of(tt < tr.end ? tt : 0, D, tilesH, tilesW);
+  if (tt < tr.end) fetch(tn);
+  for (; tt < tr.end; tt += tr.step) {
+    const Tile t = tn;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int vox = i / CH, c = i % CH;
+      if (i < SH * SW * CH) *reinterpret_cast<uint4*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16)) = xreg[k];
     }
     __syncthreads();
+    if (tt + tr.step < tr.end) {
+      tn = tile_of(tt + tr.step, D, tilesH, tilesW);
+      fetch(tn);
+    }
     f32x16 acc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace CSV (both streams on) -> where the train step's wall time goes: per queue busy time, the
+time no kernel runs at all, the time exactly one / two kernels run, and the largest idle gaps with the kernels around them.
+
+usage: timeline_gaps.py <kernel_trace.csv> [first_fraction_to_skip]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = []
+for r in csv.DictReader(open(sys.argv[1])):
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), name[:44]))
+rows.sort()
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+# steady state: the last nsteps train steps, delimited by the optimiser launches (two adam_k per step: shared + domain segment)
+adam = [e for s, e, q, n in rows if n.startswith("adam_k")]
+t0, t1 = adam[-2 * nsteps - 1], adam[-1]
+rows = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+span = rows[-1][1] - rows[0][0]
+per_q = defaultdict(int)
+for s, e, q, n in rows:
+    per_q[q] += e - s
+ev = []
+for s, e, q, n in rows:
+    ev.append((s, 1))
+    ev.append((e, -1))
+ev.sort()
+depth, last, hist = 0, ev[0][0], defaultdict(int)
+for t, d in ev:
+    hist[min(depth, 3)] += t - last
+    last = t
+    depth += d
+print("window %.3f ms = %d steps of %.3f ms, %d kernels" % (span / 1e6, nsteps, span / 1e6 / nsteps, len(rows)))
+for q, b in sorted(per_q.items(), key=lambda kv: -kv[1]):
+    print("  queue %s busy %.3f ms (%.1f %%)" % (q, b / 1e6, 100.0 * b / span))
+for k in sorted(hist):
+    print("  %d kernel(s) running: %.3f ms (%.1f %%)" % (k, hist[k] / 1e6, 100.0 * hist[k] / span))
+# idle gaps of the whole device
+gaps = []
+end = rows[0][1]
+prev = rows[0][3]
+for s, e, q, n in rows[1:]:
+    if s > end:
+        gaps.append((s - end, prev, n))
+    if e > end:
+        end, prev = e, n
+gaps.sort(reverse=True)
+print("device idle in %d gaps; by (before -> after), total us:" % len(gaps))
+agg = defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    agg[(a, b)][0] += g
+    agg[(a, b)][1] += 1
+for (a, b), (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("  %8.1f us in %3d gaps (avg %.1f)  %s -> %s" % (g / 1e3, c, g / 1e3 / c, a, b))
