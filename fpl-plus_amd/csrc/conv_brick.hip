@@ -28,16 +28,21 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 struct BK {
-  static constexpr int TD = 4, TH = 8, TW = 8, KC = 32, ROWB = 64;
-  static constexpr int SWP = 12, PL = 128, SD = TD + 2;
-  static constexpr int BRICK_BYTES = SD * PL * ROWB;          // 49152
-  static constexpr int NPB = BRICK_BYTES / 1024 / 4;          // DMA wave-instructions per wave and brick chunk (12)
-  static constexpr int THREADS = 256;
+  static constexpr int TW = 8, KC = 32, ROWB = 64, SWP = 12, THREADS = 256;
 };
-// NTW = N-tiles (32 output channels) per wave: 2 -> 128 output channels per block, 1 -> 64 (0.75 fragment reads per MFMA)
-template <int NTW>
-struct BKN : BK {
-  static constexpr int NT = 64 * NTW;
+// A block = TD depth planes x (4 WH) rows x 8 columns of output voxels x NT output channels.  Its four waves are WH row
+// groups (a wave's patch is 4 x 8 voxels per plane) x WN = 4 / WH channel groups of NTW N-tiles (32 channels) each:
+//   <4, 2, 2>: 4 x 8 x 8 x 128   <4, 2, 1>: 4 x 8 x 8 x 64   <5, 1, 1>: 5 x 4 x 8 x 128 (level 3: 10 x 20 x 20 without
+//   padding in d and h)
+template <int TD_, int WH_, int NTW_>
+struct BKG : BK {
+  static constexpr int TD = TD_, WH = WH_, NTW = NTW_, WN = 4 / WH_, TH = 4 * WH_;
+  static constexpr int NT = WN * 32 * NTW;
+  static constexpr int SD = TD + 2, SH = TH + 2;
+  static constexpr int PL = (SH * SWP + 15) / 16 * 16;        // voxel slots per plane of the LDS image: 128 / 80
+  static constexpr int BRICK_BYTES = SD * PL * ROWB;          // 49152 / 35840
+  static constexpr int NP_TOT = BRICK_BYTES / 1024;           // DMA wave-instructions per brick chunk
+  static constexpr int NPB = (NP_TOT + 3) / 4;                // ... per wave (12 / 9)
   static constexpr int WST_BYTES = 3 * NT * ROWB;             // one weight stage: 24576 / 12288
   static constexpr int NPW = WST_BYTES / 1024 / 4;            // 6 / 3
   static constexpr int LDS = 2 * BRICK_BYTES + 2 * WST_BYTES + NT * 4;
@@ -47,12 +52,12 @@ struct BKN : BK {
 __device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) ^ (m >> 3) ^ (m >> 2)) & 1); }
 __device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
 
-template <bool STATS, int NTW>
+template <bool STATS, int NTW, int TD, int WH>
 __global__ void __launch_bounds__(BK::THREADS)
 conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
                bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-               float* __restrict__ stats, int bD, int bH, int bW, int xcd) {
-  using G = BKN<NTW>;
+               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd) {
+  using G = BKG<TD, WH, NTW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bricks = smem;
   char* wring = smem + 2 * G::BRICK_BYTES;
@@ -60,12 +65,36 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, khalf = lane >> 5;
-  const int hhalf = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.y * G::NT;
-  // persistent: the block walks its share of the brick list (XCD-contiguous: neighbouring bricks, shared halos, one L2);
-  // the next brick's first chunk is fetched during the current brick's last one, the weight ring never stops
-  const FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd);
+  const int hhalf = wave / G::WN, wn = wave % G::WN;
+  // Which (output-channel tile, Cin split) = weight slice and which part of the brick list this block takes.  The dispatcher
+  // deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own 4-MB L2 (common.h):
+  //   xcd == 1: XCD j sweeps its contiguous eighth of the brick list for every slice (fplx_xcd_tiles) - neighbouring bricks,
+  //             shared halos, one L2: the levels whose weights fit an L2 beside the activations (levels 1-2);
+  //   xcd == 2: (the launcher made grid.x * U a multiple of 8, U = grid.y * grid.z slices) every XCD works on ONE slice (U
+  //             divides 8) or on U / 8 of them: the slice - 27 x NT x Cin / grid.z weights, streamed once per brick - stays
+  //             in that XCD's L2.  The deep levels' packs are 3.5-14 MB: dealt the other way every L2 streams all of it for
+  //             every brick (level 3, 256 -> 512: 122 -> 75 us).
+  int by = blockIdx.y, bz = blockIdx.z;
+  FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd == 1);
+  if (xcd == 2) {
+    const unsigned gx = gridDim.x, U = gridDim.y * gridDim.z;
+    const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x, xc = L & 7u, idx = L >> 3;
+    unsigned u, stripe;
+    if (8 % U == 0) { u = xc % U; stripe = idx * (8 / U) + xc / U; }
+    else { u = xc + 8 * (idx % (U / 8)); stripe = idx / (U / 8); }
+    by = __builtin_amdgcn_readfirstlane((int)(u % gridDim.y));
+    bz = __builtin_amdgcn_readfirstlane((int)(u / gridDim.y));
+    tr.first = __builtin_amdgcn_readfirstlane((int)stripe);
+    tr.step = gx;
+  }
+  const int n0 = by * G::NT;
+  // persistent: the next brick's first chunk is fetched during the current brick's last one, the weight ring never stops
   if (tr.first >= tr.end) return;
+
+  // blockIdx.z deals the 32-channel chunks of Cin (split-K for the small deep volumes): fp32 partial tiles, summed by
+  // splitk_finish_k (conv_mfma.hip)
+  const int c_lo = (int)((int64_t)(Cin / G::KC) * bz / gridDim.z);
+  const int nch = (int)((int64_t)(Cin / G::KC) * (bz + 1) / gridDim.z) - c_lo;
 
   // ---- DMA plumbing (see conv_fwd_march32v2): out-of-range lanes of a buffer load to LDS write zeros
   const int64_t xsample = (int64_t)D * H * W * ldx * 2;
@@ -86,7 +115,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 
   // a brick's coordinates, its descriptor (the sample's volume) and its DMA lane offsets: piece p = wave + 4 k covers LDS
   // bytes [p * 1024, +1024) of the slot, lane -> 16-byte chunk
-  struct Brick { int n, d0, h0, w0; unsigned vo[BK::NPB]; };
+  struct Brick { int n, d0, h0, w0; unsigned vo[G::NPB]; };
   auto setup = [&](int64_t tile, Brick& B) {
     int b = (int)tile;
     const int bw = b % bW; b /= bW;
@@ -100,9 +129,9 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     for (int k = 0; k < G::NPB; ++k) {
       const int ci = (wave + 4 * k) * 64 + lane;
       const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
-      const int q = L >> 7, rem = L & 127, hh = rem / G::SWP, ww = rem % G::SWP;
+      const int q = L / G::PL, rem = L % G::PL, hh = rem / G::SWP, ww = rem % G::SWP;
       const int gd = B.d0 - 1 + q, gh = B.h0 - 1 + hh, gw = B.w0 - 1 + ww;
-      const bool in = rem < 10 * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+      const bool in = q < G::SD && rem < G::SH * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
       B.vo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
     }
   };
@@ -118,26 +147,26 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     rx[3] = 0x00020000u;
 #pragma unroll
     for (int k = k0; k < k0 + cnt; ++k)
-      buf_dma(rx, B.vo[k], (unsigned)(ch * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
+      if (k < G::NPB && wave + 4 * k < G::NP_TOT)            // uniform
+        buf_dma(rx, B.vo[k], (unsigned)((c_lo + ch) * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
   };
   auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
 #pragma unroll
     for (int k = 0; k < G::NPW; ++k) {
       const int j = wave + 4 * k, kd = j / (G::NT / 16);
-      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + ch * G::KC) * 2);
+      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
       buf_dma(rw, wvo, so, wring + slot * G::WST_BYTES + j * 1024);
     }
   };
 
-  f32x16 acc[4][NTW];
+  f32x16 acc[TD][NTW];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int p = 0; p < TD; ++p)
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
 
-  const int nch = Cin / G::KC;
   Brick cur, nxt;
   int64_t tile = tr.first;
   setup(tile, cur);
@@ -151,14 +180,14 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 
   // fragment addresses: A lane base (voxel index of the patch's tap (0, 0, 0) corner voxel), B lane base
   const int L0 = (hhalf * 4 + bk_row(r)) * G::SWP + bk_col(r);
-  const int bb = (wn * (G::NT / 2) + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
-  bf16x8 fa[2][6], fb[2][3 * NTW];
+  const int bb = (wn * (32 * NTW) + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
+  bf16x8 fa[2][G::SD], fb[2][3 * NTW];
   auto load_a = [&](const char* brick, int kh, int kw, int ks, int buf) {
     int a0 = L0 + kh * G::SWP + kw;
     asm volatile("" : "+v"(a0));
     const char* p = brick + a0 * G::ROWB + (((2 * ks + khalf) ^ ((a0 >> 2) & 3)) << 4);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) fa[buf][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
+    for (int q = 0; q < G::SD; ++q) fa[buf][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
   };
   auto load_b = [&](const char* wslot, int ks, int buf) {
     int b0 = bb;
@@ -172,7 +201,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   };
   auto mfmas = [&](int buf, int kd) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < TD; ++p)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
         acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * NTW + j], acc[p][j], 0, 0, 0);
@@ -218,7 +247,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
           if (ch2 < nch) weight_stage(ch2, t92, gs & 1);
           else if (has_next) weight_stage(0, t92, gs & 1);
         }
-        if (t9 < 6) {
+        if (2 * t9 < G::NPB) {
           if (!last_ch) brick_pieces(cur, ch + 1, (cc + 1) & 1, 2 * t9, 2);
           else if (has_next) brick_pieces(nxt, 0, (cc + 1) & 1, 2 * t9, 2);
         }
@@ -259,17 +288,17 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
     const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
     const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
-    bf16_t* ycol = y + n0 + wn * (G::NT / 2) + (lane & 3) * 8;
+    bf16_t* ycol = y + n0 + wn * (32 * NTW) + (lane & 3) * 8;
     auto write_out = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < TD; ++p) {
         const int dd = d0 + p;
         if (FULL || dd < D) {                                  // uniform
           bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
 #pragma unroll
           for (int j = 0; j < NTW; ++j) {
-            const float bv = bias_s[wn * (G::NT / 2) + j * 32 + r];
+            const float bv = bias_s[wn * (32 * NTW) + j * 32 + r];
             char* tile_ = stg + ((p * NTW + j) & 1) * 2048;    // two tiles per wave, used alternately
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
@@ -298,22 +327,52 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
           for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
       }
     };
-    if (full) write_out(std::true_type{}); else write_out(std::false_type{});
+    // split-K: the fp32 tile of (plane p, N-tile j) goes through the wave's 4 KiB as [voxel row m][32 channels] and leaves as
+    // 16-byte stores into partial[z][voxel][Cout]; bias, bf16 and statistics are splitk_finish_k's
+    auto write_partial = [&]() {
+      float* pz = partial + (int64_t)bz * ((int64_t)N * D * H * W) * Cout + n0 + wn * (32 * NTW) + (lane & 7) * 4;
+      float* stf = reinterpret_cast<float*>(stg);
+#pragma unroll
+      for (int p = 0; p < TD; ++p) {
+        const int dd = d0 + p;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            stf[((i & 3) + 8 * (i >> 2) + rh) * 32 + r] = acc[p][j][i];
+            acc[p][j][i] = 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = (lane >> 3) + 8 * q;
+            const int hh = h0 + hhalf * 4 + bk_row(m), ww = w0 + bk_col(m);
+            const float4 pk = *reinterpret_cast<const float4*>(stf + m * 32 + (lane & 7) * 4);
+            if (dd < D && hh < H && ww < W)
+              *reinterpret_cast<float4*>(pz + ((((int64_t)n * D + dd) * H + hh) * W + ww) * Cout + j * 32) = pk;
+          }
+        }
+      }
+    };
+    if (partial) write_partial();
+    else if (full) write_out(std::true_type{});
+    else write_out(std::false_type{});
     if (STATS && stats) {
-      float* red = reinterpret_cast<float*>(dead + 16384);     // [2 (hhalf)][2][NT]
+      float* red = reinterpret_cast<float*>(dead + 16384);     // [WH (hhalf)][2][NT]
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const float a_ = s1[j][0] + s1[j][1], q_ = s2[j][0] + s2[j][1];
         const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
         if (lane < 32) {
-          red[(hhalf * 2 + 0) * G::NT + wn * (G::NT / 2) + j * 32 + r] = a;
-          red[(hhalf * 2 + 1) * G::NT + wn * (G::NT / 2) + j * 32 + r] = q2;
+          red[(hhalf * 2 + 0) * G::NT + wn * (32 * NTW) + j * 32 + r] = a;
+          red[(hhalf * 2 + 1) * G::NT + wn * (32 * NTW) + j * 32 + r] = q2;
         }
       }
       block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
       if (tid < 2 * G::NT) {
         const int which = tid / G::NT, c = tid % G::NT;
-        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = red[(0 * 2 + which) * G::NT + c] + red[(1 * 2 + which) * G::NT + c];
+        float t_ = red[(0 * 2 + which) * G::NT + c];
+        if (WH == 2) t_ += red[(1 * 2 + which) * G::NT + c];
+        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = t_;
       }
     }
     if (!has_next) break;
@@ -327,55 +386,110 @@ inline int brick_enabled() {
   return v;
 }
 
+struct BrickCfg { int ok, geo, ntw, nt, ksplit, bD, bH, bW; int64_t bricks; };
+
+// geo 0: 4 x 8 x 8 bricks (128 or 64 output channels per block), geo 1: 5 x 4 x 8 (128): whichever pads the volume less;
+// ksplit > 1 deals the 32-channel chunks of Cin to blockIdx.z when the bricks alone leave most of the 256 CUs idle (the
+// deep levels) - the smallest split that fills them, because each split adds an fp32 partial tensor to write and re-read
+inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
+  BrickCfg c = {};
+  if (!brick_enabled() || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return c;
+  if ((int64_t)d * h * w * cin * 2 >= ((int64_t)1 << 30)) return c;
+  const int64_t V = (int64_t)n * d * h * w;
+  const int bw = (w + 7) / 8;
+  const int64_t b0 = (int64_t)n * ((d + 3) / 4) * ((h + 7) / 8) * bw, p0 = b0 * 256;
+  const int64_t b1 = (int64_t)n * ((d + 4) / 5) * ((h + 3) / 4) * bw, p1 = b1 * 160;
+  c.geo = (cout % 128 == 0 && p1 < p0) ? 1 : 0;
+  c.nt = (c.geo == 1 || cout % 128 == 0) ? 128 : 64;
+  c.ntw = c.geo == 1 ? 1 : c.nt / 64;
+  c.bricks = c.geo ? b1 : b0;
+  c.bD = c.geo ? (d + 4) / 5 : (d + 3) / 4;
+  c.bH = c.geo ? (h + 3) / 4 : (h + 7) / 8;
+  c.bW = bw;
+  // more than 25 % padding: the tile kernel's (level 4 of the benchmark, 5 x 10 x 10, pads 1.9x: measured 47 against 48 us)
+  if ((c.geo ? p1 : p0) * 4 > V * 5 || c.bricks >= ((int64_t)1 << 24)) return c;
+  const int64_t blocks = c.bricks * (cout / c.nt);
+  const int nch = cin / BK::KC;
+  c.ksplit = 1;
+  while (blocks * c.ksplit < 192 && nch / (c.ksplit + 1) >= 2) ++c.ksplit;
+  if (blocks * c.ksplit < 192 || cout % 8 != 0 || cout > 2048) return c;
+  c.ok = 1;
+  return c;
+}
+
 }  // namespace
 
-// 1 if the brick kernel takes this 3x3x3 layer (after the march kernels have declined it)
-extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout) {
-  if (!brick_enabled() || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
-  if ((int64_t)d * h * w * cin * 2 >= ((int64_t)1 << 30)) return 0;
-  const int64_t bricks = (int64_t)n * ((d + BK::TD - 1) / BK::TD) * ((h + BK::TH - 1) / BK::TH) * ((w + BK::TW - 1) / BK::TW);
-  // padding waste of ragged bricks and chip fill: the tile kernel (voxel-linear M tiles, split-K) keeps the rest
-  const int64_t padded = bricks * BK::TD * BK::TH * BK::TW, V = (int64_t)n * d * h * w;
-  const int nt = cout % 128 == 0 ? 128 : 64;
-  return padded * 4 <= V * 5 && bricks * (cout / nt) >= 192 && bricks < ((int64_t)1 << 24);
-}
+// 1 if the brick kernel takes this 3x3x3 layer
+extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout) { return brick_cfg(n, d, h, w, cin, cout).ok; }
 // the layers a march kernel could take as well: the brick kernel is the faster one on all of them (level 1 of the benchmark,
 // 2 x 40 x 80 x 80, with statistics: 128 -> 64 305 -> 219 us against the streamed-weight march, 64 -> 128 255 -> 213 us,
 // 64 -> 64 157 -> 142 us).  A/B knob FPLX_BRICK=3: only the layers no march kernel takes (benchmarks only)
 extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout) {
   const int en = brick_enabled();
-  return en && en != 3 && fplx_brick_ok(n, d, h, w, cin, cout);
+  return en && en != 3 && brick_cfg(n, d, h, w, cin, cout).ok;
+}
+// the plan for a layer fplx_brick_ok accepts: brick geometry, Cin split (1 = none) and the number of bricks = the statistics rows
+// the kernel itself writes (with ksplit > 1 the rows are splitk_finish_k's)
+extern "C" int fplx_brick_plan(int n, int d, int h, int w, int cin, int cout, int* geo, int* ksplit, int* bricks) {
+  const BrickCfg c = brick_cfg(n, d, h, w, cin, cout);
+  if (geo) *geo = c.geo;
+  if (ksplit) *ksplit = c.ksplit;
+  if (bricks) *bricks = (int)c.bricks;
+  return c.ok;
+}
+// bricks of a given geometry (tests that call fplx_brick_conv3d_fwd_ex directly)
+extern "C" int fplx_brick_rows(int n, int d, int h, int w, int geo) {
+  return n * (geo ? (d + 4) / 5 : (d + 3) / 4) * (geo ? (h + 3) / 4 : (h + 7) / 8) * ((w + 7) / 8);
 }
 
-extern "C" int fplx_brick_rows(int n, int d, int h, int w) {
-  return n * ((d + BK::TD - 1) / BK::TD) * ((h + BK::TH - 1) / BK::TH) * ((w + BK::TW - 1) / BK::TW);
-}
-
-// returns 1 if launched, 0 if the operands do not allow it (alignment), <0 on error
-extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+// returns 1 if launched, 0 if the operands do not allow it (alignment), <0 on error.  geo / ksplit: fplx_brick_plan's, or a
+// test's choice on shapes the plan leaves to other kernels.  ksplit > 1: the kernel writes partial[ksplit][V][cout]
+// fp32 and the caller finishes (splitk_finish_k)
+extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                        int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
+                                        int ksplit, hipStream_t st) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
     return 0;
   if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30) || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
-  const int bD = (d + BK::TD - 1) / BK::TD, bH = (h + BK::TH - 1) / BK::TH, bW = (w + BK::TW - 1) / BK::TW;
-  const int ntw = cout % 128 == 0 ? 2 : 1;
+  if (geo == 1 && cout % 128 != 0) return 0;
+  if (ksplit < 1 || ksplit > cin / BK::KC || (ksplit > 1 && !partial)) return 0;
+  const int bD = geo ? (d + 4) / 5 : (d + 3) / 4, bH = geo ? (h + 3) / 4 : (h + 7) / 8, bW = (w + 7) / 8;
+  const int nt = (geo == 1 || cout % 128 == 0) ? 128 : 64;
   // persistent blocks: one per CU (LDS), each walking its share of the bricks
-  const int gy = cout / (64 * ntw);
+  const int gy = cout / nt;
   int64_t gx = (int64_t)n * bD * bH * bW;
-  const int64_t per = (256 + gy - 1) / gy;
+  const int64_t per = (256 + gy * ksplit - 1) / (gy * ksplit);
   if (gx > per) gx = per;
-  dim3 grid((unsigned)gx, gy);
-#define LAUNCH_BRICK(STATS_, NTW_)                                                                                   \
+  // XCD order (see the kernel): by weight slice when the pack does not fit an L2 beside the activations - that needs
+  // grid.x * slices to be a multiple of 8 (and 8 | slices or slices | 8) - else by brick neighbourhood
+  const int U = gy * ksplit;
+  int xcd_on = fplx_xcd_on() ? 1 : 0;
+  if (xcd_on && (int64_t)27 * cout * cin * 2 > ((int64_t)3 << 20) && (8 % U == 0 || U % 8 == 0)) {
+    const int q = U >= 8 ? 1 : 8 / U;
+    gx = (gx + q - 1) / q * q;                                 // blocks past the brick list leave at once
+    xcd_on = 2;
+  }
+  dim3 grid((unsigned)gx, gy, ksplit);
+  float* part = ksplit > 1 ? partial : nullptr;
+#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_)                                                                         \
   do {                                                                                                               \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_, NTW_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              BKN<NTW_>::LDS);                                                                       \
-    conv_fwd_brick<STATS_, NTW_><<<grid, BK::THREADS, BKN<NTW_>::LDS, st>>>(                                          \
-        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, bD, bH, bW,    \
-        fplx_xcd_on());                                                                                              \
+    using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<STATS_, NTW_, TD_, WH_>,                                   \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick<STATS_, NTW_, TD_, WH_><<<grid, BK::THREADS, G_::LDS, st>>>(                                       \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
+        bW, xcd_on);                                                                                                 \
   } while (0)
-  if (ntw == 2) { if (stats) LAUNCH_BRICK(true, 2); else LAUNCH_BRICK(false, 2); }
-  else { if (stats) LAUNCH_BRICK(true, 1); else LAUNCH_BRICK(false, 1); }
+  const bool st_ = stats && !part;
+  if (geo == 1) { if (st_) LAUNCH_BRICK(true, 1, 5, 1); else LAUNCH_BRICK(false, 1, 5, 1); }
+  else if (nt == 128) { if (st_) LAUNCH_BRICK(true, 2, 4, 2); else LAUNCH_BRICK(false, 2, 4, 2); }
+  else { if (st_) LAUNCH_BRICK(true, 1, 4, 2); else LAUNCH_BRICK(false, 1, 4, 2); }
 #undef LAUNCH_BRICK
   const int rc = fplx_check_launch("brick_conv3d_fwd");
   return rc < 0 ? rc : 1;
+}
+
+extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
+  return fplx_brick_conv3d_fwd_ex(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, nullptr, 0, 1, st);
 }

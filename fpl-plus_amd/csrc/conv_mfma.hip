@@ -1283,9 +1283,24 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
 // conv_brick.hip
 extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout);
-extern "C" int fplx_brick_rows(int n, int d, int h, int w);
-extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st);
+extern "C" int fplx_brick_plan(int n, int d, int h, int w, int cin, int cout, int* geo, int* ksplit, int* bricks);
+extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                        int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
+                                        int ksplit, hipStream_t st);
+static inline int splitk_fin_blocks(int64_t V) {
+  const int64_t fb = (V + 7) / 8;
+  return (int)(fb > 512 ? 512 : (fb < 1 ? 1 : fb));
+}
+static inline int brick_stats_rows(int n, int d, int h, int w, int cin, int cout) {
+  int geo, ks, bricks;
+  fplx_brick_plan(n, d, h, w, cin, cout, &geo, &ks, &bricks);
+  return ks > 1 ? splitk_fin_blocks((int64_t)n * d * h * w) : bricks;
+}
+static inline size_t brick_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  int geo, ks, bricks;
+  fplx_brick_plan(n, d, h, w, cin, cout, &geo, &ks, &bricks);
+  return ks > 1 ? (size_t)ks * n * d * h * w * cout * sizeof(float) : 0;
+}
 
 // mid != 0: the 27-tap pack is zero outside the middle depth plane (a Conv2d per depth slice, 2.5D levels).  Layers that
 // would go to the tile kernel run taps 9..17 only (measured 348 -> 155 us on the 128 -> 64 level-1 layer of the shipped
@@ -1300,10 +1315,10 @@ static inline bool mid_tile(int mid, int n, int d, int h, int w, int cin, int co
 static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
   const int64_t V = (int64_t)n * d * h * w;
-  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return fplx_brick_rows(n, d, h, w);
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick_stats_rows(n, d, h, w, cin, cout);
   if (fplx_march_ok(n, d, h, w, cin, cout)) return fplx_march_rows(n, d, h, w, cin, cout);
   if (stream_ok(d, h, w, cin, cout)) return stream_cfg(n, d, h, w, cout).nblk;
-  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return fplx_brick_rows(n, d, h, w);
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return brick_stats_rows(n, d, h, w, cin, cout);
   const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   if (c.ksplit > 1) return c.fin_blocks;
   return (int)c.mblocks;
@@ -1311,8 +1326,9 @@ static int stats_rows_impl(int n, int d, int h, int w, int cin, int cout, int mi
 
 static size_t fwd_ws_impl(int n, int d, int h, int w, int cin, int cout, int mid) {
   if (cin % 16 != 0 || cout % 32 != 0) return 0;
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick_ws_bytes(n, d, h, w, cin, cout);
   if (fplx_march_ok(n, d, h, w, cin, cout) || stream_ok(d, h, w, cin, cout)) return 0;
-  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return 0;
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return brick_ws_bytes(n, d, h, w, cin, cout);
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
@@ -1337,8 +1353,22 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
-  if (!mid && fplx_brick_first(n, d, h, w, cin, cout))
-    return fplx_brick_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
+  auto brick_launch = [&]() -> int {
+    int geo, ks, bricks;
+    fplx_brick_plan(n, d, h, w, cin, cout, &geo, &ks, &bricks);
+    const int64_t Vb = (int64_t)n * d * h * w;
+    if (ks > 1 && (!ws || ws_bytes < (size_t)ks * Vb * cout * sizeof(float)))
+      return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
+                       (size_t)ks * Vb * cout * sizeof(float));
+    const int rb = fplx_brick_conv3d_fwd_ex(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (float*)ws, geo, ks, st);
+    if (rb == 1 && ks > 1) {
+      splitk_finish_k<<<splitk_fin_blocks(Vb), 256, 0, st>>>((const float*)ws, ks, Vb, cout, bias, (bf16_t*)y, ldy, stats);
+      const int rf = fplx_check_launch("brick_splitk_finish");
+      if (rf < 0) return rf;
+    }
+    return rb;
+  };
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick_launch();
   if (fplx_march_ok(n, d, h, w, cin, cout))
     return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, mid);
   if (stream_ok(d, h, w, cin, cout)) {
@@ -1358,8 +1388,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     int rc0 = fplx_check_launch("mfma_conv3d_fwd_stream");
     return rc0 < 0 ? rc0 : 1;
   }
-  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout))
-    return fplx_brick_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st);
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return brick_launch();
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout, tap_cnt);
   const int ks = c.ksplit;

@@ -122,17 +122,23 @@ def test_conv3d_march_kernels_aligned_output(shape):
     np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
 
 
-@pytest.mark.parametrize("shape,direct", [
-    ((1, 64, 128, 4, 8, 8), True),            # one brick
-    ((1, 64, 128, 6, 20, 20), True),          # ragged in d, h and w
-    ((2, 96, 256, 5, 9, 17), True),           # two 128-channel blocks, three channel chunks, ragged, n = 2
-    ((1, 64, 64, 5, 10, 17), True),           # 64 output channels per block
-    ((2, 96, 192, 4, 8, 16), True),
-    ((2, 128, 128, 20, 40, 40), False),       # through the dispatcher: a level-2 layer of the benchmark
-    ((2, 128, 64, 12, 32, 64), False)])       # ... and a layer a march kernel would take as well
-def test_conv3d_brick_kernel(shape, direct):
-    """conv_fwd_brick (input-stationary 4 x 8 x 8 bricks, conv_brick.hip): forward + BN statistics against torch, bf16;
-    direct = straight into fplx_brick_conv3d_fwd for shapes the dispatcher leaves to other kernels (few / ragged bricks)"""
+@pytest.mark.parametrize("shape,geo,ks", [
+    ((1, 64, 128, 4, 8, 8), 0, 1),            # one 4 x 8 x 8 brick
+    ((1, 64, 128, 6, 20, 20), 0, 1),          # ragged in d, h and w
+    ((2, 96, 256, 5, 9, 17), 0, 1),           # two 128-channel blocks, three channel chunks, ragged, n = 2
+    ((1, 64, 64, 5, 10, 17), 0, 1),           # 64 output channels per block
+    ((2, 96, 192, 4, 8, 16), 0, 1),
+    ((1, 64, 128, 10, 20, 20), 1, 1),         # 5 x 4 x 8 bricks: level 3's geometry, ragged in w only
+    ((2, 96, 256, 7, 9, 13), 1, 1),           # ... ragged everywhere
+    ((1, 128, 128, 10, 20, 20), 1, 2),        # Cin split over blockIdx.z: fp32 partials
+    ((1, 160, 64, 6, 12, 16), 0, 3),          # ... 5 chunks over 3 splits (2 / 1 / 2), 4 x 8 x 8 bricks
+    ((2, 128, 128, 20, 40, 40), -1, 0),       # through the dispatcher: a level-2 layer of the benchmark
+    ((2, 128, 64, 12, 32, 64), -1, 0),        # ... a layer a march kernel would take as well
+    ((2, 256, 256, 10, 20, 20), -1, 0)])      # ... a level-3 layer: 5 x 4 x 8 bricks, split-K + finish
+def test_conv3d_brick_kernel(shape, geo, ks):
+    """conv_fwd_brick (input-stationary bricks, conv_brick.hip): forward + BN statistics against torch, bf16;
+    geo >= 0 = straight into fplx_brick_conv3d_fwd_ex with that geometry / Cin split, for shapes the dispatcher leaves to
+    other kernels (few / ragged bricks)"""
     import ctypes
     from fplx import ops
     lib = ops._lib.lib()
@@ -147,22 +153,27 @@ def test_conv3d_brick_kernel(shape, direct):
     wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
     y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
     bg = b.cuda()
-    if direct:
-        rows = lib.fplx_brick_rows(n, d, h, w)
+    scale = float(yr.abs().max())
+    if geo >= 0:
+        rows = lib.fplx_brick_rows(n, d, h, w, geo)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+        part = torch.full((ks, xg.shape[0], cout), 3.0, dtype=torch.float32, device="cuda") if ks > 1 else None
         vp = ctypes.c_void_p
-        rc = lib.fplx_brick_conv3d_fwd(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()), vp(bg.data_ptr()),
-                                       vp(y.data_ptr()), ctypes.c_int64(cout), n, d, h, w, cin, cout, vp(stats.data_ptr()),
-                                       vp(torch.cuda.current_stream().cuda_stream))
+        rc = lib.fplx_brick_conv3d_fwd_ex(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()), vp(bg.data_ptr()),
+                                          vp(y.data_ptr()), ctypes.c_int64(cout), n, d, h, w, cin, cout,
+                                          vp(stats.data_ptr()), vp(part.data_ptr()) if ks > 1 else None, geo, ks,
+                                          vp(torch.cuda.current_stream().cuda_stream))
         assert rc == 1
+        if ks > 1:                                   # partial sums only: bias, bf16 and statistics are the finish kernel's
+            got = (part.sum(0) + bg).float().cpu()
+            assert float((uncl(got, n, d, h, w) - yr).abs().max()) < 2e-2 * scale
+            return
     else:
         assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
         rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
-        assert rows == lib.fplx_brick_rows(n, d, h, w)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, bg, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
                        (3, 3, 3), stats)
-    scale = float(yr.abs().max())
     assert float((uncl(y.float().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
     s = stats.sum(0).cpu()
     yf = cl(yr)

@@ -47,13 +47,12 @@ def check(shape, direct):
     wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
     y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
     if direct:
-        rows = lib.fplx_brick_rows(n, d, h, w)
+        rows = lib.fplx_brick_rows(n, d, h, w, 0)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         run_direct(xg, wf, b.cuda(), y, dims, cin, cout, stats)
     else:
         assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
         rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
-        assert rows == lib.fplx_brick_rows(n, d, h, w)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin,
                        cout, (3, 3, 3), stats)
@@ -78,6 +77,10 @@ def timeit(shape, stats_on, reps=30):
     y = torch.empty(V, cout, dtype=bf, device="cuda")
     rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
     stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda") if stats_on else None
+    if "check" not in sys.argv and not stats_on:
+        g_, k_, b_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        ok_ = lib.fplx_brick_plan(n, d, h, w, cin, cout, ctypes.byref(g_), ctypes.byref(k_), ctypes.byref(b_))
+        print("plan %s: ok %d geo %d ksplit %d bricks %d" % (shape, ok_, g_.value, k_.value, b_.value))
     f = lambda: ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, None, y, ops.cl_strides(d, h, w, cout), dt, dims,
                                cin, cout, (3, 3, 3), stats)
     for _ in range(5):
@@ -104,6 +107,7 @@ if "check" in sys.argv:
     check((2, 96, 192, 4, 8, 16), True)
 L1 = ((2, 64, 64, 40, 80, 80), (2, 128, 64, 40, 80, 80), (2, 64, 128, 40, 80, 80))
 L2 = ((2, 128, 128, 20, 40, 40), (2, 128, 256, 20, 40, 40), (2, 256, 128, 20, 40, 40))
-for shp in (L1 if "l1" in sys.argv else L2):
+L3 = ((2, 256, 256, 10, 20, 20), (2, 256, 512, 10, 20, 20), (2, 512, 256, 10, 20, 20), (2, 512, 512, 5, 10, 10))
+for shp in (L1 if "l1" in sys.argv else (L3 if "l3" in sys.argv else L2)):
     timeit(shp, True)
     timeit(shp, False)
