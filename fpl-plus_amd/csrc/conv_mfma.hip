@@ -191,16 +191,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
 // k-loop is straight-line code: 2 + 14 transposed reads for step ks+1 in flight behind the 7 MFMAs of step ks
 // TWOD: the layer is a Conv2d per depth slice (2.5D levels): only the middle-plane taps 9..17 exist - wave WV owns
 // 9 + WV, 13 + WV (and 17 for wave 0): a third of the MFMAs, the other accumulators stay untouched
-template <int WV, int TW, int CIT, bool TWOD>
-__device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const char* sl0, const char* sl1,
+// COT = 2: two output-channel tiles per block (dy slab = two 32-channel planes): every x fragment - the bulk of the LDS
+// reads, one per tap - feeds two MFMAs: 1.3 transposed reads per MFMA instead of 2.3
+template <int WV, int TW, int CIT, int COT, bool TWOD>
+__device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT * COT], const char* sl0, const char* sl1,
                                                  const char* sl2, const char* dys, int lane_off) {
   constexpr int TH = 8, SW = TW + 2, NKS = TH * TW / 16;
   constexpr int NT = TWOD ? (9 - WV + 3) / 4 : (27 - WV + 3) / 4;     // 3D: 7 (6 for wave 3); 2D: 3 (wave 0) or 2
   constexpr int PLANE = (TH + 2) * SW * 64;           // one ci tile of an x slab: [voxel][32 ch]
-  bf16x8 fbw[2], faw[2][NT * CIT];
-  auto load_dy = [&](int ks) {
+  constexpr int DYPLANE = TH * TW * 64;               // one co tile of the dy slab
+  bf16x8 fbw[2][COT], faw[2][NT * CIT];
+  auto load_dy = [&](int ks, int o) {
     const int hr = ks / (TW / 16), ws = (ks % (TW / 16)) * 16;
-    return tr_frag(dys + (hr * TW + ws) * 64 + lane_off);
+    return tr_frag(dys + o * DYPLANE + (hr * TW + ws) * 64 + lane_off);
   };
   auto load_x = [&](int ks, int j) {                  // j = c * NT + i: ci tile c, tap WV + 4 i
     const int c = j / NT, i = j % NT;
@@ -210,7 +213,8 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
     const char* sl = kd == 0 ? sl0 : (kd == 1 ? sl1 : sl2);
     return tr_frag(sl + c * PLANE + ((hr + kh) * SW + ws + kw) * 64 + lane_off);
   };
-  fbw[0] = load_dy(0);
+#pragma unroll
+  for (int o = 0; o < COT; ++o) fbw[0][o] = load_dy(0, o);
 #pragma unroll
   for (int j = 0; j < NT * CIT; ++j) faw[0][j] = load_x(0, j);
   // one wave per SIMD: nothing else fills the matrix core while this wave issues a burst of LDS reads, so the
@@ -220,19 +224,25 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
   for (int ks = 0; ks < NKS; ks += 2) {
 #pragma unroll
     for (int j = 0; j < NT * CIT; ++j) {
-      if (j == 0) fbw[1] = load_dy(ks + 1);
+      if (j < COT) fbw[1][j] = load_dy(ks + 1, j);
       faw[1][j] = load_x(ks + 1, j);
       __builtin_amdgcn_sched_barrier(0);
-      acc[(j / NT) * 7 + j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][j], fbw[0], acc[(j / NT) * 7 + j % NT], 0, 0, 0);
+#pragma unroll
+      for (int o = 0; o < COT; ++o)
+        acc[(o * CIT + j / NT) * 7 + j % NT] =
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[0][j], fbw[0][o], acc[(o * CIT + j / NT) * 7 + j % NT], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     const int kn = ks + 2 < NKS ? ks + 2 : ks;      // last trip: a harmless re-read instead of branches in the gaps
 #pragma unroll
     for (int j = 0; j < NT * CIT; ++j) {
-      if (j == 0) fbw[0] = load_dy(kn);
+      if (j < COT) fbw[0][j] = load_dy(kn, j);
       faw[0][j] = load_x(kn, j);
       __builtin_amdgcn_sched_barrier(0);
-      acc[(j / NT) * 7 + j % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][j], fbw[1], acc[(j / NT) * 7 + j % NT], 0, 0, 0);
+#pragma unroll
+      for (int o = 0; o < COT; ++o)
+        acc[(o * CIT + j / NT) * 7 + j % NT] =
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(faw[1][j], fbw[1][o], acc[(o * CIT + j / NT) * 7 + j % NT], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -240,7 +250,7 @@ __device__ __forceinline__ void wgrad_depth_step(f32x16 (&acc)[7 * CIT], const c
 
 // the whole march of wave WV (its taps are compile-time constants): the wave variants never merge before the end
 // of the kernel, so the seven accumulator tiles stay in one register class (no VGPR <-> AGPR copies per depth)
-template <int TW, int WV, int CIT, bool TWOD>
+template <int TW, int WV, int CIT, int COT, bool TWOD>
 __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
                                             int64_t ldy, float* __restrict__ part, int N, int D, int H, int W, int Cin,
                                             int Cout, int tilesH, int tilesW, int dsegs, int dlen,
@@ -249,7 +259,8 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int PLANE = SLAB * 64, XSLOT = CIT * PLANE;
   char* xs = smem;                                   // [3 slots][CIT ci tiles][SLAB][32] bf16
-  char* dys = smem + 3 * XSLOT;                      // [TH*TW][32] bf16
+  char* dys = smem + 3 * XSLOT;                      // [COT co tiles][TH*TW][32] bf16
+  constexpr int DYPLANE = TH * TW * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   constexpr int wave = WV;
   int b = bid.x;
@@ -262,12 +273,13 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   const int h0 = th * TH, w0 = tw * TW, d0 = seg * dlen;
   const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
   const bf16_t* xb = x + cg * (32 * CIT);
-  const bf16_t* dyb = dy + cot * 32;
+  const bf16_t* dyb = dy + cot * (32 * COT);
 
   // async-stage split: the next depth's x slab and dy slab travel global -> registers while the current
   // depth is computed, and are committed to LDS behind the barrier that ends the depth
   constexpr int XCH = 4 * CIT;                        // 16-byte chunks per x voxel
-  constexpr int NLX = (SLAB * XCH + 255) / 256, NLY = TH * TW * 4 / 256;
+  constexpr int YCH = 4 * COT;                        // 16-byte chunks per dy voxel
+  constexpr int NLX = (SLAB * XCH + 255) / 256, NLY = TH * TW * YCH / 256;
   uint4 xreg[NLX], yreg[NLY];
   auto fetch_x = [&](int d) {
     const bool dok = d >= 0 && d < D;
@@ -295,7 +307,7 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
 #pragma unroll
     for (int k = 0; k < NLY; ++k) {
       const int i = tid + k * 256;
-      const int vox = i >> 2, ch = i & 3;
+      const int vox = i / YCH, ch = i % YCH;
       const int hh = vox / TW + h0, ww = vox % TW + w0;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (d < D && hh < H && ww < W)
@@ -307,7 +319,8 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
 #pragma unroll
     for (int k = 0; k < NLY; ++k) {
       const int i = tid + k * 256;
-      *reinterpret_cast<uint4*>(dys + (i >> 2) * 64 + (i & 3) * 16) = yreg[k];
+      const int vox = i / YCH, ch = i % YCH;
+      *reinterpret_cast<uint4*>(dys + (ch >> 2) * DYPLANE + vox * 64 + (ch & 3) * 16) = yreg[k];
     }
   };
 
@@ -315,9 +328,9 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;   // bytes
 
-  f32x16 acc[7 * CIT];
+  f32x16 acc[7 * CIT * COT];
 #pragma unroll
-  for (int i = 0; i < 7 * CIT; ++i)
+  for (int i = 0; i < 7 * CIT * COT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -338,7 +351,7 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
       const char* sl0 = xs + ((d + 0) % 3) * XSLOT;              // depth d - 1
       const char* sl1 = xs + ((d + 1) % 3) * XSLOT;              // depth d
       const char* sl2 = xs + ((d + 2) % 3) * XSLOT;              // depth d + 1
-      wgrad_depth_step<WV, TW, CIT, TWOD>(acc, sl0, sl1, sl2, dys, lane_off);
+      wgrad_depth_step<WV, TW, CIT, COT, TWOD>(acc, sl0, sl1, sl2, dys, lane_off);
     }
     __syncthreads();                             // every wave is done with depth d-1's slot and the dy slab
     if (more) {
@@ -351,35 +364,37 @@ __device__ __forceinline__ void wgrad_march(const bf16_t* __restrict__ x, int64_
   // tile leaves as 16-byte stores (4 per tile instead of 16 dword stores: the epilogue is store-issue bound)
   const int co = lane & 31, rbase = (lane >> 5) * 4;
 #pragma unroll
-  for (int c = 0; c < CIT; ++c) {
-    // pair index of (cot, ci tile cg * CIT + c) in the [Cout/32][Cin/32] enumeration the reduction kernel uses
-    const int pair = cot * (Cin / 32) + cg * CIT + c;
-    float* out = part + ((int64_t)bid.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
+  for (int o = 0; o < COT; ++o)
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int tap = (TWOD ? 9 : 0) + wave + 4 * i;        // TWOD: only taps 9..17 are written (and later reduced)
-      if (tap < (TWOD ? 18 : 27)) {
+    for (int c = 0; c < CIT; ++c) {
+      // pair index of (co tile cot * COT + o, ci tile cg * CIT + c) in the [Cout/32][Cin/32] enumeration the reduction uses
+      const int pair = (cot * COT + o) * (Cin / 32) + cg * CIT + c;
+      float* out = part + ((int64_t)bid.x * ((Cin / 32) * (Cout / 32)) + pair) * (27 * 1024);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4)
-          *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
-              make_float4(acc[c * 7 + i][4 * g4 + 0], acc[c * 7 + i][4 * g4 + 1], acc[c * 7 + i][4 * g4 + 2],
-                          acc[c * 7 + i][4 * g4 + 3]);
+      for (int i = 0; i < 7; ++i) {
+        const int tap = (TWOD ? 9 : 0) + wave + 4 * i;      // TWOD: only taps 9..17 are written (and later reduced)
+        if (tap < (TWOD ? 18 : 27)) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
+                make_float4(acc[(o * CIT + c) * 7 + i][4 * g4 + 0], acc[(o * CIT + c) * 7 + i][4 * g4 + 1],
+                            acc[(o * CIT + c) * 7 + i][4 * g4 + 2], acc[(o * CIT + c) * 7 + i][4 * g4 + 3]);
+        }
       }
     }
-  }
 }
 
-template <int TW, int CIT, bool TWOD>
+template <int TW, int CIT, int COT, bool TWOD>
 __global__ void __launch_bounds__(256)
 conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int N, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW,
                   int dsegs, int dlen, const bf16_t* __restrict__ x1, int xcd) {
   const FplxBlock bid = fplx_xcd_block(xcd);
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform
-    case 0: wgrad_march<TW, 0, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
-    case 1: wgrad_march<TW, 1, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
-    case 2: wgrad_march<TW, 2, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
-    default: wgrad_march<TW, 3, CIT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 0: wgrad_march<TW, 0, CIT, COT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 1: wgrad_march<TW, 1, CIT, COT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 2: wgrad_march<TW, 2, CIT, COT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    default: wgrad_march<TW, 3, CIT, COT, TWOD>(x, ldx, dy, ldy, part, N, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
   }
 }
 
@@ -407,7 +422,12 @@ wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Ci
   else dw[((int64_t)co * Cin + ci) * 27 + tap] = t;
 }
 
-struct WgCfg { int tw, cit, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
+struct WgCfg { int tw, cit, cot, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
+
+static inline int64_t cot_env_min_vox() {
+  static const int64_t v = [] { const char* e = getenv("FPLX_WG_COT_MINVOX"); return e ? atoll(e) : 0; }();
+  return v;
+}
 
 inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   WgCfg c;
@@ -428,6 +448,10 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
     // two ci tiles per block: dy is read once for both and x in whole 128-byte lines (-15 % at level 0/1); the small
     // deep volumes need the block count more (measured: slower below 32 K voxels per sample)
     c.cit = (cin % 64 == 0 && cit_env == 2 && (int64_t)d * h * w >= 32000) ? 2 : 1;
+    // two co tiles per block instead where Cout allows: every x fragment then feeds two MFMAs (A/B knob FPLX_WG_COT)
+    static const int cot_env = [] { const char* e = getenv("FPLX_WG_COT"); return e ? atoi(e) : 2; }();
+    c.cot = 1;
+    if (cout % 64 == 0 && cot_env == 2 && (cot_env_min_vox() <= (int64_t)d * h * w)) { c.cot = 2; c.cit = 1; }
   }
   const int tiles = n * c.tilesH * c.tilesW;
   // one block per CU at a time (LDS + 512-register waves): pick the depth split that minimises
@@ -442,7 +466,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
       const int dl = (d + cand - 1) / cand;
       if (dl < 4 && cand > 1) break;
       const int segs = (d + dl - 1) / dl;
-      const int64_t rounds = ((int64_t)tiles * (c.npairs / c.cit) * segs + 255) / 256;
+      const int64_t rounds = ((int64_t)tiles * (c.npairs / (c.cit * c.cot)) * segs + 255) / 256;
       const double cost = (double)rounds * (dl + 9.0);
       if (cost < best - 1e-9) { best = cost; ds = segs; }
     }
@@ -1463,17 +1487,17 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
   if (x1 && (c.cit != 2 || cin != 64 || ((uintptr_t)x1 % 16))) return 0;   // split x: one group of two ci tiles
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
-  dim3 grid(c.nblk, c.npairs / c.cit);
-#define LAUNCH_WG2(TW_, CIT_, TWOD_)                                                                                \
+  dim3 grid(c.nblk, c.npairs / (c.cit * c.cot));
+#define LAUNCH_WG2(TW_, CIT_, COT_, TWOD_)                                                                          \
   do {                                                                                                              \
-    const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + WG_TH * TW_) * 64;                             \
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    conv_wgrad_stream<TW_, CIT_, TWOD_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
+    const size_t lds = (size_t)(3 * CIT_ * (WG_TH + 2) * (TW_ + 2) + COT_ * WG_TH * TW_) * 64;                      \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_stream<TW_, CIT_, COT_, TWOD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    conv_wgrad_stream<TW_, CIT_, COT_, TWOD_><<<grid, 256, lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, n, d, \
                                                                 h, w, cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
   } while (0)
-#define LAUNCH_WG(TW_, CIT_) do { if (mid) LAUNCH_WG2(TW_, CIT_, true); else LAUNCH_WG2(TW_, CIT_, false); } while (0)
-  if (c.tw == 32) { if (c.cit == 2) LAUNCH_WG(32, 2); else LAUNCH_WG(32, 1); }
-  else { if (c.cit == 2) LAUNCH_WG(16, 2); else LAUNCH_WG(16, 1); }
+#define LAUNCH_WG(TW_, CIT_, COT_) do { if (mid) LAUNCH_WG2(TW_, CIT_, COT_, true); else LAUNCH_WG2(TW_, CIT_, COT_, false); } while (0)
+  if (c.tw == 32) { if (c.cot == 2) LAUNCH_WG(32, 1, 2); else if (c.cit == 2) LAUNCH_WG(32, 2, 1); else LAUNCH_WG(32, 1, 1); }
+  else { if (c.cot == 2) LAUNCH_WG(16, 1, 2); else if (c.cit == 2) LAUNCH_WG(16, 2, 1); else LAUNCH_WG(16, 1, 1); }
 #undef LAUNCH_WG
 #undef LAUNCH_WG2
   const int64_t total = (int64_t)c.npairs * 27 * 1024;

@@ -358,26 +358,31 @@ class Engine(object):
             gw = gv[key + ".weight"]
             two_d = gw.dim() == 4                      # Conv2d of a 2.5D level: only the middle-plane taps exist
             if isinstance(xin, tuple):                 # cat([skip, up]) as two tensors (train-mode BN only: db is None)
-                on_side(lambda: ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, gw, dims[l], cin, c, ws_w, two_d),
-                        d_out, xin[0], xin[1])
                 if want_dx:
                     ops.conv3d_dgrad_split2(d_out, packs[key][1], dx_view[0], dx_view[1], dims[l], cin, c, two_d)
                     if tap is not None:
                         tap(key + ".dx0", dx_view[0])
                         tap(key + ".dx1", dx_view[1])
+                on_side(lambda: ops.conv3d_wgrad_cat2(xin[0], xin[1], d_out, gw, dims[l], cin, c, ws_w, two_d),
+                        d_out, xin[0], xin[1])
                 return
-            if two_d:
-                on_side(lambda: ops.conv2d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
-                                                 dims[l], cin, c, ws_w), d_out, xin)
-            else:
-                on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
-                                                 dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
+            def wg():
+                if two_d:
+                    on_side(lambda: ops.conv2d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
+                                                     dims[l], cin, c, ws_w), d_out, xin)
+                else:
+                    on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
+                                                     dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
             if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None,
                                mid=two_d)
                 if tap is not None:
                     tap(key + ".dx", dx_view)
+            # the weight gradient is enqueued BEHIND the data gradient: the side stream's event then follows the data-gradient
+            # kernel, so the two matrix kernels of a site do not start together and split the chip - the weight gradient runs
+            # beside the next site's BatchNorm passes (memory-bound) instead (measured -0.4 % on the step)
+            wg()
 
         def block_bwd(b, d_out, want_dx, reduced=False):
             """d_out: gradient w.r.t. the block output [V, C] (overwritten).  Returns d(block input) or None."""

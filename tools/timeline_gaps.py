@@ -53,3 +53,14 @@ for g, a, b in gaps:
     agg[(a, b)][1] += 1
 for (a, b), (g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
     print("  %8.1f us in %3d gaps (avg %.1f)  %s -> %s" % (g / 1e3, c, g / 1e3 / c, a, b))
+
+# the critical path: kernels of the busiest queue (the main stream) by total time in the window
+mainq = max(per_q.items(), key=lambda kv: kv[1])[0]
+fam = defaultdict(lambda: [0, 0])
+for s_, e_, q, n in rows:
+    if q == mainq:
+        fam[n][0] += e_ - s_
+        fam[n][1] += 1
+print("main queue %s, per step:" % mainq)
+for n, (t, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])[:40]:
+    print("  %8.1f us  %5.1f launches  avg %7.1f  %s" % (t / 1e3 / nsteps, c / nsteps, t / 1e3 / c, n))
