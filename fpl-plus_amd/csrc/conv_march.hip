@@ -690,7 +690,7 @@ conv_fwd_march32v2(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
 // Same tiling, LDS image, DMA, rotation and write-out as v2; what changes is the fragment geometry - a lane is (row or
 // column r16 = lane & 15, k-group kg = lane >> 4), one MFMA spans all 32 input channels, an accumulator tile is four
 // 16 x 16 blocks (voxel half x cout half) - and the weight image's swizzle (wswz).
-template <bool STATS>
+template <bool STATS, int ASWZ>
 __global__ void __launch_bounds__(MG2::THREADS)
 conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                    const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
@@ -720,6 +720,10 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
   // lanes on 16 different bank quads (the slab keeps the (row >> 2) & 3 swizzle: its fragments start at any voxel, a
   // fixed function cannot serve every alignment, and a 2-way conflict on a third of the reads is far from the LDS limit)
   auto wswz = [](int row) { const int q = (row >> 2) & 3; return (4 - q) & 3; };
+  // slab image: the 16 x 16 x 32 A fragments (lane = voxel r16, 16-byte chunk kg = lane >> 4) are conflict-free with the chunk
+  // XORed by 2 * ((vox >> 2) & 1); the (vox >> 2) & 3 of the 32 x 32 x 16 kernels costs this read pattern 2-way conflicts in
+  // most lane groups (SQ_LDS_BANK_CONFLICT 0.31 of the LDS cycles, profiles/r02_pmc_sq_counters.txt)
+  auto aswz = [](int vox) { return ASWZ ? ((vox >> 2) & 1) << 1 : (vox >> 2) & 3; };
   auto lds_dma = [&](const void* g, char* l) {          // see conv_fwd_march32 (the resident weights come this way)
     const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
     unsigned keep;
@@ -743,7 +747,7 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
     int piece = wave + G::WAVES * k;
     if (piece > G::SLAB_DMA - 1) piece = G::SLAB_DMA - 1;      // wave 3's tenth piece repeats wave 2's (same bytes, same place)
     const int i = piece * 64 + lane;
-    const int vox = i >> 2, c = (i & 3) ^ G::swz(vox);
+    const int vox = i >> 2, c = (i & 3) ^ aswz(vox);
     const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
     const bool in = i < G::SLAB_CHUNKS && hh >= 0 && hh < H && ww >= 0 && ww < W;
     voff_s[k * G::THREADS + tid] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
@@ -851,7 +855,7 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
 #pragma unroll
     for (int rho = 0; rho < 6; ++rho) {
       const int vox = vb + rho * G::SW + kw + mh * 16;
-      fa[buf][rho] = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((kg ^ G::swz(vox)) << 4));
+      fa[buf][rho] = *reinterpret_cast<const bf16x8*>(sl + vox * G::ROWB + ((kg ^ aswz(vox)) << 4));
     }
   };
   auto load_b = [&](int kw, int kd) {                    // the six fragments (kh, cout half) of depth tap kd
@@ -1432,17 +1436,19 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                                                 ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
                                                                 c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
   } while (0)
-#define LAUNCH_M32V3(STATS_)                                                                                        \
+#define LAUNCH_M32V3X(STATS_, ASWZ_)                                                                                      \
   do {                                                                                                              \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_march32v3<STATS_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG2::LDS); \
-    conv_fwd_march32v3<STATS_><<<grid, MG2::THREADS, MG2::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march32v3<STATS_, ASWZ_>, hipFuncAttributeMaxDynamicSharedMemorySize, MG2::LDS); \
+    conv_fwd_march32v3<STATS_, ASWZ_><<<grid, MG2::THREADS, MG2::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
                                                                 ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
                                                                 c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
   } while (0)
+#define LAUNCH_M32V3(STATS_) LAUNCH_M32V3X(STATS_, 1)      /* ASWZ = 0: the 32 x 32 x 16 kernels' swizzle (A/B builds) */
       // 1: v2 everywhere; 3: v3 everywhere; 4: v3 where no statistics are wanted (its STATS form spills), v2 otherwise
       if (stats) { if (kv2 == 3) LAUNCH_M32V3(true); else LAUNCH_M32V2(true); }
       else { if (kv2 >= 3) LAUNCH_M32V3(false); else LAUNCH_M32V2(false); }
 #undef LAUNCH_M32V3
+#undef LAUNCH_M32V3X
 #undef LAUNCH_M32V2
       const int rc2 = fplx_check_launch("march32v2_conv3d_fwd");
       return rc2 < 0 ? rc2 : 1;
