@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     # every exported fplx_ symbol is declared (nm view)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T fplx_" in l and "fplx_mfma_" not in l and "fplx_edge_" not in l
-                      and "fplx_march_" not in l)  # cross-file internals
+                      and "fplx_march_" not in l and "fplx_brick_" not in l)  # cross-file internals
     assert exported == names, set(exported) ^ set(names)
     # error path works without a GPU: bad arguments are rejected before any launch
     assert lib.fplx_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == -5
