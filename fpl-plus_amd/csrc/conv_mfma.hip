@@ -60,6 +60,48 @@ conv_fwd_direct(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
   constexpr int NTAPS = MODE == 0 ? 27 : (MODE == 1 ? 8 : 4), SD = MODE == 2 ? 1 : 2;
+  if (MODE != 0 && gridDim.z == 1) {
+    // Transposed-convolution data gradient: no padding, so a tap is a block-uniform offset from the lane's tap-0 row and
+    // the (tap, 16-channel step) loop is a flat stream of independent loads.  Four steps are kept in flight per wave: the
+    // plain loop below waits out a full memory round trip per step (up1 of the benchmark, 327 MB: 102 us = 3.3 TB/s)
+    constexpr int P = 4;
+    const bf16_t* a0[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int64_t vi = (((int64_t)vn[t] * SD * D + SD * vd[t]) * 2 * H + 2 * vh[t]) * 2 * W + 2 * vw[t];
+      a0[t] = x + (vok[t] ? vi : 0) * ldx + kh8;
+    }
+    const bf16_t* b0[NTL];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) b0[j] = wp + ((int64_t)(n0 + j * 32 + r)) * Cin + kh8;
+    const int KS = Cin / 16, NIT = NTAPS * KS;
+    bf16x8 ra[P][MT], rb[P][NTL];
+    auto fetch = [&](int it, int u) {
+      const int tap = it / KS, kc = (it - tap * KS) * 16;
+      const int64_t toff = ((int64_t)((tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1)) * ldx + kc;   // uniform
+      const int64_t woff = (int64_t)tap * Cout * Cin + kc;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) ra[u][t] = vok[t] ? *reinterpret_cast<const bf16x8*>(a0[t] + toff) : zero;
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) rb[u][j] = *reinterpret_cast<const bf16x8*>(b0[j] + woff);
+    };
+#pragma unroll
+    for (int u = 0; u < P; ++u) fetch(u < NIT ? u : NIT - 1, u);
+    for (int it = 0; it < NIT; it += P) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        if (it + u < NIT) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+              acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[u][t], rb[u][j], acc[t][j], 0, 0, 0);
+        }
+        const int nx = it + P + u;
+        fetch(nx < NIT ? nx : NIT - 1, u);            // past the end: a harmless re-read (keeps the loop branch-free)
+      }
+    }
+  } else
   for (int tap = blockIdx.z; tap < NTAPS; tap += gridDim.z) {
     const bf16_t* ap[MT];
     bool aok[MT];
@@ -568,6 +610,99 @@ deconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
         const int64_t ov = ((vv * sd * D + sd * d0 + (tap >> 2)) * 2 * H + 2 * h0 + ((tap >> 1) & 1)) * 2 * W + 2 * w0 + (tap & 1);
         y[ov * ldy + co] = (bf16_t)(acc[t][i] + bv);
       }
+    }
+  }
+}
+
+// deconv_fwd_rows: ConvTranspose3d(k=2,s=2) forward as a streaming kernel for the shallow levels (Cin <= 128, Cout 32 | 64),
+// where the op is pure HBM traffic (up1 of the benchmark: 66 MB in, 262 MB out; deconv_fwd_mfma above: 118 us = 2.8 TB/s,
+// short-lived waves with one tile each, half-line stores per tap).  Persistent blocks walk tiles of 32 consecutive input
+// voxels; wave (i, j) of a block owns the output rows (2d + i, 2h + j): its taps k = 0, 1 are the two w-neighbours
+// (2w, 2w + 1), i.e. one contiguous piece of 2 * Cout channels per input voxel.  The wave's weight fragments (2 taps x
+// Cout / 32 x Cin / 16) live in registers for the whole kernel, the next tile's x rows are requested before the current
+// tile's MFMAs, and the result leaves through an LDS tile [voxel][k][Cout] as 16-byte stores whose lanes run along
+// whole output rows.
+template <int KS, int NTC>        // Cin / 16, Cout / 32
+__global__ void __launch_bounds__(256)
+deconv_fwd_rows(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
+                bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int xcd) {
+  constexpr int CIN = KS * 16, COUT = NTC * 32, RB = 2 * COUT * 2, CPR = RB / 16;     // row bytes / chunks of the LDS tile
+  __shared__ __attribute__((aligned(16))) char tile_all[4][32 * RB];
+  __shared__ int64_t obase_all[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, khalf = lane >> 5, kh8 = khalf * 8;
+  const int ti = wave >> 1, tj = wave & 1;
+  const int64_t V = (int64_t)N * D * H * W, ntiles = (V + 31) / 32;
+  bf16x8 bfr[2][NTC][KS];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+      for (int sx = 0; sx < KS; ++sx)
+        bfr[k][nt][sx] = *reinterpret_cast<const bf16x8*>(wf + ((int64_t)(ti * 4 + tj * 2 + k) * COUT + nt * 32 + r) * CIN +
+                                                          sx * 16 + kh8);
+  float bv[NTC];
+#pragma unroll
+  for (int nt = 0; nt < NTC; ++nt) bv[nt] = bias ? bias[nt * 32 + r] : 0.f;
+  char* tile = tile_all[wave];
+  int64_t* obase = obase_all[wave];
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  bf16x8 an[KS];
+  auto fetch = [&](int64_t tt) {
+    const int64_t v = tt * 32 + r;
+    const bf16_t* ap = x + (v < V ? v : 0) * ldx + kh8;
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) an[sx] = v < V ? *reinterpret_cast<const bf16x8*>(ap + sx * 16) : zero;
+  };
+  int64_t tt = tr.first;
+  if (tt < tr.end) fetch(tt);
+  for (; tt < tr.end; tt += tr.step) {
+    bf16x8 a[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) a[sx] = an[sx];
+    if (tt + tr.step < tr.end) fetch(tt + tr.step);
+    // this lane's voxel -> its first output voxel (2d + i, 2h + j, 2w) of the wave's row pair; -1 past the end
+    if (lane < 32) {
+      const int64_t v = tt * 32 + r;
+      int64_t ob = -1;
+      if (v < V) {
+        unsigned q = (unsigned)v;
+        const int w0 = (int)(q % (unsigned)W); q /= (unsigned)W;
+        const int h0 = (int)(q % (unsigned)H); q /= (unsigned)H;
+        const int d0 = (int)(q % (unsigned)D); q /= (unsigned)D;
+        ob = (((int64_t)q * 2 * D + 2 * d0 + ti) * 2 * H + 2 * h0 + tj) * 2 * W + 2 * w0;
+      }
+      obase[r] = ob;
+    }
+    f32x16 acc[2][NTC];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][nt][i] = 0.f;
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) acc[k][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sx], bfr[k][nt][sx], acc[k][nt], 0, 0, 0);
+      }
+    // accumulator: lane = channel r of N-tile nt, registers = voxels  ->  tile[voxel][k][channel]
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int nt = 0; nt < NTC; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          *reinterpret_cast<bf16_t*>(tile + ((i & 3) + 8 * (i >> 2) + 4 * khalf) * RB + k * (COUT * 2) + nt * 64 + r * 2) =
+              (bf16_t)(acc[k][nt][i] + bv[nt]);
+    // 16-byte stores: consecutive lanes run along a voxel's 2 * Cout channels, then along w
+#pragma unroll
+    for (int q = 0; q < 32 * CPR / 64; ++q) {
+      const int e = lane + 64 * q, vox = e / CPR, c = e % CPR;
+      const int k = c / (CPR / 2), cc = c % (CPR / 2);
+      const uint4 pk = *reinterpret_cast<const uint4*>(tile + vox * RB + c * 16);
+      const int64_t ob = obase[vox];
+      if (ob >= 0) *reinterpret_cast<uint4*>(y + (ob + k) * ldy + cc * 8) = pk;
     }
   }
 }
@@ -1513,8 +1648,26 @@ extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf,
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)wf % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   if (V >= ((int64_t)1 << 31)) return 0;
-  dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
   const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
+  {
+    static const int krows = [] { const char* e = getenv("FPLX_DECONV_ROWS"); return e ? atoi(e) : 1; }();   // A/B knob
+    const int ks = cin / 16, ntc = cout / 32;
+    if (krows && sd == 2 && vec_ok && V >= 32 * 1024 && ((ks == 4 && ntc == 1) || (ks == 8 && ntc == 2) || (ks == 8 && ntc == 1) ||
+                                                         (ks == 4 && ntc == 2))) {
+      const int64_t nt = (V + 31) / 32;
+      const unsigned nb = (unsigned)(nt < 1024 ? nt : 1024);
+#define LAUNCH_DR(KS_, NTC_) deconv_fwd_rows<KS_, NTC_><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, \
+                                                                           (bf16_t*)y, ldy, n, d, h, w, fplx_xcd_on())
+      if (ks == 4 && ntc == 1) LAUNCH_DR(4, 1);
+      else if (ks == 8 && ntc == 2) LAUNCH_DR(8, 2);
+      else if (ks == 8 && ntc == 1) LAUNCH_DR(8, 1);
+      else LAUNCH_DR(4, 2);
+#undef LAUNCH_DR
+      int rc = fplx_check_launch("mfma_deconv2_fwd_rows");
+      return rc < 0 ? rc : 1;
+    }
+  }
+  dim3 grid((unsigned)((V + 127) / 128), cout / 32, sd);      // blockIdx.z = depth tap i (4 in-plane taps per block)
   deconv_fwd_mfma<<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d,
                                                    h, w, cin, cout, sd, vec_ok, fplx_xcd_on());
   int rc = fplx_check_launch("mfma_deconv2_fwd");

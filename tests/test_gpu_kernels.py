@@ -238,7 +238,10 @@ def test_conv3d_cat2_split_concat(shape):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("shape", [(2, 12, 7, 3, 4, 5), (2, 64, 32, 3, 4, 5), (1, 128, 64, 2, 5, 9), (1, 32, 32, 4, 4, 7),
-                                   (1, 96, 32, 2, 3, 67)])
+                                   (1, 96, 32, 2, 3, 67),
+                                   # >= 32768 input voxels, Cin 64 | 128, Cout 32 | 64: the streaming forward
+                                   # (deconv_fwd_rows), ragged last tile, two samples; the pipelined data gradient
+                                   (2, 64, 32, 9, 37, 50), (1, 128, 64, 8, 65, 63)])
 def test_deconv2_fwd_bwd(dtype, tol, shape):
     from fplx import ops
     n, cin, cout, d, h, w = shape
