@@ -90,10 +90,15 @@ class Engine(object):
         self._pack_cache = None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True):
+    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1):
         """x: fp32 [N, Cin, D, H, W] contiguous on the GPU -> logits fp32 [N, class_num, D, H, W].
         train: BatchNorm uses batch statistics (and updates the running ones);
-        drop_on: list of 9 bools - dropout active per ConvBlockND."""
+        drop_on: list of 9 bools - dropout active per ConvBlockND.
+        mc > 1 (inference only: eval-mode BatchNorm, nothing kept): `mc` Monte-Carlo passes of test-time dropout over the SAME
+        input in one call -> logits [mc * N, ...], pass-major.  Equal to forward(x.repeat(mc, 1, 1, 1, 1)) - the dropout
+        masks are keyed by the element index of the mc * N batch - but the encoder levels above the first active dropout see
+        the same input in every pass and are computed ONCE (the shipped configs drop out at levels 2-4 only: levels 0 and 1,
+        the two most expensive, run once instead of `mc` times; reference: agent_seg.py:898-909 runs the whole net per pass)."""
         net = self.net
         ops.require_gpu(x)
         if x.dim() != 5:
@@ -119,10 +124,25 @@ class Engine(object):
             self._pack_cache = None if train else (adt, packs)
         else:
             packs = self._pack_cache[1]
-        dims = [(N, D, H, W)]
+        if mc > 1 and (train or keep):
+            raise ValueError("fplx: Monte-Carlo replication (mc > 1) is an inference mode: eval-mode BatchNorm, keep=False")
+        # first encoder level whose input differs between Monte-Carlo passes (the level after the first active dropout)
+        rep = 5
+        if mc > 1:
+            act = [b for b in range(5) if drop_on[b] and net.block_modules[b].dropout_p > 0]
+            rep = act[0] if act else 5
+            if rep == 5:                                 # no dropout is active: every pass is the same forward
+                logits, _ = self.forward(x, domain, train, drop_on, seed, step, keep, 1)
+                return logits.repeat(mc, 1, 1, 1, 1), None
+        NM = N * mc
+        dims = [(NM, D, H, W)]                           # decoder view: every level holds all passes
         for l in range(4):
-            dims.append((N, dims[l][1] // pds[l], dims[l][2] // 2, dims[l][3] // 2))
+            dims.append((NM, dims[l][1] // pds[l], dims[l][2] // 2, dims[l][3] // 2))
         vox = [n * d * h * w for (n, d, h, w) in dims]
+        # encoder view: levels < rep hold ONE copy.  (The first conv site of block `rep` is still shared - its dropout is
+        # what makes the passes differ - but replicating its input keeps the element indices the masks are keyed by.)
+        edims = [((N if l < rep else NM),) + dims[l][1:] for l in range(5)]
+        evox = [n * d * h * w for (n, d, h, w) in edims]
 
         sv = Saved()
         sv.x, sv.dims, sv.domain, sv.train, sv.seed, sv.step = x, dims, domain, train, seed, step
@@ -149,8 +169,10 @@ class Engine(object):
                 skips.append(cats[l][:, :ft[l]])
                 ups.append(cats[l][:, ft[l]:])
         sv.cats, sv.skips, sv.split = cats, skips, split
+        # shared encoder levels write their skip once; it is copied into the decoder's (all-passes) buffer afterwards
+        eskips = [empty(evox[l], ft[l]) if evox[l] != vox[l] else skips[l] for l in range(4)]
 
-        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None):
+        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None, dims=dims, vox=vox):
             """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view; pool = (pooled, pd): the
             MaxPool of out_view is produced by the same pass (tail of a DownBlock)"""
             conv, bn, prelu = site
@@ -181,31 +203,39 @@ class Engine(object):
                 ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
             return y, bnbuf, pp
 
-        def conv_block(b, xin, xs, x_dt, cin, l, out_view, pool=None):
+        def conv_block(b, xin, xs, x_dt, cin, l, out_view, pool=None, dims=dims, vox=vox):
             blk = net.block_modules[b]
             key = net.block_keys[b]
             c = ft[l]
             a1 = empty(vox[l], c)
             sid = step * 16 + b
             y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + "." + blk.cname(1),
-                                    (blk.conv_of(1), blk.bn_of(1), blk.relu_1), l, a1, blk.dropout_p, sid, drop_on[b])
+                                    (blk.conv_of(1), blk.bn_of(1), blk.relu_1), l, a1, blk.dropout_p, sid, drop_on[b],
+                                    dims=dims, vox=vox)
             y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + "." + blk.cname(2),
-                                   (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False, pool)
+                                   (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False, pool,
+                                   dims=dims, vox=vox)
             sv.blocks.append(dict(xin=xin, xs=xs, x_dt=x_dt, cin=cin, l=l, y1=y1, bn1=bn1, p1=p1, sid=sid, a1=a1,
                                   y2=y2, bn2=bn2, out=out_view))
 
         # ---- encoder
         cur, cur_s, cur_dt, cur_c = x, ops.planar_strides(Cin, D, H, W), F32, Cin
+        if rep == 0 and mc > 1:
+            cur = x.repeat(mc, 1, 1, 1, 1)
         for i in range(5):
-            out_view = skips[i] if i < 4 else empty(vox[4], ft[4])
+            out_view = eskips[i] if i < 4 else empty(evox[4], ft[4])
             fused = i < 4 and self.use_fused_pool and ops.bn_pool_fused_ok(ft[i], adt)
-            pooled = empty(vox[i + 1], ft[i]) if i < 4 else None
-            conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view, (pooled, pds[i]) if fused else None)
+            pooled = empty(evox[i] // (pds[i] * 4), ft[i]) if i < 4 else None
+            conv_block(i, cur, cur_s, cur_dt, cur_c, i, out_view, (pooled, pds[i]) if fused else None, dims=edims, vox=evox)
             if i < 4:
                 if not fused:
-                    ops.maxpool2_fwd(out_view, pooled, dims[i], ft[i], pds[i])
+                    ops.maxpool2_fwd(out_view, pooled, edims[i], ft[i], pds[i])
+                if eskips[i] is not skips[i]:          # one copy -> every pass's slot of the decoder input
+                    skips[i].view(mc, evox[i], ft[i])[:] = eskips[i]
+                if evox[i + 1] != pooled.shape[0]:     # the next level is the first one that differs between passes
+                    pooled = pooled.repeat(mc, 1)
                 sv.pooled.append(pooled)
-                cur, cur_s, cur_dt, cur_c = pooled, ops.cl_strides(*dims[i + 1][1:], ft[i]), a_dt, ft[i]
+                cur, cur_s, cur_dt, cur_c = pooled, ops.cl_strides(*edims[i + 1][1:], ft[i]), a_dt, ft[i]
             else:
                 cur = out_view
         # ---- decoder
@@ -229,7 +259,7 @@ class Engine(object):
             cur = out
         # ---- out_conv (1x3x3) -> fp32 planar logits
         ncls = net.n_class
-        logits = torch.empty((N, ncls, D, H, W), dtype=torch.float32, device=dev)
+        logits = torch.empty((NM, ncls, D, H, W), dtype=torch.float32, device=dev)
         ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
                        ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
         return logits, (sv if keep else None)

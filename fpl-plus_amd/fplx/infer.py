@@ -73,27 +73,34 @@ class Inferer(object):
                 window[0], window[1], window[2], fl, len(flips))
 
     # ------------------------------------------------------------------ batched path (single-output networks)
-    def _forward_chunks(self, patches_in, n, domain_label, passes):
-        """patches_in [B, C, wd, wh, ww] with B = passes * flips * tiles * n -> logits [B, classes, wd, wh, ww]"""
+    def _forward_chunks(self, patches, n, domain_label, passes):
+        """patches [nb, C, wd, wh, ww] with nb = flips * tiles * n -> logits [passes * nb, classes, wd, wh, ww], pass-major.
+        Monte-Carlo passes see the same patches; their dropout masks differ per sample of the batch.  A network that offers
+        forward_mc (fplx.UNet2D5_dsbn in eval mode) computes the part above its first active dropout once for all passes."""
         model = self.model
-        B = patches_in.shape[0]
-        per = patches_in[0, 0].numel()
+        nb = patches.shape[0]
+        per = patches[0, 0].numel()
         if getattr(model, 'training', False):
             chunk = n                                     # train-mode BatchNorm: the reference's batches, one tile each
         else:
-            chunk = max(n, (self.max_batch_voxels // max(per, 1)) // n * n)
+            chunk = max(n, (self.max_batch_voxels // max(per * passes, 1)) // n * n)
         dom = int(domain_label[0]) if domain_label is not None else 0
+        shared = passes > 1 and hasattr(model, "forward_mc") and not getattr(model, 'training', False)
         out = None
-        for b0 in range(0, B, chunk):
-            b1 = min(B, b0 + chunk)
-            dl = torch.full((b1 - b0,), dom, dtype=torch.long)
-            o = model(patches_in[b0:b1], domain_label=dl)
+        for b0 in range(0, nb, chunk):
+            b1 = min(nb, b0 + chunk)
+            m = b1 - b0
+            if shared:
+                o = model.forward_mc(patches[b0:b1], torch.full((m,), dom, dtype=torch.long), passes)
+            else:
+                xin = patches[b0:b1] if passes == 1 else patches[b0:b1].repeat(passes, 1, 1, 1, 1)
+                o = model(xin, domain_label=torch.full((m * passes,), dom, dtype=torch.long))
             if isinstance(o, (tuple, list)):
                 return None                               # several outputs: the generic path handles it
             if out is None:
-                out = torch.empty((B,) + tuple(o.shape[1:]), dtype=torch.float32, device=o.device)
-            out[b0:b1] = o
-        return out
+                out = torch.empty((passes, nb) + tuple(o.shape[1:]), dtype=torch.float32, device=o.device)
+            out[:, b0:b1] = o.view((passes, m) + tuple(o.shape[1:]))
+        return out.view((passes * nb,) + tuple(out.shape[2:]))
 
     def _run_batched(self, image, domain_label, passes):
         window, starts, flips = self._plan(image)
@@ -105,9 +112,7 @@ class Inferer(object):
         cargs = self._c_args(tuple(image.shape), window, starts, flips)
         one = torch.empty((nb, image.shape[1]) + tuple(window), dtype=torch.float32, device=image.device)
         call("fplx_sw_extract", ops.ptr(image), *cargs, ops.ptr(one), ops.stream())
-        # Monte-Carlo passes see the same patches; their dropout masks differ per sample of the batch
-        patches_in = one if passes == 1 else one.unsqueeze(0).expand(passes, *one.shape).reshape((passes * nb,) + tuple(one.shape[1:]))
-        logits = self._forward_chunks(patches_in, n, domain_label, passes)
+        logits = self._forward_chunks(one, n, domain_label, passes)
         if logits is None:
             return None
         classes = logits.shape[1]

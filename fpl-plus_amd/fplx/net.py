@@ -290,6 +290,23 @@ class UNet2D5_dsbn(nn.Module):
         reference flips for test-time dropout, agent_seg.py:845-852)"""
         return [m.dropout.training and m.dropout_p > 0 for m in self.block_modules]
 
+    def forward_mc(self, x, domain_label, passes):
+        """`passes` Monte-Carlo forwards (test-time dropout) of the same batch in one call -> [passes * N, classes, D, H, W],
+        pass-major; the encoder levels above the first active dropout are computed once (Engine.forward, mc).  Inference
+        only: eval-mode BatchNorm (the reference's test-time dropout, agent_seg.py:845-852, flips the Dropout children only)."""
+        if self.training:
+            raise RuntimeError("fplx: forward_mc needs eval-mode BatchNorm (net.eval(); Dropout children may be in train mode)")
+        if not x.is_cuda:
+            raise RuntimeError("fplx UNet2D5_dsbn runs on the GPU only (libfplx.so HIP kernels); got a CPU tensor")
+        self._ensure_flat()
+        domain = 0 if domain_label is None else int(domain_label[0])
+        step = self._fwd_counter
+        self._fwd_counter += 1
+        with torch.no_grad():
+            logits, _ = self.engine.forward(x, domain, False, self.dropout_active(), self.dropout_seed, step, keep=False,
+                                            mc=int(passes))
+        return logits
+
     def forward(self, x, domain_label=None):
         if not x.is_cuda:
             raise RuntimeError("fplx UNet2D5_dsbn runs on the GPU only (libfplx.so HIP kernels); got a CPU tensor")

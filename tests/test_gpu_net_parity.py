@@ -143,6 +143,40 @@ def test_dropout_stream_matches_oracle_philox():
         assert np.abs(got - ref).max() < LOGIT_TOL
 
 
+@pytest.mark.parametrize("prec,drop", [("fp32", [0, 0, 0.3, 0.4, 0.5]), ("bf16", [0, 0, 0.3, 0.4, 0.5]),
+                                       ("fp32", [0.2, 0, 0, 0, 0.5]), ("fp32", [0, 0, 0, 0, 0])])
+def test_monte_carlo_passes_share_the_encoder_levels_above_the_first_dropout(prec, drop):
+    """forward_mc (test-time dropout, `passes` forwards of one batch in one call, encoder levels above the first active
+    dropout computed once) == the plain forward of the batch repeated `passes` times: same Philox element indices, so the
+    same masks (reference: agent_seg.py:898-909 runs the whole network once per pass)"""
+    name, passes = "tiny", 3
+    net, p = _net(name, prec, drop)
+    x = torch.from_numpy(detdata.normal("x." + name, SHAPES[name])).cuda()
+    net.eval()
+    for m in net.modules():
+        if type(m) == torch.nn.Dropout:
+            m.train()
+    net.dropout_seed = 5
+    dl = torch.ones(x.shape[0], dtype=torch.long)
+    with torch.no_grad():
+        net._fwd_counter = 11
+        ref = net(x.repeat(passes, 1, 1, 1, 1), domain_label=dl.repeat(passes))
+        net._fwd_counter = 11
+        got = net.forward_mc(x, dl, passes)
+    assert got.shape == ref.shape
+    scale = float(ref.abs().max())
+    tol = 1e-5 if prec == "fp32" else 2e-2           # bf16: the split-K plans differ with the batch size
+    assert float((got - ref).abs().max()) <= tol * scale
+    n = x.shape[0]
+    if any(drop):
+        assert not torch.equal(got[:n], got[n:2 * n])        # the passes differ
+    else:
+        assert torch.equal(got[:n], got[n:2 * n])
+    net.train()
+    with pytest.raises(RuntimeError):
+        net.forward_mc(x, dl, passes)
+
+
 def test_error_behaviour_mirrors_reference():
     import fplx
     net, p = _net("tiny")

@@ -1,16 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_net_parity.py -m gpu -x -q 2>&1 | tail -n 2
-export TMPDIR=/tmp FPLX_SIDE_STREAM=0
-mkdir -p gpurun_out/tl
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl/trace -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing > gpurun_out/tl/trace.log 2>&1
-f=$(find gpurun_out/tl/trace -name "*kernel_trace.csv" | head -1)
-python tools/trace_summary.py $f gpurun_out/tl/by_shape.csv > /dev/null
-grep -i "direct\|deconv_fwd" gpurun_out/tl/by_shape.csv
-rm -rf gpurun_out/tl/trace
-unset FPLX_SIDE_STREAM
-for p in 1 0; do
-FPLX_DECONV_ROWS=$p timeout 600 python bench.py --no-cpu-baseline 2>&1 | grep '"metric"' | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print('rows $p', d['value'], d['ms_per_step'])"
-done
+timeout 1500 python -m pytest tests/test_gpu_net_parity.py tests/test_gpu_loss_filter_parity.py -m gpu -x -q 2>&1 | tail -n 6
+timeout 300 python tools/fpl_infer_bench.py 2>&1 | tail -n 4
