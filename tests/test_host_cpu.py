@@ -32,6 +32,32 @@ def test_library_exports_every_declared_symbol():
     assert lib.fplx_num_partials(1) == 1 and lib.fplx_num_partials(10 ** 9) == 512
 
 
+def test_brick_kernel_plan_for_the_benchmark_layers():
+    """host-side dispatch of conv_fwd_brick (conv_brick.hip): geometry, Cin split and statistics rows for the benchmark's
+    levels - pure host code, no launch"""
+    import ctypes
+    from fplx import _lib
+    lib = _lib.lib()
+
+    def plan(n, d, h, w, cin, cout):
+        g, k, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        lib.fplx_brick_plan.restype = ctypes.c_int
+        ok = lib.fplx_brick_plan(n, d, h, w, cin, cout, ctypes.byref(g), ctypes.byref(k), ctypes.byref(b))
+        return ok, g.value, k.value, b.value
+
+    assert plan(2, 40, 80, 80, 64, 64) == (1, 0, 1, 2000)          # level 1: 4 x 8 x 8 bricks, 64 channels per block
+    assert plan(2, 20, 40, 40, 128, 128) == (1, 0, 1, 250)         # level 2
+    assert plan(2, 10, 20, 20, 256, 256) == (1, 1, 2, 60)          # level 3: 5 x 4 x 8 bricks, Cin split in two
+    assert plan(2, 10, 20, 20, 256, 512) == (1, 1, 1, 60)
+    assert plan(2, 5, 10, 10, 512, 512)[0] == 0                    # level 4 pads 1.9x: the tile kernel's
+    assert plan(2, 80, 160, 160, 32, 32)[0] == 0 and plan(2, 80, 160, 160, 64, 32)[0] == 0   # level 0: the march kernels'
+    # the rows the dispatcher promises: bricks, or the split-K finish kernel's blocks
+    assert lib.fplx_conv3d_stats_rows(2, 20, 40, 40, 128, 128, 3, 3, 3, 1, 1) == 250
+    assert lib.fplx_conv3d_stats_rows(2, 10, 20, 20, 256, 256, 3, 3, 3, 1, 1) == 512
+    assert lib.fplx_conv3d_fwd_ws_bytes(2, 10, 20, 20, 256, 256, 3, 3, 3, 1, 1) == 2 * 8000 * 256 * 4
+    assert lib.fplx_conv3d_fwd_ws_bytes(2, 20, 40, 40, 128, 128, 3, 3, 3, 1, 1) == 0
+
+
 def test_parse_config_matches_reference_parser(golden_dir):
     import fplx
     cfg = fplx.parse_config(os.path.join(golden_dir, "sample_vs.cfg"))
