@@ -179,6 +179,16 @@ def test_conv3d_brick_kernel(shape, geo, ks):
     yf = cl(yr)
     np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
     np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
+    if geo < 0 and lib.fplx_brick_ok(n, d, h, w, cout, cin) == 1:
+        # the data gradient is the same kernel on the mirrored pack (no bias, no statistics)
+        dy = q(torch.from_numpy(detdata.normal("b.dy%s" % (shape,), (n, cout, d, h, w))))
+        xr = x.clone().requires_grad_(True)
+        F.conv3d(xr, wt, None, padding=1).backward(dy)
+        _, wb = ops.pack_conv_weight(wt.cuda(), bf, want_wb=True)
+        dx = torch.full((xg.shape[0], cin), 7.0, dtype=bf, device="cuda")
+        ops.conv3d_fwd(cl(dy).to(bf).cuda(), ops.cl_strides(d, h, w, cout), dt, wb, None, dx, ops.cl_strides(d, h, w, cin), dt,
+                       dims, cout, cin, (3, 3, 3), None)
+        assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < 2e-2 * float(xr.grad.abs().max())
 
 
 @pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70)])

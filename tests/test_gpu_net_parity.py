@@ -220,10 +220,14 @@ MARCH_CASES = {
                 bilinear=False, num_domains=2, net_type="UNet2D5_dsbn"), (1, 1, 32, 64, 128)),
     "m4": (dict(in_chns=4, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0, 0, 0], conv_dims=[3] * 5, class_num=2,
                 bilinear=False, num_domains=2, net_type="UNet2D5_dsbn"), (2, 4, 16, 64, 64)),
+    # two samples: level 1 (2 x 16 x 32 x 64) then has the 256 bricks conv_fwd_brick wants - its forward (with statistics)
+    # and data-gradient forms run inside the network here
+    "b2": (dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0, 0, 0], conv_dims=[3] * 5, class_num=2,
+                bilinear=False, num_domains=2, net_type="UNet2D5_dsbn"), (2, 1, 32, 64, 128)),
 }
 
 
-@pytest.mark.parametrize("case", ["m1", "m4"])
+@pytest.mark.parametrize("case", ["m1", "m4", "b2"])
 def test_bf16_march_kernels_end_to_end_against_oracle(case):
     """The bf16 bench path end to end (march / tile / stream-wgrad MFMA kernels, split concat, bf16 activations) against the
     oracle that rounds to bf16 at the same points: logits <= 2e-2 of their range, every weight gradient within 0.1
@@ -236,6 +240,8 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
     n, cin, D, H, W = shape
     lib = _lib.lib()
     assert lib.fplx_conv3d_cat2_ok(n, D, H, W, 64, 32) == 1                 # the level-0 split concat + march path is taken
+    if case == "b2":                                                        # level 1 runs on the brick kernel
+        assert lib.fplx_brick_first(n, D // 2, H // 2, W // 2, 64, 64) == 1 and lib.fplx_brick_first(n, D // 2, H // 2, W // 2, 128, 64) == 1
     x = torch.from_numpy(detdata.normal("x." + case, shape))
     y = torch.from_numpy(detdata.ball_label((D, H, W), min(D, H, W) / 3.0, n=n, offsets=[(0, 1, -2), (1, -3, 2)][:n]))
     net = fplx.UNet2D5_dsbn(p)
