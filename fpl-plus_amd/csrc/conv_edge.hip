@@ -437,6 +437,126 @@ outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 }
 
 // ------------------------------------------------------------------------------------------
+// out_conv data gradient on the matrix cores.  dx[v][ci] = sum over (tap, class) of dlogits[class][v + tap] * wb[tap][ci][class]
+// is a GEMM with K = 9 * classes, far too thin to matter - but as VALU work (outconv_dgrad_valu) it is 576 FMAs per voxel
+// and sets that kernel's time (125 us for 295 MB at the benchmark shape).  The fp32 dlogits must not simply be rounded to
+// bf16 (the VALU kernel multiplies them in fp32): each value goes in as TWO bf16 terms, hi = bf16(g) and lo = bf16(g - hi),
+// adjacent in K against the same weight, which carries 16 mantissa bits into an fp32 accumulation of <= 72 products that is
+// rounded to bf16 (8 bits) at the end.  One 8 x 32 in-plane tile at a time (grid-strided): the fp32 dlogit planes with
+// their in-plane halo sit in LDS (next tile prefetched into registers), a wave owns two rows of the tile, the B fragments
+// (weights) stay in registers, the result leaves through the per-wave LDS transpose as 16-byte stores.
+template <int NT>                 // C0 / 32
+__global__ void __launch_bounds__(256)
+outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx,
+                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
+  constexpr int C0 = NT * 32, MAXK = 5;              // k-steps of 16: 8 (tap, class) pairs x (hi, lo) each; ncls <= 4 -> <= 5
+  __shared__ float gs[4 * SH * SW];                  // [class][SH][SW]
+  __shared__ __attribute__((aligned(16))) char stg_all[4][32 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  const int npairs = 9 * ncls, ksteps = (npairs + 7) / 8;
+  const int64_t Vs = (int64_t)D * H * W;
+  // B fragments: lane = ci, its 8 k-values of step s are the pairs 8 s + 4 khalf + (0..3), each twice (hi and lo terms)
+  bf16x8 bfr[MAXK][NT];
+#pragma unroll
+  for (int sx = 0; sx < MAXK; ++sx)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pr = 8 * sx + 4 * khalf + e;
+        bf16_t wv = (bf16_t)0.f;
+        if (pr < npairs) wv = wb[((int64_t)(pr / ncls) * C0 + j * 32 + r) * ncls + pr % ncls];
+        bfr[sx][j][2 * e] = wv;
+        bfr[sx][j][2 * e + 1] = wv;
+      }
+  // this lane's (tap, class) pairs -> LDS offsets of the dlogit tile (relative to the lane's voxel), -1 = padding
+  int goff[MAXK][4];
+#pragma unroll
+  for (int sx = 0; sx < MAXK; ++sx)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pr = 8 * sx + 4 * khalf + e;
+      const int tap = pr / ncls, cls = pr % ncls;
+      goff[sx][e] = pr < npairs ? (cls * SH + tap / 3) * SW + tap % 3 : -1;
+    }
+  constexpr int NLD = (4 * SH * SW + 255) / 256;
+  float greg[NLD];
+  auto fetch = [&](const Tile& t) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int ww = i % SW, hh = (i / SW) % SH, cls = i / (SH * SW);
+      const int h = t.h0 + hh - 1, w = t.w0 + ww - 1;
+      float v = 0.f;
+      if (cls < ncls && h >= 0 && h < H && w >= 0 && w < W)
+        v = dl[((int64_t)t.n * ncls + cls) * Vs + ((int64_t)t.d * H + h) * W + w];
+      greg[k] = v;
+    }
+  };
+  char* stg = stg_all[wave];
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  int64_t tt = tr.first;
+  Tile tn = tile_of(tt < tr.end ? tt : 0, D, tilesH, tilesW);
+  if (tt < tr.end) fetch(tn);
+  for (; tt < tr.end; tt += tr.step) {
+    const Tile t = tn;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < 4 * SH * SW) gs[i] = greg[k];
+    }
+    __syncthreads();
+    if (tt + tr.step < tr.end) {
+      tn = tile_of(tt + tr.step, D, tilesH, tilesW);
+      fetch(tn);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int hr = wave * 2 + m;                     // tile row of this M-tile; lane r = column
+      const float* g0 = gs + hr * SW + r;
+      f32x16 acc[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+#pragma unroll
+      for (int sx = 0; sx < MAXK; ++sx) {
+        if (sx < ksteps) {                             // uniform
+          bf16x8 a;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = goff[sx][e] >= 0 ? g0[goff[sx][e]] : 0.f;
+            const bf16_t hi = (bf16_t)g;
+            a[2 * e] = hi;
+            a[2 * e + 1] = (bf16_t)(g - (float)hi);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[sx][j], acc[j], 0, 0, 0);
+        }
+      }
+      const int h = t.h0 + hr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          *reinterpret_cast<bf16_t*>(stg + ((i & 3) + 8 * (i >> 2) + 4 * khalf) * 64 + r * 2) = (bf16_t)acc[j][i];
+        if (h < H) {                                   // wave-uniform
+          const int64_t vrow = (((int64_t)t.n * D + t.d) * H + h) * W + t.w0;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int wu = (lane >> 2) + 16 * half;
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + wu * 64 + (lane & 3) * 16);
+            if (t.w0 + wu < W) *reinterpret_cast<uint4*>(dx + (vrow + wu) * ldx + j * 32 + (lane & 3) * 8) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // out_conv weight gradient: rows = ci (32 per block column), cols = classes (padded to 32), K = voxels.
 // x tile [voxel][32 ch] with an in-plane halo in LDS (transposed reads), dlogits straight from the
 // fp32 planes; the 9 taps are dealt to the 4 waves (3/2/2/2).
@@ -620,6 +740,18 @@ extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx
   if (!(c0 == 16 || c0 == 32 || c0 == 64) || ncls > 4 || ldx % 8 != 0 || ((uintptr_t)dx % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   if (V >= ((int64_t)1 << 31)) return 0;                      // 32-bit voxel decode in the kernel
+  {
+    static const int kmf = [] { const char* e = getenv("FPLX_OUTCONV_DGRAD_MFMA"); return e ? atoi(e) : 1; }();   // A/B knob
+    if (kmf && (c0 == 32 || c0 == 64) && ncls <= 4 && ldx % 8 == 0 && ((uintptr_t)dx % 16) == 0) {
+      int th, tw;
+      const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+      const int nbm = (int)(nt < 2048 ? nt : 2048);
+      if (c0 == 32) outconv_dgrad_mfma<1><<<nbm, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+      else outconv_dgrad_mfma<2><<<nbm, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+      int rcm = fplx_check_launch("edge_outconv_dgrad_mfma");
+      return rcm < 0 ? rcm : 1;
+    }
+  }
   const unsigned nb = (unsigned)((V + 255) / 256);
   if (c0 == 16) outconv_dgrad_valu<16><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
   else if (c0 == 32) outconv_dgrad_valu<32><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
