@@ -159,8 +159,14 @@ def test_conv3d_brick_kernel(shape, geo, ks):
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         part = torch.full((ks, xg.shape[0], cout), 3.0, dtype=torch.float32, device="cuda") if ks > 1 else None
         vp = ctypes.c_void_p
-        rc = lib.fplx_brick_conv3d_fwd_ex(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()), vp(bg.data_ptr()),
-                                          vp(y.data_ptr()), ctypes.c_int64(cout), n, d, h, w, cin, cout,
+        # operands as channel slices of wider buffers (a concat half as input, a concat half as output): ld > channels
+        xw = torch.full((xg.shape[0], cin + 64), 9.0, dtype=bf, device="cuda")
+        xw[:, 32:32 + cin] = xg
+        xg = xw[:, 32:32 + cin]
+        yw = torch.full((xg.shape[0], cout + 32), 7.0, dtype=bf, device="cuda")
+        y = yw[:, 8:8 + cout]
+        rc = lib.fplx_brick_conv3d_fwd_ex(vp(xg.data_ptr()), ctypes.c_int64(cin + 64), vp(wf.data_ptr()), vp(bg.data_ptr()),
+                                          vp(y.data_ptr()), ctypes.c_int64(cout + 32), n, d, h, w, cin, cout,
                                           vp(stats.data_ptr()), vp(part.data_ptr()) if ks > 1 else None, geo, ks,
                                           vp(torch.cuda.current_stream().cuda_stream))
         assert rc == 1
@@ -168,13 +174,14 @@ def test_conv3d_brick_kernel(shape, geo, ks):
             got = (part.sum(0) + bg).float().cpu()
             assert float((uncl(got, n, d, h, w) - yr).abs().max()) < 2e-2 * scale
             return
+        assert float(yw[:, :8].float().abs().max()) == 7.0 and float(yw[:, 8 + cout:].float().min()) == 7.0   # nothing beside the slice
     else:
         assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
         rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, bg, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
                        (3, 3, 3), stats)
-    assert float((uncl(y.float().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
+    assert float((uncl(y.float().contiguous().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
     s = stats.sum(0).cpu()
     yf = cl(yr)
     np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
