@@ -7,9 +7,13 @@ Workload (BASELINE.json configs[1] / SURVEY.md section 8d cfg2): UNet2D5_dsbn al
 One step = zero-grad -> forward -> loss -> backward -> (RCCL all-reduce) -> Adam for ONE batch of one
 domain; the domain alternates 0/1 per step.  Inputs are resident in HBM before the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
-N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-(one rank per GPU, weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+    python bench.py --gpus N --steps K --warmup W [--repeats R]
+N > 1: one rank per GPU over RCCL, weak scaling (per-GPU batch fixed).  Either the driver launches the ranks
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) or - when RANK is not in the
+environment - this process starts them itself as a child `torch.distributed.run` BEFORE it touches the GPU, relays rank
+0's JSON line and exits with the child's code.  Every rank checks WORLD_SIZE == --gpus and fails loudly otherwise.
+The K-step timed region (barrier + synchronize on both sides, max over ranks) is run R times (default 5) in the one
+command; `ms_per_step` / `value` are those of the MEDIAN region, min / max are reported beside it.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -212,15 +216,23 @@ def cpu_baseline():
                 break
         return times
 
-    crop = steps((1, 1, 32, 80, 80), 5, 12.0)
+    crop = steps((1, 1, 32, 80, 80), 4, 8.0)
     t_crop = float(np.median(crop[1:])) if len(crop) > 1 else crop[0]
     est_full = t_crop * 10.0 * SHAPE[0]
     note = "crop 1x1x32x80x80 (1/10 volume): %.2f s/step" % t_crop
-    if est_full <= 90.0:
+    if est_full <= 45.0:
+        # two full steps: the first one pays oneDNN primitive creation, first-touch page faults and allocator growth for the
+        # full-size tensors; the SECOND is the baseline (an un-warmed single step understated the CPU)
+        full = steps(SHAPE, 2, 1e9)
+        t_full = min(full[1:]) if len(full) > 1 else full[0]
+        value = SHAPE[0] / t_full
+        sample = ("full fp32 train steps at the benchmark shape %dx1x80x160x160: %s s, the fastest after the first is the "
+                  "baseline; %s" % (SHAPE[0], ", ".join("%.1f" % t for t in full), note))
+    elif est_full <= 90.0:
         t_full = steps(SHAPE, 1, 0.0)[0]
         value = SHAPE[0] / t_full
-        sample = ("ONE full fp32 train step at the benchmark shape %dx1x80x160x160 (no warm-up), %.1f s; %s" % (
-            SHAPE[0], t_full, note))
+        sample = ("ONE full fp32 train step at the benchmark shape %dx1x80x160x160 (no warm-up: a lower bound of the CPU "
+                  "rate), %.1f s; %s" % (SHAPE[0], t_full, note))
     else:
         value = (1.0 / 10.0) / t_crop
         sample = "extrapolated from the " + note + " (a full step would take about %.0f s here)" % est_full
@@ -228,18 +240,51 @@ def cpu_baseline():
             "sample": "32-base UNet-DSBN, DiceLoss + Adam, oracle/torch_ref.py, %d threads: %s" % (cores, sample)}
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N ranks as a child `python -m torch.distributed.run` (this process has
+    not initialised the GPU and never will), relay rank 0's JSON line, return the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if proc.returncode == 0 and len(lines) == 1:
+        print(lines[0])
+        return 0
+    sys.stderr.write("bench.py: the %d-rank child exited with code %d and printed %d result line(s)\n%s\n"
+                     % (n, proc.returncode, len(lines), proc.stdout[-2000:]))
+    return proc.returncode or 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--launch", action="store_true", help="start the ranks as a child torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1 or args.warmup < 0:
+        ap.error("--gpus, --steps, --repeats must be >= 1 and --warmup >= 0")
+
+    if (args.gpus > 1 or args.launch) and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))            # nothing has touched the GPU yet: the ranks are CHILD processes
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d - refusing to print a line for the wrong world size\n"
+                         % (args.gpus, world))
+        sys.exit(2)
     use_dist = world > 1 or (os.environ.get("FPLX_DDP_FORCE", "0") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -267,21 +312,25 @@ def main():
         return out
 
     run(0, args.warmup)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = run(args.warmup, args.steps)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    regions, k0, out = [], args.warmup, None
+    for _ in range(args.repeats):                    # each region: EXACTLY --steps steps between barrier + synchronize pairs
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run(k0, args.steps)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+        k0 += args.steps
+    if use_dist:                                     # a region's time = the slowest rank's
+        tt = torch.tensor(regions, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        regions = [float(v) for v in tt.tolist()]
+    dt = float(np.median(regions))
     loss = float(out[0].item())
 
     # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
@@ -291,7 +340,7 @@ def main():
         timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
         side = net.engine.use_side_stream
         net.engine.use_side_stream = False      # one kernel at a time: clean per-launch durations
-        run(args.warmup + args.steps, 2)
+        run(k0, 2)
         torch.cuda.synchronize()
         net.engine.use_side_stream = side
         timer.on = False
@@ -322,6 +371,8 @@ def main():
         res = {
             "metric": "3D volumes/sec (train step, 80x160x160)", "value": round(vols / dt, 4), "unit": "volumes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "repeats": args.repeats, "ms_per_step_min": round(min(regions) / args.steps * 1e3, 3),
+            "ms_per_step_max": round(max(regions) / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "UNet3D-DSBN 32-base-ch bf16 (fp32 master weights), per-GPU batch 2x1x80x160x160 "
                                    "synthetic VS crops, DiceLoss + Adam, domain alternating per step",

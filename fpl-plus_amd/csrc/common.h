@@ -6,7 +6,6 @@
 #include <stdarg.h>
 #include <string.h>
 #include "../../include/fplx.h"
-#include <cstdlib>
 
 typedef __bf16 bf16_t;
 
@@ -116,9 +115,43 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   return t;
 }
 #endif
-static inline int fplx_xcd_on() {
-  static const int v = [] { const char* e = getenv("FPLX_XCD"); return e ? atoi(e) : 1; }();
-  return v;
-}
-
-
+// ---- tuning table (fplx_set_tuning / fplx_get_tuning, include/fplx.h): ONE process-wide table of named integer knobs
+// for A/B measurements - every default is the shipped configuration and no knob changes a result, only which kernel /
+// geometry computes it.  It replaces the getenv() statics the dispatchers used to cache; it is the library's only
+// mutable state (relaxed atomics: a knob may be flipped between launches from any thread).
+//   X(id, key, default)
+#define FPLX_KNOB_LIST(X)                                                                                              \
+  X(XCD, "xcd", 1)                         /* 0: hardware block order (fplx_xcd_block off) */                           \
+  X(BRICK, "brick", 1)                     /* 0: no brick kernel; 3: only layers no march kernel takes */               \
+  X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
+  X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
+  X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \
+  X(OUTCONV_DGRAD_MFMA, "outconv_dgrad_mfma", 1)                                                                       \
+  X(PACK_TILED, "pack_tiled", 1)                                                                                       \
+  X(PACK_MULTI, "pack_multi", 1)                                                                                       \
+  X(MARCH, "march", 1)                     /* 0: previous-generation stream kernels; 2: Cin = 32 march only */          \
+  X(MARCH64_FW, "march64_fw", 0)           /* 16 / 32: force the footprint of the Cin = 64 march */                     \
+  X(MARCH_DS, "march_ds", 0)               /* > 0: force the depth split of the march kernels */                        \
+  X(MARCH128, "march128", 1)                                                                                           \
+  X(MARCH32_V2, "march32_v2", 4)           /* 0: 8-wave kernel; 1: v2 everywhere; 4: v2 forward + v3 data gradient */   \
+  X(WG_COT_MINVOX, "wg_cot_minvox", 0)                                                                                 \
+  X(WG_TW, "wg_tw", 0)                                                                                                 \
+  X(WG_CIT, "wg_cit", 2)                                                                                               \
+  X(WG_COT, "wg_cot", 2)                                                                                               \
+  X(WG_DS, "wg_ds", 0)                                                                                                 \
+  X(STREAM_MIN_W, "stream_min_w", 64)                                                                                  \
+  X(TILE_MT, "tile_mt", 0)                                                                                             \
+  X(TILE_NT, "tile_nt", 0)                                                                                             \
+  X(TILE_KS, "tile_ks", 0)                                                                                             \
+  X(MID_TILE, "mid_tile", 1)                                                                                           \
+  X(DECONV_ROWS, "deconv_rows", 1)                                                                                     \
+  X(EW_GROUP, "ew_group", 1)
+enum FplxKnobId {
+#define FPLX_KNOB_ENUM(id, key, def) FPLX_K_##id,
+  FPLX_KNOB_LIST(FPLX_KNOB_ENUM)
+#undef FPLX_KNOB_ENUM
+  FPLX_K_COUNT
+};
+extern "C" __attribute__((visibility("hidden"))) int64_t fplx_knob_values[FPLX_K_COUNT];     // conv_generic.hip
+static inline int64_t fplx_knob(int id) { return __atomic_load_n(&fplx_knob_values[id], __ATOMIC_RELAXED); }
+static inline int fplx_xcd_on() { return (int)fplx_knob(FPLX_K_XCD); }

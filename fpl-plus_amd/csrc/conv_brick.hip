@@ -382,8 +382,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 }
 
 inline int brick_enabled() {
-  static const int v = [] { const char* e = getenv("FPLX_BRICK"); return e ? atoi(e) : 1; }();   // A/B knob (benchmarks only)
-  return v;
+  return (int)fplx_knob(FPLX_K_BRICK);              // A/B knob (benchmarks only)
 }
 
 struct BrickCfg { int ok, geo, ntw, nt, ksplit, bD, bH, bW; int64_t bricks; };
@@ -400,6 +399,13 @@ inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
   const int64_t b0 = (int64_t)n * ((d + 3) / 4) * ((h + 7) / 8) * bw, p0 = b0 * 256;
   const int64_t b1 = (int64_t)n * ((d + 4) / 5) * ((h + 3) / 4) * bw, p1 = b1 * 160;
   c.geo = (cout % 128 == 0 && p1 < p0) ? 1 : 0;
+  // tests (fplx_set_tuning "brick_geo" / "brick_ksplit"): this geometry / Cin split on every layer the kernel can compute at
+  // all, also where the plan would leave it to another kernel (few or ragged bricks)
+  const int force_geo = (int)fplx_knob(FPLX_K_BRICK_GEO), force_ks = (int)fplx_knob(FPLX_K_BRICK_KSPLIT);
+  if (force_geo >= 0) {
+    if (force_geo > 1 || (force_geo == 1 && cout % 128 != 0)) return c;
+    c.geo = force_geo;
+  }
   c.nt = (c.geo == 1 || cout % 128 == 0) ? 128 : 64;
   c.ntw = c.geo == 1 ? 1 : c.nt / 64;
   c.bricks = c.geo ? b1 : b0;
@@ -407,12 +413,19 @@ inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.bH = c.geo ? (h + 3) / 4 : (h + 7) / 8;
   c.bW = bw;
   // more than 25 % padding: the tile kernel's (level 4 of the benchmark, 5 x 10 x 10, pads 1.9x: measured 47 against 48 us)
-  if ((c.geo ? p1 : p0) * 4 > V * 5 || c.bricks >= ((int64_t)1 << 24)) return c;
+  if (c.bricks >= ((int64_t)1 << 24) || cout % 8 != 0 || cout > 2048) return c;
   const int64_t blocks = c.bricks * (cout / c.nt);
   const int nch = cin / BK::KC;
   c.ksplit = 1;
+  if (force_geo >= 0 || force_ks > 0) {
+    if (force_ks > nch) return c;
+    if (force_ks > 0) c.ksplit = force_ks;
+    c.ok = 1;
+    return c;
+  }
+  if ((c.geo ? p1 : p0) * 4 > V * 5) return c;
   while (blocks * c.ksplit < 192 && nch / (c.ksplit + 1) >= 2) ++c.ksplit;
-  if (blocks * c.ksplit < 192 || cout % 8 != 0 || cout > 2048) return c;
+  if (blocks * c.ksplit < 192) return c;
   c.ok = 1;
   return c;
 }

@@ -663,8 +663,7 @@ inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   return (int64_t)n * d * (*th) * (*tw);                  // < 2^31 for anything that fits in memory (256 voxels per tile)
 }
 inline int edge_blocks(int64_t ntiles, int mult = 1) {
-  static int cap = -1;
-  if (cap < 0) { const char* e = getenv("FPLX_EDGE_BLOCKS"); cap = e ? atoi(e) : 1024; }   // tuning knob (benchmarks only)
+  const int cap = (int)fplx_knob(FPLX_K_EDGE_BLOCKS);       // tuning knob (benchmarks only)
   const int64_t c = (int64_t)cap * mult;
   return (int)(ntiles < c ? ntiles : c);
 }
@@ -741,7 +740,7 @@ extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx
   const int64_t V = (int64_t)n * d * h * w;
   if (V >= ((int64_t)1 << 31)) return 0;                      // 32-bit voxel decode in the kernel
   {
-    static const int kmf = [] { const char* e = getenv("FPLX_OUTCONV_DGRAD_MFMA"); return e ? atoi(e) : 1; }();   // A/B knob
+    const int kmf = (int)fplx_knob(FPLX_K_OUTCONV_DGRAD_MFMA);   // A/B knob
     if (kmf && (c0 == 32 || c0 == 64) && ncls <= 4 && ldx % 8 == 0 && ((uintptr_t)dx % 16) == 0) {
       int th, tw;
       const int64_t nt = tiles_of(n, d, h, w, &th, &tw);

@@ -412,6 +412,7 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
                                     size_t ws_bytes, hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int cout, int mid, int* kernel, int* geo, int* ksplit);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
@@ -466,6 +467,46 @@ int fplx_last_error(char* buf, size_t n) {
 
 int fplx_num_partials(int64_t voxels) { return fplx_rows_for(voxels); }
 
+/* ---- tuning table (common.h: FPLX_KNOB_LIST) ---- */
+int64_t fplx_knob_values[FPLX_K_COUNT] = {
+#define FPLX_KNOB_DEF(id, key, def) def,
+    FPLX_KNOB_LIST(FPLX_KNOB_DEF)
+#undef FPLX_KNOB_DEF
+};
+static const char* const knob_keys[FPLX_K_COUNT] = {
+#define FPLX_KNOB_KEY(id, key, def) key,
+    FPLX_KNOB_LIST(FPLX_KNOB_KEY)
+#undef FPLX_KNOB_KEY
+};
+static int knob_index(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < FPLX_K_COUNT; ++i)
+    if (strcmp(key, knob_keys[i]) == 0) return i;
+  return -1;
+}
+int fplx_set_tuning(const char* key, int64_t value) {
+  const int i = knob_index(key);
+  FPLX_REQUIRE(i >= 0, FPLX_E_BADSHAPE, "set_tuning: unknown key '%s'", key ? key : "(null)");
+  __atomic_store_n(&fplx_knob_values[i], value, __ATOMIC_RELAXED);
+  return FPLX_OK;
+}
+int fplx_get_tuning(const char* key, int64_t* value) {
+  const int i = knob_index(key);
+  FPLX_REQUIRE(i >= 0 && value, FPLX_E_BADSHAPE, "get_tuning: unknown key '%s'", key ? key : "(null)");
+  *value = fplx_knob(i);
+  return FPLX_OK;
+}
+int fplx_tuning_key(int index, char* buf, size_t n) {
+  if (index < 0 || index >= FPLX_K_COUNT) return -1;
+  const size_t l = strlen(knob_keys[index]);
+  if (buf && n) {
+    const size_t c = l < n - 1 ? l : n - 1;
+    memcpy(buf, knob_keys[index], c);
+    buf[c] = 0;
+  }
+  return (int)l;
+}
+
 int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin, int kd, int kh, int kw, int dt,
                           fplx_stream_t stream) {
   FPLX_REQUIRE(w && wf, FPLX_E_NULL, "pack_conv_weight: null pointer");
@@ -476,7 +517,7 @@ int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin,
   if (dt == FPLX_F32)
     pack_conv_w<float><<<grid_for(total, 256, 1024), 256, 0, st>>>(w, (float*)wf, (float*)wb, cout, cin, taps);
   else if (dt == FPLX_BF16) {
-    static const bool tiled = [] { const char* e = getenv("FPLX_PACK_TILED"); return !e || atoi(e) != 0; }();
+    const bool tiled = fplx_knob(FPLX_K_PACK_TILED) != 0;
     if (tiled && taps == 27 && cin % PK_CI == 0 && cout % PK_CO == 0 && ((uintptr_t)w % 16 == 0) &&
         ((uintptr_t)wf % 16 == 0) && ((uintptr_t)wb % 16 == 0))
       pack_conv_w27_tiled<<<(cout / PK_CO) * (cin / PK_CI), 256, 0, st>>>(w, (bf16_t*)wf, (bf16_t*)wb, cout, cin);
@@ -492,8 +533,8 @@ int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf
                                    const int* cin, int dt, fplx_stream_t stream) {
   FPLX_REQUIRE(w && wf && wb && cout && cin, FPLX_E_NULL, "pack_conv_weights_batched: null pointer");
   FPLX_REQUIRE(n > 0 && n <= PK_MAX, FPLX_E_BADSHAPE, "pack_conv_weights_batched: %d layers (1..%d)", n, PK_MAX);
-  static const bool tiled = [] { const char* e = getenv("FPLX_PACK_TILED"); return !e || atoi(e) != 0; }();
-  static const bool multi = [] { const char* e = getenv("FPLX_PACK_MULTI"); return !e || atoi(e) != 0; }();   // A/B knob
+  const bool tiled = fplx_knob(FPLX_K_PACK_TILED) != 0;
+  const bool multi = fplx_knob(FPLX_K_PACK_MULTI) != 0;     // A/B knob
   PackTable t;
   t.n = 0;
   t.first[0] = 0;
@@ -589,6 +630,23 @@ size_t fplx_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout, i
   if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3)
     return fplx_mfma_conv3d_fwd_ws_bytes(n, d, h, w, cin, cout);
   return 0;
+}
+
+int fplx_conv3d_plan_query(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt,
+                           int* kernel, int* geometry, int* ksplit, int* stats_rows) {
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, FPLX_E_BADSHAPE, "conv3d_plan_query: bad shape");
+  int k = FPLX_KERNEL_GENERIC, g = -1, ks = 1;
+  if (x_dt == FPLX_BF16 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3) fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, 0, &k, &g, &ks);
+  else if (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && kd == 3 && kh == 3 && kw == 3 && fplx_edge_stem_rows(n, d, h, w, cin, cout) > 0)
+    k = FPLX_KERNEL_STEM;
+  else if (kd == 1 && kh == 3 && kw == 3 && ((x_dt == FPLX_BF16 && y_dt == FPLX_F32 && (cin == 16 || cin == 32 || cin == 64) && cout <= 4) ||
+                                             (x_dt == FPLX_F32 && y_dt == FPLX_BF16 && (cout == 16 || cout == 32 || cout == 64) && cin <= 4)))
+    k = FPLX_KERNEL_OUTCONV;
+  if (kernel) *kernel = k;
+  if (geometry) *geometry = g;
+  if (ksplit) *ksplit = ks;
+  if (stats_rows) *stats_rows = fplx_conv3d_stats_rows(n, d, h, w, cin, cout, kd, kh, kw, x_dt, y_dt);
+  return FPLX_OK;
 }
 
 int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,

@@ -1335,12 +1335,7 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
 struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk, fw; };
 
 inline int march_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FPLX_MARCH");                 // tuning knob (benchmarks only): 0 = previous kernel
-    v = e ? atoi(e) : 1;
-  }
-  return v;
+  return (int)fplx_knob(FPLX_K_MARCH);                    // tuning knob (benchmarks only): 0 = previous kernel
 }
 
 inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
@@ -1348,7 +1343,7 @@ inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
   int fh = cin >= 64 ? MG64::FH : MG::FH;
   c.fw = 32;
   if (cin >= 64) {                                           // 16 x 16 footprint when it wastes less area than 8 x 32
-    static const int kfw = [] { const char* e = getenv("FPLX_MARCH64_FW"); return e ? atoi(e) : 0; }();
+    const int kfw = (int)fplx_knob(FPLX_K_MARCH64_FW);
     const int64_t a32 = (int64_t)((h + 7) / 8) * 8 * ((w + 31) / 32) * 32;
     const int64_t a16 = (int64_t)((h + 15) / 16) * 16 * ((w + 15) / 16) * 16;
     if ((kfw == 0 && a16 < a32) || kfw == 16) { c.fw = 16; fh = 16; }
@@ -1369,8 +1364,8 @@ inline MarchCfg march_cfg(int n, int d, int h, int w, int cin, int cout) {
     if (cost < best - 1e-9) { best = cost; best_ds = segs; }
   }
   {
-    const char* e = getenv("FPLX_MARCH_DS");               // tuning knob (benchmarks only)
-    if (e && atoi(e) > 0) best_ds = atoi(e);
+    const int e = (int)fplx_knob(FPLX_K_MARCH_DS);           // tuning knob (benchmarks only)
+    if (e > 0) best_ds = e;
   }
   c.dlen = (d + best_ds - 1) / best_ds;
   c.dsegs = (d + c.dlen - 1) / c.dlen;
@@ -1386,7 +1381,7 @@ extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout) {
   if (cin == 32) return h >= 16;
   if (cin == 64) return en == 1 && h >= 8 && (int64_t)h * w * 64 * 2 < (int64_t)1 << 31;
   if (cin == 128) {                                          // streamed-weight form of the Cin = 64 kernel
-    static const int k128 = [] { const char* e = getenv("FPLX_MARCH128"); return e ? atoi(e) : 1; }();   // A/B knob
+    const int k128 = (int)fplx_knob(FPLX_K_MARCH128);        // A/B knob
     return k128 && en == 1 && h >= 8 && (int64_t)h * w * 128 * 2 < (int64_t)1 << 31;
   }
   return 0;
@@ -1427,7 +1422,7 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   }
   if (x1) return 0;
   {
-    static const int kv2 = [] { const char* e = getenv("FPLX_MARCH32_V2"); return e ? atoi(e) : 4; }();   // A/B knob
+    const int kv2 = (int)fplx_knob(FPLX_K_MARCH32_V2);       // A/B knob
     if (kv2 && !twod && h % MG2::FH == 0 && w % MG2::FW == 0 && (int64_t)d * h * w * ldx * 2 <= ((int64_t)1 << 30)) {
 #define LAUNCH_M32V2(STATS_)                                                                                        \
   do {                                                                                                              \

@@ -467,8 +467,7 @@ wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Ci
 struct WgCfg { int tw, cit, cot, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
 
 static inline int64_t cot_env_min_vox() {
-  static const int64_t v = [] { const char* e = getenv("FPLX_WG_COT_MINVOX"); return e ? atoll(e) : 0; }();
-  return v;
+  return fplx_knob(FPLX_K_WG_COT_MINVOX);
 }
 
 inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
@@ -478,20 +477,19 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   // shorter k-loop per depth step costs as much as the padding saves (measured +-5 %), so 32 stays
   c.tw = (w >= 64 || (w >= 32 && (w + 15) / 16 * 16 >= (w + 31) / 32 * 32)) ? 32 : 16;
   {
-    static const int ktw = [] { const char* e = getenv("FPLX_WG_TW"); return e ? atoi(e) : 0; }();   // tuning knob
+    const int ktw = (int)fplx_knob(FPLX_K_WG_TW);   // tuning knob
     if (ktw == 16 || ktw == 32) c.tw = ktw;
   }
   c.tilesH = (h + WG_TH - 1) / WG_TH;
   c.tilesW = (w + c.tw - 1) / c.tw;
   c.npairs = (cin / 32) * (cout / 32);
   {
-    static int cit_env = -1;
-    if (cit_env < 0) { const char* e = getenv("FPLX_WG_CIT"); cit_env = e ? atoi(e) : 2; }   // tuning knob
+    const int cit_env = (int)fplx_knob(FPLX_K_WG_CIT);   // tuning knob
     // two ci tiles per block: dy is read once for both and x in whole 128-byte lines (-15 % at level 0/1); the small
     // deep volumes need the block count more (measured: slower below 32 K voxels per sample)
     c.cit = (cin % 64 == 0 && cit_env == 2 && (int64_t)d * h * w >= 32000) ? 2 : 1;
     // two co tiles per block instead where Cout allows: every x fragment then feeds two MFMAs (A/B knob FPLX_WG_COT)
-    static const int cot_env = [] { const char* e = getenv("FPLX_WG_COT"); return e ? atoi(e) : 2; }();
+    const int cot_env = (int)fplx_knob(FPLX_K_WG_COT);
     c.cot = 1;
     if (cout % 64 == 0 && cot_env == 2 && (cot_env_min_vox() <= (int64_t)d * h * w)) { c.cot = 2; c.cit = 1; }
   }
@@ -503,7 +501,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
   int ds = 1;
   {
     double best = 1e30;
-    const char* e = getenv("FPLX_WG_DS");               // tuning knob (benchmarks only)
+    const int e = (int)fplx_knob(FPLX_K_WG_DS);          // tuning knob (benchmarks only)
     for (int cand = 1; cand <= d; ++cand) {
       const int dl = (d + cand - 1) / cand;
       if (dl < 4 && cand > 1) break;
@@ -512,7 +510,7 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
       const double cost = (double)rounds * (dl + 9.0);
       if (cost < best - 1e-9) { best = cost; ds = segs; }
     }
-    if (e && atoi(e) > 0) ds = atoi(e);
+    if (e > 0) ds = e;
   }
   c.dlen = (d + ds - 1) / ds;
   c.dsegs = (d + c.dlen - 1) / c.dlen;
@@ -1080,12 +1078,7 @@ conv_fwd_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
 
 struct StreamCfg { int tilesH, tilesW, dsegs, dlen, nblk; };
 inline int stream_min_w() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("FPLX_STREAM_MIN_W");       // tuning knob (benchmarks only)
-    v = e ? atoi(e) : 64;
-  }
-  return v;
+  return (int)fplx_knob(FPLX_K_STREAM_MIN_W);          // tuning knob (benchmarks only)
 }
 inline bool stream_ok(int d, int h, int w, int cin, int cout) {
   // below W = 128 (level 1) the LDS-tiled GEMM kernel is faster whenever it applies (Cout % 64 == 0)
@@ -1399,7 +1392,7 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout, int taps = 27) {
   if (c.tile_nt && cin % 64 == 0) {
     // 256-voxel tiles: measured +-2 % at level 2 and -15 % on the 64-wide level-1 layer, so they stay a tuning knob
     // (FPLX_TILE_MT=256) - the kernel is not simply L2-bandwidth-bound
-    static const int kmt = [] { const char* e = getenv("FPLX_TILE_MT"); return e ? atoi(e) : 0; }();
+    const int kmt = (int)fplx_knob(FPLX_K_TILE_MT);
     if (kmt == 256) c.tile_mt = 256;
   }
   c.mblocks = c.tile_nt ? (V + c.tile_mt - 1) / c.tile_mt : (V + 4 * c.mt * 32 - 1) / (4 * c.mt * 32);
@@ -1416,8 +1409,7 @@ inline DirectCfg direct_cfg(int64_t V, int cin, int cout, int taps = 27) {
   }
   if (c.tile_mt == 256) c.ksplit = 1;                        // chosen only where it fills the chip by itself
   {  // tuning knobs: FPLX_TILE_NT=64 forces the narrow tile, FPLX_TILE_KS forces the tap split (1/3/9/27)
-    static const int knt = [] { const char* e = getenv("FPLX_TILE_NT"); return e ? atoi(e) : 0; }();
-    static const int kks = [] { const char* e = getenv("FPLX_TILE_KS"); return e ? atoi(e) : 0; }();
+    const int knt = (int)fplx_knob(FPLX_K_TILE_NT), kks = (int)fplx_knob(FPLX_K_TILE_KS);
     if (knt == 64 && c.tile_nt == 128) c.tile_nt = 64;
     if (kks == 1 || kks == 3 || kks == 9 || kks == 27) c.ksplit = kks;
   }
@@ -1466,7 +1458,7 @@ static inline size_t brick_ws_bytes(int n, int d, int h, int w, int cin, int cou
 // config); where a march kernel applies it keeps all 27 taps - its 1.0 PFLOP/s on three times the work still beats the
 // tile kernel's short-K form (111 vs 117 us at 64 -> 64, 52 vs 70 us at 32 -> 64).  Same result either way.
 static inline bool mid_tile(int mid, int n, int d, int h, int w, int cin, int cout) {
-  static const bool on = [] { const char* e = getenv("FPLX_MID_TILE"); return !e || atoi(e) != 0; }();   // A/B knob
+  const bool on = fplx_knob(FPLX_K_MID_TILE) != 0;          // A/B knob
   return mid && on && cin % 32 == 0 && cout % 64 == 0 && !fplx_march_ok(n, d, h, w, cin, cout) &&
          !stream_ok(d, h, w, cin, cout);
 }
@@ -1491,6 +1483,21 @@ static size_t fwd_ws_impl(int n, int d, int h, int w, int cin, int cout, int mid
   const int64_t V = (int64_t)n * d * h * w;
   const DirectCfg c = direct_cfg(V, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
   return c.ksplit > 1 ? (size_t)c.ksplit * V * cout * sizeof(float) : 0;
+}
+
+// the dispatch order of mfma_fwd_impl as data (fplx_conv3d_plan_query): kernel family, brick geometry, reduction split
+extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int cout, int mid, int* kernel, int* geo, int* ksplit) {
+  *kernel = FPLX_KERNEL_GENERIC; *geo = -1; *ksplit = 1;
+  if (cin % 16 != 0 || cout % 32 != 0 || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
+  auto brick = [&]() { int b; fplx_brick_plan(n, d, h, w, cin, cout, geo, ksplit, &b); *kernel = FPLX_KERNEL_BRICK; return 1; };
+  if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick();
+  if (fplx_march_ok(n, d, h, w, cin, cout)) { *kernel = FPLX_KERNEL_MARCH; return 1; }
+  if (stream_ok(d, h, w, cin, cout)) { *kernel = FPLX_KERNEL_STREAM; return 1; }
+  if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return brick();
+  const DirectCfg c = direct_cfg((int64_t)n * d * h * w, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);
+  *kernel = c.tile_nt ? FPLX_KERNEL_TILE : FPLX_KERNEL_DIRECT;
+  *ksplit = c.ksplit;
+  return 1;
 }
 
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout) {
@@ -1650,7 +1657,7 @@ extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf,
   if (V >= ((int64_t)1 << 31)) return 0;
   const int vec_ok = ldy % 8 == 0 && ((uintptr_t)y % 16) == 0;
   {
-    static const int krows = [] { const char* e = getenv("FPLX_DECONV_ROWS"); return e ? atoi(e) : 1; }();   // A/B knob
+    const int krows = (int)fplx_knob(FPLX_K_DECONV_ROWS);    // A/B knob
     const int ks = cin / 16, ntc = cout / 32;
     if (krows && sd == 2 && vec_ok && V >= 32 * 1024 && ((ks == 4 && ntc == 1) || (ks == 8 && ntc == 2) || (ks == 8 && ntc == 1) ||
                                                          (ks == 4 && ntc == 2))) {

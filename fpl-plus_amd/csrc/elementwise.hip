@@ -796,8 +796,7 @@ bool vec_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* 
 }  // namespace
 
 static inline bool ew_group_form() {     // A/B knob (benchmarks only): FPLX_EW_GROUP=0 selects the flat-index kernels
-  static const bool on = [] { const char* e = getenv("FPLX_EW_GROUP"); return !e || atoi(e) != 0; }();
-  return on;
+  return fplx_knob(FPLX_K_EW_GROUP) != 0;
 }
 
 #define DISPATCH_VEC(T, OK, KERNEL, ...)                         \

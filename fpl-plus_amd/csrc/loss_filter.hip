@@ -336,9 +336,11 @@ inline int grid1(int64_t v, int cap) {
 
 extern "C" {
 
-// rows to ALLOCATE per sample: the partial rows the kernels use plus 4 spare ones - behind the N x rows x K partials of a call
-// the spare N x 4 x K floats hold the per-sample sums and the batch totals as doubles ((N + 1) x K)
-int fplx_loss_rows(int64_t voxels_per_sample) { return loss_rows(voxels_per_sample) + 4; }
+// rows to ALLOCATE per sample: the partial rows the kernels use plus 5 spare ones - behind the N x rows x K partials of a call
+// the spare N x 5 x K floats hold the per-sample sums and the batch totals as doubles ((N + 1) x K doubles = 2 (N + 1) K floats)
+// plus the one float the 8-byte alignment of that region may cost (K is odd): 2 (N + 1) K + 1 <= 5 N K for every N >= 1.
+// (With 4 spare rows N = 1 and an odd rows x K overran the buffer by one float: ADVICE r02.)
+int fplx_loss_rows(int64_t voxels_per_sample) { return loss_rows(voxels_per_sample) + 5; }
 
 static int seg_loss_check(const char* what, const float* logits, const float* label, int n, int c, int64_t v) {
   FPLX_REQUIRE(logits && label, FPLX_E_NULL, "%s: null pointer", what);

@@ -86,7 +86,43 @@ def lib():
         fn = getattr(_lib, name)
         fn.restype = ret
         fn.argtypes = argtypes
+    _apply_env_tuning()
     return _lib
+
+
+def tuning_keys():
+    """names of the library's tuning knobs (fplx_tuning_key)"""
+    keys, buf, i = [], ctypes.create_string_buffer(64), 0
+    while lib().fplx_tuning_key(i, buf, 64) >= 0:
+        keys.append(buf.value.decode())
+        i += 1
+    return keys
+
+
+def set_tuning(key, value):
+    """fplx_set_tuning: A/B knob of the kernel dispatchers (benchmarks and tests only; no knob changes a result)"""
+    check(lib().fplx_set_tuning(key.encode(), int(value)))
+
+
+def get_tuning(key):
+    v = ctypes.c_int64()
+    check(lib().fplx_get_tuning(key.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def _apply_env_tuning():
+    """The library itself never reads the environment; the benchmark tools' FPLX_<KEY>=<int> variables (FPLX_BRICK=0,
+    FPLX_MARCH32_V2=1, ...) are translated here, once, when the library is loaded."""
+    buf, i = ctypes.create_string_buffer(64), 0
+    while _lib.fplx_tuning_key(i, buf, 64) >= 0:
+        key = buf.value.decode()
+        env = os.environ.get("FPLX_" + key.upper())
+        if env is not None:
+            try:
+                _lib.fplx_set_tuning(key.encode(), int(env))
+            except ValueError:
+                raise ValueError("fplx: FPLX_%s=%r is not an integer" % (key.upper(), env))
+        i += 1
 
 
 def last_error():

@@ -60,11 +60,14 @@ class SegmentationAgent(object):
         self.tensor_type = config['dataset'].get('tensor_type', 'float')
         self.fpl_uda = config['training'].get('train_fpl_uda', False) if 'training' in config else False
         # one process per GPU: the process group comes up BEFORE anything touches the device
-        self.distributed = ddp.init_from_env()
-        self.rank, self.world = ddp.rank(), (ddp.world_size() if self.distributed else 1)
+        # (the device is resolved ONCE, from the config's gpus list, and the group is bound to it: ADVICE r02)
         gpus = self._gpus()
         lr_ = ddp.local_rank()
-        self.device = torch.device("cuda:{0:}".format((gpus[lr_] if lr_ < len(gpus) else lr_) if self.distributed else gpus[0]))
+        under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+        index = (gpus[lr_] if lr_ < len(gpus) else lr_) if under_launcher else gpus[0]
+        self.distributed = ddp.init_from_env(device=index)
+        self.rank, self.world = ddp.rank(), (ddp.world_size() if self.distributed else 1)
+        self.device = torch.device("cuda:{0:}".format(index if self.distributed else gpus[0]))
         self.transform_list = []
         self.transform_dict = TransformDict
         self.test_set = None
@@ -465,7 +468,9 @@ class SegmentationAgent(object):
         states = [torch.load(n, map_location=self.device, weights_only=False)['model_state_dict'] for n in ckpt_names]
         outputs = {}
         with torch.no_grad():
-            for data in self.test_loader:
+            for case_no, data in enumerate(self.test_loader):
+                if self.distributed and case_no % self.world != self.rank:
+                    continue                 # volumes are sharded over the ranks, as in infer(): one writer per output file
                 images = self.convert_tensor_type(data['image']).to(self.device)
                 dl = domian_label * torch.ones(images.shape[0], dtype=torch.long)
                 acc = None

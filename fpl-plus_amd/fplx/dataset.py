@@ -127,6 +127,8 @@ class BatchLoader(object):
             raise ValueError("fplx BatchLoader: batch size {0:} is not a multiple of the {1:} ranks".format(batch_size, world))
 
     def __len__(self):
+        if self.world > 1:                               # the ragged last batch is dropped on all ranks (__iter__)
+            return len(self.dataset) // self.batch_size
         return (len(self.dataset) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):

@@ -7,7 +7,9 @@ The only collective of the hot path is the all-reduce(sum) of the flat fp32 grad
 issued in a few large buckets as soon as backward has finished the layers of a bucket, so the
 transfer of the deep (parameter-heavy, compute-light) blocks hides behind the backward of the
 shallow (compute-heavy, parameter-light) ones.  BatchNorm statistics stay per rank, as they do
-per replica under DataParallel; division by world size is folded into the Adam kernel.
+per replica under DataParallel.  Nothing is divided by the world size: the loss is evaluated
+over the FULL batch of all ranks (fplx_seg_loss_sums -> all-reduce of the batch totals ->
+fplx_seg_loss_from_sums), so the ranks' gradients ADD UP to its gradient (train.py, loss.py).
 
 Works on any backend: the CPU tests run it over gloo with world_size 2.
 """
@@ -59,11 +61,14 @@ class GradAllReducer(object):
         self._works = []
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, device=None):
     """One process per GPU, launched by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment): select the GPU and create the process group - BEFORE anything else touches the device.  Returns True
     when a group with more than one rank (or FPLX_DDP_FORCE=1) is up.  Backend: nccl (= RCCL over xGMI); FPLX_DDP_BACKEND
-    overrides it (the 2-rank tests on one GPU use gloo)."""
+    overrides it (the 2-rank tests on one GPU use gloo).
+    device: the CUDA device index this rank's tensors will live on (default: LOCAL_RANK).  The process group is bound to
+    THAT device - a config whose `gpus` list is not [0 .. n-1] must pass the same index the agent places its network on,
+    or the collectives run on a device the tensors are not on."""
     if not dist.is_available():
         return False
     if dist.is_initialized():
@@ -75,7 +80,7 @@ def init_from_env(backend=None):
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     backend = backend or os.environ.get("FPLX_DDP_BACKEND", "nccl")
-    local = local_rank()
+    local = local_rank() if device is None else int(device)
     if backend == "nccl":
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))

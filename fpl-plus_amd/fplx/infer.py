@@ -6,8 +6,8 @@ constructor config (`sliding_window_enable`, `sliding_window_size`, `sliding_win
   extract   every tile of every flip (and of every Monte-Carlo pass, `run_mc`) gathered into one batch on the device
             (fplx_sw_extract);
   forward   the network runs on chunks of that batch (eval-mode networks: BatchNorm uses running statistics, samples are
-            independent; a network in train mode keeps the reference's one-forward-per-tile batches, because its batch
-            statistics would change);
+            independent; a network in train mode keeps the reference's one-forward-per-tile batches - and run_mc its
+            pass-by-pass loop - because its batch statistics would change);
   merge     every output voxel is formed by the reference's additions in the reference's order (tile order w, h, d; flips
             ((o1 + o2) + o3 + o4) / 4) by a gather kernel (fplx_sw_merge) - independent of the chunking.
 
@@ -138,6 +138,10 @@ class Inferer(object):
         """`passes` stochastic runs of `run` (test-time dropout: agent_seg.py:898-909 calls run() six times) in one batch.
         -> [passes, N, classes, D, H, W]"""
         self.model = model
+        if getattr(model, 'training', False) and passes > 1:
+            # train-mode BatchNorm (testing.evaluation_mode = False): batch statistics - and the running-statistics update -
+            # belong to ONE pass's tile batch, so the passes run one after the other exactly as the reference's loop does
+            return torch.stack([self.run(model, image, domain_label) for _ in range(passes)])
         outs = self._run_batched(image, domain_label, passes) if image.is_cuda else None
         if outs is None:
             outs = torch.stack([self._run_generic(image, domain_label) for _ in range(passes)])

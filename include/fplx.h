@@ -9,7 +9,12 @@
  *
  * Conventions
  *  - plain C: raw device pointers + sizes.  The CALLER owns every buffer (including
- *    workspaces); the library allocates nothing and keeps no mutable global state.
+ *    workspaces); the library allocates nothing.  Its only mutable state is the table of
+ *    integer tuning knobs behind fplx_set_tuning (A/B measurements; the defaults are the shipped
+ *    configuration and no knob changes a result, only which kernel computes it) and the calling
+ *    thread's last error message.  The library never reads the environment.
+ *  - only the functions declared here are exported (the library is built with
+ *    -fvisibility=hidden; tests/test_host_cpu.py compares `nm -D` with this file).
  *  - activations are NDHWC ("channels last"): element (n,d,h,w,c) of a tensor with voxel
  *    stride `ld` (elements, >= C) lives at ((n*D+d)*H+h)*W+w)*ld + c.  ld > C addresses a
  *    channel slice of a wider buffer (the skip/up concat of UpBlock is never materialised).
@@ -29,6 +34,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)
 
 typedef void* fplx_stream_t; /* hipStream_t */
 
@@ -48,6 +54,25 @@ int fplx_version(void);
 int fplx_last_error(char* buf, size_t n);
 /* number of partial-sum rows the reduction kernels write for a tensor of `voxels` voxels */
 int fplx_num_partials(int64_t voxels);
+
+/* ------------------------------------------------------------------ tuning knobs and plan queries
+ * (no reference counterpart: the reference's kernels are cuDNN's, chosen by torch.backends.cudnn.benchmark,
+ *  agent_seg.py:737-738 sets deterministic = True / benchmark = False)
+ * fplx_set_tuning / fplx_get_tuning: named integer knobs that select among equivalent kernels / launch geometries
+ *   ("xcd", "brick", "march", "march32_v2", "wg_cot", "tile_ks", ...; fplx_tuning_key enumerates them: returns the key's
+ *   length and copies it, or -1 past the end).  Unknown key: FPLX_E_BADSHAPE.  Benchmarks and tests only.
+ * fplx_conv3d_plan_query: which kernel family fplx_conv3d_fwd dispatches this layer to (for 16-byte aligned NDHWC bf16
+ *   operands; FPLX_KERNEL_*), the brick geometry (0: 4x8x8, 1: 5x4x8; -1 for other families), the split of the reduction
+ *   dimension (1 = none) and the statistics rows - pure host code, no launch. */
+enum {
+  FPLX_KERNEL_GENERIC = 0, FPLX_KERNEL_DIRECT = 1, FPLX_KERNEL_TILE = 2, FPLX_KERNEL_STREAM = 3, FPLX_KERNEL_MARCH = 4,
+  FPLX_KERNEL_BRICK = 5, FPLX_KERNEL_STEM = 6, FPLX_KERNEL_OUTCONV = 7
+};
+int fplx_set_tuning(const char* key, int64_t value);
+int fplx_get_tuning(const char* key, int64_t* value);
+int fplx_tuning_key(int index, char* buf, size_t n);
+int fplx_conv3d_plan_query(int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw, int x_dt, int y_dt,
+                           int* kernel, int* geometry, int* ksplit, int* stats_rows);
 
 /* ------------------------------------------------------------------ weight packing
  * nn.Conv3d weight [Cout][Cin][KD][KH][KW] fp32 (net/net3d/unet2d5_dsbn.py:54-55, 293-294)
@@ -252,8 +277,8 @@ int fplx_upsample2_bwd(const void* dy, int64_t ldy, void* dx, int64_t ldx, int n
  * regulariser (net_run_dsbn/agent_seg.py:352-354) + hard-Dice train metric
  * (agent_seg.py:472-476).  logits / label: fp32 [N,C,D,H,W] contiguous (C <= 8);
  * pixel_weight fp32 [N,1,D,H,W] or NULL.
- *   part   fp32 workspace [N][rows][FPLX_LOSS_K(C)], rows = fplx_loss_rows(D*H*W) (partial rows + spare rows that hold the
- *          per-sample sums as doubles)
+ *   part   fp32 workspace [N][rows][FPLX_LOSS_K(C)], rows = fplx_loss_rows(D*H*W) (partial rows + 5 spare rows that hold the
+ *          per-sample sums and batch totals as (N + 1) x K doubles, 8-byte aligned: exactly N*rows*K floats are touched)
  *   cfg    host floats: w_dice, w_ce, w_dice_img (per-sample Dice x image_weight), w_entropy
  *   image_weight fp32 [N] device or NULL (needed iff w_dice_img != 0)
  *   out    fp32 device [4 + C]: total loss, dice term, ce term, entropy term, hard class Dice[C]
@@ -371,6 +396,7 @@ int fplx_surface_edge_points(const unsigned char* img, int d, int h, int w, unsi
 int fplx_surface_min_dist(const int* query_zyx, int64_t nq, const int* seed_zyx, int64_t ns, float sz, float sy, float sx,
                           float* out, fplx_stream_t stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -78,8 +78,21 @@ def dsbn(x, sd, key, domain, train, update_stats=True):
     return (x - mean.view(sh)) * torch.rsqrt(var.view(sh) + BN_EPS) * w.view(sh) + b.view(sh)
 
 
+PRELU_TAPS = None      # tests set a list: every prelu() call appends (slope tensor, min(x, 0)) with the gradient retained
+
+
 def prelu(x, slope):
-    return torch.where(x > 0, x, x * slope)  # nn.PReLU(), one shared slope (unet2d5_dsbn.py:62-63)
+    """nn.PReLU(), one shared slope (unet2d5_dsbn.py:62-63).  With PRELU_TAPS set the same values and gradients are formed
+    as max(x, 0) + slope * min(x, 0) (bit-identical: one of the two terms is an exact zero) and min(x, 0) keeps its gradient,
+    so that a test can form the slope gradient's cancellation scale sum |d out * min(x, 0)|."""
+    if PRELU_TAPS is None:
+        return torch.where(x > 0, x, x * slope)
+    zero = torch.zeros((), dtype=x.dtype)
+    neg = torch.where(x > 0, zero, x)
+    if neg.requires_grad:
+        neg.retain_grad()
+    PRELU_TAPS.append((slope, neg))
+    return torch.where(x > 0, x, zero) + neg * slope
 
 
 def fold_depth(x):

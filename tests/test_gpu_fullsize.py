@@ -140,6 +140,74 @@ def test_agent_fpl_inference_pipeline():
     assert not np.array_equal(recorded[0], recorded[1])
 
 
+def test_config4_mc_inference_and_filter_at_full_size():
+    """BASELINE config 4 at its size (reference agent_seg.py:897-931, infer_func.py:188-222): the 32-base bf16 network,
+    eval-mode BatchNorm + test-time dropout, one hrT2-sized volume 1 x 1 x 48 x 160 x 272 through the shipped sliding window
+    (28 x 128 x 128, stride = window: 12 tiles), (a) T = 4 Monte-Carlo passes and (b) the reference-literal 6 passes x 4-flip
+    TTA = 24 forwards per tile.  Two runs are bit-identical; the batched plan equals the tile-by-tile loop of forwards (dropout
+    off: the masks are keyed by the element index inside a forward batch); hard pseudo-labels and filter scalars are those of
+    the numpy oracle on the recorded logits."""
+    import fplx
+    from oracle import np_ref as N
+    torch.manual_seed(4)
+    net = fplx.UNet2D5_dsbn(dict(NET)).cuda()
+    # a network that has seen data: a few train steps give BatchNorm running statistics and non-trivial logits
+    ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+    b = _batch(10)
+    for i in range(2):
+        ts.step(b[0], b[1], 1)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn((1, 1, 48, 160, 272), generator=g).cuda()
+    dl = torch.ones(1, dtype=torch.long)
+    cfg = dict(sliding_window_enable=True, sliding_window_size=[28, 128, 128], sliding_window_stride=[28, 128, 128],
+               class_num=2)
+
+    def dropout(on):
+        net.eval()
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.train(on)
+
+    with torch.no_grad():
+        # ---- batched plan == the literal loop of forwards (deterministic network)
+        dropout(False)
+        for tta in (0, 1):
+            inf = fplx.Inferer(dict(cfg, tta_mode=tta))
+            a = inf.run(net, x, dl)
+            inf.model = net
+            lit = inf._run_generic(x, dl)
+            rng = float(lit.abs().max())
+            # (bf16 activations: a forward of 12 tiles and a forward of one tile pick different split-K plans at the deep
+            # levels, so single bf16 roundings may differ - not the arithmetic)
+            assert float((a - lit).abs().max()) <= 3e-2 * rng, tta
+            agree = float((fplx.filter.hard_label(a) == fplx.filter.hard_label(lit)).float().mean())
+            assert agree >= 0.999, (tta, agree)
+        # ---- Monte-Carlo passes at size
+        dropout(True)
+        net.dropout_seed = 5
+        for passes, tta in ((4, 0), (6, 1)):
+            inf = fplx.Inferer(dict(cfg, tta_mode=tta))
+            runs = []
+            for rep in range(2):
+                net._fwd_counter = 3
+                runs.append(inf.run_mc(net, x, dl, passes)[:, 0].clone())
+            assert tuple(runs[0].shape) == (passes, 2, 48, 160, 272)
+            assert torch.equal(runs[0], runs[1])                                # bitwise reproducible
+            assert not torch.equal(runs[0][0], runs[0][1])                       # the passes differ: dropout is active
+            r = fplx.ops.mc_filter(runs[0], want_maps=True)
+            ref = N.fpl_filter(runs[0].cpu().numpy())
+            assert np.array_equal(r["hards"].cpu().numpy(), ref["hards"])        # pseudo-label masks: bit exact
+            st = r["stats"].cpu().numpy()
+            m_gpu = r["means"].cpu().numpy()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                pred_gpu = (-1.0 * (m_gpu * np.log(m_gpu + 1e-6))) > 0.01
+            assert int(st[1]) == int(pred_gpu.sum())
+            assert int((pred_gpu != (ref["uncertainty"] > 0.01)).sum()) <= 2
+            assert abs(st[0] - float(ref["vars"])) <= 2e-5 * float(ref["vars"]) + 1e-12
+            if ref["boundary"] >= 50:
+                assert abs(st[2] - float(ref["uncer_one"])) <= 2e-5 * float(ref["uncer_one"]) + 1e-12
+
+
 def test_bench_under_torchrun_exercises_the_rccl_path():
     """bench.py launched the way the driver launches it (torch.distributed.run, one rank per GPU) with
     FPLX_DDP_FORCE=1, so that on this 1-GPU box the RCCL process group, the bucketed asynchronous all-reduces of the
@@ -158,6 +226,19 @@ def test_bench_under_torchrun_exercises_the_rccl_path():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 10 and np.isfinite(d["final_loss"])
+    assert d["repeats"] == 5 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    # the other way: no launcher - `bench.py --gpus 1` runs in-process, and with --launch it starts the rank itself as a child
+    # torch.distributed.run (what `bench.py --gpus N`, N > 1, does when RANK is not set) and relays rank 0's line
+    env_nolaunch = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    tail = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--repeats", "2", "--no-kernel-timing", "--no-cpu-baseline"]
+    for extra in ([], ["--launch"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + tail + extra, cwd=root, env=env_nolaunch,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 1 and d["steps"] == 2 and d["repeats"] == 2 and d["value"] > 10
 
 
 def test_config5_full_size_weighted_dual_domain_step():

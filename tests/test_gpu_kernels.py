@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 import detdata
+from util import plan_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -106,7 +107,7 @@ def test_conv3d_march_kernels_aligned_output(shape):
     b = torch.from_numpy(detdata.normal("m.b%s" % (shape,), (cout,)))
     yr = F.conv3d(x, wt, b, padding=1)
     bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
-    assert ops._lib.lib().fplx_march_ok(n, d, h, w, cin, cout) == 1
+    assert plan_kernel(n, d, h, w, cin, cout) == 4                # FPLX_KERNEL_MARCH
     xg = cl(x).to(bf).cuda()
     wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
     y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
@@ -137,11 +138,10 @@ def test_conv3d_march_kernels_aligned_output(shape):
     ((2, 256, 256, 10, 20, 20), -1, 0)])      # ... a level-3 layer: 5 x 4 x 8 bricks, split-K + finish
 def test_conv3d_brick_kernel(shape, geo, ks):
     """conv_fwd_brick (input-stationary bricks, conv_brick.hip): forward + BN statistics against torch, bf16;
-    geo >= 0 = straight into fplx_brick_conv3d_fwd_ex with that geometry / Cin split, for shapes the dispatcher leaves to
-    other kernels (few / ragged bricks)"""
-    import ctypes
+    geo >= 0: the tuning knobs "brick_geo" / "brick_ksplit" force that geometry / Cin split (+ its split-K finish) on shapes
+    the dispatcher leaves to other kernels (few / ragged bricks)"""
     from fplx import ops
-    lib = ops._lib.lib()
+    _lib = ops._lib
     n, cin, cout, d, h, w = shape
     q = lambda t: t.bfloat16().float()
     x = q(torch.from_numpy(detdata.normal("b.x%s" % (shape,), (n, cin, d, h, w))))
@@ -155,28 +155,26 @@ def test_conv3d_brick_kernel(shape, geo, ks):
     bg = b.cuda()
     scale = float(yr.abs().max())
     if geo >= 0:
-        rows = lib.fplx_brick_rows(n, d, h, w, geo)
-        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
-        part = torch.full((ks, xg.shape[0], cout), 3.0, dtype=torch.float32, device="cuda") if ks > 1 else None
-        vp = ctypes.c_void_p
         # operands as channel slices of wider buffers (a concat half as input, a concat half as output): ld > channels
         xw = torch.full((xg.shape[0], cin + 64), 9.0, dtype=bf, device="cuda")
         xw[:, 32:32 + cin] = xg
         xg = xw[:, 32:32 + cin]
         yw = torch.full((xg.shape[0], cout + 32), 7.0, dtype=bf, device="cuda")
         y = yw[:, 8:8 + cout]
-        rc = lib.fplx_brick_conv3d_fwd_ex(vp(xg.data_ptr()), ctypes.c_int64(cin + 64), vp(wf.data_ptr()), vp(bg.data_ptr()),
-                                          vp(y.data_ptr()), ctypes.c_int64(cout + 32), n, d, h, w, cin, cout,
-                                          vp(stats.data_ptr()), vp(part.data_ptr()) if ks > 1 else None, geo, ks,
-                                          vp(torch.cuda.current_stream().cuda_stream))
-        assert rc == 1
-        if ks > 1:                                   # partial sums only: bias, bf16 and statistics are the finish kernel's
-            got = (part.sum(0) + bg).float().cpu()
-            assert float((uncl(got, n, d, h, w) - yr).abs().max()) < 2e-2 * scale
-            return
+        _lib.set_tuning("brick_geo", geo)
+        _lib.set_tuning("brick_ksplit", ks)
+        try:
+            assert plan_kernel(n, d, h, w, cin, cout, full=True)[:3] == (5, geo, ks)      # FPLX_KERNEL_BRICK, as forced
+            rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+            stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
+            ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin + 64), dt, wf, bg, y, ops.cl_strides(d, h, w, cout + 32), dt, dims,
+                           cin, cout, (3, 3, 3), stats)
+        finally:
+            _lib.set_tuning("brick_geo", -1)
+            _lib.set_tuning("brick_ksplit", 0)
         assert float(yw[:, :8].float().abs().max()) == 7.0 and float(yw[:, 8 + cout:].float().min()) == 7.0   # nothing beside the slice
     else:
-        assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
+        assert plan_kernel(n, d, h, w, cin, cout) == 5
         rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, bg, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
@@ -186,7 +184,7 @@ def test_conv3d_brick_kernel(shape, geo, ks):
     yf = cl(yr)
     np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
     np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
-    if geo < 0 and lib.fplx_brick_ok(n, d, h, w, cout, cin) == 1:
+    if geo < 0 and plan_kernel(n, d, h, w, cout, cin) == 5:
         # the data gradient is the same kernel on the mirrored pack (no bias, no statistics)
         dy = q(torch.from_numpy(detdata.normal("b.dy%s" % (shape,), (n, cout, d, h, w))))
         xr = x.clone().requires_grad_(True)
@@ -454,3 +452,111 @@ def test_fused_downblock_tail_equals_the_separate_passes():
         assert torch.equal(dx_f, dx_ref)
         tot_ref, tot_f = part_ref.double().sum(0), part_f.double().sum(0)          # the rows partition the voxels differently
         assert float((tot_ref - tot_f).abs().max()) <= 1e-5 * float(tot_ref.abs().max()) + 1e-9
+
+
+def _bn_site_setup(n, d, h, w, c, tag):
+    """a BatchNorm site in bf16: pre-BN tensor y [V, C] with per-channel offsets / scales, affine parameters, PReLU slope,
+    batch statistics through the library (fplx_channel_stats -> fplx_bn_train_finalize)"""
+    from fplx import ops
+    v = n * d * h * w
+    g = torch.Generator().manual_seed(11 + c)
+    y = (torch.randn(v, c, generator=g) * (0.5 + torch.rand(c, generator=g)) + torch.randn(c, generator=g)).bfloat16()
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    slope = torch.full((1,), 0.25)
+    yg = y.cuda()
+    rows = ops.num_partials(v)
+    stats = torch.empty((rows, 2, c), dtype=torch.float32, device="cuda")
+    ops.call("fplx_channel_stats", ops.ptr(yg), c, v, c, ops.BF16, ops.ptr(stats), ops.stream())
+    bnbuf = torch.empty((4, c), dtype=torch.float32, device="cuda")
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.bn_train_finalize(stats, rows, c, v, gamma.cuda(), beta.cuda(), rm, rv, nbt, bnbuf)
+    return v, y, yg, gamma, beta, slope, bnbuf
+
+
+def _bn_site_torch(y, gamma, beta, slope, keep, p):
+    """float64 autograd of BatchNorm(train) -> PReLU -> dropout with a SUPPLIED keep mask, on the bf16 values of y"""
+    yd = y.double().requires_grad_(True)
+    gd, bd, sd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True), slope.double().requires_grad_(True)
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    z = (yd - mean) * torch.rsqrt(var + 1e-5) * gd + bd
+    a = torch.where(z > 0, z, z * sd)
+    if p > 0:
+        a = a * keep.double() * float(np.float32(1.0 / (1.0 - float(np.float32(p)))))
+    return yd, gd, bd, sd, a
+
+
+@pytest.mark.parametrize("shape,p", [((2, 8, 32, 32, 32), 0.0),      # level-0-like: 32 channels, the group-stationary kernels
+                                     ((1, 6, 20, 24, 128), 0.3),     # level-2-like with dropout (Philox masks from the oracle)
+                                     ((2, 4, 16, 16, 64), 0.5),
+                                     ((1, 5, 10, 10, 512), 0.0),     # level 4: 64 channel groups, few voxels
+                                     ((1, 3, 7, 9, 16), 0.4)])       # ragged voxel count, 2 groups
+def test_bn_act_bf16_kernels_against_torch_autograd(shape, p):
+    """bf16 bn_act_fwd_g_k / bn_act_bwd_reduce_k / bn_act_bwd_finalize_k / bn_act_bwd_apply_g_k against float64 torch
+    autograd of BatchNorm3d(train) + PReLU + dropout with the supplied mask (these kernels produce the d gamma /
+    d beta / d slope the end-to-end rule is loose on; so far they were only compared with each other).
+    dx <= 2e-2 of its max (bf16 storage), d gamma / d beta / d slope <= 1e-2 relative."""
+    from fplx import ops
+    from oracle import np_ref as N
+    n, d, h, w, c = shape
+    v, y, yg, gamma, beta, slope, bnbuf = _bn_site_setup(n, d, h, w, c, "a")
+    seed, sid = 1234, 7
+    keep = torch.from_numpy(N.philox_keep_mask(seed, sid, v * c, p).reshape(v, c)) if p > 0 else None
+    yd, gd, bd, sd, a_ref = _bn_site_torch(y, gamma, beta, slope, keep, p)
+    a = torch.empty_like(yg)
+    ops.bn_act_fwd(yg, a, bnbuf, slope.cuda(), p, seed, sid, c)
+    amax = float(a_ref.abs().max())
+    assert float((a.float().cpu().double() - a_ref.detach()).abs().max()) < 1e-2 * amax
+    if p > 0:                                    # the mask itself: exactly the oracle's Philox stream
+        assert bool(((a.float().cpu() == 0) | keep).all()) and float((a.float().cpu()[~keep]).abs().max()) == 0.0
+    g = torch.Generator().manual_seed(5)
+    dout = (torch.randn(v, c, generator=g) * 0.01).bfloat16()
+    a_ref.backward(dout.double())
+    dgamma, dbeta, dslope = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
+    part = torch.empty((ops.num_partials(v), 2 * c + 1), dtype=torch.float32, device="cuda")
+    coef = torch.empty((2, c), dtype=torch.float32, device="cuda")
+    dy = torch.empty_like(yg)
+    ops.bn_act_bwd(yg, dout.cuda(), dy, bnbuf, slope.cuda(), p, seed, sid, c, True, dgamma, dbeta, dslope, part, coef)
+    dx_ref = yd.grad
+    assert float((dy.float().cpu().double() - dx_ref).abs().max()) < 2e-2 * float(dx_ref.abs().max())
+    for got, ref in ((dgamma, gd.grad), (dbeta, bd.grad), (dslope, sd.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-2 * float(ref.abs().max()), (got, ref)
+    # a sign error anywhere would show: none of these sums cancels on this data
+    assert float(sd.grad.abs()) > 10 * float((dslope.cpu().double() - sd.grad).abs())
+
+
+@pytest.mark.parametrize("shape,pd", [((2, 8, 32, 32, 32), 2), ((1, 6, 16, 24, 64), 1), ((1, 4, 8, 8, 128), 2)])
+def test_pool_bwd_bn_reduce_bf16_against_torch_autograd(shape, pd):
+    """the fused DownBlock tail - fplx_bn_act_pool_fwd, then fplx_pool_bwd_bn_reduce -> bn_act_bwd(reduced) - against float64
+    autograd of BatchNorm(train) -> PReLU -> {skip, MaxPool}; the pooling sees the bf16-stored a2 in both (straight-through
+    rounding in the reference), so the arg-max agrees except where fp32 / fp64 round a2 differently (a handful of voxels)."""
+    from fplx import ops
+    n, d, h, w, c = shape
+    v, y, yg, gamma, beta, slope, bnbuf = _bn_site_setup(n, d, h, w, c, "p")
+    yd, gd, bd, sd, a_ref = _bn_site_torch(y, gamma, beta, slope, None, 0.0)
+    a_q = a_ref + (a_ref.detach().float().bfloat16().double() - a_ref.detach())        # value rounded, gradient straight through
+    a5 = a_q.view(n, d, h, w, c).permute(0, 4, 1, 2, 3)
+    k = (pd, 2, 2)
+    pooled_ref = F.max_pool3d(a5, k, k)
+    do, ho, wo = d // pd, h // 2, w // 2
+    vo = n * do * ho * wo
+    g = torch.Generator().manual_seed(9)
+    dyp = (torch.randn(vo, c, generator=g) * 0.01).bfloat16()
+    dskip = (torch.randn(v, c, generator=g) * 0.01).bfloat16()
+    loss = (pooled_ref.permute(0, 2, 3, 4, 1).reshape(vo, c) * dyp.double()).sum() + (a_q * dskip.double()).sum()
+    loss.backward()
+    a2, pooled = torch.empty_like(yg), torch.empty((vo, c), dtype=torch.bfloat16, device="cuda")
+    ops.bn_act_pool_fwd(yg, a2, pooled, bnbuf, slope.cuda(), (n, d, h, w), c, pd)
+    assert float((pooled.float().cpu().double() - pooled_ref.detach().permute(0, 2, 3, 4, 1).reshape(vo, c)).abs().max()) < \
+        1e-2 * float(pooled_ref.abs().max())
+    part = torch.empty((ops.num_partials(v), 2 * c + 1), dtype=torch.float32, device="cuda")
+    coef = torch.empty((2, c), dtype=torch.float32, device="cuda")
+    d_a2 = torch.empty_like(yg)
+    ops.pool_bwd_bn_reduce(yg, dyp.cuda(), dskip.cuda(), d_a2, bnbuf, slope.cuda(), (n, d, h, w), c, part, pd)
+    dgamma, dbeta, dslope = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
+    ops.bn_act_bwd(yg, d_a2, d_a2, bnbuf, slope.cuda(), 0.0, 0, 0, c, True, dgamma, dbeta, dslope, part, coef, reduced=True)
+    err = (d_a2.float().cpu().double() - yd.grad).abs()
+    lim = 2e-2 * float(yd.grad.abs().max())
+    assert int((err > lim).sum()) <= 8, (int((err > lim).sum()), float(err.max()), lim)      # arg-max flips at rounding ties
+    for got, ref in ((dgamma, gd.grad), (dbeta, bd.grad), (dslope, sd.grad)):
+        assert float((got.cpu().double() - ref).abs().max()) < 1e-2 * float(ref.abs().max()), (got, ref)

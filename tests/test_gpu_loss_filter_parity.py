@@ -84,6 +84,29 @@ def _check_params(sd, g, variant, step):
             assert (diff <= 5e-5 * step + 1e-4 * np.abs(ref)).mean() >= 0.99, k
 
 
+def test_seg_loss_fwd_stays_inside_the_documented_part_buffer():
+    """with N = 1 and an odd rows x K the 8-byte aligned (N + 1) x K doubles behind the partial rows ended one
+    float past N x fplx_loss_rows x K.  Sub-allocate exactly what include/fplx.h documents, poison what follows."""
+    from fplx import ops
+    from oracle import torch_ref as R
+    for (n, c, vol) in [(1, 2, (4, 16, 16)), (1, 2, (9, 32, 48)), (1, 3, (5, 16, 16)), (2, 2, (3, 16, 16))]:
+        v = vol[0] * vol[1] * vol[2]
+        k = ops.loss_k(c)
+        need = n * ops.loss_rows(v) * k
+        arena = torch.full((need + 64,), -777.0, dtype=torch.float32, device="cuda")
+        part = arena[:need]
+        g = torch.Generator().manual_seed(3)
+        logits = torch.randn((n, c) + vol, generator=g)
+        lab = torch.nn.functional.one_hot(torch.randint(0, c, (n,) + vol, generator=g), c).permute(0, 4, 1, 2, 3).float().contiguous()
+        out = torch.empty(4 + c, dtype=torch.float32, device="cuda")
+        coef = torch.empty(n * c * 2 + 2, dtype=torch.float32, device="cuda")
+        ops.seg_loss_fwd(logits.cuda(), lab.cuda(), None, None, (1.0, 0.0, 0.0, 0.0), True, part, out, coef)
+        torch.cuda.synchronize()
+        assert bool((arena[need:] == -777.0).all()), (n, c, vol)
+        ref = float(R.dice_loss(logits, lab))
+        assert abs(float(out[0]) - ref) < 1e-5
+
+
 @pytest.mark.parametrize("variant", ["dice", "dice_pw", "combined"])
 def test_training_all_agent_matches_reference(golden_dir, variant):
     """SegmentationAgent.training_all through the drop-in registry/agent surface (autograd mode)."""

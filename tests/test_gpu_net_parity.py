@@ -8,7 +8,7 @@ import torch
 
 import detdata
 from make_golden_cfg import NETS, SHAPES, label_for
-from util import load_det_weights, max_rel
+from util import load_det_weights, max_rel, plan_kernel
 
 pytestmark = pytest.mark.gpu
 
@@ -227,6 +227,9 @@ MARCH_CASES = {
 }
 
 
+SLOPE_CANCEL = 0.02      # bound on |error| / sum |terms| of a PReLU slope gradient (calibrated: profiles/r03_parity_bf16_*.txt)
+
+
 @pytest.mark.parametrize("case", ["m1", "m4", "b2"])
 def test_bf16_march_kernels_end_to_end_against_oracle(case):
     """The bf16 bench path end to end (march / tile / stream-wgrad MFMA kernels, split concat, bf16 activations) against the
@@ -241,7 +244,7 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
     lib = _lib.lib()
     assert lib.fplx_conv3d_cat2_ok(n, D, H, W, 64, 32) == 1                 # the level-0 split concat + march path is taken
     if case == "b2":                                                        # level 1 runs on the brick kernel
-        assert lib.fplx_brick_first(n, D // 2, H // 2, W // 2, 64, 64) == 1 and lib.fplx_brick_first(n, D // 2, H // 2, W // 2, 128, 64) == 1
+        assert plan_kernel(n, D // 2, H // 2, W // 2, 64, 64) == 5 and plan_kernel(n, D // 2, H // 2, W // 2, 128, 64) == 5   # FPLX_KERNEL_BRICK
     x = torch.from_numpy(detdata.normal("x." + case, shape))
     y = torch.from_numpy(detdata.ball_label((D, H, W), min(D, H, W) / 3.0, n=n, offsets=[(0, 1, -2), (1, -3, 2)][:n]))
     net = fplx.UNet2D5_dsbn(p)
@@ -252,9 +255,18 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
     loss = fplx.DiceLoss()({"prediction": lt, "ground_truth": y.cuda()})
     loss.backward()
     sd, prm = R.split_state(detdata.state_dict_3d(p))
-    ref = R.unet_forward(sd, p, x, dom, True, act_dtype=torch.bfloat16)
-    rl = R.dice_loss(ref, y)
-    rl.backward()
+    R.PRELU_TAPS = []
+    try:
+        ref = R.unet_forward(sd, p, x, dom, True, act_dtype=torch.bfloat16)
+        rl = R.dice_loss(ref, y)
+        rl.backward()
+        # a PReLU slope gradient is ONE number: sum_i d out_i * min(z_i, 0).  Its noise lives on the scale of the terms it adds
+        # up, S = sum_i |d out_i * min(z_i, 0)| (the oracle's own terms), not on the scale of the - often nearly cancelled -
+        # total: the per-site cancellation scale replaces round 2's blanket 0.05 x (largest slope gradient) allowance
+        slope_terms = {id(sl): float((ng.grad / float(sl.detach()) * ng.detach()).abs().sum())
+                       for sl, ng in R.PRELU_TAPS if ng.grad is not None}
+    finally:
+        R.PRELU_TAPS = None
     rng = float(ref.detach().abs().max())
     dlt = lt.detach().cpu().numpy() - ref.detach().numpy()
     err, rms = float(np.abs(dlt).max()), float(np.sqrt((dlt.astype(np.float64) ** 2).mean()))
@@ -267,8 +279,7 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
     R.dice_loss(ref32, y).backward()
     gap = float((ref32.detach() - ref.detach()).abs().max())
     named = dict(net.named_parameters())
-    worst, bad = {}, {}
-    slope_scale = max(float(t.grad.abs().max()) for k, t in prm.items() if t.grad is not None and ".relu_" in k)
+    worst, bad, cancel = {}, {}, {}
     for k, t in prm.items():
         if t.grad is None:
             continue
@@ -281,11 +292,14 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
         e, nr, gk = float(np.linalg.norm(g - r)), float(np.linalg.norm(r)), float(np.linalg.norm(r32 - r))
         worst[k] = (e / max(nr, 1e-30), gk / max(nr, 1e-30))
         # within 0.1 relative L2 of the bf16 oracle, or no further from it than 1.5 x the oracle's own fp32 result is (two
-        # independent bf16 realisations of the same noise differ by sqrt(2) of it).  A PReLU slope gradient is ONE number, a
-        # sum over a whole tensor that cancels to near zero at some layers: its scale is the largest slope gradient.
+        # independent bf16 realisations of the same noise differ by sqrt(2) of it).  A PReLU slope gradient is ONE number that
+        # cancels to near zero at some layers: SLOPE_CANCEL of the sum of its terms' magnitudes (above) is its third bound;
+        # the kernels that form it are pinned per kernel against torch autograd on data that does not cancel
+        # (tests/test_gpu_kernels.py::test_bn_act_bf16_kernels_against_torch_autograd: 1e-2 relative).
         tol = max(0.1 * nr, 1.5 * gk)
-        if r.size == 1:
-            tol = max(tol, 0.05 * slope_scale)
+        if r.size == 1 and id(t) in slope_terms:
+            cancel[k] = (e / max(slope_terms[id(t)], 1e-30), nr / max(slope_terms[id(t)], 1e-30))
+            tol = max(tol, SLOPE_CANCEL * slope_terms[id(t)])
         if e > tol:
             bad[k] = worst[k]
     os.makedirs("gpurun_out", exist_ok=True)
@@ -294,6 +308,8 @@ def test_bf16_march_kernels_end_to_end_against_oracle(case):
             err, rms, rng, gap, loss.item(), rl.item()))
         for k, v in sorted(worst.items(), key=lambda kv: -kv[1][0]):
             f.write("%-44s rel L2 %.4f   (oracle fp32-vs-bf16 %.4f)\n" % (k, v[0], v[1]))
+        for k, v in sorted(cancel.items(), key=lambda kv: -kv[1][0]):
+            f.write("%-44s slope gradient: error %.5f, value %.5f of the sum of its terms' magnitudes\n" % (k, v[0], v[1]))
     # logits: max error within 3e-2 of the range and below the oracle's own bf16 gap, rms within 5e-3 of the range
     assert err < 3e-2 * rng and err < gap + 1e-3 * rng, (err, rng, gap)
     assert rms < 5e-3 * rng, (rms, rng)

@@ -23,8 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.fplx_version() >= 1
     # every exported fplx_ symbol is declared (nm view)
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
-    exported = sorted(l.split()[-1] for l in out.splitlines() if " T fplx_" in l and "fplx_mfma_" not in l and "fplx_edge_" not in l
-                      and "fplx_march_" not in l and "fplx_brick_" not in l)  # cross-file internals
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)      # every exported function, whatever its name
     assert exported == names, set(exported) ^ set(names)
     # error path works without a GPU: bad arguments are rejected before any launch
     assert lib.fplx_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) == -5
@@ -32,25 +31,48 @@ def test_library_exports_every_declared_symbol():
     assert lib.fplx_num_partials(1) == 1 and lib.fplx_num_partials(10 ** 9) == 512
 
 
+def test_tuning_table_round_trip_and_env_translation():
+    """fplx_set_tuning / fplx_get_tuning / fplx_tuning_key, and the FPLX_<KEY> environment translation of fplx/_lib.py"""
+    from fplx import _lib
+    keys = _lib.tuning_keys()
+    assert "brick" in keys and "march32_v2" in keys and "xcd" in keys and len(set(keys)) == len(keys) >= 20
+    assert _lib.get_tuning("brick") == 1 and _lib.get_tuning("march32_v2") == 4
+    _lib.set_tuning("brick", 3)
+    try:
+        assert _lib.get_tuning("brick") == 3
+    finally:
+        _lib.set_tuning("brick", 1)
+    with pytest.raises(ValueError):
+        _lib.set_tuning("no_such_knob", 1)
+    code = "import sys; sys.path.insert(0, %r); from fplx import _lib; print(_lib.get_tuning('brick'), _lib.get_tuning('tile_ks'))" % (
+        os.path.dirname(os.path.dirname(_lib.__file__)),)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                         env=dict(os.environ, FPLX_BRICK="0", FPLX_TILE_KS="9"))
+    assert out.stdout.split() == ["0", "9"], out.stderr[-500:]
+
+
 def test_brick_kernel_plan_for_the_benchmark_layers():
     """host-side dispatch of conv_fwd_brick (conv_brick.hip): geometry, Cin split and statistics rows for the benchmark's
-    levels - pure host code, no launch"""
+    levels - pure host code, no launch (fplx_conv3d_plan_query)"""
     import ctypes
     from fplx import _lib
     lib = _lib.lib()
 
     def plan(n, d, h, w, cin, cout):
-        g, k, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        lib.fplx_brick_plan.restype = ctypes.c_int
-        ok = lib.fplx_brick_plan(n, d, h, w, cin, cout, ctypes.byref(g), ctypes.byref(k), ctypes.byref(b))
-        return ok, g.value, k.value, b.value
+        """(brick kernel?, geometry, Cin split, statistics rows) through the declared plan query"""
+        kern, g, k, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert lib.fplx_conv3d_plan_query(n, d, h, w, cin, cout, 3, 3, 3, _lib.BF16, _lib.BF16, ctypes.byref(kern), ctypes.byref(g),
+                                          ctypes.byref(k), ctypes.byref(r)) == 0
+        return int(kern.value == BRICK), g.value, k.value, r.value, kern.value
 
-    assert plan(2, 40, 80, 80, 64, 64) == (1, 0, 1, 2000)          # level 1: 4 x 8 x 8 bricks, 64 channels per block
-    assert plan(2, 20, 40, 40, 128, 128) == (1, 0, 1, 250)         # level 2
-    assert plan(2, 10, 20, 20, 256, 256) == (1, 1, 2, 60)          # level 3: 5 x 4 x 8 bricks, Cin split in two
-    assert plan(2, 10, 20, 20, 256, 512) == (1, 1, 1, 60)
-    assert plan(2, 5, 10, 10, 512, 512)[0] == 0                    # level 4 pads 1.9x: the tile kernel's
-    assert plan(2, 80, 160, 160, 32, 32)[0] == 0 and plan(2, 80, 160, 160, 64, 32)[0] == 0   # level 0: the march kernels'
+    GENERIC, DIRECT, TILE, STREAM, MARCH, BRICK, STEM, OUTCONV = range(8)           # FPLX_KERNEL_* of include/fplx.h
+    assert plan(2, 40, 80, 80, 64, 64)[:4] == (1, 0, 1, 2000)      # level 1: 4 x 8 x 8 bricks, 64 channels per block: rows = bricks
+    assert plan(2, 20, 40, 40, 128, 128)[:4] == (1, 0, 1, 250)     # level 2
+    assert plan(2, 10, 20, 20, 256, 256)[:4] == (1, 1, 2, 512)     # level 3: 5 x 4 x 8 bricks, Cin split in two: the finish kernel's rows
+    assert plan(2, 10, 20, 20, 256, 512)[:4] == (1, 1, 1, 60)
+    assert plan(2, 5, 10, 10, 512, 512)[4] == TILE                 # level 4 pads 1.9x: the tile kernel's
+    assert plan(2, 80, 160, 160, 32, 32)[4] == MARCH and plan(2, 80, 160, 160, 64, 32)[4] == MARCH   # level 0: the march kernels'
+    assert plan(2, 80, 160, 160, 48, 48)[4] == GENERIC
     # the rows the dispatcher promises: bricks, or the split-K finish kernel's blocks
     assert lib.fplx_conv3d_stats_rows(2, 20, 40, 40, 128, 128, 3, 3, 3, 1, 1) == 250
     assert lib.fplx_conv3d_stats_rows(2, 10, 20, 20, 256, 256, 3, 3, 3, 1, 1) == 512
@@ -222,3 +244,19 @@ def test_filter_cut_points_are_numpys():
         assert np.array_equal(pred(w), (w >= lo) & (w <= hi))
     coarse = np.arange(0, int(np.float32(1.0).view(np.uint32)) + 1, 4099, dtype=np.uint32)
     assert np.array_equal(pred(coarse), (coarse >= lo) & (coarse <= hi))
+
+
+def test_bench_refuses_a_world_size_that_is_not_its_gpus_argument():
+    """`bench.py --gpus N` must never print a line for another world size (--gpus was parsed and ignored):
+    under a launcher with WORLD_SIZE != N it exits 2 before touching any GPU; without a launcher and N > 1 it starts the
+    ranks itself - here, without GPUs, the child fails and the parent relays the failure instead of a result line."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout
+    if not torch.cuda.is_available():
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                            "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and '"metric"' not in r.stdout and "2-rank child" in r.stderr

@@ -21,17 +21,12 @@ def cl(t):
     return t.permute(0, 2, 3, 4, 1).contiguous().view(-1, t.shape[1])
 
 
-def run_direct(xg, wf, bias, y, dims, cin, cout, stats):
-    """straight into fplx_brick_conv3d_fwd (shapes fplx_brick_ok would leave to the tile kernel)"""
-    n, d, h, w = dims
-    lib.fplx_brick_conv3d_fwd.restype = ctypes.c_int
-    vp = ctypes.c_void_p
-    rc = lib.fplx_brick_conv3d_fwd(vp(xg.data_ptr()), ctypes.c_int64(cin), vp(wf.data_ptr()),
-                                   vp(bias.data_ptr()) if bias is not None else None, vp(y.data_ptr()),
-                                   ctypes.c_int64(cout), n, d, h, w, cin, cout,
-                                   vp(stats.data_ptr()) if stats is not None else None,
-                                   vp(torch.cuda.current_stream().cuda_stream))
-    assert rc == 1, rc
+def plan(n, d, h, w, cin, cout):
+    """(kernel family, geometry, ksplit, rows) from the declared plan query (5 = FPLX_KERNEL_BRICK)"""
+    kern, g, k, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib.fplx_conv3d_plan_query(n, d, h, w, cin, cout, 3, 3, 3, dt, dt, ctypes.byref(kern), ctypes.byref(g), ctypes.byref(k),
+                               ctypes.byref(r))
+    return kern.value, g.value, k.value, r.value
 
 
 def check(shape, direct):
@@ -46,16 +41,16 @@ def check(shape, direct):
     xg = cl(x).to(bf).cuda()
     wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
     y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
-    if direct:
-        rows = lib.fplx_brick_rows(n, d, h, w, 0)
-        stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
-        run_direct(xg, wf, b.cuda(), y, dims, cin, cout, stats)
-    else:
-        assert lib.fplx_brick_ok(n, d, h, w, cin, cout) == 1
+    if direct:                 # geometry 0 forced on shapes the plan would leave to the tile kernel
+        ops._lib.set_tuning("brick_geo", 0)
+    try:
+        assert plan(n, d, h, w, cin, cout)[0] == 5
         rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
         stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda")
         ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y, ops.cl_strides(d, h, w, cout), dt, dims, cin,
                        cout, (3, 3, 3), stats)
+    finally:
+        ops._lib.set_tuning("brick_geo", -1)
     torch.cuda.synchronize()
     got = y.float().cpu().view(n, d, h, w, cout).permute(0, 4, 1, 2, 3)
     scale = float(yr.abs().max())
@@ -78,9 +73,7 @@ def timeit(shape, stats_on, reps=30):
     rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
     stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device="cuda") if stats_on else None
     if "check" not in sys.argv and not stats_on:
-        g_, k_, b_ = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        ok_ = lib.fplx_brick_plan(n, d, h, w, cin, cout, ctypes.byref(g_), ctypes.byref(k_), ctypes.byref(b_))
-        print("plan %s: ok %d geo %d ksplit %d bricks %d" % (shape, ok_, g_.value, k_.value, b_.value))
+        print("plan %s: kernel %d geo %d ksplit %d rows %d" % ((shape,) + plan(n, d, h, w, cin, cout)))
     f = lambda: ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, None, y, ops.cl_strides(d, h, w, cout), dt, dims,
                                cin, cout, (3, 3, 3), stats)
     for _ in range(5):
@@ -95,7 +88,7 @@ def timeit(shape, stats_on, reps=30):
     us = e0.elapsed_time(e1) * 1000 / reps
     fl = 2.0 * V * 27 * cin * cout
     print("time %s stats=%d brick_ok=%d: %.1f us  %.3f PFLOP/s (%.3f of 2.5)" %
-          (shape, stats_on, lib.fplx_brick_ok(n, d, h, w, cin, cout), us, fl / us / 1e9, fl / us / 1e9 / 2.5), flush=True)
+          (shape, stats_on, int(plan(n, d, h, w, cin, cout)[0] == 5), us, fl / us / 1e9, fl / us / 1e9 / 2.5), flush=True)
 
 
 if "check" in sys.argv:
