@@ -141,21 +141,29 @@ def test_agent_fpl_inference_pipeline():
 
 
 def test_config4_mc_inference_and_filter_at_full_size():
-    """BASELINE config 4 at its size (reference agent_seg.py:897-931, infer_func.py:188-222): the 32-base bf16 network,
-    eval-mode BatchNorm + test-time dropout, one hrT2-sized volume 1 x 1 x 48 x 160 x 272 through the shipped sliding window
-    (28 x 128 x 128, stride = window: 12 tiles), (a) T = 4 Monte-Carlo passes and (b) the reference-literal 6 passes x 4-flip
-    TTA = 24 forwards per tile.  Two runs are bit-identical; the batched plan equals the tile-by-tile loop of forwards (dropout
+    """BASELINE config 4 at its size (reference agent_seg.py:897-931, infer_func.py:188-222): the 32-base bf16 network in
+    the shipped 2.5D pattern (conv_dims [2, 2, 3, 3, 3], config_dual/data_vs/vs_t1s_g.cfg:58 - the all-3D network cannot take
+    the shipped 28-slice window: four depth poolings), eval-mode BatchNorm + test-time dropout, one hrT2-sized volume
+    1 x 1 x 48 x 160 x 272 through the shipped sliding window (28 x 128 x 128, stride = window: 12 tiles), (a) T = 4 Monte-Carlo
+    passes and (b) the reference-literal 6 passes x 4-flip TTA = 24 forwards per tile.  Two runs are bit-identical; the batched plan equals the tile-by-tile loop of forwards (dropout
     off: the masks are keyed by the element index inside a forward batch); hard pseudo-labels and filter scalars are those of
     the numpy oracle on the recorded logits."""
     import fplx
     from oracle import np_ref as N
     torch.manual_seed(4)
-    net = fplx.UNet2D5_dsbn(dict(NET)).cuda()
-    # a network that has seen data: a few train steps give BatchNorm running statistics and non-trivial logits
+    net = fplx.UNet2D5_dsbn(dict(NET, conv_dims=[2, 2, 3, 3, 3])).cuda()
+    # a network that has seen data: a few train steps on shipped-size crops (4 x 1 x 28 x 128 x 128) give BatchNorm running
+    # statistics and non-trivial logits
     ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
-    b = _batch(10)
+    gen = torch.Generator().manual_seed(12)
+    xb = torch.randn((4, 1, 28, 128, 128), generator=gen).cuda()
+    lb = torch.zeros((4, 2, 28, 128, 128))
+    lb[:, 0] = 1.0
+    lb[:, 0, 8:20, 40:90, 40:90] = 0.0
+    lb[:, 1, 8:20, 40:90, 40:90] = 1.0
+    lb = lb.cuda()
     for i in range(2):
-        ts.step(b[0], b[1], 1)
+        ts.step(xb, lb, 1)
     g = torch.Generator().manual_seed(8)
     x = torch.randn((1, 1, 48, 160, 272), generator=g).cuda()
     dl = torch.ones(1, dtype=torch.long)

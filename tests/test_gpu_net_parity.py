@@ -227,7 +227,7 @@ MARCH_CASES = {
 }
 
 
-SLOPE_CANCEL = 0.02      # bound on |error| / sum |terms| of a PReLU slope gradient (calibrated: profiles/r03_parity_bf16_*.txt)
+SLOPE_CANCEL = 0.01      # bound on |error| / sum |terms| of a PReLU slope gradient (measured max 0.0062: profiles/r03_parity_bf16_*.txt)
 
 
 @pytest.mark.parametrize("case", ["m1", "m4", "b2"])
