@@ -126,6 +126,8 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \
+  X(STEM_ROWS, "stem_rows", 1)             /* 0: the tile kernel for in_chns = 1 too */                                 \
+  X(OUTCONV_T, "outconv_t", 1)             /* 0: the 32 x 32 out_conv forward (classes as columns) */                    \
   X(OUTCONV_DGRAD_MFMA, "outconv_dgrad_mfma", 1)                                                                       \
   X(PACK_TILED, "pack_tiled", 1)                                                                                       \
   X(PACK_MULTI, "pack_multi", 1)                                                                                       \
@@ -139,12 +141,15 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(WG_CIT, "wg_cit", 2)                                                                                               \
   X(WG_COT, "wg_cot", 2)                                                                                               \
   X(WG_DS, "wg_ds", 0)                                                                                                 \
+  X(WG_VOX, "wg_vox", 1)                   /* 0: footprint march everywhere; 2: voxel GEMM wherever it can run */           \
+  X(WG_VOX_MAXV, "wg_vox_maxv", 10000)     /* largest voxel count (whole batch) the voxel-GEMM weight gradient takes */    \
   X(STREAM_MIN_W, "stream_min_w", 64)                                                                                  \
   X(TILE_MT, "tile_mt", 0)                                                                                             \
   X(TILE_NT, "tile_nt", 0)                                                                                             \
   X(TILE_KS, "tile_ks", 0)                                                                                             \
   X(MID_TILE, "mid_tile", 1)                                                                                           \
   X(DECONV_ROWS, "deconv_rows", 1)                                                                                     \
+  X(DECONV_DGRAD_ROWS, "deconv_dgrad_rows", 1)  /* 0: conv_fwd_direct for the shallow transposed-convolution data gradients */ \
   X(EW_GROUP, "ew_group", 1)
 enum FplxKnobId {
 #define FPLX_KNOB_ENUM(id, key, def) FPLX_K_##id,

@@ -185,6 +185,161 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// stem_fwd_rows (in_chns = 1, round 3): the same convolution without LDS, barriers or tiles.  The kernel above spends 7 us
+// per 256-voxel tile on a chain of (commit -> barrier -> 16 two-byte LDS gathers per fragment -> MFMA -> 16 two-byte LDS
+// stores -> 16-byte global stores), 1.2 TB/s for an operation that only has to WRITE 131 MB.  Here a wave owns 32
+// consecutive voxels of one row at a time and computes the TRANSPOSED product D[cout][voxel] = W[cout][k] X^T[k][voxel]:
+//   * B operand (lane = voxel r, k-octet = lane / 32): the lane's 16 input values come straight from global memory (fp32
+//     planar, 27-fold reuse served by L1 / L2) through a buffer descriptor - out-of-tensor addresses read as zeros, the
+//     in-tensor wrap-arounds of the zero padding (d +- 1, h +- 1, w +- 1 outside the volume) are cleared by selects;
+//   * the 27 taps are dealt to the 32 k-slots so that slot (s, j) has the SAME kw in both lane halves (p = 8 s + j: kw =
+//     p % 3, (kd, kh) = p / 3 + 5 (lane / 32)): kw is an immediate of the load, the (kd, kh) row is one of 6 lane
+//     offsets, validity of a row is one bit of a per-tile scalar mask;
+//   * A operand = the weights in the same slot order, two fragments for the whole kernel; the bias is the MFMA's C input;
+//   * a lane ends up with 16 output channels of ONE voxel; two v_permlane32_swap exchanges between the lane halves turn
+//     them into two runs of 8 consecutive channels = two 16-byte stores per lane, whole 64-byte voxel rows per wave;
+//   * BatchNorm statistics: 16 + 16 running sums per lane, reduced once at the end of the kernel.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2e;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
+
+__global__ void __launch_bounds__(256, 4)
+stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
+              bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
+              float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd) {
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, khalf = lane >> 5;
+  // k-slot p = 8 s + j of lane half khalf: combo = p / 3 + 5 khalf (kd = combo / 3, kh = combo % 3), kw = p % 3
+  // (low half: slots 0-14 = combos 0-4, slot 15 spare; high half: slots 0-11 = combos 5-8, slots 12-15 spare)
+  auto slot_tap = [&](int p, int kh_) { return p < (kh_ ? 12 : 15) ? (p / 3 + 5 * kh_) * 3 + p % 3 : -1; };
+  bf16x8 afr[2];                                     // A: row = output channel r, the lane's 8 k-slots of step s
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = slot_tap(8 * s_ + j, khalf);
+      afr[s_][j] = tap >= 0 ? wf[((int64_t)tap * Cout + co0 + r)] : (bf16_t)0.f;      // pack [tap][Cout][Cin = 1]
+    }
+  f32x16 cinit;                                      // D[row = channel (i & 3) + 8 (i >> 2) + 4 khalf][col = voxel r]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) cinit[i] = bias ? bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf] : 0.f;
+  // the lane's six (kd, kh) rows as element offsets relative to the voxel (combo c + 5 khalf)
+  int roff[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const int cb = c + 5 * khalf;
+    roff[c] = cb < 9 ? ((cb / 3 - 1) * H + (cb % 3 - 1)) * W : 0;
+  }
+  const int64_t xbytes = (int64_t)N * D * H * W * 4;
+  // (the launcher keeps the input below 2 GiB; raw buffer, no stride: out-of-range offsets read as zeros)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
+  float ssum[16], qsum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ssum[i] = 0.f; qsum[i] = 0.f; }
+
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
+  struct Seg { int n, d, h, w0; };
+  auto seg_of = [&](int64_t tt) {
+    unsigned t = (unsigned)tt * 4u + (unsigned)wave;
+    Seg g;
+    g.w0 = (int)(t % (unsigned)tilesW) * 32; t /= (unsigned)tilesW;
+    g.h = (int)(t % (unsigned)H); t /= (unsigned)H;
+    g.d = (int)(t % (unsigned)D);
+    g.n = (int)(t / (unsigned)D);                    // >= N: a segment past the end of the list (the last tile may be ragged)
+    return g;
+  };
+  // the segment's 16 loads per lane.  Byte offset of (row c, kw): a VECTOR offset that is negative (= huge, out of range -> 0)
+  // exactly when the element lies before the tensor.  (A scalar offset must not carry the kw shift: the range check sees the
+  // vector offset alone, and a row that starts one element before the tensor would lose its two valid taps.)
+  auto issue = [&](const Seg& g, float (&xv)[16]) {
+    const int vidx = ((g.n * D + g.d) * H + g.h) * W + g.w0 + r;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int c = p / 3, kw = p % 3;
+      const unsigned off = g.n < N ? (unsigned)(vidx + roff[c < 6 ? c : 5] + kw - 1) * 4u : 0x80000000u;
+      xv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+    }
+  };
+  auto consume = [&](const Seg& g, const float (&xv)[16]) {
+    if (g.n >= N) return;                            // wave-uniform
+    const int n = g.n, d = g.d, h = g.h;
+    // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
+    unsigned dh = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const int dd = d + c / 3 - 1, hh = h + c % 3 - 1;
+      if (dd >= 0 && dd < D && hh >= 0 && hh < H) dh |= 1u << c;
+    }
+    const unsigned dhl = dh >> (5 * khalf);
+    const int wv = g.w0 + r;
+    const bool wl = wv - 1 >= 0 && wv - 1 < W, wc = wv < W, wr = wv + 1 < W;
+    bf16x8 bfr[2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int c = p / 3, kw = p % 3;
+      const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
+      bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[p] : 0.f);
+    }
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], cinit, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1], bfr[1], acc, 0, 0, 0);
+    if (wc) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
+    }
+    // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the swaps the low half holds 0-7 and 16-23, the high
+    // half 8-15 and 24-31 of its voxel
+    unsigned pk[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16_t e0 = (bf16_t)acc[4 * q], e1 = (bf16_t)acc[4 * q + 1], e2 = (bf16_t)acc[4 * q + 2], e3 = (bf16_t)acc[4 * q + 3];
+      pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+      pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)                    // (q0, q1) and (q2, q3): high half of the first <-> low half of the second
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+        pk[4 * g2 + e] = sw[0];
+        pk[4 * g2 + 2 + e] = sw[1];
+      }
+    if (wc) {
+      bf16_t* dst = y + ((int64_t)(((n * D + d) * H + h)) * W + wv) * ldy + co0 + 8 * khalf;
+      *reinterpret_cast<u32x4e*>(dst) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
+      *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
+    }
+  };
+  // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured: 134 us
+  // against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
+  float xa[16];
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    const Seg ga = seg_of(tt);
+    issue(ga, xa);
+    consume(ga, xa);
+  }
+  if (stats) {
+    // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); qsum[i] += __shfl_xor(qsum[i], o, 64); }
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ch = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+        red[wave][0][ch] = ssum[i];
+        red[wave][1][ch] = qsum[i];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // stem weight gradient: rows = (ci, tap) padded to 32*RT, cols = 32 output channels, K = voxels
 template <int CIN>
 __global__ void __launch_bounds__(256)
@@ -385,6 +540,101 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
             const int w = t.w0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
             if (w < W) orow[w] = acc[m][i] + bv;
           }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// outconv_fwd_t (round 3, Cin = 32 | 64): the same tile pipeline with the product TRANSPOSED and on the 16 x 16 x 32 shape:
+// D[class][voxel] = W[class][k] X^T[k][voxel].  The kernel above pads 2 classes to the 32 columns of a 32 x 32 tile (its matrix
+// pipe is busy a third of the time computing zeros), re-reads its B fragments from LDS for every tile and writes the logits
+// as 4-byte scattered stores from four lanes.  Here the classes are the 16 ROWS of the tile (half the padding, one MFMA per
+// tap spans all 32 channels), the weights are the A operand and live in registers for the whole kernel (9 fragments), the only
+// LDS traffic of a tile is one 16-byte read per (tap, 16 voxels), and the result comes out voxel-contiguous: lanes 0-15 hold
+// class 0 / 1 (registers 0 / 1) of 16 consecutive voxels = 64-byte stores into the planar logits.
+typedef __attribute__((ext_vector_type(4))) float f32x4e;
+template <int KS32>      // Cin / 32
+__global__ void __launch_bounds__(256, KS32 == 1 ? 3 : 1)     // Cin = 32: three blocks per CU (the per-tile chain is latency, occupancy hides it)
+outconv_fwd_t(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
+              float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
+  constexpr int CIN = KS32 * 32, ROWB = CIN * 2, CH = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) char xs[SH * SW * ROWB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const int64_t Vs = (int64_t)D * H * W;
+  // A fragments: row = class r16 (zero rows beyond ncls), the lane's 8 channels 8 kg .. 8 kg + 7 of 32-channel step s
+  bf16x8 afr[9][KS32];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int s_ = 0; s_ < KS32; ++s_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        afr[tap][s_][j] = r16 < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r16) * CIN + s_ * 32 + 8 * kg + j] : (bf16_t)0.f;
+  f32x4e cinit;                                       // D rows 4 kg + i = classes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cinit[i] = (bias && 4 * kg + i < ncls) ? bias[4 * kg + i] : 0.f;
+  auto swz = [](int vox) { return (vox / (16 / CH)) % CH; };
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
+  constexpr int NLD = (SH * SW * CH + 255) / 256;
+  uint4 xreg[NLD];
+  auto fetch = [&](const Tile& t) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int vox = i / CH, c = i % CH;
+      const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < SH * SW * CH && h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + c * 8);
+      xreg[k] = v;
+    }
+  };
+  int64_t tt = tr.first;
+  Tile tn = tile_of(tt < tr.end ? tt : 0, D, tilesH, tilesW);
+  if (tt < tr.end) fetch(tn);
+  for (; tt < tr.end; tt += tr.step) {
+    const Tile t = tn;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int vox = i / CH, c = i % CH;
+      if (i < SH * SW * CH) *reinterpret_cast<uint4*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16)) = xreg[k];
+    }
+    __syncthreads();
+    if (tt + tr.step < tr.end) {
+      tn = tile_of(tt + tr.step, D, tilesH, tilesW);
+      fetch(tn);
+    }
+    // a wave owns rows 2 wave, 2 wave + 1 of the tile: four segments of 16 voxels
+    f32x4e acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = cinit;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+      for (int s_ = 0; s_ < KS32; ++s_) {
+        const int c = 4 * s_ + kg;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int vox = (wave * 2 + (q >> 1) + kh) * SW + (q & 1) * 16 + r16 + kw;
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16));
+          acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[tap][s_], b, acc[q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = t.h0 + wave * 2 + (q >> 1), w = t.w0 + (q & 1) * 16 + r16;
+      if (h < H && w < W) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int cls = 4 * kg + i;
+          if (cls < ncls) out[((int64_t)t.n * ncls + cls) * Vs + ((int64_t)t.d * H + h) * W + w] = acc[q][i];
         }
       }
     }
@@ -688,6 +938,15 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
+  if (cin == 1 && vec_ok && fplx_knob(FPLX_K_STEM_ROWS) && (int64_t)n * d * h * w < ((int64_t)1 << 29)) {
+    // in_chns = 1: the LDS-free row kernel; the same number of blocks (= statistics rows) as the tile kernel
+    const int tilesW = (w + 31) / 32;
+    const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
+    for (int co0 = 0; co0 < cout; co0 += 32)
+      stem_fwd_rows<<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+    int rc0 = fplx_check_launch("edge_stem_fwd_rows");
+    return rc0 < 0 ? rc0 : 1;
+  }
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1)
       stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok, fplx_xcd_on());
@@ -727,6 +986,12 @@ extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = (int)(nt < 2048 ? nt : 2048);
+  if ((cin == 32 || cin == 64) && ncls <= 16 && fplx_knob(FPLX_K_OUTCONV_T)) {
+    if (cin == 32) outconv_fwd_t<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+    else outconv_fwd_t<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
+    int rct = fplx_check_launch("edge_outconv_fwd_t");
+    return rct < 0 ? rct : 1;
+  }
   if (cin == 16) outconv_fwd_mfma<1><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
   else if (cin == 32) outconv_fwd_mfma<2><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());
   else outconv_fwd_mfma<4><<<nb, 256, 0, st>>>((const bf16_t*)x, ldx, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on());

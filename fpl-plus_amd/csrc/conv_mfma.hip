@@ -520,6 +520,319 @@ inline WgCfg wg_cfg(int n, int d, int h, int w, int cin, int cout) {
 }
 
 // ------------------------------------------------------------------------------------------
+// conv_wgrad_vox: the same weight gradient for the SMALL volumes of the deep levels (2 x 20 x 40 x 40 and below), where the
+// footprint march above pads its 8 x 16 tiles 1.2-2.6 x and writes one 110-KB partial tile per footprint and channel
+// pair (level 4: 112 MB of partials for 2 MB of operands).  Here the reduction dimension is the LINEAR voxel index: a
+// block owns a channel-pair group (32 ci x 32 COT co, all 27 taps dealt to its 4 waves exactly as above - same
+// accumulators, same partial-tile format, same reduction kernel) and a contiguous voxel range [k0, k1) of the whole
+// batch, walked in chunks of 128 voxels = 8 k-steps.  In linear order a tap is a constant row shift
+// (kd - 1) H W + (kh - 1) W + (kw - 1); what the shift must not do is wrap around a row, a slice or a sample:
+//   * depth: the three kd planes are staged separately (rows [chunk - W - 1, chunk + 128 + W + 1) shifted by -HW, 0, +HW);
+//     a source row whose depth cannot belong to a valid pair (d = D - 1 for kd = 0, d = 0 for kd = 2), or that lies outside
+//     the tensor, is staged as zeros;
+//   * height / width: an x fragment holds 8 consecutive voxels per lane, so the pairs whose OUTPUT voxel sits on the
+//     border the tap leaves through (h = 0 for kh = 0, h = H - 1 for kh = 2, likewise w) are removed by one 16-byte AND
+//     mask per (tap column, 8-voxel group), built per chunk from ballots over a per-voxel border code (a byte table the
+//     block computes once with multiply-high divisions) - 4 VALU per fragment, no second copy of x in LDS.
+// No padding waste (every MFMA row is a real voxel), K-split only as far as needed to fill the chip, x and dy of a deep
+// level (4-8 MB) stay in L2 / Infinity Cache across the pair groups.
+constexpr int VX_KC = 128, VX_MAXW = 40, VX_XR_MAX = VX_KC + 2 * VX_MAXW + 2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+
+struct VoxGeo { int V, D, H, W, HW; unsigned mW, mH, mD; int kper, S; };   // mX = ceil(2^32 / X): q = umulhi(u, mX) for u < 2^26
+
+// LDS of conv_wgrad_vox: two slots of {three x planes, COT dy planes, the chunk's masks} + the border-code table.  The
+// slot strides are compile-time constants (W enters only the row count inside a plane), so the slot is an immediate in
+// every LDS read of the unrolled chunk.
+template <int COT>
+struct VXL {
+  static constexpr int X_SLOT = 3 * VX_XR_MAX * 64, DY_SLOT = COT * VX_KC * 64, MK_SLOT = 9 * 16 * 16;
+  static constexpr int X0 = 0, DY0 = 2 * X_SLOT, MK0 = DY0 + 2 * DY_SLOT, VC0 = MK0 + 2 * MK_SLOT;
+};
+
+// what the staging of the NEXT chunk needs (wave-uniform unless noted)
+struct VoxStage {
+  const bf16_t* xg;        // x + this block's 32 input channels
+  const bf16_t* dyg;       // dy + this block's 32 COT output channels
+  int64_t ldx, ldy;
+  const unsigned char* vc; // border codes, entry t <-> voxel tb0 + t
+  int tb0, tbn, XR, W, HW, k1;
+};
+
+// staging item m (0 .. NLX + NLY - 1) of chunk kn: x rows first (16-byte column tid & 3 of row tid / 4 + 64 m of the three
+// planes; a row that must read as zeros loads voxel 0 and is cleared by selects - no divergent control flow, and a plain
+// global load: a pointer select with a zero constant would make it a FLAT one), then dy
+template <int COT>
+struct VXS {
+  static constexpr int NLX = (3 * VX_XR_MAX * 4 + 255) / 256, NLY = VX_KC * 4 * COT / 256, NA = 7, NB = NLX + NLY - NA;
+  static_assert(NB <= 7 && NB >= 0, "two batches of at most 7 items");
+  static __device__ __forceinline__ uint4 load(const VoxStage& sg, int kn, int tid, int m) {
+    uint4 v;
+    bool ok;
+    if (m < NLX) {
+      const int rr = (tid >> 2) + m * 64;
+      const int pl = (rr >= sg.XR ? 1 : 0) + (rr >= 2 * sg.XR ? 1 : 0), row = rr - pl * sg.XR;
+      const int u = kn + row - (sg.W + 1) + (pl - 1) * sg.HW;
+      const int t = u - sg.tb0;
+      const bool in = rr < 3 * sg.XR && t >= 0 && t < sg.tbn;
+      const unsigned c = sg.vc[in ? t : 0];
+      ok = in && c != 0xFFu && !((pl == 0 && (c & 2u)) || (pl == 2 && (c & 1u)));
+      v = *reinterpret_cast<const uint4*>(sg.xg + (int64_t)(ok ? u : 0) * sg.ldx + (tid & 3) * 8);
+    } else {
+      const int i = tid + (m - NLX) * 256;
+      const int vox = i / (4 * COT), ch = i % (4 * COT);
+      const int v_ = kn + vox;
+      ok = v_ < sg.k1;
+      v = *reinterpret_cast<const uint4*>(sg.dyg + (int64_t)(ok ? v_ : 0) * sg.ldy + ch * 8);
+    }
+    return ok ? v : make_uint4(0, 0, 0, 0);
+  }
+  static __device__ __forceinline__ void store(const VoxStage& sg, char* xw_n, char* dy_n, int tid, int m, const uint4& v) {
+    if (m < NLX) {
+      const int i = tid + m * 256;
+      if (i < 3 * sg.XR * 4) *reinterpret_cast<uint4*>(xw_n + i * 16) = v;     // planes are contiguous: row i / 4, column i % 4
+    } else {
+      const int i = tid + (m - NLX) * 256;
+      const int vox = i / (4 * COT), ch = i % (4 * COT);
+      *reinterpret_cast<uint4*>(dy_n + (ch >> 2) * (VX_KC * 64) + vox * 64 + (ch & 3) * 16) = v;
+    }
+  }
+  // the chunk's masks: wave wv (0 or 1) takes 64 voxels; lane e -> (combo e / 8, octet e % 8), then combo 8
+  static __device__ __forceinline__ void masks(const VoxStage& sg, char* mk_n, int kn, int wv, int lane) {
+    const unsigned c = sg.vc[kn - sg.tb0 + wv * 64 + lane];
+    const uint64_t h0 = __ballot(c & 4), h2 = __ballot(c & 8), w0 = __ballot(c & 16), w2 = __ballot(c & 32);
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      const int e = rnd * 64 + lane;
+      if (e < 72) {
+        const int combo = e >> 3, jj = e & 7, kh = combo / 3, kw = combo - 3 * kh;
+        const uint64_t inv = (kh == 0 ? h0 : (kh == 2 ? h2 : 0)) | (kw == 0 ? w0 : (kw == 2 ? w2 : 0));
+        const unsigned by = (unsigned)(inv >> (8 * jj)) & 0xFFu;
+        u32x4v m_;
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_)
+          m_[q_] = ((by >> (2 * q_)) & 1u ? 0u : 0xFFFFu) | ((by >> (2 * q_ + 1)) & 1u ? 0u : 0xFFFF0000u);
+        *reinterpret_cast<u32x4v*>(mk_n + (combo * 16 + wv * 8 + jj) * 16) = m_;
+      }
+    }
+  }
+};
+
+// One chunk of 128 voxels for wave WV out of slot SL; meanwhile the next chunk (kn >= 0) travels global -> registers ->
+// slot SL ^ 1 in two batches of at most 7 sixteen-byte items per lane, issued and committed at fixed items of the MFMA
+// stream (one wave per SIMD: everything that is not an MFMA sits in an MFMA gap), and waves 0 / 1 build its masks.
+// NKS: k-steps computed (8 = the whole chunk).  The block's FIRST chunk is staged by a pass with NKS = 1 over a zeroed slot 0
+// (14 MFMAs that add zeros): a staging-only prologue beside the march makes hipcc move the accumulators out of the AGPRs
+// (160 spills), the same code as one more link of the MFMA chain does not.
+template <int WV, int COT, int SL, int NKS = VX_KC / 16>
+__device__ __forceinline__ void wgrad_vox_chunk(f32x16 (&acc)[7 * COT], const char* const (&xb)[7], const char* dyb,
+                                                const char* mkb, char* smem, const VoxStage& sg, int kn, int tid, int lane) {
+  using L = VXL<COT>;
+  using S = VXS<COT>;
+  constexpr int NT = (27 - WV + 3) / 4;               // 7 taps (6 for wave 3): tap = WV + 4 i
+  constexpr int DYPLANE = VX_KC * 64, NI = NKS * NT;
+  constexpr int XOFF = SL * L::X_SLOT, DOFF = SL * L::DY_SLOT, MOFF = SL * L::MK_SLOT;
+  constexpr int PD = 3, RING = PD + 1;
+  constexpr int NA = S::NA, NB = S::NB;
+  // commit A + issue B | commit B | masks (A is issued at item 0); positions that exist for the 6-tap wave too
+  constexpr int T_A1 = NI < 18 ? NI : 18, T_B1 = NI < 38 ? NI : 38, T_MK = NI < 42 ? NI : 42;
+  bf16x8 fbw[2][COT], far[RING];
+  u32x4v mkr[RING];
+  uint4 st[7];
+  const bool more = kn >= 0;
+  char* xw_n = smem + L::X0 + (SL ^ 1) * L::X_SLOT;
+  char* dy_n = smem + L::DY0 + (SL ^ 1) * L::DY_SLOT;
+  char* mk_n = smem + L::MK0 + (SL ^ 1) * L::MK_SLOT;
+  auto masked = [](int j) { const int tap = WV + 4 * j; return ((tap / 3) % 3) != 1 || (tap % 3) != 1; };
+  auto load_item = [&](int t) {                        // t = ks * NT + j
+    const int ks = t / NT, j = t % NT, tap = WV + 4 * j;
+    far[t % RING] = tr_frag(xb[j] + XOFF + ks * 1024);
+    if (masked(j)) mkr[t % RING] = *reinterpret_cast<const u32x4v*>(mkb + MOFF + ((tap % 9) * 16 + 2 * ks) * 16);
+  };
+#pragma unroll
+  for (int o = 0; o < COT; ++o) fbw[0][o] = tr_frag(dyb + DOFF + o * DYPLANE);
+#pragma unroll
+  for (int t = 0; t < PD; ++t) load_item(t);
+  auto item = [&](int t) {
+    const int ks = t / NT, j = t % NT;
+    if (t + PD < NI) load_item(t + PD);
+    if (j < COT && ks + 1 < NKS) fbw[(ks + 1) & 1][j] = tr_frag(dyb + DOFF + j * DYPLANE + (ks + 1) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a = far[t % RING];
+    if (masked(j)) a = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4v, a) & mkr[t % RING]);
+#pragma unroll
+    for (int o = 0; o < COT; ++o)
+      acc[o * 7 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fbw[ks & 1][o], acc[o * 7 + j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // straight-line segments of the item stream (each loop has constant bounds and a small body: fully unrolled, so every
+  // ring index, tap and LDS offset is a constant), the staging steps between them
+  if (more) {
+#pragma unroll
+    for (int m = 0; m < NA; ++m) st[m] = S::load(sg, kn, tid, m);
+  }
+#pragma unroll
+  for (int t = 0; t < T_A1; ++t) item(t);
+  if (more) {
+#pragma unroll
+    for (int m = 0; m < NA; ++m) S::store(sg, xw_n, dy_n, tid, m, st[m]);
+#pragma unroll
+    for (int m = 0; m < NB; ++m) st[m] = S::load(sg, kn, tid, NA + m);
+  }
+#pragma unroll
+  for (int t = T_A1; t < T_B1; ++t) item(t);
+  if (more) {
+#pragma unroll
+    for (int m = 0; m < NB; ++m) S::store(sg, xw_n, dy_n, tid, NA + m, st[m]);
+  }
+#pragma unroll
+  for (int t = T_B1; t < T_MK; ++t) item(t);
+  if (more && WV < 2) S::masks(sg, mk_n, kn, WV, lane);
+#pragma unroll
+  for (int t = T_MK; t < NI; ++t) item(t);
+}
+
+template <int WV, int COT>
+__device__ __forceinline__ void wgrad_vox_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                                int64_t ldy, float* __restrict__ part, int Cin, int Cout, const VoxGeo g,
+                                                const FplxBlock bid) {
+  using L = VXL<COT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int W = g.W, HW = g.HW, V = g.V;
+  const int XR = VX_KC + 2 * W + 2, xplane = XR * 64;
+  unsigned char* vc = reinterpret_cast<unsigned char*>(smem + L::VC0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ncit = Cin / 32;
+  const int cot = bid.y / ncit, cit = bid.y % ncit;
+  const int k0 = bid.x * g.kper;
+  const int k1 = (k0 + g.kper < V) ? k0 + g.kper : V;
+
+  // border codes of the voxels this block can touch: bit 0 d == 0, 1 d == D-1, 2 h == 0, 3 h == H-1, 4 w == 0, 5 w == W-1
+  const int halo = HW + W + 1;
+  const int tb0 = k0 - halo, tbn = (k1 - k0 + VX_KC - 1) / VX_KC * VX_KC + 2 * halo;
+  for (int t = tid; t < tbn; t += 256) {
+    const int u = tb0 + t;
+    unsigned char c = 0xFF;
+    if (u >= 0 && u < V) {
+      const unsigned q1 = __umulhi((unsigned)u, g.mW), w_ = (unsigned)u - q1 * (unsigned)W;
+      const unsigned q2 = __umulhi(q1, g.mH), h_ = q1 - q2 * (unsigned)g.H;
+      const unsigned q3 = __umulhi(q2, g.mD), d_ = q2 - q3 * (unsigned)g.D;
+      c = (unsigned char)((d_ == 0 ? 1 : 0) | (d_ == (unsigned)g.D - 1 ? 2 : 0) | (h_ == 0 ? 4 : 0) |
+                          (h_ == (unsigned)g.H - 1 ? 8 : 0) | (w_ == 0 ? 16 : 0) | (w_ == (unsigned)W - 1 ? 32 : 0));
+    }
+    vc[t] = c;
+  }
+  VoxStage sg;
+  sg.xg = x + cit * 32; sg.dyg = dy + cot * (32 * COT); sg.ldx = ldx; sg.ldy = ldy; sg.vc = vc;
+  sg.tb0 = tb0; sg.tbn = tbn; sg.XR = XR; sg.W = W; sg.HW = HW; sg.k1 = k1;
+  for (int i = tid; i < L::VC0 / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);   // slot 0 reads as zeros
+
+  // transposed-read lane geometry (tr_frag): group gq = lane / 16 -> k-octet gq >> 1, channel half gq & 1
+  const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lane_off = (8 * (gq >> 1) + q) * 64 + (16 * (gq & 1) + 4 * pp) * 2;
+  constexpr int NT = (27 - WV + 3) / 4;
+  const char* xb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = j < NT ? WV + 4 * j : WV;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    xb[j] = smem + L::X0 + kd * xplane + (kh * W + kw) * 64 + lane_off;
+  }
+  const char* dyb = smem + L::DY0 + lane_off;
+  const char* mkb = smem + L::MK0 + (gq >> 1) * 16;
+
+  f32x16 acc[7 * COT];
+#pragma unroll
+  for (int i = 0; i < 7 * COT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  int kc = k0;
+  __syncthreads();                                         // the code table and the zeroed slot are complete
+  wgrad_vox_chunk<WV, COT, 0, 1>(acc, xb, dyb, mkb, smem, sg, k0, tid, lane);      // stages chunk k0 into slot 1
+  __syncthreads();
+  for (;;) {
+    {
+      const int kn = kc + VX_KC < k1 ? kc + VX_KC : -1;
+      wgrad_vox_chunk<WV, COT, 1>(acc, xb, dyb, mkb, smem, sg, kn, tid, lane);
+      __syncthreads();
+      kc += VX_KC;
+      if (kc >= k1) break;
+    }
+    {
+      const int kn = kc + VX_KC < k1 ? kc + VX_KC : -1;
+      wgrad_vox_chunk<WV, COT, 0>(acc, xb, dyb, mkb, smem, sg, kn, tid, lane);
+      __syncthreads();
+      kc += VX_KC;
+      if (kc >= k1) break;
+    }
+  }
+  // partial tiles, the format of conv_wgrad_stream: part[split][pair][tap][co][ci]
+  const int co = lane & 31, rbase = (lane >> 5) * 4;
+#pragma unroll
+  for (int o = 0; o < COT; ++o) {
+    const int pair = (cot * COT + o) * ncit + cit;
+    float* out = part + ((int64_t)bid.x * (ncit * (Cout / 32)) + pair) * (27 * 1024);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int tap = WV + 4 * i;
+      if (tap < 27) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
+              make_float4(acc[o * 7 + i][4 * g4 + 0], acc[o * 7 + i][4 * g4 + 1], acc[o * 7 + i][4 * g4 + 2],
+                          acc[o * 7 + i][4 * g4 + 3]);
+      }
+    }
+  }
+}
+
+template <int COT>
+__global__ void __launch_bounds__(256)
+conv_wgrad_vox(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+               float* __restrict__ part, int Cin, int Cout, VoxGeo g, int xcd) {
+  const FplxBlock bid = fplx_xcd_block(xcd);               // y fastest: the pair groups of one voxel range share an L2
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: wgrad_vox_march<0, COT>(x, ldx, dy, ldy, part, Cin, Cout, g, bid); break;
+    case 1: wgrad_vox_march<1, COT>(x, ldx, dy, ldy, part, Cin, Cout, g, bid); break;
+    case 2: wgrad_vox_march<2, COT>(x, ldx, dy, ldy, part, Cin, Cout, g, bid); break;
+    default: wgrad_vox_march<3, COT>(x, ldx, dy, ldy, part, Cin, Cout, g, bid); break;
+  }
+}
+
+struct VoxCfg { int ok, cot, npairs; VoxGeo g; size_t ws, lds; };
+// deep levels only: small volumes (the footprint march wins where its tiles fit and the voxel count amortises its
+// partial tiles), W <= 40 (LDS windows), 3 x 3 x 3 in all three dimensions (not the 2.5D middle-plane form)
+inline VoxCfg vox_cfg(int n, int d, int h, int w, int cin, int cout) {
+  VoxCfg c = {};
+  const int64_t V = (int64_t)n * d * h * w;
+  const int mode = (int)fplx_knob(FPLX_K_WG_VOX);           // 0: never, 1: the rule below, 2: wherever the kernel can run (tests)
+  if (!mode || cin % 32 != 0 || cout % 32 != 0 || w > VX_MAXW || w < 2 || h < 2 || d < 2 || V >= ((int64_t)1 << 24)) return c;
+  if (mode == 1 && V > (int64_t)fplx_knob(FPLX_K_WG_VOX_MAXV)) return c;
+  c.cot = cout % 64 == 0 ? 2 : 1;
+  c.npairs = (cin / 32) * (cout / 32);
+  const int groups = c.npairs / c.cot;
+  const int chunks = (int)((V + VX_KC - 1) / VX_KC);
+  int S = (256 + groups - 1) / groups;                       // just enough voxel ranges to give every CU a block
+  if (S > chunks) S = chunks;
+  if (S < 1) S = 1;
+  const int cper = (chunks + S - 1) / S;
+  S = (chunks + cper - 1) / cper;
+  VoxGeo& g = c.g;
+  g.V = (int)V; g.D = d; g.H = h; g.W = w; g.HW = h * w;
+  g.mW = (unsigned)((((uint64_t)1 << 32) + w - 1) / w);
+  g.mH = (unsigned)((((uint64_t)1 << 32) + h - 1) / h);
+  g.mD = (unsigned)((((uint64_t)1 << 32) + d - 1) / d);
+  g.kper = cper * VX_KC; g.S = S;
+  c.ws = (size_t)S * c.npairs * 27 * 1024 * sizeof(float);
+  c.lds = (size_t)(c.cot == 2 ? VXL<2>::VC0 : VXL<1>::VC0) + (size_t)(g.kper + 2 * (g.HW + w + 1)) + 16;
+  c.lds = (c.lds + 15) / 16 * 16;
+  if (c.lds > 160 * 1024) return c;
+  c.ok = 1;
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------
 // ConvTranspose3d(k=2,s=2) forward: rows = input voxels, K = Cin, one 32x32 accumulator per tap
 // (4 taps per block, blockIdx.z picks the half); every result row is scattered to its own output
 // voxel (2d+i, 2h+j, 2w+k) of the concat buffer.  HBM-bound (8 output voxels per input voxel).
@@ -1380,6 +1693,114 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// deconv_dgrad_rows: data gradient of ConvTranspose3d(k = 2, s = 2) for the shallow levels (Cout = 32 | 64 channels of dy,
+// Cin = 64 | 128): dx[parent][ci] = sum over the parent's 8 children and co of dy[child][co] w[ci][co][tap] - no reuse, a pure
+// stream of dy (262 MB at level 0).  conv_fwd_direct<.., 1> gathers its fragments straight from global memory, 16 bytes
+// per lane at a 128-byte stride: every wave instruction touches 32 cache lines for 1 KiB (96 us = 3.4 TB/s alone, 195 us
+// beside the weight-gradient stream).  Here a block takes MB parents of one row at a time; their children are four
+// CONTIGUOUS child-row pieces (128 Cout/32 bytes per parent and (i, j)), fetched with fully coalesced 16-byte loads into
+// registers one segment ahead and committed to LDS with the 16-byte chunk index XOR-ed by (parent & 7) (the fragment
+// reads of 16 lanes then hit 8 different slots: 2-way instead of 8-way conflicts).  The product is TRANSPOSED,
+// D[ci][parent] = Wb[ci][k] dy^T[k][parent]: the weights are the A operand and stay in registers for the whole kernel, a lane
+// ends up with 16 input channels of ONE parent, two v_permlane32_swap exchanges make them two 16-byte stores.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2d;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4d;
+template <int CO32, int NTW>       // Cout / 32 (1 | 2), Cin / 32 (2 | 4): four wave tiles = (4 / NTW) parent tiles x NTW channel tiles
+__global__ void __launch_bounds__(256)
+deconv_dgrad_rows(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx,
+                  int64_t ldx, int N, int D, int H, int W, int segsW, int64_t nseg, int xcd) {
+  constexpr int COUT = CO32 * 32, CIN = NTW * 32, MB = 32 * 4 / NTW, U = 8 * CO32;        // U: 16-byte chunks per (parent, i, j)
+  constexpr int NIT = 4 * MB * U / 256, KS = 2 * CO32;                                    // k-steps of 16 per tap
+  __shared__ __attribute__((aligned(16))) char sm[4 * MB * U * 16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, kq = lane >> 5;
+  const int mt = wave / NTW, n0 = (wave % NTW) * 32;
+  bf16x8 afr[8][KS];                                  // A: row = input channel n0 + r, the lane's 8 output channels of (tap, s)
+#pragma unroll
+  for (int tap = 0; tap < 8; ++tap)
+#pragma unroll
+    for (int s_ = 0; s_ < KS; ++s_)
+      afr[tap][s_] = *reinterpret_cast<const bf16x8*>(wb + ((int64_t)tap * CIN + n0 + r) * COUT + s_ * 16 + 8 * kq);
+  const FplxTileRange tr = fplx_xcd_tiles(nseg, xcd);
+  struct Seg { int n, d, h, w0; };
+  auto seg_of = [&](int64_t t64) {
+    unsigned t = (unsigned)t64;
+    Seg o;
+    o.w0 = (int)(t % (unsigned)segsW) * MB; t /= (unsigned)segsW;
+    o.h = (int)(t % (unsigned)H); t /= (unsigned)H;
+    o.d = (int)(t % (unsigned)D);
+    o.n = (int)(t / (unsigned)D);
+    return o;
+  };
+  uint4 reg[NIT];
+  auto fetch = [&](const Seg& g) {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int e = tid + 256 * k;
+      const int q = e % U, p = (e / U) % MB, ij = e / (U * MB);
+      const int kk = q / (4 * CO32), cc = q % (4 * CO32);
+      const bool ok = g.w0 + p < W;
+      const int64_t child = (((int64_t)g.n * 2 * D + 2 * g.d + (ij >> 1)) * 2 * H + 2 * g.h + (ij & 1)) * 2 * W + 2 * (g.w0 + (ok ? p : 0)) + kk;
+      const uint4 v = *reinterpret_cast<const uint4*>(dy + child * ldy + cc * 8);
+      reg[k] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  int64_t tt = tr.first;
+  Seg gn = seg_of(tt < tr.end ? tt : 0);
+  if (tt < tr.end) fetch(gn);
+  for (; tt < tr.end; tt += tr.step) {
+    const Seg g = gn;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int e = tid + 256 * k;
+      const int q = e % U, p = (e / U) % MB, ij = e / (U * MB);
+      *reinterpret_cast<uint4*>(sm + (((ij * MB + p) * U) + (q ^ (p & 7))) * 16) = reg[k];
+    }
+    __syncthreads();
+    if (tt + tr.step < tr.end) {
+      gn = seg_of(tt + tr.step);
+      fetch(gn);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap) {
+      const int ij = tap >> 1, kk = tap & 1;
+#pragma unroll
+      for (int s_ = 0; s_ < KS; ++s_) {
+        const int q = kk * (4 * CO32) + 2 * s_ + kq;
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sm + (((ij * MB + mt * 32 + r) * U) + (q ^ (r & 7))) * 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tap][s_], b, acc, 0, 0, 0);
+      }
+    }
+    // D rows = channels n0 + (i & 3) + 8 (i >> 2) + 4 kq of parent r: quads -> 8-channel runs by two half-wave swaps
+    unsigned pk[8];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const bf16_t e0 = (bf16_t)acc[4 * q4], e1 = (bf16_t)acc[4 * q4 + 1], e2 = (bf16_t)acc[4 * q4 + 2], e3 = (bf16_t)acc[4 * q4 + 3];
+      pk[2 * q4] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+      pk[2 * q4 + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const u32x2d sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+        pk[4 * g2 + e] = sw[0];
+        pk[4 * g2 + 2 + e] = sw[1];
+      }
+    const int wv = g.w0 + mt * 32 + r;
+    if (wv < W) {
+      bf16_t* dst = dx + ((((int64_t)g.n * D + g.d) * H + g.h) * W + wv) * ldx + n0 + 8 * kq;
+      *reinterpret_cast<u32x4d*>(dst) = u32x4d{pk[0], pk[1], pk[2], pk[3]};
+      *reinterpret_cast<u32x4d*>(dst + 16) = u32x4d{pk[4], pk[5], pk[6], pk[7]};
+    }
+  }
+}
+
 struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt, tile_mt; int64_t mblocks; };
 
 inline DirectCfg direct_cfg(int64_t V, int cin, int cout, int taps = 27) {
@@ -1616,7 +2037,9 @@ extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, i
 
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 32 != 0 || cout % 32 != 0) return 0;
-  return wg_cfg(n, d, h, w, cin, cout).ws;
+  const size_t a = wg_cfg(n, d, h, w, cin, cout).ws;
+  const VoxCfg v = vox_cfg(n, d, h, w, cin, cout);          // the larger of the two: the 2.5D form of a layer never takes vox
+  return (v.ok && v.ws > a) ? v.ws : a;
 }
 
 // returns 1 if handled, 0 if not applicable, <0 on error.  dw fp32 [Cout][Cin][27]
@@ -1626,6 +2049,24 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
                                       const void* x1, int mid) {
   if (cin % 32 != 0 || cout % 32 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16))
     return 0;
+  if (!x1 && !mid) {
+    const VoxCfg v = vox_cfg(n, d, h, w, cin, cout);
+    if (v.ok) {
+      if (ws_bytes < v.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, v.ws);
+      dim3 grid(v.g.S, v.npairs / v.cot);
+      if (v.cot == 2) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_vox<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
+        conv_wgrad_vox<2><<<grid, 256, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
+      } else {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_vox<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
+        conv_wgrad_vox<1><<<grid, 256, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
+      }
+      const int64_t total = (int64_t)v.npairs * 27 * 1024;
+      wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, v.g.S, v.npairs, cin, cout, dw, 0);
+      int rcv = fplx_check_launch("mfma_conv3d_wgrad_vox");
+      return rcv < 0 ? rcv : 1;
+    }
+  }
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
   if (x1 && (c.cit != 2 || cin != 64 || ((uintptr_t)x1 % 16))) return 0;   // split x: one group of two ci tiles
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
@@ -1687,6 +2128,20 @@ extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* 
   if (cout % 16 != 0 || cin % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16) || ((uintptr_t)wb % 16)) return 0;
   const int64_t V = (int64_t)n * d * h * w;
   if (V * 8 >= ((int64_t)1 << 31)) return 0;                 // the kernel decodes voxel indices in 32 bits
+  // shallow levels: the coalesced row-segment stream (deconv_dgrad_rows)
+  if (sd == 2 && fplx_knob(FPLX_K_DECONV_DGRAD_ROWS) && V >= 16 * 1024 && ldx % 8 == 0 && ((uintptr_t)dx % 16) == 0 &&
+      ((cout == 32 && cin == 64) || (cout == 64 && cin == 128))) {
+    const int mb = cin == 64 ? 64 : 32;
+    const int segsW = (w + mb - 1) / mb;
+    const int64_t nseg = (int64_t)n * d * h * segsW;
+    const unsigned nb = (unsigned)(nseg < 512 ? nseg : 512);           // persistent: two blocks per CU (registers)
+    if (cout == 32)
+      deconv_dgrad_rows<1, 2><<<nb, 256, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, segsW, nseg, fplx_xcd_on());
+    else
+      deconv_dgrad_rows<2, 4><<<nb, 256, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, segsW, nseg, fplx_xcd_on());
+    int rcr = fplx_check_launch("mfma_deconv2_dgrad_rows");
+    return rcr < 0 ? rcr : 1;
+  }
 #define LAUNCH_DD(MT_, NTL_, MODE_, GRID_)                                                                          \
   conv_fwd_direct<MT_, NTL_, MODE_><<<GRID_, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr, \
                                                                       (bf16_t*)dx, ldx, n, d, h, w, cout, cin, nullptr)

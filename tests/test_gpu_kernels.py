@@ -333,7 +333,10 @@ def test_fused_adam_matches_torch():
         ops.adam_step(p, g.cuda(), m, v, 1e-3, 0, 1e-5)
 
 
-@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32)])
+@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32),
+                                   # in_chns = 1 runs the LDS-free row kernel (stem_fwd_rows): a volume of one row, a width
+                                   # one past a segment, a single voxel, several samples
+                                   (1, 1, 32, 1, 1, 40), (3, 1, 32, 5, 7, 161), (1, 1, 32, 1, 1, 1), (2, 1, 64, 6, 20, 96)])
 def test_stem_kernels_bf16(shape):
     """fp32 NCDHW network input -> bf16 NDHWC (MFMA stem kernels): forward + statistics, weight gradient"""
     from fplx import ops
@@ -560,3 +563,45 @@ def test_pool_bwd_bn_reduce_bf16_against_torch_autograd(shape, pd):
     assert int((err > lim).sum()) <= 8, (int((err > lim).sum()), float(err.max()), lim)      # arg-max flips at rounding ties
     for got, ref in ((dgamma, gd.grad), (dbeta, bd.grad), (dslope, sd.grad)):
         assert float((got.cpu().double() - ref).abs().max()) < 1e-2 * float(ref.abs().max()), (got, ref)
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 256, 256, 10, 20, 20),       # level 3 of the benchmark (5 x 4 x 8 = 8000 voxels: 63 chunks, 8 voxel ranges)
+    (2, 512, 512, 5, 10, 10),        # level 4: 1000 voxels, the last chunk ragged, HW = 100 < chunk
+    (2, 64, 128, 20, 40, 40),        # level 2: W at the kernel's limit (40)
+    (3, 32, 96, 3, 7, 9),            # odd everything, n = 3, Cout % 64 != 0 (one co tile per block), tiny volume (567 voxels)
+    (1, 96, 64, 2, 2, 2),            # 8 voxels: every pair crosses a border
+    (1, 64, 64, 9, 33, 17)])         # K split whose ranges cut through rows and slices
+def test_conv3d_wgrad_vox_kernel(shape):
+    """conv_wgrad_vox (voxel-GEMM weight gradient of the deep levels, conv_mfma.hip): against torch autograd, bf16 operands,
+    forced on every shape by the tuning knob wg_vox = 2; and the same numbers as the footprint march (wg_vox = 0) up to the
+    order of the fp32 additions."""
+    from fplx import ops
+    _lib = ops._lib
+    n, cin, cout, d, h, w = shape
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.from_numpy(detdata.normal("vx.x%s" % (shape,), (n, cin, d, h, w))))
+    dy = q(torch.from_numpy(detdata.normal("vx.dy%s" % (shape,), (n, cout, d, h, w))))
+    wr = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, wr, None, padding=1).backward(dy)
+    bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
+    # operands as channel slices of wider buffers (ld > channels)
+    xw = torch.full((n * d * h * w, cin + 32), 3.0, dtype=bf, device="cuda")
+    xw[:, 8:8 + cin] = cl(x).to(bf).cuda()
+    dyw = torch.full((n * d * h * w, cout + 16), 5.0, dtype=bf, device="cuda")
+    dyw[:, 16:] = cl(dy).to(bf).cuda()
+    xg, dyg = xw[:, 8:8 + cin], dyw[:, 16:]
+    got = {}
+    for mode in (2, 0):
+        _lib.set_tuning("wg_vox", mode)
+        try:
+            ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+            dw = torch.full((cout, cin, 3, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin + 32), dt, dyg, ops.cl_strides(d, h, w, cout + 16), dt, dw, None,
+                             dims, cin, cout, (3, 3, 3), ws)
+            got[mode] = dw.cpu()
+        finally:
+            _lib.set_tuning("wg_vox", 1)
+    scale = float(wr.grad.abs().max())
+    assert float((got[2] - wr.grad).abs().max()) < 1e-4 * scale + 1e-6, float((got[2] - wr.grad).abs().max()) / scale
+    assert float((got[2] - got[0]).abs().max()) < 1e-4 * scale + 1e-6

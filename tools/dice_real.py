@@ -1,17 +1,23 @@
 """Real-data arm of the Dice comparison (north_star: "Dice on VS hrT2 within +-0.5 of the reference"):
 the 13 NIfTI volumes the reference ships (`tools/copy_refdata.sh` -> tests/golden/_refdata/) through fplx's own data path
 (fplx.nifti reader, NiftyDataset, the GPU transforms of config_dual/data_vs/vs_t1s_g.cfg: NormalizeWithMeanStd, Pad,
-RandomCrop[28,128,128] with foreground focus, RandomFlip, LabelToProbability), trained the way that config trains the
-stage-"g" segmentor: domain 0 = {ceT1, ceT1-hrT2-ceT1_cc, ceT1-hrT2-ceT1_ac} (train_ceT1_like.csv), domain 1 =
-{ceT1-hrT2_cyc, ceT1-hrT2_auxcyc} (train_hrT2_like.csv), all with the label of case vs_gk_99, `training_all` iterations
-(train_batch_size 4 over 3 and 2 cases: one batch of all cases per iteration, one Adam step), UNet2D5_dsbn with conv_dims [2, 2, 3, 3, 3] and the shipped dropout.
-Evaluated on the three REAL hrT2 cases that come with labels (hrT2_valid 95, hrT2_test 9, hrT2_train 98), domain 1,
-sliding window 28 x 128 x 128 + 4-flip TTA, eval-mode BatchNorm, Dice by fplx.evaluation.binary_dice.
-Arms: fp32 parity mode (the stand-in for the reference: logits match its CPU path to 1e-3) and bf16 (the benchmarked
-kernels), PAIRED per seed: same initial weights, same crops and flips (Python `random` / torch generator re-seeded), same
-dropout masks.  With one labelled case per domain this is a smoke-level experiment on real data, not the paper's result.
+RandomCrop[28,128,128] with foreground focus, RandomFlip, LabelToProbability), UNet2D5_dsbn with conv_dims [2, 2, 3, 3, 3]
+and the shipped dropout, `training_all` iterations (one batch of all cases per domain, one Adam step).
 
-    python tools/dice_real.py [--seeds 6] [--iters 300] [--base 16] [--out gpurun_out/dice_real.txt]
+Two protocols (--protocol):
+  loo   (default) leave-one-out over the three REAL hrT2 cases that come with labels (hrT2_valid 95, hrT2_test 9,
+        hrT2_train 98): domain 1 trains on the other two real hrT2 cases (their own labels) + the two translated hrT2-like
+        volumes (label of case 99), domain 0 on ceT1 + its two translated copies; the held-out hrT2 case is segmented
+        (sliding window 28 x 128 x 128 + 4-flip TTA, eval-mode BatchNorm) - "Dice on VS hrT2" with target supervision,
+        as far as three labelled cases allow.
+  uda   the stage-"g" setting of vs_t1s_g.cfg: NO hrT2 label is used (domain 1 = translated volumes only), all three
+        real hrT2 cases are test cases.  With ONE labelled source case the target Dice is chaotic (0 - 80 %): kept as the
+        record of round 3's first run (profiles/r03_dice_real_uda.txt).
+Arms: fp32 parity mode (the stand-in for the reference: logits match its CPU path to 1e-3) and bf16 (the benchmarked
+kernels), PAIRED per run: same initial weights, same crops and flips (Python `random` / torch generator re-seeded), same
+dropout masks.
+
+    python tools/dice_real.py [--protocol loo] [--seeds 4] [--iters 300] [--base 16] [--out gpurun_out/dice_real.txt]
 """
 import argparse
 import os
@@ -48,12 +54,13 @@ TF = {"task": "segmentation", "normalizewithmeanstd_channels": [0], "normalizewi
       "labeltoprobability_class_num": 2, "labeltoprobability_inverse": False}
 
 
-def loaders(tmp, seed):
+def loaders(tmp, seed, train_rows):
+    """train_rows: per domain a list of (image, label) paths relative to DATA"""
     gen = torch.Generator().manual_seed(seed)
     out = []
     for d in (0, 1):
-        csv = os.path.join(tmp, "train_%d.csv" % d)
-        open(csv, "w").write("image,label\n" + "".join("%s,%s\n" % (f, LAB99) for f in TRAIN[d]))
+        csv = os.path.join(tmp, "train_%d_%d.csv" % (d, seed))
+        open(csv, "w").write("image,label\n" + "".join("%s,%s\n" % r for r in train_rows[d]))
         tr = Compose(build_transforms(["NormalizeWithMeanStd", "Pad", "RandomCrop", "RandomFlip", "LabelToProbability"], dict(TF)))
         out.append(BatchLoader(NiftyDataset(DATA, csv, 1, True, tr, "cuda:0", cache=True), 4, True, gen))
     return out
@@ -67,7 +74,7 @@ def batches(loader):
             yield b
 
 
-def run_arm(p, prec, init, seed, iters, tmp, eval_cases):
+def run_arm(p, prec, init, seed, iters, tmp, eval_cases, train_rows):
     random.seed(seed)
     torch.manual_seed(seed)
     net = fplx.UNet2D5_dsbn(dict(p, precision=prec))
@@ -75,7 +82,7 @@ def run_arm(p, prec, init, seed, iters, tmp, eval_cases):
     net.cuda()
     net.dropout_seed = 4321
     ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
-    l0, l1 = loaders(tmp, seed)
+    l0, l1 = loaders(tmp, seed, train_rows)
     g0, g1 = batches(l0), batches(l1)
     losses = []
     for it in range(iters):
@@ -96,7 +103,8 @@ def run_arm(p, prec, init, seed, iters, tmp, eval_cases):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--seeds", type=int, default=6)
+    ap.add_argument("--protocol", default="loo", choices=["loo", "uda"])
+    ap.add_argument("--seeds", type=int, default=4)
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--base", type=int, default=16)
     ap.add_argument("--out", default=None)
@@ -107,29 +115,38 @@ def main():
     p = dict(in_chns=1, feature_chns=[b, 2 * b, 4 * b, 8 * b, 16 * b], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[2, 2, 3, 3, 3],
              class_num=2, bilinear=False, num_domains=2, net_type="UNet2D5_dsbn")
     from fplx.nifti import load_image_as_nd_array
-    eval_cases = []
+    cases = []
     for f, l in EVAL:                      # test chain of the cfg: NormalizeWithMeanStd, Pad (a no-op on 30/40 x 160 x 272)
         img = torch.from_numpy(np.asarray(load_image_as_nd_array(os.path.join(DATA, f))["data_array"], np.float32)).cuda()
         img = fplx.ops.normalize_mean_std(img.contiguous())
         lab = torch.from_numpy(np.asarray(load_image_as_nd_array(os.path.join(DATA, l))["data_array"][0], np.uint8)).cuda()
-        eval_cases.append((img[None], lab))
+        cases.append((img[None], lab))
+    src = [[(f, LAB99) for f in TRAIN[0]], [(f, LAB99) for f in TRAIN[1]]]
+    if a.protocol == "uda":
+        folds = [("all three hrT2 cases", src, cases)]
+    else:
+        folds = []
+        for k in range(len(EVAL)):
+            rows1 = src[1] + [EVAL[m] for m in range(len(EVAL)) if m != k]
+            folds.append(("held out " + EVAL[k][0], [src[0], rows1], [cases[k]]))
     res = {"fp32": [], "bf16": []}
-    lines = ["real data (13 shipped volumes): %d-base UNet2D5_dsbn conv_dims [2,2,3,3,3], dropout [0,0,.3,.4,.5], %d training_all iterations of "
-             "3 + 2 crops 28x128x128, evaluated on %d real hrT2 cases (domain 1, sliding window + 4-flip TTA)" % (b, a.iters, len(EVAL))]
+    lines = ["real data (13 shipped volumes), protocol %s: %d-base UNet2D5_dsbn conv_dims [2,2,3,3,3], dropout [0,0,.3,.4,.5], %d training_all "
+             "iterations (crops 28x128x128), sliding window + 4-flip TTA on the test case(s)" % (a.protocol, b, a.iters)]
     with tempfile.TemporaryDirectory() as tmp:
-        for seed in range(a.seeds):
-            torch.manual_seed(1000 + seed)
-            init = fplx.UNet2D5_dsbn(dict(p)).state_dict()
-            row = []
-            for prec in ("fp32", "bf16"):
-                losses, dice = run_arm(p, prec, init, 50 + seed, a.iters, tmp, eval_cases)
-                res[prec].append(dice)
-                row.append("%s: loss %.4f -> %.4f, Dice %s" % (prec, losses[0], float(np.mean(losses[-5:])), " ".join("%.2f" % v for v in dice)))
-            lines.append("seed %d | %s" % (seed, " | ".join(row)))
-            print(lines[-1], flush=True)
+        for fi, (fname, rows, evals) in enumerate(folds):
+            for seed in range(a.seeds):
+                torch.manual_seed(1000 + 10 * fi + seed)
+                init = fplx.UNet2D5_dsbn(dict(p)).state_dict()
+                row = []
+                for prec in ("fp32", "bf16"):
+                    losses, dice = run_arm(p, prec, init, 50 + 10 * fi + seed, a.iters, tmp, evals, rows)
+                    res[prec].append(dice)
+                    row.append("%s: loss %.4f -> %.4f, Dice %s" % (prec, losses[0], float(np.mean(losses[-5:])), " ".join("%.2f" % v for v in dice)))
+                lines.append("%s, seed %d | %s" % (fname, seed, " | ".join(row)))
+                print(lines[-1], flush=True)
     r32, r16 = np.asarray(res["fp32"]), np.asarray(res["bf16"])
-    lines.append("mean Dice: fp32 %.2f (std over seeds %.2f), bf16 %.2f (std %.2f)" % (r32.mean(), r32.mean(1).std(), r16.mean(), r16.mean(1).std()))
-    rep, st = paired_report("bf16 - fp32 on real hrT2", r32, r16)
+    lines.append("mean Dice: fp32 %.2f (std over runs %.2f), bf16 %.2f (std %.2f)" % (r32.mean(), r32.mean(1).std(), r16.mean(), r16.mean(1).std()))
+    rep, st = paired_report("bf16 - fp32 on real hrT2 (%s)" % a.protocol, r32, r16)
     lines += rep
     text = "\n".join(lines)
     print(text)
