@@ -52,11 +52,12 @@ struct BKG : BK {
 __device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) ^ (m >> 3) ^ (m >> 2)) & 1); }
 __device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
 
-template <bool STATS, int NTW, int TD, int WH>
+// ACT (inference, eval-mode BatchNorm folded into the pack): PReLU(slope) in the write-out (STATS must be false)
+template <bool STATS, int NTW, int TD, int WH, bool ACT = false>
 __global__ void __launch_bounds__(BK::THREADS)
 conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
                bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd) {
+               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr) {
   using G = BKG<TD, WH, NTW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bricks = smem;
@@ -289,6 +290,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
     const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
     bf16_t* ycol = y + n0 + wn * (32 * NTW) + (lane & 3) * 8;
+    const float slope_v = ACT ? *slope_p : 0.f;
     auto write_out = [&](auto full_c) {
       constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
@@ -304,6 +306,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
             for (int i = 0; i < 16; i += 2) {
               const int m = (i & 3) + 8 * (i >> 2) + rh;       // rows m, m + 1
               f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
+              if (ACT) { o[0] = o[0] > 0.f ? o[0] : o[0] * slope_v; o[1] = o[1] > 0.f ? o[1] : o[1] * slope_v; }
               *reinterpret_cast<bf16_t*>(tile_ + m * 64 + r * 2) = (bf16_t)o[0];
               *reinterpret_cast<bf16_t*>(tile_ + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
               if (STATS) {
@@ -458,9 +461,9 @@ extern "C" int fplx_brick_rows(int n, int d, int h, int w, int geo) {
 // returns 1 if launched, 0 if the operands do not allow it (alignment), <0 on error.  geo / ksplit: fplx_brick_plan's, or a
 // test's choice on shapes the plan leaves to other kernels.  ksplit > 1: the kernel writes partial[ksplit][V][cout]
 // fp32 and the caller finishes (splitk_finish_k)
-extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                        int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
-                                        int ksplit, hipStream_t st) {
+extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                         int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
+                                         int ksplit, hipStream_t st, const float* slope) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
     return 0;
   if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30) || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
@@ -494,15 +497,31 @@ extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* 
         bW, xcd_on);                                                                                                 \
   } while (0)
   const bool st_ = stats && !part;
-  if (geo == 1) { if (st_) LAUNCH_BRICK(true, 1, 5, 1); else LAUNCH_BRICK(false, 1, 5, 1); }
+#define LAUNCH_BRICK_ACT(NTW_, TD_, WH_)                                                                              \
+  do {                                                                                                               \
+    using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true>,                              \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick<false, NTW_, TD_, WH_, true><<<grid, BK::THREADS, G_::LDS, st>>>(                                  \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+        bH, bW, xcd_on, slope);                                                                                      \
+  } while (0)
+  if (slope && !part) {               // (with a Cin split the activation is the finish kernel's)
+    if (geo == 1) LAUNCH_BRICK_ACT(1, 5, 1);
+    else if (nt == 128) LAUNCH_BRICK_ACT(2, 4, 2);
+    else LAUNCH_BRICK_ACT(1, 4, 2);
+  }
+  else if (geo == 1) { if (st_) LAUNCH_BRICK(true, 1, 5, 1); else LAUNCH_BRICK(false, 1, 5, 1); }
   else if (nt == 128) { if (st_) LAUNCH_BRICK(true, 2, 4, 2); else LAUNCH_BRICK(false, 2, 4, 2); }
   else { if (st_) LAUNCH_BRICK(true, 1, 4, 2); else LAUNCH_BRICK(false, 1, 4, 2); }
+#undef LAUNCH_BRICK_ACT
 #undef LAUNCH_BRICK
   const int rc = fplx_check_launch("brick_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }
 
-extern "C" int fplx_brick_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st) {
-  return fplx_brick_conv3d_fwd_ex(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, nullptr, 0, 1, st);
+extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                        int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
+                                        int ksplit, hipStream_t st) {
+  return fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, partial, geo, ksplit, st, nullptr);
 }

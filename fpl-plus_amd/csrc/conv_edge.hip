@@ -828,9 +828,51 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
-  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
-    const Tile t = tile_of(tt, D, tilesH, tilesW);
+  // the next tile's rows (x with its in-plane halo, the dlogit planes) travel global -> registers while this tile computes
+  // (round 3; the synchronous fill left every block idle for a memory round trip per tile, as in the forward kernel)
+  constexpr int NLX = (SH * SW * 4 + 255) / 256, NLG = 4 * TH * TW / 256;      // ncls <= 4 on the prefetched path
+  uint4 xreg[NLX];
+  float greg[NLG];
+  const bool pre = ncls <= 4;
+  auto fetch = [&](const Tile& t) {
+#pragma unroll
+    for (int k = 0; k < NLX; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int vox = i >> 2, ch = i & 3;
+      const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (i < SH * SW * 4 && h >= 0 && h < H && w >= 0 && w < W)
+        v = *reinterpret_cast<const uint4*>(x + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldx + cit * 32 + ch * 8);
+      xreg[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLG; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      const int co = i / (TH * TW), vox = i % (TH * TW);
+      const int h = t.h0 + vox / TW, w = t.w0 + vox % TW;
+      float v = 0.f;
+      if (co < ncls && h < H && w < W) v = dl[((int64_t)t.n * ncls + co) * Vs + ((int64_t)t.d * H + h) * W + w];
+      greg[k] = v;
+    }
+  };
+  int64_t tt = tr.first;
+  Tile tn = tile_of(tt < tr.end ? tt : 0, D, tilesH, tilesW);
+  if (pre && tt < tr.end) fetch(tn);
+  for (; tt < tr.end; tt += tr.step) {
+    const Tile t = pre ? tn : tile_of(tt, D, tilesH, tilesW);
     __syncthreads();
+    if (pre) {
+#pragma unroll
+      for (int k = 0; k < NLX; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < SH * SW * 4) *reinterpret_cast<uint4*>(xs + (i >> 2) * 64 + (i & 3) * 16) = xreg[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NLG; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < ncls * TH * TW) dls[i / (TH * TW)][i % (TH * TW)] = (bf16_t)greg[k];
+      }
+    } else {
     for (int i = threadIdx.x; i < SH * SW * 4; i += 256) {
       const int vox = i >> 2, ch = i & 3;
       const int h = t.h0 + vox / SW - 1, w = t.w0 + vox % SW - 1;
@@ -846,7 +888,12 @@ outconv_wgrad_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __res
       if (h < H && w < W) v = dl[((int64_t)t.n * ncls + co) * Vs + ((int64_t)t.d * H + h) * W + w];
       dls[co][vox] = (bf16_t)v;
     }
+    }
     __syncthreads();
+    if (pre && tt + tr.step < tr.end) {
+      tn = tile_of(tt + tr.step, D, tilesH, tilesW);
+      fetch(tn);
+    }
     // k-steps two at a time with the fragments of the next step requested before the MFMAs of the current one
     auto load_ks = [&](int ks, bf16x8& fb, bf16x8 (&fa)[3]) {
       const int hr = ks >> 1, ws = (ks & 1) * 16;

@@ -412,6 +412,13 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
                                     size_t ws_bytes, hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int cout, int mid);
+extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, const float* slope, void* y,
+                                        int64_t ldy, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                                        int mid, hipStream_t st);
+extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                         int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                         const void* x1, void* y1, int twod, const float* slope, int nmod0);
 extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int cout, int mid, int* kernel, int* geo, int* ksplit);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout);
@@ -779,6 +786,30 @@ static int dgrad_split2_impl(const void* dy, int64_t ldy, const void* wb, void* 
   const int r = fplx_march_conv3d_fwd(dy, ldy, wb, nullptr, dx0, ldx, n, d, h, w, cout, cin, nullptr,
                                       (hipStream_t)stream, nullptr, dx1, mid);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_dgrad_split2: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+
+/* ---- inference: conv + (eval-mode BatchNorm folded into pack and bias by the caller) + PReLU in one kernel ---- */
+int fplx_conv3d_fwd_act_ok(int n, int d, int h, int w, int cin, int cout, int mid, int cat2) {
+  if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+  if (cat2) return fplx_conv3d_cat2_ok(n, d, h, w, cin, cout);           // the Cin = 64 march on two half-slabs
+  return fplx_mfma_conv3d_act_ok(n, d, h, w, cin, cout, mid ? 1 : 0);
+}
+
+int fplx_conv3d_fwd_act(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias, const float* prelu_slope,
+                        void* y, int64_t ldy, int n, int d, int h, int w, int cin, int cout, int mid, int n_x0, void* ws,
+                        size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x0 && wp && bias && prelu_slope && y, FPLX_E_NULL, "conv3d_fwd_act: null pointer");
+  FPLX_REQUIRE(n_x0 == 0 || (x1 && n_x0 > 0 && n % n_x0 == 0), FPLX_E_BADSHAPE,
+               "conv3d_fwd_act: n_x0 = %d needs the two-tensor form and must divide n = %d", n_x0, n);
+  FPLX_REQUIRE(fplx_conv3d_fwd_act_ok(n, d, h, w, cin, cout, mid, x1 != nullptr), FPLX_E_BADSHAPE,
+               "conv3d_fwd_act: no fused kernel for n=%d d=%d h=%d w=%d cin=%d cout=%d (fplx_conv3d_fwd_act_ok)", n, d, h, w, cin, cout);
+  int r;
+  if (x1) r = fplx_march_conv3d_fwd_act(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, (hipStream_t)stream, x1, nullptr,
+                                        mid ? 1 : 0, prelu_slope, n_x0 == n ? 0 : n_x0);
+  else r = fplx_mfma_conv3d_fwd_act(x0, ldx, wp, bias, prelu_slope, y, ldy, n, d, h, w, cin, cout, ws, ws_bytes, mid ? 1 : 0,
+                                    (hipStream_t)stream);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_act: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
 }
 

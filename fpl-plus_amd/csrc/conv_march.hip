@@ -107,12 +107,13 @@ __device__ __forceinline__ void march_step(const char* __restrict__ sl, const ch
 // TWOD: the pack is a Conv2d in the middle depth plane (2.5D levels, fplx_pack_conv2d_weight): a slab feeds only its own
 // output depth, through the kd = 1 taps - step mask 2, a third of the MFMAs, no depth halo; the accumulator roles and
 // the write-out pipeline are the same (K0 stays zero and keeps re-initialising K1 through the role shift).
-template <bool TWOD>
+// ACT (inference, eval-mode BatchNorm folded into the pack): the write-out applies PReLU(slope) and keeps no statistics
+template <bool TWOD, bool ACT = false>
 __global__ void __launch_bounds__(MG::THREADS)
 conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
-                 bf16_t* __restrict__ y1, int ysplit, int xcd) {
+                 bf16_t* __restrict__ y1, int ysplit, int xcd, const float* __restrict__ slope_p = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef FPLX_STAMP
   const long long st_launch = __builtin_amdgcn_s_memtime();
@@ -219,12 +220,14 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   const int64_t yslice = (int64_t)H * W * ldy * 2;        // bytes per output depth
   const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
   const bool sok0 = w0 + (lane >> 2) < W, sok1 = w0 + (lane >> 2) + 16 < W;
+  const float slope_v = ACT ? *slope_p : 0.f;
   auto retire_elem = [&](f32x16& A, int m, int i) {       // voxel i of M-tile m: statistics + bf16 into the LDS tile
     const int wu = (i & 3) + 8 * (i >> 2);
-    const float ov = A[i] + bv;
+    float ov = A[i] + bv;
+    if (ACT) ov = ov > 0.f ? ov : ov * slope_v;
     *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
 #ifndef FPLX_ABL_NOSTATS
-    if ((m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
+    if (!ACT && (m ? hok1 : hok0) && ((wmask >> i) & 1u)) {
       ssum += ov;
       qsum = fmaf(ov, ov, qsum);
     }
@@ -690,12 +693,12 @@ conv_fwd_march32v2(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
 // Same tiling, LDS image, DMA, rotation and write-out as v2; what changes is the fragment geometry - a lane is (row or
 // column r16 = lane & 15, k-group kg = lane >> 4), one MFMA spans all 32 input channels, an accumulator tile is four
 // 16 x 16 blocks (voxel half x cout half) - and the weight image's swizzle (wswz).
-template <bool STATS, int ASWZ>
+template <bool STATS, int ASWZ, bool ACT = false>
 __global__ void __launch_bounds__(MG2::THREADS)
 conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                    const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                    int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
-                   bf16_t* __restrict__ y1, int ysplit, int xcd) {
+                   bf16_t* __restrict__ y1, int ysplit, int xcd, const float* __restrict__ slope_p = nullptr) {
   using G = MG2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;
@@ -805,11 +808,13 @@ conv_fwd_march32v3(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __re
   const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
   // M-tile m of set A: bias, statistics, bf16 -> LDS tile (m & 1) -> two 16-byte stores per lane.  A lane holds, for its
   // two channels r16 and 16 + r16, the voxels 4 kg + i of either 16-voxel half: half mh is written by retire_half(.., mh)
+  const float slope_v = ACT ? *slope_p : 0.f;
   auto retire_half = [&](const f32x4 (&A)[4], int m, int mh) {
     char* w_ = stg + (m & 1) * G::STAGE_BYTES + (mh * 16 + 4 * kg) * 64 + r16 * 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float o0 = A[mh * 2 + 0][i] + bv0, o1 = A[mh * 2 + 1][i] + bv1;
+      float o0 = A[mh * 2 + 0][i] + bv0, o1 = A[mh * 2 + 1][i] + bv1;
+      if (ACT) { o0 = o0 > 0.f ? o0 : o0 * slope_v; o1 = o1 > 0.f ? o1 : o1 * slope_v; }
       *reinterpret_cast<bf16_t*>(w_ + i * 64) = (bf16_t)o0;
       *reinterpret_cast<bf16_t*>(w_ + i * 64 + 32) = (bf16_t)o1;
       if (STATS) { ssum0 += o0; qsum0 = fmaf(o0, o0, qsum0); ssum1 += o1; qsum1 = fmaf(o1, o1, qsum1); }
@@ -1101,12 +1106,12 @@ __device__ __forceinline__ void march64_half(const char* __restrict__ sl, const 
 // the slab slots - quarter-step hf computes from slab slot hf & 1 and weight slot hf & 1 while the DMA fills the other
 // two with quarter hf + 1 (55 KB of weights + 21 KB of slab per 108 MFMAs per wave, all L2 hits: the pack is shared by
 // every block).  The tile kernel this replaces re-gathers its A tile from L2 for each of the 27 taps.
-template <class G, bool TWOD, int NQ>          // TWOD: see conv_fwd_march32
+template <class G, bool TWOD, int NQ, bool ACT = false>          // TWOD, ACT: see conv_fwd_march32
 __global__ void __launch_bounds__(256)
 conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
                  const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
                  int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
-                 const bf16_t* __restrict__ x1, int xcd) {
+                 const bf16_t* __restrict__ x1, int xcd, const float* __restrict__ slope_p = nullptr, int nmod0 = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* slabs = smem;                                        // [2 channel halves][SLAB][32]
   char* wbuf = smem + 2 * G::SLAB_BYTES;                  // [2 channel halves][27][32 co][32 ci]
@@ -1146,7 +1151,9 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     soff[k] = i >= G::SLAB_CHUNKS ? -2 : (in ? (int)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : -1);
   }
   const int64_t xslice = (int64_t)H * W * ldx * 2;
-  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)n * D * xslice;
+  // nmod0 > 0 (inference, Monte-Carlo passes over a shared encoder): x holds nmod0 samples, sample n reads x[n % nmod0] - the
+  // skip tensor of the shared levels is not replicated per pass
+  const char* xn = reinterpret_cast<const char*>(x) + (int64_t)(nmod0 > 0 ? n % nmod0 : n) * D * xslice;
   // channel half 1: the next 32 channels of x, or a second tensor (torch.cat([x, x1], 1) never materialised)
   const char* xn1 = reinterpret_cast<const char*>(x1 ? x1 : x + 32) + (int64_t)n * D * xslice;
   auto slab_piece = [&](int s, int hf, int k) {             // piece k of channel part hf of slab s -> slot hf & 1
@@ -1220,11 +1227,13 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
     sok[m][0] = wok && hb + m * G::HPM < H;
     sok[m][1] = G::FW == 32 ? (sok[m][0] && w0 + (lane >> 2) + 16 < W) : (wok && hb + m * G::HPM + 1 < H);
   }
+  const float slope_v = ACT ? *slope_p : 0.f;
   auto retire_elem = [&](f32x16& A, int m, int i) {
     const int wu = (i & 3) + 8 * (i >> 2);
-    const float ov = A[i] + bv;
+    float ov = A[i] + bv;
+    if (ACT) ov = ov > 0.f ? ov : ov * slope_v;
     *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
-    if (((m ? wmask1 : wmask0) >> i) & 1u) {
+    if (!ACT && (((m ? wmask1 : wmask0) >> i) & 1u)) {
       ssum += ov;
       qsum = fmaf(ov, ov, qsum);
     }
@@ -1394,9 +1403,10 @@ extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout) {
 // returns 1 if launched, 0 if the pointers do not allow the vector stores, <0 on error
 // twod: the pack is a Conv2d in the middle depth plane (fplx_pack_conv2d_weight) - the Cin = 32 march then runs its
 // kd = 1 taps only (same result, a third of the MFMAs)
-extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
-                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
-                                     const void* x1, void* y1, int twod) {
+// slope != NULL (inference): PReLU in the write-out, no statistics (stats must be NULL)
+extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                         int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                         const void* x1, void* y1, int twod, const float* slope, int nmod0) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0 ||
       ((uintptr_t)x1 % 16) != 0 || ((uintptr_t)y1 % 16) != 0)
     return 0;
@@ -1406,10 +1416,17 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
     if (y1 || (cin == 128 && x1)) return 0;
 #define LAUNCH_M64Q(G_, TWOD_, NQ_)                                                                                 \
   do {                                                                                                              \
+    if (slope) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_, NQ_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+      conv_fwd_march64<G_, TWOD_, NQ_, true><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+                                                                         (bf16_t*)y, ldy, n, d, h, w, cout, nullptr, c.tilesH, \
+                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on(), slope, nmod0); \
+    } else {                                                                                                        \
     (void)hipFuncSetAttribute((const void*)conv_fwd_march64<G_, TWOD_, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
     conv_fwd_march64<G_, TWOD_, NQ_><<<grid, G_::THREADS, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
                                                                          (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
                                                                          c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
+    }                                                                                                               \
   } while (0)
 #define LAUNCH_M64(G_, TWOD_) do { if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2); } while (0)
     using G16 = MG64T<16>;
@@ -1440,7 +1457,13 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
   } while (0)
 #define LAUNCH_M32V3(STATS_) LAUNCH_M32V3X(STATS_, 1)      /* ASWZ = 0: the 32 x 32 x 16 kernels' swizzle (A/B builds) */
       // 1: v2 everywhere; 3: v3 everywhere; 4: v3 where no statistics are wanted (its STATS form spills), v2 otherwise
-      if (stats) { if (kv2 == 3) LAUNCH_M32V3(true); else LAUNCH_M32V2(true); }
+      if (slope) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_march32v3<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MG2::LDS);
+        conv_fwd_march32v3<false, 1, true><<<grid, MG2::THREADS, MG2::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
+                                                                ldy, n, d, h, w, cout, nullptr, c.tilesH, c.tilesW, c.dsegs,
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on(), slope);
+      }
+      else if (stats) { if (kv2 == 3) LAUNCH_M32V3(true); else LAUNCH_M32V2(true); }
       else { if (kv2 >= 3) LAUNCH_M32V3(false); else LAUNCH_M32V2(false); }
 #undef LAUNCH_M32V3
 #undef LAUNCH_M32V3X
@@ -1456,8 +1479,23 @@ extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp,
                                                                 ldy, n, d, h, w, cout, stats, c.tilesH, c.tilesW, c.dsegs, \
                                                                 c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on()); \
   } while (0)
-  if (twod) LAUNCH_M32(true); else LAUNCH_M32(false);
+#define LAUNCH_M32A(TWOD_)                                                                                          \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march32<TWOD_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MG::LDS); \
+    conv_fwd_march32<TWOD_, true><<<grid, MG::THREADS, MG::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, \
+                                                                ldy, n, d, h, w, cout, nullptr, c.tilesH, c.tilesW, c.dsegs, \
+                                                                c.dlen, (bf16_t*)y1, y1 ? cout / 64 : cout / 32, fplx_xcd_on(), slope); \
+  } while (0)
+  if (slope) { if (twod) LAUNCH_M32A(true); else LAUNCH_M32A(false); }
+  else if (twod) LAUNCH_M32(true); else LAUNCH_M32(false);
+#undef LAUNCH_M32A
 #undef LAUNCH_M32
   const int rc = fplx_check_launch("march_conv3d_fwd");
   return rc < 0 ? rc : 1;
+}
+
+extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                     int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                     const void* x1, void* y1, int twod) {
+  return fplx_march_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, x1, y1, twod, nullptr, 0);
 }

@@ -1654,7 +1654,8 @@ conv_fwd_tile(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restric
 // split-K finish: y = bf16(sum_z partial[z] + bias), statistics rows; thread = voxel-lane x 8 channels
 __global__ void __launch_bounds__(256)
 splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, const float* __restrict__ bias,
-                bf16_t* __restrict__ y, int64_t ldy, float* __restrict__ stats) {
+                bf16_t* __restrict__ y, int64_t ldy, float* __restrict__ stats, const float* __restrict__ slope_p = nullptr) {
+  const float slope_v = slope_p ? *slope_p : 1.f;      // inference: PReLU on the finished sum (1 = identity: x > 0 ? x : x * 1)
   const int G = Cout / 8;                      // channel groups per voxel (<= 256 by construction)
   const int VL = 256 / G;
   const int g = threadIdx.x % G, vl = threadIdx.x / G;
@@ -1674,7 +1675,10 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
       }
       bf16x8 ov;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ov[j] = (bf16_t)o[j]; s[j] += o[j]; q[j] = fmaf(o[j], o[j], q[j]); }
+      for (int j = 0; j < 8; ++j) {
+        o[j] = o[j] > 0.f ? o[j] : o[j] * slope_v;
+        ov[j] = (bf16_t)o[j]; s[j] += o[j]; q[j] = fmaf(o[j], o[j], q[j]);
+      }
       *reinterpret_cast<bf16x8*>(y + v * ldy + c0) = ov;
     }
   if (!stats) return;
@@ -1852,6 +1856,12 @@ extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
                                      const void* x1, void* y1, int twod);
+extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                         int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
+                                         const void* x1, void* y1, int twod, const float* slope, int nmod0);
+extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
+                                         int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
+                                         int ksplit, hipStream_t st, const float* slope);
 // conv_brick.hip
 extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout);
@@ -1934,9 +1944,11 @@ extern "C" size_t fplx_mfma_conv3d_mid_fwd_ws_bytes(int n, int d, int h, int w, 
   return fwd_ws_impl(n, d, h, w, cin, cout, 1);
 }
 
+// slope != NULL (inference: eval-mode BatchNorm folded into the pack): PReLU in the kernel's write-out or in the split-K
+// finish; the caller has checked fplx_mfma_conv3d_act_ok (the stream / unsplit tile / direct kernels have no such form)
 static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy, int n, int d,
                          int h, int w, int cin, int cout, float* stats, void* ws, size_t ws_bytes, int mid,
-                         hipStream_t st) {
+                         hipStream_t st, const float* slope = nullptr) {
   if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
@@ -1947,9 +1959,9 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     if (ks > 1 && (!ws || ws_bytes < (size_t)ks * Vb * cout * sizeof(float)))
       return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
                        (size_t)ks * Vb * cout * sizeof(float));
-    const int rb = fplx_brick_conv3d_fwd_ex(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (float*)ws, geo, ks, st);
+    const int rb = fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (float*)ws, geo, ks, st, slope);
     if (rb == 1 && ks > 1) {
-      splitk_finish_k<<<splitk_fin_blocks(Vb), 256, 0, st>>>((const float*)ws, ks, Vb, cout, bias, (bf16_t*)y, ldy, stats);
+      splitk_finish_k<<<splitk_fin_blocks(Vb), 256, 0, st>>>((const float*)ws, ks, Vb, cout, bias, (bf16_t*)y, ldy, stats, slope);
       const int rf = fplx_check_launch("brick_splitk_finish");
       if (rf < 0) return rf;
     }
@@ -1957,8 +1969,9 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   };
   if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick_launch();
   if (fplx_march_ok(n, d, h, w, cin, cout))
-    return fplx_march_conv3d_fwd(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, mid);
+    return fplx_march_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, st, nullptr, nullptr, mid, slope, 0);
   if (stream_ok(d, h, w, cin, cout)) {
+    if (slope) return 0;
     const StreamCfg sc = stream_cfg(n, d, h, w, cout);
     dim3 grid(sc.nblk, cout / 32);
     if (cin == 32) {
@@ -1980,6 +1993,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   const DirectCfg c = direct_cfg(V, cin, cout, tap_cnt);
   const int ks = c.ksplit;
   float* partial = nullptr;
+  if (slope && ks <= 1) return 0;                          // no activation form of the unsplit tile / direct kernels
   if (ks > 1) {
     // the statistics row count was promised for the split-K path: the workspace is mandatory here
     if (!ws || ws_bytes < (size_t)ks * V * cout * sizeof(float))
@@ -2001,7 +2015,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     else if (c.tile_nt == 128) { if (k64) LAUNCH_TILE(128, 64, 128); else LAUNCH_TILE(128, 32, 128); }
     else { if (k64) LAUNCH_TILE(64, 64, 128); else LAUNCH_TILE(64, 32, 128); }
 #undef LAUNCH_TILE
-    if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
+    if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats, slope);
     int rct = fplx_check_launch("mfma_conv3d_fwd_tile");
     return rct < 0 ? rct : 1;
   }
@@ -2013,7 +2027,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     conv_fwd_direct<4, 1, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
                                                            ldy, n, d, h, w, cin, cout, stats, partial);
   if (ks > 1)
-    splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats);
+    splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats, slope);
   int rc = fplx_check_launch("mfma_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }
@@ -2028,6 +2042,18 @@ extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* 
                                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
                                         size_t ws_bytes, hipStream_t st) {
   return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, ws, ws_bytes, 1, st);
+}
+
+// 1 if the layer's forward kernel has the PReLU write-out (or finishes through splitk_finish_k)
+extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int cout, int mid) {
+  int kernel, geo, ks;
+  if (!fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
+  return kernel == FPLX_KERNEL_BRICK || kernel == FPLX_KERNEL_MARCH || ((kernel == FPLX_KERNEL_TILE || kernel == FPLX_KERNEL_DIRECT) && ks > 1);
+}
+extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, const float* slope, void* y,
+                                        int64_t ldy, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
+                                        int mid, hipStream_t st) {
+  return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, ws, ws_bytes, mid, st, slope);
 }
 
 extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout) {

@@ -40,6 +40,11 @@ class Engine(object):
         self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
         self.use_split_cat = os.environ.get("FPLX_SPLIT_CAT", "1") != "0"     # A/B knob (benchmarks only)
         self.use_fused_pool = os.environ.get("FPLX_FUSED_POOL", "1") != "0"   # A/B knob (benchmarks only)
+        # inference (eval-mode BatchNorm, nothing kept for a backward, bf16): BatchNorm folded into the packs, PReLU in the
+        # convolution's write-out - the BN-apply passes of the sites without active dropout disappear (FPLX_EVAL_FUSE=0: off)
+        self.use_eval_fusion = os.environ.get("FPLX_EVAL_FUSE", "1") != "0"
+        self.stem_wgrad_on_main = os.environ.get("FPLX_STEM_WG_MAIN", "1") != "0"   # A/B knob (benchmarks only)
+        self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # block_joins: the main stream waits for the weight-gradient stream at every block boundary of backward.
         # None = decide per network (see backward()); tools/race25.py sets it to bisect.
         self.block_joins = None
@@ -88,6 +93,29 @@ class Engine(object):
 
     def invalidate(self):
         self._pack_cache = None
+        self._fold_cache = {}
+
+    def _folded(self, adt, domain, key, conv, bn):
+        """forward pack and bias of a convolution with its eval-mode BatchNorm folded in (dsbn.py:54-57 on running statistics:
+        z = scale (conv(x; w) + b) + shift = conv(x; scale w) + (scale b + shift)); cached until the parameters or the
+        running statistics change (invalidate(), any train-mode forward)"""
+        ck = (adt, domain)
+        tab = self._fold_cache.setdefault(ck, {})
+        if key not in tab:
+            bnm = bn.bns[domain]
+            with torch.no_grad():
+                scale = bnm.weight.detach().float() * torch.rsqrt(bnm.running_var.float() + bnm.eps)
+                shift = bnm.bias.detach().float() - bnm.running_mean.float() * scale
+                w = conv.weight.detach().float()
+                wf_ = (w * scale.view(-1, *([1] * (w.dim() - 1)))).contiguous()
+                b = conv.bias.detach().float() if conv.bias is not None else torch.zeros_like(scale)
+                biasf = (b * scale + shift).contiguous()
+                if w.dim() == 4:
+                    wf, _ = ops.pack_conv2d_weight(wf_, adt, False)
+                else:
+                    wf, _ = ops.pack_conv_weight(wf_, adt, False)
+            tab[key] = (wf, biasf)
+        return tab[key]
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1):
@@ -124,6 +152,9 @@ class Engine(object):
             self._pack_cache = None if train else (adt, packs)
         else:
             packs = self._pack_cache[1]
+        if train:
+            self._fold_cache = {}                        # the running statistics are about to change
+        fuse = self.use_eval_fusion and not train and not keep and adt == torch.bfloat16
         if mc > 1 and (train or keep):
             raise ValueError("fplx: Monte-Carlo replication (mc > 1) is an inference mode: eval-mode BatchNorm, keep=False")
         # first encoder level whose input differs between Monte-Carlo passes (the level after the first active dropout)
@@ -172,12 +203,36 @@ class Engine(object):
         # shared encoder levels write their skip once; it is copied into the decoder's (all-passes) buffer afterwards
         eskips = [empty(evox[l], ft[l]) if evox[l] != vox[l] else skips[l] for l in range(4)]
 
-        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None, dims=dims, vox=vox):
+        # Monte-Carlo passes over a shared encoder: where the decoder's first convolution of a level is the fused two-tensor
+        # kernel, it reads the ONE copy of the skip tensor modulo the batch (n_x0) instead of a copy per pass
+        skip_mod = [0, 0, 0, 0]
+        if fuse and mc > 1:
+            for l in range(4):
+                blk = net.block_modules[8 - l]
+                p_on = blk.dropout_p if drop_on[8 - l] else 0.0
+                if (l < rep and split[l] and p_on == 0.0 and
+                        ops.conv3d_fwd_act_ok(dims[l], 2 * ft[l], ft[l], blk.conv_of(1).weight.dim() == 4, True)):
+                    skip_mod[l] = edims[l][0]
+
+        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None, dims=dims, vox=vox, n_x0=0):
             """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view; pool = (pooled, pd): the
             MaxPool of out_view is produced by the same pass (tail of a DownBlock)"""
             conv, bn, prelu = site
             cout = conv.weight.shape[0]
             mid = conv.weight.dim() == 4           # Conv2d of a 2.5D level: its pack lives in the middle depth plane
+            pp = p if dropout_active else 0.0
+            cat2 = isinstance(xin, tuple)
+            if (fuse and pp == 0.0 and (cat2 or x_dt == a_dt) and ops.conv3d_fwd_act_ok(dims[l], cin, cout, mid, cat2) and
+                    all(ops.ld_of(t) % 8 == 0 and t.data_ptr() % 16 == 0 for t in ((xin if cat2 else (xin,)) + (out_view,)))):
+                # inference: conv + folded BatchNorm + PReLU in one kernel, straight into the site's output
+                wf, biasf = self._folded(adt, domain, key, conv, bn)
+                ops.conv3d_fwd_act(xin[0] if cat2 else xin, xin[1] if cat2 else None, wf, biasf, prelu.weight, out_view, dims[l],
+                                   cin, cout, mid, n_x0)
+                if pool is not None:
+                    ops.maxpool2_fwd(out_view, pool[0], dims[l], cout, pool[1])
+                return None, None, pp
+            if n_x0:
+                raise RuntimeError("fplx: the shared skip tensor of level %d was planned for the fused kernel" % l)
             y = empty(vox[l], cout)
             bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
             bnm = bn.bns[domain]
@@ -196,14 +251,13 @@ class Engine(object):
                                       bnm.running_var, bnm.num_batches_tracked, bnbuf, bnm.momentum, bnm.eps)
             else:
                 ops.bn_eval_prepare(bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var, bnbuf, bnm.eps)
-            pp = p if dropout_active else 0.0
             if pool is not None:
                 ops.bn_act_pool_fwd(y, out_view, pool[0], bnbuf, prelu.weight, dims[l], cout, pool[1])
             else:
                 ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
             return y, bnbuf, pp
 
-        def conv_block(b, xin, xs, x_dt, cin, l, out_view, pool=None, dims=dims, vox=vox):
+        def conv_block(b, xin, xs, x_dt, cin, l, out_view, pool=None, dims=dims, vox=vox, n_x0=0):
             blk = net.block_modules[b]
             key = net.block_keys[b]
             c = ft[l]
@@ -211,7 +265,7 @@ class Engine(object):
             sid = step * 16 + b
             y1, bn1, p1 = conv_site(xin, xs, x_dt, cin, key + "." + blk.cname(1),
                                     (blk.conv_of(1), blk.bn_of(1), blk.relu_1), l, a1, blk.dropout_p, sid, drop_on[b],
-                                    dims=dims, vox=vox)
+                                    dims=dims, vox=vox, n_x0=n_x0)
             y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + "." + blk.cname(2),
                                    (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False, pool,
                                    dims=dims, vox=vox)
@@ -230,7 +284,7 @@ class Engine(object):
             if i < 4:
                 if not fused:
                     ops.maxpool2_fwd(out_view, pooled, edims[i], ft[i], pds[i])
-                if eskips[i] is not skips[i]:          # one copy -> every pass's slot of the decoder input
+                if eskips[i] is not skips[i] and not skip_mod[i]:      # one copy -> every pass's slot of the decoder input
                     skips[i].view(mc, evox[i], ft[i])[:] = eskips[i]
                 if evox[i + 1] != pooled.shape[0]:     # the next level is the first one that differs between passes
                     pooled = pooled.repeat(mc, 1)
@@ -254,8 +308,8 @@ class Engine(object):
                 ops.deconv2_fwd(cur, packs["up%d.%s" % (j + 1, up.tname())][0], tr.bias, ups[l], dims[l + 1], ft[l + 1],
                                 ft[l], pds[l])
             out = empty(vox[l], ft[l])
-            xin = (skips[l], ups[l]) if split[l] else cats[l]
-            conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out)
+            xin = ((eskips[l] if skip_mod[l] else skips[l]), ups[l]) if split[l] else cats[l]
+            conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out, n_x0=skip_mod[l])
             cur = out
         # ---- out_conv (1x3x3) -> fp32 planar logits
         ncls = net.n_class
@@ -379,7 +433,8 @@ class Engine(object):
         outconv_wgrad()
         ready("out_conv.bias")
 
-        def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view, reduced=False):
+        def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view, reduced=False,
+                     wgrad_here=False):
             """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy.
             reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)"""
             c = ft[l]
@@ -402,7 +457,14 @@ class Engine(object):
                         d_out, xin[0], xin[1])
                 return
             def wg():
-                if two_d:
+                if wgrad_here:
+                    # the LAST weight gradient of backward (the stem's): nothing follows it on this stream, while the second
+                    # stream is still busy with the previous site's - on this stream the two run side by side instead of one
+                    # after the other (the step's tail showed 70 us of stem_wgrad alone on the device, r03 timeline)
+                    fn = ops.conv2d_wgrad if two_d else ops.conv3d_wgrad
+                    args = (xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db, dims[l], cin, c)
+                    fn(*(args + ((ws,) if two_d else ((3, 3, 3), ws))))
+                elif two_d:
                     on_side(lambda: ops.conv2d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
                                                      dims[l], cin, c, ws_w), d_out, xin)
                 else:
@@ -433,7 +495,8 @@ class Engine(object):
             else:
                 d_in = empty(vox[l], cin) if want_dx else None
             site_bwd(key + "." + mod.cname(1), key + "." + mod.bname(1), key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"],
-                     blk["sid"], d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in)
+                     blk["sid"], d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in,
+                     wgrad_here=(b == 0 and side_on and self.stem_wgrad_on_main))
             return d_in
 
         # ---- decoder, up4 .. up1

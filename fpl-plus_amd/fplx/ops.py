@@ -190,6 +190,29 @@ def conv3d_wgrad_cat2(x0, x1, dy, dw, dims, cin, cout, ws, mid=False):
          ptr(dw), n, d, h, w, cin, cout, ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
+def conv3d_fwd_act_ok(dims, cin, cout, mid=False, cat2=False):
+    """True if the layer's forward kernel has the fused (folded eval-mode BatchNorm) + PReLU write-out"""
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv3d_fwd_act_ok(n, d, h, w, cin, cout, 1 if mid else 0, 1 if cat2 else 0) == 1
+
+
+def conv3d_fwd_act(x0, x1, wp, bias, slope, y, dims, cin, cout, mid=False, n_x0=0):
+    """inference: y = PReLU(conv(x; wp) + bias) with the eval-mode BatchNorm already folded into wp / bias; x1: the second half
+    of a channel concatenation (or None); n_x0: x0 holds that many samples, read modulo (0 = all).  bf16 NDHWC 2-D views."""
+    n, d, h, w = dims
+    ws = None
+    need = conv3d_fwd_ws_bytes(dims, cin, cout, (3, 3, 3), BF16, BF16, mid)
+    if need:
+        key = (y.device, torch.cuda.current_stream(y.device).cuda_stream)
+        if key not in _fwd_ws or _fwd_ws[key].numel() < need:
+            _fwd_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=y.device)
+        ws = _fwd_ws[key]
+    if x1 is not None:
+        assert ld_of(x0) == ld_of(x1)
+    call("fplx_conv3d_fwd_act", ptr(x0), ptr(x1), ld_of(x0), ptr(wp), ptr(bias), ptr(slope), ptr(y), ld_of(y), n, d, h, w, cin,
+         cout, 1 if mid else 0, int(n_x0), ptr(ws), 0 if ws is None else ws.numel(), stream())
+
+
 def _dc(sd):
     return "fplx_deconv2_" if sd == 2 else "fplx_deconv122_"
 

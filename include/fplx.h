@@ -139,6 +139,22 @@ int fplx_conv3d_dgrad_split2(const void* dy, int64_t ldy, const void* wb, void* 
 int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
                            int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream);
 
+/* ------------------------------------------------------------------ inference: convolution + BatchNorm(eval) + PReLU in one kernel
+ * ConvBlockND in eval mode (unet2d5_dsbn.py:74-81 with dsbn.py:54-57 on running statistics): BatchNorm is then a fixed
+ * per-channel affine map, z = scale (conv(x; w) + b) + shift = conv(x; scale w) + (scale b + shift).  The CALLER folds scale
+ * into the weights before packing them (fplx_pack_conv_weight / _conv2d_weight) and passes bias = scale b + shift; the
+ * kernel applies PReLU(prelu_slope[0]) in its write-out, so the separate fplx_bn_act_fwd pass disappears.  bf16 NDHWC
+ * operands, 3x3x3 (mid != 0: a Conv2d pack in the middle depth plane).  x1 != NULL: the input is cat([x0, x1], channel)
+ * of two cin/2-channel tensors (fplx_conv3d_fwd_cat2).  Only for layers fplx_conv3d_fwd_act_ok accepts (the depth-march,
+ * brick and split-K kernels); FPLX_E_BADSHAPE otherwise - callers fall back to fplx_conv3d_fwd + fplx_bn_act_fwd.
+ * n_x0 (two-tensor form only; 0 = n): x0 holds n_x0 samples and sample i reads x0[i % n_x0] - the Monte-Carlo passes of
+ * test-time dropout (agent_seg.py:898-909) share the encoder levels above the first active dropout, whose skip tensor is
+ * then not replicated per pass.  ws: fplx_conv3d_fwd_ws_bytes / fplx_conv2d_fwd_ws_bytes of the layer. */
+int fplx_conv3d_fwd_act_ok(int n, int d, int h, int w, int cin, int cout, int mid, int cat2);
+int fplx_conv3d_fwd_act(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias,
+                        const float* prelu_slope, void* y, int64_t ldy, int n, int d, int h, int w, int cin, int cout,
+                        int mid, int n_x0, void* ws, size_t ws_bytes, fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ transposed convolution
  * nn.ConvTranspose3d(k=2,s=2) (unet2d5_dsbn.py:152,181).  x: [N,D,H,W,Cin] ld ldx;
  * y: [N,2D,2H,2W,Cout] ld ldy (normally the upper channel half of the concat buffer, line 182). */

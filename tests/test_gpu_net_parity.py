@@ -357,3 +357,63 @@ def test_upsample2_matches_torch_interpolate(dtype, sd):
     dx = torch.empty_like(xg)
     ops.upsample2_bwd(cl(gy).to(dtype).cuda(), dx, (n, d, h, w), c, sd)
     assert float((dx.float().cpu() - cl(xr.grad)).abs().max()) < tol * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("dims,shape", [([3, 3, 3, 3, 3], (2, 1, 16, 64, 64)), ([3, 3, 3, 3, 3], (1, 1, 32, 48, 80)),
+                                         ([2, 2, 3, 3, 3], (2, 1, 12, 64, 64)), ([2, 2, 3, 3, 3], (3, 1, 28, 128, 128))])
+def test_eval_fusion_matches_the_separate_batchnorm_passes(dims, shape):
+    """inference with the eval-mode BatchNorm folded into the packs and PReLU in the convolution write-out
+    (fplx_conv3d_fwd_act; reference semantics unet2d5_dsbn.py:74-81 + dsbn.py:54-57 on running statistics) against the
+    same network with the separate fplx_bn_act_fwd passes (engine.use_eval_fusion = False), bf16, 32-base: logits within bf16
+    noise (the rounding points move: the pre-BatchNorm tensor is no longer stored), hard labels agree, and the Monte-Carlo
+    forward (shared encoder prefix, one copy of the level-0 skip read modulo the batch, active dropout at levels 2-4) agrees
+    with the plain forward of the repeated batch."""
+    import fplx
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=dims, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    torch.manual_seed(7)
+    net = fplx.UNet2D5_dsbn(p).cuda()
+    # non-trivial running statistics and BatchNorm parameters
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if k.endswith("running_mean"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+            elif k.endswith("running_var"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.8 + 0.6)
+            elif ".bns." in k and k.endswith("weight"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.75)
+            elif ".bns." in k and k.endswith("bias"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+    net.engine.invalidate()
+    net.eval()
+    x = torch.randn(shape, generator=g).cuda()
+    dl = torch.ones(shape[0], dtype=torch.long)
+    outs = {}
+    with torch.no_grad():
+        for fused in (True, False):
+            net.engine.use_eval_fusion = fused
+            net.engine.invalidate()
+            outs[fused] = net(x, domain_label=dl)
+        rng = float(outs[False].abs().max())
+        assert float((outs[True] - outs[False]).abs().max()) <= 3e-2 * rng, float((outs[True] - outs[False]).abs().max()) / rng
+        agree = float((fplx.filter.hard_label(outs[True]) == fplx.filter.hard_label(outs[False])).float().mean())
+        assert agree >= 0.995, agree
+        # the other domain's BatchNorm set gives a different fold (DSBN)
+        net.engine.use_eval_fusion = True
+        other = net(x, domain_label=torch.zeros(shape[0], dtype=torch.long))
+        assert float((other - outs[True]).abs().max()) > 1e-3 * rng
+        # Monte-Carlo passes: shared prefix == repeated batch, with the fused kernels in both
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.train()
+        net.dropout_seed = 11
+        net._fwd_counter = 5
+        mc = net.forward_mc(x, dl, 3)
+        net._fwd_counter = 5
+        rep = net(x.repeat(3, 1, 1, 1, 1), domain_label=dl.repeat(3))
+        # same dropout masks, same arithmetic - but the shared levels run with batch N here and 3 N there, and the dispatcher may
+        # pick another split / kernel (or the unfused form) for another batch: single bf16 roundings may differ, nothing else
+        assert float((mc - rep).abs().max()) <= 2e-2 * rng, float((mc - rep).abs().max()) / rng
+        assert float((fplx.filter.hard_label(mc) == fplx.filter.hard_label(rep)).float().mean()) >= 0.995
+        assert float((mc[:shape[0]] - mc[shape[0]:2 * shape[0]]).abs().max()) > 1e-3 * rng       # the passes differ

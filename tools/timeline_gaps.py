@@ -64,3 +64,28 @@ for s_, e_, q, n in rows:
 print("main queue %s, per step:" % mainq)
 for n, (t, c) in sorted(fam.items(), key=lambda kv: -kv[1][0])[:40]:
     print("  %8.1f us  %5.1f launches  avg %7.1f  %s" % (t / 1e3 / nsteps, c / nsteps, t / 1e3 / c, n))
+
+# who is alone on the device: time with exactly one kernel running, by queue (the second stream's exposed tail shows up here)
+ev2 = []
+for s_, e_, q, n in rows:
+    ev2.append((s_, 1, q, n))
+    ev2.append((e_, -1, q, n))
+ev2.sort(key=lambda t: (t[0], t[1]))
+active, last_t = {}, ev2[0][0]
+alone, alone_k = defaultdict(int), defaultdict(int)
+for t, d, q, n in ev2:
+    if len(active) == 1:
+        (qq, nn), = active.items()
+        alone[qq] += t - last_t
+        alone_k[(qq, nn)] += t - last_t
+    last_t = t
+    if d > 0:
+        active[q] = n
+    else:
+        active.pop(q, None)
+print("alone on the device, per step:")
+for q, v in sorted(alone.items(), key=lambda kv: -kv[1]):
+    print("  queue %s: %.1f us" % (q, v / 1e3 / nsteps))
+    for (qq, nn), vv in sorted(alone_k.items(), key=lambda kv: -kv[1]):
+        if qq == q and qq != mainq and vv / 1e3 / nsteps > 5:
+            print("      %8.1f us  %s" % (vv / 1e3 / nsteps, nn))
