@@ -1805,6 +1805,82 @@ deconv_dgrad_rows(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// deconv_dgrad_small: the same data gradient for the small deep volumes (<= 16 K parents, dy 128 | 256 | ... channels), where
+// conv_fwd_direct<1, 2, 1> is ONE latency chain per block: 64 blocks x 128 dependent (tap, k-step) iterations at level 4
+// (48 us for 4 GFLOP).  Here a block = 32 parents x 64 input channels and its four waves SPLIT THE EIGHT TAPS (two each):
+// a quarter of the chain per wave, four times the blocks (every CU busy), the four partial tiles summed through LDS in a
+// fixed order.  Operand fragments straight from global / L2 (16 B per lane), eight k-steps in flight.
+__global__ void __launch_bounds__(256)
+deconv_dgrad_small(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx,
+                   int64_t ldx, int N, int D, int H, int W, int Cout, int Cin) {
+  __shared__ float red[4][2][1024];                   // [wave][col tile][row 32 x col 32]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, kh8 = (lane >> 5) * 8;
+  const int64_t V = (int64_t)N * D * H * W;
+  const int64_t v = (int64_t)blockIdx.x * 32 + r;
+  const int n0 = blockIdx.y * 64;
+  const bool ok = v < V;
+  unsigned q = (unsigned)(ok ? v : 0);
+  const int vw = (int)(q % (unsigned)W); q /= (unsigned)W;
+  const int vh = (int)(q % (unsigned)H); q /= (unsigned)H;
+  const int vd = (int)(q % (unsigned)D);
+  const int vn = (int)(q / (unsigned)D);
+  const bf16_t* a0 = dy + ((((int64_t)vn * 2 * D + 2 * vd) * 2 * H + 2 * vh) * 2 * W + 2 * vw) * ldy + kh8;
+  const bf16_t* b0 = wb + ((int64_t)(n0 + r)) * Cout + kh8;
+  const bf16_t* b1 = b0 + (int64_t)32 * Cout;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int KS = Cout / 16, NIT = 2 * KS;             // this wave's taps: 2 wave, 2 wave + 1
+  constexpr int P = 8;
+  bf16x8 ra[P], rb0[P], rb1[P];
+  auto fetch = [&](int it, int u) {
+    const int tap = 2 * wave + it / KS, kc = (it % KS) * 16;
+    const int64_t toff = ((int64_t)((tap >> 2) * 2 * H + ((tap >> 1) & 1)) * 2 * W + (tap & 1)) * ldy + kc;      // uniform
+    const int64_t woff = (int64_t)tap * Cin * Cout + kc;
+    ra[u] = ok ? *reinterpret_cast<const bf16x8*>(a0 + toff) : zero;
+    rb0[u] = *reinterpret_cast<const bf16x8*>(b0 + woff);
+    rb1[u] = *reinterpret_cast<const bf16x8*>(b1 + woff);
+  };
+#pragma unroll
+  for (int u = 0; u < P; ++u) fetch(u < NIT ? u : NIT - 1, u);
+  for (int it = 0; it < NIT; it += P) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      if (it + u < NIT) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[u], rb0[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[u], rb1[u], acc1, 0, 0, 0);
+      }
+      const int nx = it + P + u;
+      fetch(nx < NIT ? nx : NIT - 1, u);              // past the end: a harmless re-read (keeps the loop branch-free)
+    }
+  }
+  const int rh = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (i & 3) + 8 * (i >> 2) + rh;
+    red[wave][0][row * 32 + r] = acc0[i];
+    red[wave][1][row * 32 + r] = acc1[i];
+  }
+  __syncthreads();
+  // thread t -> 8 consecutive channels of one parent: row t / 8, channels 8 (t % 8) of the block's 64
+  const int row = threadIdx.x >> 3, c8 = (threadIdx.x & 7) * 8;
+  const int64_t vo = (int64_t)blockIdx.x * 32 + row;
+  if (vo < V) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 + j;
+      const float* p_ = &red[0][c >> 5][row * 32 + (c & 31)];
+      o[j] = (bf16_t)((p_[0] + p_[2048]) + (p_[4096] + p_[6144]));
+    }
+    *reinterpret_cast<bf16x8*>(dx + vo * ldx + n0 + c8) = o;
+  }
+}
+
 struct DirectCfg { int mt, ntl, ksplit, fin_blocks, tile_nt, tile_mt; int64_t mblocks; };
 
 inline DirectCfg direct_cfg(int64_t V, int cin, int cout, int taps = 27) {
@@ -2167,6 +2243,16 @@ extern "C" int fplx_mfma_deconv2_dgrad(const void* dy, int64_t ldy, const void* 
       deconv_dgrad_rows<2, 4><<<nb, 256, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, segsW, nseg, fplx_xcd_on());
     int rcr = fplx_check_launch("mfma_deconv2_dgrad_rows");
     return rcr < 0 ? rcr : 1;
+  }
+  // small deep volumes: the taps split over the waves of a block (deconv_dgrad_small)
+  // (only where the direct kernel's grid leaves half the chip idle: at 8000 parents, 252 blocks, it is the faster one - 28
+  // against 38 us - at 1000 parents, 64 blocks, 46 against 16 us)
+  if (sd == 2 && fplx_knob(FPLX_K_DECONV_DGRAD_ROWS) && ((V + 127) / 128) * (cin / 64) < 128 && cin % 64 == 0 && cout % 16 == 0 &&
+      ldx % 8 == 0 && ((uintptr_t)dx % 16) == 0) {
+    dim3 gs((unsigned)((V + 31) / 32), cin / 64);
+    deconv_dgrad_small<<<gs, 256, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, cout, cin);
+    int rcs = fplx_check_launch("mfma_deconv2_dgrad_small");
+    return rcs < 0 ? rcs : 1;
   }
 #define LAUNCH_DD(MT_, NTL_, MODE_, GRID_)                                                                          \
   conv_fwd_direct<MT_, NTL_, MODE_><<<GRID_, DIRECT_THREADS, 0, st>>>((const bf16_t*)dy, ldy, (const bf16_t*)wb, nullptr, \

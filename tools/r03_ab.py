@@ -48,7 +48,7 @@ def main():
     bo = torch.zeros(ncls, device=dev)
     ab("out_conv fwd 32->2", "outconv_t", (1, 0), lambda: ops.conv3d_fwd(feat, cl(d, h, w, c0), ops.BF16, wof, bo, logits, pl(ncls, d, h, w),
                                                                           ops.F32, dims, c0, ncls, (1, 3, 3), None), v * c0 * 2 + v * ncls * 4)
-    for (dd, cin, cout) in (((2, 40, 80, 80), 64, 32), ((2, 20, 40, 40), 128, 64)):
+    for (dd, cin, cout) in (((2, 40, 80, 80), 64, 32), ((2, 20, 40, 40), 128, 64), ((2, 10, 20, 20), 256, 128), ((2, 5, 10, 10), 512, 256)):
         nn, d1, h1, w1 = dd
         v1 = nn * d1 * h1 * w1
         dy = torch.randn(v1 * 8, cout, device=dev).to(bf)
