@@ -738,6 +738,176 @@ pool_bwd_bn_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__
   }
 }
 
+// Round 3: the same two passes with the lanes laid along the INPUT row.  Above, a thread owns a pooled voxel and reads its 8
+// window voxels - consecutive lanes read 64-byte pieces 128 bytes apart (every wave load touches twice the lines it uses, 17
+// loads and 200 registers per thread): 1.6 TB/s at level 0 where the plain BatchNorm reduction reads at 5.  Here a thread
+// owns one input COLUMN of a window - voxel w of row pair (h, h + 1) of the pd depths, VEC channels - so that a wave load is
+// one contiguous kilobyte; the two columns of a window are the lanes l and l ^ G (consecutive w, W even), which exchange
+// their candidate maxima by a lane shuffle.  First-maximum rule: window index t = 4 dd + 2 hh + ww, a lane scans its own
+// positions in ascending t, the pair keeps the larger value and, on ties, the smaller t - the same winner as the scan over
+// all eight.  Same arithmetic and rounding points per element as the kernels above: dx / a2 / pooled are bit-identical,
+// the partial rows differ only in how the voxels are dealt to them.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+bn_act_pool_fwd_col_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_t ldo, T* __restrict__ pooled,
+                      int64_t ldp, const float* __restrict__ scale, const float* __restrict__ shift,
+                      const float* __restrict__ slope_p, int N, int D, int H, int W, int C, int pd) {
+  const int G = C / VEC, VL = EW_THREADS / G;            // host: G a power of two <= 32
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const int Do = D / pd, Ho = H / 2;
+  const unsigned units = (unsigned)N * Do * Ho * W;     // (n, d_o, ho, w): host keeps this below 2^31
+  const float slope = *slope_p;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; }
+  // the loop bound is rounded up to whole lane PAIRS being active together (units is even, VL is even)
+  for (unsigned u = blockIdx.x * VL + vl; u < units; u += gridDim.x * VL) {
+    unsigned q = u;
+    const int w = (int)(q % (unsigned)W); q /= (unsigned)W;
+    const int ho = (int)(q % (unsigned)Ho); q /= (unsigned)Ho;
+    const int d_o = (int)(q % (unsigned)Do);
+    const int64_t n = q / (unsigned)Do;
+    float a[4][VEC], best[VEC];
+    int64_t vis[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= 2 * pd) break;
+      vis[t] = ((n * D + pd * d_o + (t >> 1)) * H + 2 * ho + (t & 1)) * W + w;
+      ldv_nt<T, VEC>(y + vis[t] * ldy + c0, a[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) best[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= 2 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z = fmaf(a[t][j], sc[j], sh[j]);
+        z = z > 0.f ? z : z * slope;
+        z = (float)(T)z;                                 // what the skip tensor stores and the pooling compares
+        a[t][j] = z;
+        best[j] = z > best[j] ? z : best[j];
+      }
+      stv<T, VEC>(out + vis[t] * ldo + c0, a[t]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float o = __shfl_xor(best[j], G, 64);
+      best[j] = o > best[j] ? o : best[j];
+    }
+    if (!(w & 1)) stv<T, VEC>(pooled + (int64_t)(u >> 1) * ldp + c0, best);     // u / 2 = ((n Do + d_o) Ho + ho) Wo + w / 2
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(EW_THREADS)
+pool_bwd_bn_reduce_col_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dy, int64_t lddy,
+                         const T* __restrict__ dskip, int64_t lds, T* __restrict__ dx, int64_t ldo,
+                         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
+                         const float* __restrict__ shift, const float* __restrict__ slope_p, int N, int D, int H, int W, int C,
+                         int pd, float* __restrict__ part) {
+  const int G = C / VEC, VL = EW_THREADS / G;            // host: G a power of two <= 32
+  const int g = threadIdx.x % G, vl = threadIdx.x / G, c0 = g * VEC;
+  const int Do = D / pd, Ho = H / 2;
+  const unsigned units = (unsigned)N * Do * Ho * W;
+  const float slope = *slope_p;
+  float sdz[VEC], sdx[VEC], sds = 0.f, m[VEC], rs[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sdz[j] = sdx[j] = 0.f;
+    m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j];
+  }
+  for (unsigned u = blockIdx.x * VL + vl; u < units; u += gridDim.x * VL) {
+    unsigned q = u;
+    const int w = (int)(q % (unsigned)W); q /= (unsigned)W;
+    const int ho = (int)(q % (unsigned)Ho); q /= (unsigned)Ho;
+    const int d_o = (int)(q % (unsigned)Do);
+    const int64_t n = q / (unsigned)Do;
+    float gr[VEC], best[VEC], a[4][VEC], o[4][VEC];
+    int arg[VEC];
+    int64_t vis[4];
+    ldv<T, VEC>(dy + (int64_t)(u >> 1) * lddy + c0, gr);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= 2 * pd) break;
+      vis[t] = ((n * D + pd * d_o + (t >> 1)) * H + 2 * ho + (t & 1)) * W + w;
+      ldv<T, VEC>(y + vis[t] * ldy + c0, a[t]);
+      if (dskip) ldv<T, VEC>(dskip + vis[t] * lds + c0, o[t]);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[t][j] = 0.f;
+      }
+    }
+    // own candidates in ascending window index t8 = 4 dd + 2 hh + ww (ww = w & 1)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; arg[j] = 8; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= 2 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float z = fmaf(a[t][j], sc[j], sh[j]);
+        z = z > 0.f ? z : z * slope;
+        z = (float)(T)z;                                 // the stored activation the forward pooling compared
+        if (z > best[j]) { best[j] = z; arg[j] = 2 * t + (w & 1); }
+      }
+    }
+    // the pair's winner: larger value, on ties the smaller window index (= the first maximum of the scan over all eight)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float ob = __shfl_xor(best[j], G, 64);
+      const int oa = __shfl_xor(arg[j], G, 64);
+      if (ob > best[j] || (ob == best[j] && oa < arg[j])) arg[j] = -1;       // the other column holds the maximum
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= 2 * pd) break;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float dv = (float)(T)(o[t][j] + ((arg[j] == 2 * t + (w & 1)) ? gr[j] : 0.f));     // d(a2) as stored
+        o[t][j] = dv;
+        const float z = fmaf(a[t][j], sc[j], sh[j]);
+        const float dz = z > 0.f ? dv : dv * slope;
+        sds += z > 0.f ? 0.f : dv * z;
+        sdz[j] += dz;
+        sdx[j] = fmaf(dz, (a[t][j] - m[j]) * rs[j], sdx[j]);
+      }
+      stv<T, VEC>(dx + vis[t] * ldo + c0, o[t]);
+    }
+  }
+  // per-block partial row, as bn_act_bwd_reduce_k writes it (butterfly over the lanes of a channel group, 4 waves via LDS)
+  __shared__ float red[EW_THREADS / 64 * 64][2 * VEC + 1];
+  float* row = part + (int64_t)blockIdx.x * (2 * C + 1);
+  for (int ofs = G; ofs < 64; ofs <<= 1) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sdz[j] += __shfl_xor(sdz[j], ofs, 64); sdx[j] += __shfl_xor(sdx[j], ofs, 64); }
+    sds += __shfl_xor(sds, ofs, 64);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[wave * 64 + lane][j] = sdz[j]; red[wave * 64 + lane][VEC + j] = sdx[j]; }
+    red[wave * 64 + lane][2 * VEC] = sds;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < EW_THREADS / 64; ++wv) { t0 += red[wv * 64 + threadIdx.x][j]; t1 += red[wv * 64 + threadIdx.x][VEC + j]; }
+      row[c0 + j] = t0;
+      row[C + c0 + j] = t1;
+    }
+  }
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int wv = 0; wv < EW_THREADS / 64; ++wv)
+      for (int k = 0; k < G; ++k) t += red[wv * 64 + k][2 * VEC];
+    row[2 * C] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EW_THREADS)
 adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -1013,6 +1183,10 @@ int fplx_bn_act_pool_fwd(const void* y, int64_t ldy, void* out, int64_t ldo, voi
   if (rc != FPLX_OK) return rc;
   FPLX_REQUIRE(vec_ok<bf16_t>(y, ldy, out, ldo, pooled, ldp, c), FPLX_E_BADSHAPE, "bn_act_pool_fwd: pointers / leading dimensions not 16-byte aligned");
   const int64_t vo = (int64_t)n * (d / pd) * (h / 2) * (w / 2);
+  if (fplx_knob(FPLX_K_POOL_COL) && c / 8 <= 32 && 2 * vo < ((int64_t)1 << 31))       // lanes along the input row (round 3)
+    bn_act_pool_fwd_col_k<bf16_t, 8><<<ew_grid(2 * vo * (c / 8)), EW_THREADS, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)y, ldy, (bf16_t*)out, ldo, (bf16_t*)pooled, ldp, scale, shift, slope, n, d, h, w, c, pd);
+  else
   bn_act_pool_fwd_k<bf16_t, 8><<<ew_grid(vo * (c / 8)), EW_THREADS, 0, (hipStream_t)stream>>>(
       (const bf16_t*)y, ldy, (bf16_t*)out, ldo, (bf16_t*)pooled, ldp, scale, shift, slope, n, d, h, w, c, pd);
   return fplx_check_launch("bn_act_pool_fwd");
@@ -1028,6 +1202,11 @@ int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t 
   FPLX_REQUIRE(vec_ok<bf16_t>(y, ldy, dy, lddy, dx, ldo, c) && vec_ok<bf16_t>(dskip, lds, nullptr, 0, nullptr, 0, c), FPLX_E_BADSHAPE,
                "pool_bwd_bn_reduce: pointers / leading dimensions not 16-byte aligned");
   const int rows = fplx_rows_for((int64_t)n * d * h * w);          // the partial rows bn_act_bwd_finalize expects for this tensor
+  if (fplx_knob(FPLX_K_POOL_COL) && c / 8 <= 32 && (int64_t)n * (d / pd) * (h / 2) * w < ((int64_t)1 << 31))
+    pool_bwd_bn_reduce_col_k<bf16_t, 8><<<rows, EW_THREADS, 0, (hipStream_t)stream>>>(
+        (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (const bf16_t*)dskip, lds, (bf16_t*)dx, ldo, mean, rstd, scale, shift, slope, n,
+        d, h, w, c, pd, part);
+  else
   pool_bwd_bn_reduce_k<bf16_t, 8><<<rows, EW_THREADS, 0, (hipStream_t)stream>>>(
       (const bf16_t*)y, ldy, (const bf16_t*)dy, lddy, (const bf16_t*)dskip, lds, (bf16_t*)dx, ldo, mean, rstd, scale, shift, slope, n,
       d, h, w, c, pd, part);

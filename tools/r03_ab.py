@@ -58,5 +58,26 @@ def main():
            v1 * 8 * cout * 2 + v1 * cin * 2)
 
 
+def pool_ab():
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    for (dims, c) in (((2, 80, 160, 160), 32), ((2, 40, 80, 80), 64), ((2, 20, 40, 40), 128)):
+        n, d, h, w = dims
+        v, vo = n * d * h * w, n * d * h * w // 8
+        y = torch.randn(v, c, device=dev).to(bf)
+        dsk = (torch.randn(v, c, device=dev) * 0.01).to(bf)
+        dyp = (torch.randn(vo, c, device=dev) * 0.01).to(bf)
+        bnbuf = torch.stack([torch.zeros(c), torch.ones(c), torch.ones(c), torch.zeros(c)]).to(dev)
+        slope = torch.full((1,), 0.25, device=dev)
+        a2, pooled, dx = torch.empty_like(y), torch.empty(vo, c, device=dev, dtype=bf), torch.empty_like(y)
+        part = torch.empty((ops.num_partials(v), 2 * c + 1), device=dev)
+        ab("bn_act_pool_fwd %s C=%d" % (dims, c), "pool_col", (1, 0), lambda: ops.bn_act_pool_fwd(y, a2, pooled, bnbuf, slope, dims, c, 2),
+           v * c * 4 + vo * c * 2)
+        ab("pool_bwd_bn_reduce %s C=%d" % (dims, c), "pool_col", (1, 0),
+           lambda: ops.pool_bwd_bn_reduce(y, dyp, dsk, dx, bnbuf, slope, dims, c, part, 2), v * c * 6 + vo * c * 2)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pool":
+        pool_ab()
+        sys.exit(0)
     main()
