@@ -44,7 +44,7 @@ def main():
         _lib.set_tuning("wg_vox", 1)
         a, b = sorted(res[0])[2], sorted(res[2])[2]
         fl = 2.0 * v * 27 * cin * cout
-        print("%-28s %10.1f %10.1f %8.2f   vox: %.3f of 2.5 PFLOP/s" % ("%s %d->%d" % (dims, cin, cout), a, b, a / b, fl / b / 1e6 / 2.5e6 * 1e0))
+        print("%-28s %10.1f %10.1f %8.2f   vox: %.3f of 2.5 PFLOP/s" % ("%s %d->%d" % (dims, cin, cout), a, b, a / b, fl / (b * 1e-6) / 2.5e15))
         if dims[0] == 2:
             tot[0] += a
             tot[1] += b
