@@ -53,11 +53,15 @@ __device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) 
 __device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
 
 // ACT (inference, eval-mode BatchNorm folded into the pack): PReLU(slope) in the write-out (STATS must be false)
-template <bool STATS, int NTW, int TD, int WH, bool ACT = false>
+// CAT2 (inference forms only): the input is the channel concatenation of TWO tensors of Cin / 2 channels and one leading
+// dimension - chunks below Cin / 2 come from x, sample n % nmod0 (nmod0 > 0: the skip tensor that the Monte-Carlo passes
+// share, one copy for all of them), the rest from x1
+template <bool STATS, int NTW, int TD, int WH, bool ACT = false, bool CAT2 = false>
 __global__ void __launch_bounds__(BK::THREADS)
 conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
                bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr) {
+               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr,
+               const bf16_t* __restrict__ x1 = nullptr, int nmod0 = 0) {
   using G = BKG<TD, WH, NTW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bricks = smem;
@@ -116,13 +120,14 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 
   // a brick's coordinates, its descriptor (the sample's volume) and its DMA lane offsets: piece p = wave + 4 k covers LDS
   // bytes [p * 1024, +1024) of the slot, lane -> 16-byte chunk
-  struct Brick { int n, d0, h0, w0; unsigned vo[G::NPB]; };
+  struct Brick { int n, n0, d0, h0, w0; unsigned vo[G::NPB]; };
   auto setup = [&](int64_t tile, Brick& B) {
     int b = (int)tile;
     const int bw = b % bW; b /= bW;
     const int bh = b % bH; b /= bH;
     const int bd = b % bD; b /= bD;
     B.n = __builtin_amdgcn_readfirstlane(b);
+    B.n0 = (CAT2 && nmod0 > 0) ? __builtin_amdgcn_readfirstlane(b % nmod0) : B.n;
     B.d0 = __builtin_amdgcn_readfirstlane(bd * G::TD);
     B.h0 = __builtin_amdgcn_readfirstlane(bh * G::TH);
     B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
@@ -140,7 +145,13 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
   const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
   auto brick_pieces = [&](const Brick& B, int ch, int slot, int k0, int cnt) {     // pieces k0 .. k0 + cnt - 1 of chunk ch
+    int c = c_lo + ch;                                                            // uniform
     const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
+    if (CAT2) {
+      const int half = Cin / (2 * G::KC);
+      if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
+      else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
+    }
     u32x4 rx;
     rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
     rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
@@ -149,7 +160,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #pragma unroll
     for (int k = k0; k < k0 + cnt; ++k)
       if (k < G::NPB && wave + 4 * k < G::NP_TOT)            // uniform
-        buf_dma(rx, B.vo[k], (unsigned)((c_lo + ch) * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
+        buf_dma(rx, B.vo[k], (unsigned)(c * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
   };
   auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
 #pragma unroll
@@ -463,8 +474,11 @@ extern "C" int fplx_brick_rows(int n, int d, int h, int w, int geo) {
 // fp32 and the caller finishes (splitk_finish_k)
 extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                          int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
-                                         int ksplit, hipStream_t st, const float* slope) {
+                                         int ksplit, hipStream_t st, const float* slope, const void* x1, int nmod0) {
   if (ldy % 8 != 0 || ((uintptr_t)y % 16) != 0 || ldx % 8 != 0 || ((uintptr_t)x % 16) != 0 || ((uintptr_t)wp % 16) != 0)
+    return 0;
+  // two-tensor input: the activation forms without a Cin split only
+  if (x1 && (((uintptr_t)x1 % 16) != 0 || !slope || ksplit != 1 || cin % (2 * BK::KC) != 0 || nmod0 < 0 || (nmod0 && n % nmod0)))
     return 0;
   if ((int64_t)d * h * w * ldx * 2 >= ((int64_t)1 << 30) || cin % BK::KC != 0 || cin < 64 || cout % 64 != 0) return 0;
   if (geo == 1 && cout % 128 != 0) return 0;
@@ -506,7 +520,21 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
         (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
         bH, bW, xcd_on, slope);                                                                                      \
   } while (0)
-  if (slope && !part) {               // (with a Cin split the activation is the finish kernel's)
+#define LAUNCH_BRICK_ACT2(NTW_, TD_, WH_)                                                                             \
+  do {                                                                                                               \
+    using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true, true>,                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick<false, NTW_, TD_, WH_, true, true><<<grid, BK::THREADS, G_::LDS, st>>>(                            \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+        bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                            \
+  } while (0)
+  if (x1) {
+    if (geo == 1) LAUNCH_BRICK_ACT2(1, 5, 1);
+    else if (nt == 128) LAUNCH_BRICK_ACT2(2, 4, 2);
+    else LAUNCH_BRICK_ACT2(1, 4, 2);
+  }
+  else if (slope && !part) {          // (with a Cin split the activation is the finish kernel's)
     if (geo == 1) LAUNCH_BRICK_ACT(1, 5, 1);
     else if (nt == 128) LAUNCH_BRICK_ACT(2, 4, 2);
     else LAUNCH_BRICK_ACT(1, 4, 2);
@@ -514,6 +542,7 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
   else if (geo == 1) { if (st_) LAUNCH_BRICK(true, 1, 5, 1); else LAUNCH_BRICK(false, 1, 5, 1); }
   else if (nt == 128) { if (st_) LAUNCH_BRICK(true, 2, 4, 2); else LAUNCH_BRICK(false, 2, 4, 2); }
   else { if (st_) LAUNCH_BRICK(true, 1, 4, 2); else LAUNCH_BRICK(false, 1, 4, 2); }
+#undef LAUNCH_BRICK_ACT2
 #undef LAUNCH_BRICK_ACT
 #undef LAUNCH_BRICK
   const int rc = fplx_check_launch("brick_conv3d_fwd");
@@ -523,5 +552,6 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
 extern "C" int fplx_brick_conv3d_fwd_ex(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                         int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
                                         int ksplit, hipStream_t st) {
-  return fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, partial, geo, ksplit, st, nullptr);
+  return fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, partial, geo, ksplit, st, nullptr, nullptr,
+                                   0);
 }

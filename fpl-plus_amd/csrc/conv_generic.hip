@@ -413,6 +413,10 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     size_t ws_bytes, hipStream_t st);
 extern "C" size_t fplx_mfma_conv3d_fwd_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int cout, int mid);
+extern "C" int fplx_mfma_conv3d_act_cat2_ok(int n, int d, int h, int w, int cin, int cout, int mid);
+extern "C" int fplx_mfma_conv3d_fwd_act_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias,
+                                             const float* slope, void* y, int64_t ldy, int n, int d, int h, int w, int cin,
+                                             int cout, int nmod0, hipStream_t st);
 extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, const float* slope, void* y,
                                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,
                                         int mid, hipStream_t st);
@@ -792,7 +796,8 @@ static int dgrad_split2_impl(const void* dy, int64_t ldy, const void* wb, void* 
 /* ---- inference: conv + (eval-mode BatchNorm folded into pack and bias by the caller) + PReLU in one kernel ---- */
 int fplx_conv3d_fwd_act_ok(int n, int d, int h, int w, int cin, int cout, int mid, int cat2) {
   if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
-  if (cat2) return fplx_conv3d_cat2_ok(n, d, h, w, cin, cout);           // the Cin = 64 march on two half-slabs
+  if (cat2)                                     // the Cin = 64 march on two half-slabs; the brick kernel's two-tensor form
+    return fplx_conv3d_cat2_ok(n, d, h, w, cin, cout) || fplx_mfma_conv3d_act_cat2_ok(n, d, h, w, cin, cout, mid ? 1 : 0);
   return fplx_mfma_conv3d_act_ok(n, d, h, w, cin, cout, mid ? 1 : 0);
 }
 
@@ -805,8 +810,12 @@ int fplx_conv3d_fwd_act(const void* x0, const void* x1, int64_t ldx, const void*
   FPLX_REQUIRE(fplx_conv3d_fwd_act_ok(n, d, h, w, cin, cout, mid, x1 != nullptr), FPLX_E_BADSHAPE,
                "conv3d_fwd_act: no fused kernel for n=%d d=%d h=%d w=%d cin=%d cout=%d (fplx_conv3d_fwd_act_ok)", n, d, h, w, cin, cout);
   int r;
-  if (x1) r = fplx_march_conv3d_fwd_act(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, (hipStream_t)stream, x1, nullptr,
-                                        mid ? 1 : 0, prelu_slope, n_x0 == n ? 0 : n_x0);
+  if (x1 && fplx_conv3d_cat2_ok(n, d, h, w, cin, cout))
+    r = fplx_march_conv3d_fwd_act(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, (hipStream_t)stream, x1, nullptr,
+                                  mid ? 1 : 0, prelu_slope, n_x0 == n ? 0 : n_x0);
+  else if (x1)
+    r = fplx_mfma_conv3d_fwd_act_cat2(x0, x1, ldx, wp, bias, prelu_slope, y, ldy, n, d, h, w, cin, cout, n_x0 == n ? 0 : n_x0,
+                                      (hipStream_t)stream);
   else r = fplx_mfma_conv3d_fwd_act(x0, ldx, wp, bias, prelu_slope, y, ldy, n, d, h, w, cin, cout, ws, ws_bytes, mid ? 1 : 0,
                                     (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_act: pointers / leading dimensions not 16-byte aligned");

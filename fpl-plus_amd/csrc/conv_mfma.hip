@@ -1937,7 +1937,7 @@ extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void*
                                          const void* x1, void* y1, int twod, const float* slope, int nmod0);
 extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                          int n, int d, int h, int w, int cin, int cout, float* stats, float* partial, int geo,
-                                         int ksplit, hipStream_t st, const float* slope);
+                                         int ksplit, hipStream_t st, const float* slope, const void* x1, int nmod0);
 // conv_brick.hip
 extern "C" int fplx_brick_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_brick_first(int n, int d, int h, int w, int cin, int cout);
@@ -2035,7 +2035,8 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     if (ks > 1 && (!ws || ws_bytes < (size_t)ks * Vb * cout * sizeof(float)))
       return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
                        (size_t)ks * Vb * cout * sizeof(float));
-    const int rb = fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (float*)ws, geo, ks, st, slope);
+    const int rb = fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, (float*)ws, geo, ks, st, slope,
+                                             nullptr, 0);
     if (rb == 1 && ks > 1) {
       splitk_finish_k<<<splitk_fin_blocks(Vb), 256, 0, st>>>((const float*)ws, ks, Vb, cout, bias, (bf16_t*)y, ldy, stats, slope);
       const int rf = fplx_check_launch("brick_splitk_finish");
@@ -2125,6 +2126,21 @@ extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int 
   int kernel, geo, ks;
   if (!fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
   return kernel == FPLX_KERNEL_BRICK || kernel == FPLX_KERNEL_MARCH || ((kernel == FPLX_KERNEL_TILE || kernel == FPLX_KERNEL_DIRECT) && ks > 1);
+}
+// the two-tensor input (x0 || x1, Cin / 2 channels each, one leading dimension; x0 read modulo nmod0 samples) of the brick
+// kernel's activation form: the 3D layers it takes first, unsplit in Cin
+extern "C" int fplx_mfma_conv3d_act_cat2_ok(int n, int d, int h, int w, int cin, int cout, int mid) {
+  int kernel, geo, ks;
+  if (mid || cin % 64 != 0 || !fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
+  return kernel == FPLX_KERNEL_BRICK && ks == 1;
+}
+extern "C" int fplx_mfma_conv3d_fwd_act_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias,
+                                             const float* slope, void* y, int64_t ldy, int n, int d, int h, int w, int cin,
+                                             int cout, int nmod0, hipStream_t st) {
+  if (!fplx_mfma_conv3d_act_cat2_ok(n, d, h, w, cin, cout, 0) || !mfma_applicable(ldx, ldy, cin, cout, x0, y, wp)) return 0;
+  int geo, ks, bricks;
+  fplx_brick_plan(n, d, h, w, cin, cout, &geo, &ks, &bricks);
+  return fplx_brick_conv3d_fwd_act(x0, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, geo, ks, st, slope, x1, nmod0);
 }
 extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* wp, const float* bias, const float* slope, void* y,
                                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes,

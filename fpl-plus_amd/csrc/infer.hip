@@ -20,7 +20,16 @@ struct SwPlan {
   int nflips;
   int flips[4];                     // bit0: W axis flipped, bit1: H axis flipped
   int sd[SW_MAX], sh[SW_MAX], sw[SW_MAX];
+  int passes, chunk, nb;            // sw_merge: Monte-Carlo passes, patches per network call, patches in all (nflips tiles n)
 };
+
+// Where patch j of pass q lies in the prediction buffer (in patches): the network ran on chunks of `chunk` consecutive patches
+// and wrote, per chunk, all passes one after the other ([chunks][passes][m_c]; only the last chunk is shorter).
+__device__ __forceinline__ int64_t patch_slot(const SwPlan& p, int q, int64_t j) {
+  const int64_t c0 = j / p.chunk * p.chunk;
+  const int64_t mc = p.nb - c0 < p.chunk ? p.nb - c0 : p.chunk;
+  return c0 * p.passes + q * mc + (j - c0);
+}
 
 // patches: [nflips][tiles][n][c][wd][wh][ww]
 __global__ void __launch_bounds__(SW_THREADS) sw_extract_k(const float* __restrict__ image, float* __restrict__ patches, SwPlan p) {
@@ -52,11 +61,14 @@ __device__ __forceinline__ void cover(const int* __restrict__ s, int ns, int win
     if (s[k] <= q && q < s[k] + win) { if (k < lo) lo = k; hi = k; }
 }
 
-// patches: [nflips][tiles][n][c][wd][wh][ww] (c = class channels here) -> out [n][c][d][h][w]
+// patches: patch j = (f tiles + t) n + nn of pass q at patch_slot(q, j), each [c][wd][wh][ww] (c = class channels here)
+// -> out [passes][n][c][d][h][w]; blockIdx.y = pass
 __global__ void __launch_bounds__(SW_THREADS) sw_merge_k(const float* __restrict__ patches, float* __restrict__ out, SwPlan p) {
   const int64_t per = (int64_t)p.wd * p.wh * p.ww;
   const int64_t tiles = (int64_t)p.nd * p.nh * p.nw;
   const int64_t total = (int64_t)p.n * p.c * p.d * p.h * p.w;
+  const int q = blockIdx.y;
+  out += q * total;
   for (int64_t i = (int64_t)blockIdx.x * SW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * SW_THREADS) {
     int64_t r = i;
     const int x = (int)(r % p.w); r /= p.w;
@@ -78,7 +90,7 @@ __global__ void __launch_bounds__(SW_THREADS) sw_merge_k(const float* __restrict
           for (int id = d0; id <= d1; ++id) {
             // duplicate starts (the clamped last tile) are separate tiles in the reference's list: each adds once
             const int64_t t = ((int64_t)iw * p.nh + ih) * p.nd + id;
-            const int64_t base = ((((int64_t)f * tiles + t) * p.n + nn) * p.c + ch) * per;
+            const int64_t base = (patch_slot(p, q, ((int64_t)f * tiles + t) * p.n + nn) * p.c + ch) * per;
             acc += patches[base + ((int64_t)(z - p.sd[id]) * p.wh + (yy - p.sh[ih])) * p.ww + (xx - p.sw[iw])];
             cnt += 1.f;
           }
@@ -86,6 +98,42 @@ __global__ void __launch_bounds__(SW_THREADS) sw_merge_k(const float* __restrict
       tot = (f == 0) ? o : tot + o;
     }
     out[i] = p.nflips > 1 ? tot / (float)p.nflips : tot;
+  }
+}
+
+// The same sums where there is no window (ONE tile = the image, the FPL+ selection's whole-volume forwards) and W % 4 == 0:
+// out = ((o1 + o2) + o3 + o4) / nflips with o_f the flip's prediction read back-to-front along the flipped axes - four
+// consecutive w per thread as 16-byte loads (a W flip reads the mirrored 16 bytes and reverses them in registers).
+__global__ void __launch_bounds__(SW_THREADS) sw_merge_whole_k(const float* __restrict__ patches, float* __restrict__ out, SwPlan p) {
+  const int w4 = p.w >> 2;
+  const int64_t per = (int64_t)p.d * p.h * p.w;
+  const int64_t rows = (int64_t)p.n * p.c * p.d * p.h;          // rows of w4 float4
+  const int64_t total4 = rows * w4;
+  const int q = blockIdx.y;
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(out + q * rows * p.w);
+  for (int64_t i = (int64_t)blockIdx.x * SW_THREADS + threadIdx.x; i < total4; i += (int64_t)gridDim.x * SW_THREADS) {
+    const int x4 = (int)(i % w4);
+    int64_t r = i / w4;
+    const int y = (int)(r % p.h); r /= p.h;
+    const int z = (int)(r % p.d); r /= p.d;
+    const int ch = (int)(r % p.c);
+    const int nn = (int)(r / p.c);
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int f = 0; f < p.nflips; ++f) {
+      const int yy = (p.flips[f] & 2) ? p.h - 1 - y : y;
+      const bool fw = p.flips[f] & 1;
+      const int xx = fw ? p.w - 4 - 4 * x4 : 4 * x4;
+      const int64_t base = (patch_slot(p, q, (int64_t)f * p.n + nn) * p.c + ch) * per;
+      float4 v = *reinterpret_cast<const float4*>(patches + base + ((int64_t)z * p.h + yy) * p.w + xx);
+      if (fw) v = make_float4(v.w, v.z, v.y, v.x);
+      if (f == 0) tot = v;
+      else { tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w; }
+    }
+    if (p.nflips > 1) {
+      const float k = (float)p.nflips;
+      tot.x /= k; tot.y /= k; tot.z /= k; tot.w /= k;
+    }
+    o4[i] = tot;
   }
 }
 
@@ -99,6 +147,7 @@ int make_plan(SwPlan& p, int n, int c, int d, int h, int w, const int* sd, int n
   FPLX_REQUIRE(wd > 0 && wh > 0 && ww > 0 && wd <= d && wh <= h && ww <= w, FPLX_E_BADSHAPE, "%s: window larger than the image", what);
   p.n = n; p.c = c; p.d = d; p.h = h; p.w = w; p.wd = wd; p.wh = wh; p.ww = ww; p.nd = nd; p.nh = nh; p.nw = nw; p.nflips = nflips;
   for (int i = 0; i < 4; ++i) p.flips[i] = i < nflips ? flips[i] : 0;
+  p.passes = 1; p.nb = nflips * nd * nh * nw * n; p.chunk = p.nb;
   const int* src[3] = {sd, sh, sw};
   int* dst[3] = {p.sd, p.sh, p.sw};
   const int cnt[3] = {nd, nh, nw}, win[3] = {wd, wh, ww}, ext[3] = {d, h, w};
@@ -139,15 +188,30 @@ int fplx_sw_extract(const float* image, int n, int c, int d, int h, int w, const
   return fplx_check_launch("sw_extract");
 }
 
-int fplx_sw_merge(const float* patches, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
-                  int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* out,
-                  fplx_stream_t stream) {
+int fplx_sw_merge_mc(const float* patches, int passes, int chunk, int n, int c, int d, int h, int w, const int* starts_d, int nd,
+                     const int* starts_h, int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips,
+                     int nflips, float* out, fplx_stream_t stream) {
   FPLX_REQUIRE(patches && out, FPLX_E_NULL, "sw_merge: null pointer");
   SwPlan p;
   const int rc = make_plan(p, n, c, d, h, w, starts_d, nd, starts_h, nh, starts_w, nw, wd, wh, ww, flips, nflips, "sw_merge");
   if (rc != FPLX_OK) return rc;
-  sw_merge_k<<<blocks_for((int64_t)n * c * d * h * w), SW_THREADS, 0, (hipStream_t)stream>>>(patches, out, p);
+  FPLX_REQUIRE(passes >= 1 && passes <= 65535 && chunk >= 1, FPLX_E_BADSHAPE, "sw_merge: passes %d, chunk %d", passes, chunk);
+  p.passes = passes;
+  p.chunk = chunk < p.nb ? chunk : p.nb;
+  const int64_t total = (int64_t)n * c * d * h * w;
+  const bool whole = nd * nh * nw == 1 && w % 4 == 0 && ((uintptr_t)patches % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (whole)
+    sw_merge_whole_k<<<dim3(blocks_for(total / 4), passes), SW_THREADS, 0, (hipStream_t)stream>>>(patches, out, p);
+  else
+    sw_merge_k<<<dim3(blocks_for(total), passes), SW_THREADS, 0, (hipStream_t)stream>>>(patches, out, p);
   return fplx_check_launch("sw_merge");
+}
+
+int fplx_sw_merge(const float* patches, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
+                  int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* out,
+                  fplx_stream_t stream) {
+  return fplx_sw_merge_mc(patches, 1, nflips * nd * nh * nw * n, n, c, d, h, w, starts_d, nd, starts_h, nh, starts_w, nw, wd, wh,
+                          ww, flips, nflips, out, stream);
 }
 
 }  // extern "C"

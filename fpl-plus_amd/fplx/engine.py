@@ -118,7 +118,7 @@ class Engine(object):
         return tab[key]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1):
+    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1, out=None):
         """x: fp32 [N, Cin, D, H, W] contiguous on the GPU -> logits fp32 [N, class_num, D, H, W].
         train: BatchNorm uses batch statistics (and updates the running ones);
         drop_on: list of 9 bools - dropout active per ConvBlockND.
@@ -126,8 +126,10 @@ class Engine(object):
         input in one call -> logits [mc * N, ...], pass-major.  Equal to forward(x.repeat(mc, 1, 1, 1, 1)) - the dropout
         masks are keyed by the element index of the mc * N batch - but the encoder levels above the first active dropout see
         the same input in every pass and are computed ONCE (the shipped configs drop out at levels 2-4 only: levels 0 and 1,
-        the two most expensive, run once instead of `mc` times; reference: agent_seg.py:898-909 runs the whole net per pass)."""
+        the two most expensive, run once instead of `mc` times; reference: agent_seg.py:898-909 runs the whole net per pass).
+        out: where the logits go (fp32 [mc * N, class_num, D, H, W], contiguous) instead of a new tensor."""
         net = self.net
+        logits_out = out
         ops.require_gpu(x)
         if x.dim() != 5:
             raise ValueError('expected 5D input (got {}D input)'.format(x.dim()))   # dsbn.py:61-64
@@ -164,7 +166,10 @@ class Engine(object):
             rep = act[0] if act else 5
             if rep == 5:                                 # no dropout is active: every pass is the same forward
                 logits, _ = self.forward(x, domain, train, drop_on, seed, step, keep, 1)
-                return logits.repeat(mc, 1, 1, 1, 1), None
+                if logits_out is None:
+                    return logits.repeat(mc, 1, 1, 1, 1), None
+                logits_out.view((mc,) + tuple(logits.shape))[:] = logits
+                return logits_out, None
         NM = N * mc
         dims = [(NM, D, H, W)]                           # decoder view: every level holds all passes
         for l in range(4):
@@ -189,6 +194,14 @@ class Engine(object):
         # (a backward through eval-mode BatchNorm also needs the conv bias gradient: that case keeps the buffer)
         can_split = self.use_split_cat and adt == torch.bfloat16 and (train or not keep)
         split = [can_split and ops.conv3d_cat2_ok(dims[l], 2 * ft[l], ft[l]) for l in range(4)]
+        if fuse:
+            # inference: also wherever the fused kernel has a two-tensor form and runs (no active dropout at that site) - the
+            # Monte-Carlo passes then share ONE copy of the level's skip tensor (skip_mod below)
+            for l in range(4):
+                blk = net.block_modules[8 - l]
+                if (can_split and not split[l] and not (drop_on[8 - l] and blk.dropout_p > 0) and
+                        ops.conv3d_fwd_act_ok(dims[l], 2 * ft[l], ft[l], blk.conv_of(1).weight.dim() == 4, True)):
+                    split[l] = True
         cats, skips, ups = [], [], []
         for l in range(4):
             if split[l]:
@@ -313,7 +326,12 @@ class Engine(object):
             cur = out
         # ---- out_conv (1x3x3) -> fp32 planar logits
         ncls = net.n_class
-        logits = torch.empty((NM, ncls, D, H, W), dtype=torch.float32, device=dev)
+        logits = logits_out
+        if logits is None:
+            logits = torch.empty((NM, ncls, D, H, W), dtype=torch.float32, device=dev)
+        elif (tuple(logits.shape) != (NM, ncls, D, H, W) or logits.dtype != torch.float32 or logits.device != dev
+              or not logits.is_contiguous()):
+            raise ValueError("fplx: out must be a contiguous fp32 tensor of shape %s on %s" % ((NM, ncls, D, H, W), dev))
         ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
                        ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
         return logits, (sv if keep else None)

@@ -74,9 +74,12 @@ class Inferer(object):
 
     # ------------------------------------------------------------------ batched path (single-output networks)
     def _forward_chunks(self, patches, n, domain_label, passes):
-        """patches [nb, C, wd, wh, ww] with nb = flips * tiles * n -> logits [passes * nb, classes, wd, wh, ww], pass-major.
+        """patches [nb, C, wd, wh, ww] with nb = flips * tiles * n -> (logits, chunk): the network runs on chunks of `chunk`
+        consecutive patches and each call leaves all passes of its chunk, pass-major, in its slice of the one buffer
+        [chunks][passes][patches of the chunk][classes, wd, wh, ww] - the layout fplx_sw_merge_mc reads.
         Monte-Carlo passes see the same patches; their dropout masks differ per sample of the batch.  A network that offers
-        forward_mc (fplx.UNet2D5_dsbn in eval mode) computes the part above its first active dropout once for all passes."""
+        forward_mc (fplx.UNet2D5_dsbn in eval mode) computes the part above its first active dropout once for all passes
+        and writes its logits straight into the slice."""
         model = self.model
         nb = patches.shape[0]
         per = patches[0, 0].numel()
@@ -84,23 +87,30 @@ class Inferer(object):
             chunk = n                                     # train-mode BatchNorm: the reference's batches, one tile each
         else:
             chunk = max(n, (self.max_batch_voxels // max(per * passes, 1)) // n * n)
+        chunk = min(chunk, nb)
         dom = int(domain_label[0]) if domain_label is not None else 0
-        shared = passes > 1 and hasattr(model, "forward_mc") and not getattr(model, 'training', False)
-        out = None
+        shared = (hasattr(model, "forward_mc") and not getattr(model, 'training', False)
+                  and (passes > 1 or not torch.is_grad_enabled()))
+
+        def buffer(classes):
+            return torch.empty((passes * nb, classes) + tuple(patches.shape[2:]), dtype=torch.float32, device=patches.device)
+
+        out = buffer(model.n_class) if shared else None
         for b0 in range(0, nb, chunk):
             b1 = min(nb, b0 + chunk)
             m = b1 - b0
             if shared:
-                o = model.forward_mc(patches[b0:b1], torch.full((m,), dom, dtype=torch.long), passes)
-            else:
-                xin = patches[b0:b1] if passes == 1 else patches[b0:b1].repeat(passes, 1, 1, 1, 1)
-                o = model(xin, domain_label=torch.full((m * passes,), dom, dtype=torch.long))
+                model.forward_mc(patches[b0:b1], torch.full((m,), dom, dtype=torch.long), passes,
+                                 out=out[b0 * passes:(b0 + m) * passes])
+                continue
+            xin = patches[b0:b1] if passes == 1 else patches[b0:b1].repeat(passes, 1, 1, 1, 1)
+            o = model(xin, domain_label=torch.full((m * passes,), dom, dtype=torch.long))
             if isinstance(o, (tuple, list)):
-                return None                               # several outputs: the generic path handles it
+                return None, chunk                        # several outputs: the generic path handles it
             if out is None:
-                out = torch.empty((passes, nb) + tuple(o.shape[1:]), dtype=torch.float32, device=o.device)
-            out[:, b0:b1] = o.view((passes, m) + tuple(o.shape[1:]))
-        return out.view((passes * nb,) + tuple(out.shape[2:]))
+                out = buffer(o.shape[1])
+            out[b0 * passes:(b0 + m) * passes] = o
+        return out, chunk
 
     def _run_batched(self, image, domain_label, passes):
         window, starts, flips = self._plan(image)
@@ -112,15 +122,13 @@ class Inferer(object):
         cargs = self._c_args(tuple(image.shape), window, starts, flips)
         one = torch.empty((nb, image.shape[1]) + tuple(window), dtype=torch.float32, device=image.device)
         call("fplx_sw_extract", ops.ptr(image), *cargs, ops.ptr(one), ops.stream())
-        logits = self._forward_chunks(one, n, domain_label, passes)
+        logits, chunk = self._forward_chunks(one, n, domain_label, passes)
         if logits is None:
             return None
         classes = logits.shape[1]
         outs = torch.empty((passes, n, classes) + tuple(image.shape[2:]), dtype=torch.float32, device=image.device)
         margs = self._c_args((n, classes) + tuple(image.shape[2:]), window, starts, flips)
-        lg = logits.view((passes, nb, classes) + tuple(window))
-        for p in range(passes):
-            call("fplx_sw_merge", ops.ptr(lg[p]), *margs, ops.ptr(outs[p]), ops.stream())
+        call("fplx_sw_merge_mc", ops.ptr(logits), passes, chunk, *margs, ops.ptr(outs), ops.stream())
         return outs
 
     # ------------------------------------------------------------------ public surface

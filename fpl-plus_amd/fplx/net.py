@@ -290,10 +290,11 @@ class UNet2D5_dsbn(nn.Module):
         reference flips for test-time dropout, agent_seg.py:845-852)"""
         return [m.dropout.training and m.dropout_p > 0 for m in self.block_modules]
 
-    def forward_mc(self, x, domain_label, passes):
+    def forward_mc(self, x, domain_label, passes, out=None):
         """`passes` Monte-Carlo forwards (test-time dropout) of the same batch in one call -> [passes * N, classes, D, H, W],
         pass-major; the encoder levels above the first active dropout are computed once (Engine.forward, mc).  Inference
-        only: eval-mode BatchNorm (the reference's test-time dropout, agent_seg.py:845-852, flips the Dropout children only)."""
+        only: eval-mode BatchNorm (the reference's test-time dropout, agent_seg.py:845-852, flips the Dropout children only).
+        out: optional contiguous fp32 destination of that shape (the Inferer's prediction buffer: no copy afterwards)."""
         if self.training:
             raise RuntimeError("fplx: forward_mc needs eval-mode BatchNorm (net.eval(); Dropout children may be in train mode)")
         if not x.is_cuda:
@@ -304,7 +305,7 @@ class UNet2D5_dsbn(nn.Module):
         self._fwd_counter += 1
         with torch.no_grad():
             logits, _ = self.engine.forward(x, domain, False, self.dropout_active(), self.dropout_seed, step, keep=False,
-                                            mc=int(passes))
+                                            mc=int(passes), out=out)
         return logits
 
     def forward(self, x, domain_label=None):

@@ -145,7 +145,8 @@ int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const vo
  * into the weights before packing them (fplx_pack_conv_weight / _conv2d_weight) and passes bias = scale b + shift; the
  * kernel applies PReLU(prelu_slope[0]) in its write-out, so the separate fplx_bn_act_fwd pass disappears.  bf16 NDHWC
  * operands, 3x3x3 (mid != 0: a Conv2d pack in the middle depth plane).  x1 != NULL: the input is cat([x0, x1], channel)
- * of two cin/2-channel tensors (fplx_conv3d_fwd_cat2).  Only for layers fplx_conv3d_fwd_act_ok accepts (the depth-march,
+ * of two cin/2-channel tensors (as fplx_conv3d_fwd_cat2; here also the brick kernel's layers, e.g. 64 || 64 -> 64 at level
+ * 1).  Only for layers fplx_conv3d_fwd_act_ok accepts (the depth-march,
  * brick and split-K kernels); FPLX_E_BADSHAPE otherwise - callers fall back to fplx_conv3d_fwd + fplx_bn_act_fwd.
  * n_x0 (two-tensor form only; 0 = n): x0 holds n_x0 samples and sample i reads x0[i % n_x0] - the Monte-Carlo passes of
  * test-time dropout (agent_seg.py:898-909) share the encoder levels above the first active dropout, whose skip tensor is
@@ -384,13 +385,21 @@ int fplx_set_weight(float* pixel_weight, int64_t n, float image_weight, fplx_str
  *                   the flipped image.
  *  fplx_sw_merge:   predictions [nflips][tiles][n][c][wd][wh][ww] (c = classes) -> out [n][c][d][h][w]: per flip the
  *                   sum over the covering tiles IN TILE ORDER divided by their number (no division when there is one
- *                   tile), flipped back, then ((o1 + o2) + o3 + o4) / nflips - the reference's additions in its order. */
+ *                   tile), flipped back, then ((o1 + o2) + o3 + o4) / nflips - the reference's additions in its order.
+ *  fplx_sw_merge_mc: the same for `passes` Monte-Carlo predictions of every patch in ONE launch (agent_seg.py:898-909 calls
+ *                   the inferer once per pass) -> out [passes][n][c][d][h][w], reading the predictions where the network wrote
+ *                   them: it ran on chunks of `chunk` consecutive patches (the last one shorter) and each call produced all
+ *                   passes of its chunk, pass-major - [chunks][passes][patches of the chunk][c][wd][wh][ww].
+ *                   fplx_sw_merge == passes 1, chunk = all patches. */
 int fplx_sw_extract(const float* image, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
                     int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* patches,
                     fplx_stream_t stream);
 int fplx_sw_merge(const float* patches, int n, int c, int d, int h, int w, const int* starts_d, int nd, const int* starts_h,
                   int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips, int nflips, float* out,
                   fplx_stream_t stream);
+int fplx_sw_merge_mc(const float* patches, int passes, int chunk, int n, int c, int d, int h, int w, const int* starts_d, int nd,
+                     const int* starts_h, int nh, const int* starts_w, int nw, int wd, int wh, int ww, const int* flips,
+                     int nflips, float* out, fplx_stream_t stream);
 
 /* ------------------------------------------------------------------ evaluation
  * Exact voxel counts behind binary_dice / binary_iou / rve / volume (PyMIC/pymic/util/evaluation_seg_train.py:21-50,

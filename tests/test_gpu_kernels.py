@@ -605,3 +605,41 @@ def test_conv3d_wgrad_vox_kernel(shape):
     scale = float(wr.grad.abs().max())
     assert float((got[2] - wr.grad).abs().max()) < 1e-4 * scale + 1e-6, float((got[2] - wr.grad).abs().max()) / scale
     assert float((got[2] - got[0]).abs().max()) < 1e-4 * scale + 1e-6
+
+
+@pytest.mark.parametrize("shape", [
+    (4, 64, 32, 16, 32, 64),       # the depth march on two 32-channel half-slabs (level 0), x0 shared by 2 passes
+    (4, 128, 64, 16, 32, 44),      # the brick kernel's two-tensor form (level 1: 64 || 64 -> 64), ragged bricks in W
+    (2, 256, 128, 16, 32, 48),     # level 2: 128 || 128 -> 128 (128-wide output tile)
+    (3, 128, 64, 12, 40, 40)])     # n = 3 (x0 shared by all three)
+def test_conv3d_fwd_act_two_tensor_form(shape):
+    """fplx_conv3d_fwd_act with x1 != NULL (the decoder's first convolution on skip || up without the concatenation) and
+    n_x0 (x0 = the ONE skip tensor all Monte-Carlo passes share, read modulo the batch): bit-identical to the same kernel
+    family on the materialised concatenation, and within bf16 of torch's conv3d + PReLU."""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    dims, half, bf = (n, d, h, w), cin // 2, torch.bfloat16
+    assert ops.conv3d_fwd_act_ok(dims, cin, cout, False, True)
+    q = lambda t: t.bfloat16().float()
+    wt = q(torch.from_numpy(detdata.normal("act2.w%s" % (shape,), (cout, cin, 3, 3, 3))) * (2.0 / (27 * cin)) ** 0.5)
+    bias = torch.from_numpy(detdata.normal("act2.b%s" % (shape,), (cout,))).float()
+    slope = torch.tensor([0.2])
+    wp, _ = ops.pack_conv_weight(wt.cuda(), bf, False)
+    for n0 in (n, 1 if n % 2 else n // 2):
+        x0 = q(torch.from_numpy(detdata.normal("act2.x0%s%d" % (shape, n0), (n0, half, d, h, w))))
+        x1 = q(torch.from_numpy(detdata.normal("act2.x1%s" % (shape,), (n, half, d, h, w))))
+        full = torch.cat([x0.repeat(n // n0, 1, 1, 1, 1), x1], 1)
+        ref = F.prelu(F.conv3d(full, wt, bias, padding=1), slope)
+        y2 = torch.full((n * d * h * w, cout + 8), 7.0, dtype=bf, device="cuda")
+        ops.conv3d_fwd_act(cl(x0).to(bf).cuda(), cl(x1).to(bf).cuda(), wp, bias.cuda(), slope.cuda(), y2[:, :cout], dims, cin, cout,
+                           False, 0 if n0 == n else n0)
+        assert bool((y2[:, cout:] == 7.0).all())
+        err = float((y2[:, :cout].float().cpu() - cl(ref)).abs().max())
+        assert err < 2e-2 * float(ref.abs().max()), (n0, err)
+        if ops.conv3d_fwd_act_ok(dims, cin, cout, False, False):
+            y1 = torch.empty((n * d * h * w, cout), dtype=bf, device="cuda")
+            ops.conv3d_fwd_act(cl(full).to(bf).cuda(), None, wp, bias.cuda(), slope.cuda(), y1, dims, cin, cout, False, 0)
+            if plan_kernel(n, d, h, w, cin, cout) == 5:       # the brick kernel both ways: same order of additions
+                assert torch.equal(y1, y2[:, :cout]), n0
+            else:
+                assert float((y1.float() - y2[:, :cout].float()).abs().max()) < 2e-2 * float(ref.abs().max())

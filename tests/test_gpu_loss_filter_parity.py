@@ -274,6 +274,42 @@ def test_batched_inferer_equals_the_tile_by_tile_loop():
         assert torch.equal(small.run(net, x, dl), fplx.Inferer(c).run(net, x, dl))
 
 
+@pytest.mark.parametrize("case", ["tiles", "whole", "whole_odd_w"])
+def test_sw_merge_mc_reads_the_chunked_pass_major_buffer(case):
+    """fplx_sw_merge_mc (all Monte-Carlo passes in one launch, predictions left where the network's chunked calls wrote them:
+    [chunks][passes][patches of the chunk]) == fplx_sw_merge per pass on that pass's patches gathered into one contiguous batch;
+    and for the whole-volume case (no window: the 16-byte fast path where W % 4 == 0) == the reference's expression
+    ((o1 + flip_H(o2)) + flip_W(o3) + flip_HW(o4)) / 4 of infer_func.py:199-219, bit for bit."""
+    from fplx import ops
+    from fplx._lib import call
+    from fplx.infer import Inferer, _FLIPS_TTA
+    n, classes, passes, chunk = 2, 3, 3, 5                       # 4 flips x tiles x 2 samples: the last chunk is ragged
+    shape = {"tiles": (10, 24, 20), "whole": (6, 10, 24), "whole_odd_w": (6, 10, 22)}[case]
+    cfg = dict(tta_mode=1, class_num=classes)
+    if case == "tiles":
+        cfg.update(sliding_window_enable=True, sliding_window_size=[8, 16, 16], sliding_window_stride=[4, 8, 12])
+    inf = Inferer(cfg)
+    img = torch.zeros((n, 1) + shape, device="cuda")
+    window, starts, flips = inf._plan(img)
+    tiles = len(starts[0]) * len(starts[1]) * len(starts[2])
+    nb = len(flips) * tiles * n
+    assert nb % chunk != 0
+    pred = torch.from_numpy(detdata.normal("swmc.%s" % case, (passes, nb, classes) + tuple(window))).cuda()
+    buf = torch.cat([pred[:, b0:b0 + chunk].reshape((-1, classes) + tuple(window)) for b0 in range(0, nb, chunk)])
+    margs = Inferer._c_args((n, classes) + shape, window, starts, flips)
+    got = torch.full((passes, n, classes) + shape, float("nan"), device="cuda")
+    call("fplx_sw_merge_mc", ops.ptr(buf), passes, chunk, *margs, ops.ptr(got), ops.stream())
+    for q in range(passes):
+        one = torch.empty((n, classes) + shape, device="cuda")
+        call("fplx_sw_merge", ops.ptr(pred[q].contiguous()), *margs, ops.ptr(one), ops.stream())
+        assert torch.equal(got[q], one), q
+    if case != "tiles":
+        o = pred.view((passes, 4, n, classes) + shape)
+        assert _FLIPS_TTA == (0, 2, 1, 3)
+        ref = ((o[:, 0] + torch.flip(o[:, 1], [-2])) + torch.flip(o[:, 2], [-1]) + torch.flip(o[:, 3], [-2, -1])) / 4
+        assert torch.equal(got, ref)
+
+
 def test_ckpt_mode_3_ensemble_is_the_mean_of_the_checkpoints_logits(tmp_path):
     """agent_seg.py:966-1019: np.mean over the checkpoints' predictions, then the usual hard labels."""
     import fplx
