@@ -65,6 +65,54 @@ normalize_k(const float* __restrict__ x, float* __restrict__ y, int64_t n, const
     y[i] = (x[i] - mean) / sd;
 }
 
+// NormalizeWithMeanStd_ignore_non_positive (normalize.py:55-66): moments over the voxels > 0 only, and the others replaced
+// by the caller's noise volume (the reference draws numpy.random.normal on the host; the draw stays there)
+__global__ void __launch_bounds__(SP_THREADS)
+moments_pos_sum_k(const float* __restrict__ x, int64_t n, double* __restrict__ part, double* __restrict__ cnt) {
+  __shared__ double red[SP_THREADS], redc[SP_THREADS];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS)
+    if (x[i] > 0.f) { s += (double)x[i]; c += 1.0; }
+  red[threadIdx.x] = s; redc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = SP_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; redc[threadIdx.x] += redc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[blockIdx.x] = red[0]; cnt[blockIdx.x] = redc[0]; }
+}
+
+__global__ void __launch_bounds__(SP_THREADS)
+moments_pos_dev_k(const float* __restrict__ x, int64_t n, const double* __restrict__ sums, const double* __restrict__ cnt, int rows,
+                  double* __restrict__ part) {
+  __shared__ double red[SP_THREADS];
+  const double mean = total_of(sums, rows) / total_of(cnt, rows);
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS)
+    if (x[i] > 0.f) { const double d = (double)x[i] - mean; s += d * d; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = SP_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(SP_THREADS)
+normalize_pos_k(const float* __restrict__ x, const float* __restrict__ noise, float* __restrict__ y, int64_t n,
+                const double* __restrict__ sums, const double* __restrict__ cnt, const double* __restrict__ devs, int rows,
+                float* __restrict__ out_ms) {
+  const double m = total_of(cnt, rows);
+  const float mean = (float)(total_of(sums, rows) / m);
+  const float sd = (float)sqrt(total_of(devs, rows) / m);
+  if (out_ms && blockIdx.x == 0 && threadIdx.x == 0) { out_ms[0] = mean; out_ms[1] = sd; }
+  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+    const float v = x[i];                                    // x may alias y
+    y[i] = (v <= 0.f) ? noise[i] : (v - mean) / sd;        // the reference's test (a NaN stays a NaN)
+  }
+}
+
 // numpy.pad(mode='reflect') index map: mirror without repeating the edge, any number of reflections
 __device__ __forceinline__ int reflect_index(int i, int n) {
   if (n == 1) return 0;
@@ -254,7 +302,7 @@ inline int sp_grid(int64_t total) {
 
 extern "C" {
 
-size_t fplx_normalize_ws_bytes(void) { return 2 * SP_BLOCKS * sizeof(double); }
+size_t fplx_normalize_ws_bytes(void) { return 3 * SP_BLOCKS * sizeof(double); }
 
 int fplx_normalize_mean_std(const float* x, float* y, int64_t n, const float* mean_std, void* ws, size_t ws_bytes,
                             float* out_mean_std, fplx_stream_t stream) {
@@ -270,6 +318,21 @@ int fplx_normalize_mean_std(const float* x, float* y, int64_t n, const float* me
   }
   normalize_k<<<sp_grid(n), SP_THREADS, 0, st>>>(x, y, n, sums, devs, SP_BLOCKS, mean_std, out_mean_std);
   return fplx_check_launch("normalize_mean_std");
+}
+
+int fplx_normalize_positive(const float* x, const float* noise, float* y, int64_t n, void* ws, size_t ws_bytes,
+                            float* out_mean_std, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && noise && y && n > 0, FPLX_E_NULL, "normalize_positive: null pointer / empty volume");
+  FPLX_REQUIRE(ws && ws_bytes >= 3 * SP_BLOCKS * sizeof(double), FPLX_E_WORKSPACE, "normalize_positive: workspace %zu < %zu", ws_bytes,
+               3 * SP_BLOCKS * sizeof(double));
+  hipStream_t st = (hipStream_t)stream;
+  double* sums = (double*)ws;
+  double* devs = sums + SP_BLOCKS;
+  double* cnt = devs + SP_BLOCKS;
+  moments_pos_sum_k<<<SP_BLOCKS, SP_THREADS, 0, st>>>(x, n, sums, cnt);
+  moments_pos_dev_k<<<SP_BLOCKS, SP_THREADS, 0, st>>>(x, n, sums, cnt, SP_BLOCKS, devs);
+  normalize_pos_k<<<sp_grid(n), SP_THREADS, 0, st>>>(x, noise, y, n, sums, cnt, devs, SP_BLOCKS, out_mean_std);
+  return fplx_check_launch("normalize_positive");
 }
 
 int fplx_pad_reflect(const void* x, void* y, int elem_bytes, int c, int d, int h, int w, int lo_d, int lo_h, int lo_w,

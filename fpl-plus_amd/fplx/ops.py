@@ -428,6 +428,19 @@ def normalize_mean_std(x, mean_std=None, out=None, want_moments=False):
     return (out, got) if want_moments else out
 
 
+def normalize_positive(x, noise, out=None, want_moments=False):
+    """NormalizeWithMeanStd_ignore_non_positive: (x - mean) / std with the moments of the voxels > 0; noise elsewhere"""
+    require_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and noise.dtype == torch.float32 and noise.is_contiguous()
+    assert noise.numel() == x.numel()
+    out = torch.empty_like(x) if out is None else out
+    nb = _lib.lib().fplx_normalize_ws_bytes()
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=x.device)
+    got = torch.empty(2, dtype=torch.float32, device=x.device) if want_moments else None
+    call("fplx_normalize_positive", ptr(x), ptr(noise), ptr(out), x.numel(), ptr(ws), nb, ptr(got), stream())
+    return (out, got) if want_moments else out
+
+
 def pad_reflect(x, lower, out_size):
     """numpy.pad(x, mode='reflect') of a [C,D,H,W] volume to out_size (D,H,W) with lower margins `lower`"""
     require_gpu(x)

@@ -13,6 +13,8 @@ import json
 import math
 import random
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -52,9 +54,7 @@ class NormalizeWithMeanStd(AbstractTransform):
         self.chns = params['normalizewithmeanstd_channels']
         self.mean = params.get('normalizewithmeanstd_mean', None)
         self.std = params.get('normalizewithmeanstd_std', None)
-        if params.get('normalizewithmeanstd_ignore_non_positive', False):
-            raise ValueError("fplx.transform: NormalizeWithMeanStd_ignore_non_positive is not supported "
-                             "(no FPL+ config uses it)")
+        self.ignore_np = params.get('normalizewithmeanstd_ignore_non_positive', False)
         self.inverse = params.get('normalizewithmeanstd_inverse', False)
 
     def __call__(self, sample):
@@ -65,6 +65,19 @@ class NormalizeWithMeanStd(AbstractTransform):
             self.std = [None] * len(chns)
         for i, chn in enumerate(chns):
             ms = None if self.mean[i] is None else (self.mean[i], self.std[i])
+            if self.ignore_np:
+                # normalize.py:55-66: moments over the positive voxels (only when none are given), the others replaced by
+                # numpy.random.normal(0, 1) - drawn on the host from numpy's global generator for the WHOLE channel, as the
+                # reference does, so that a seeded run reproduces its numbers
+                noise = torch.from_numpy(np.random.normal(0, 1, size=tuple(image[chn].shape)).astype(np.float32))
+                noise = noise.to(image.device)
+                if ms is None:
+                    ops.normalize_positive(image[chn], noise, out=image[chn])
+                else:
+                    keep = ~(image[chn] <= 0)
+                    ops.normalize_mean_std(image[chn], ms, out=image[chn])
+                    image[chn] = torch.where(keep, image[chn], noise)
+                continue
             ops.normalize_mean_std(image[chn], ms, out=image[chn])      # in place, like the reference
         sample['image'] = image
         return sample

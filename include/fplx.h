@@ -356,6 +356,9 @@ int fplx_pixel_weight(const uint8_t* a, const uint8_t* b, int64_t v, int apply_s
  * the host (fplx/transform.py, Python `random` in the reference's order).
  *  normalize: y = (x - mean) / std per call (one channel); mean_std == NULL -> float32 mean / population std of x
  *             (PyMIC/pymic/transform/normalize.py:43-68); ws of fplx_normalize_ws_bytes() bytes; out_mean_std may be NULL
+ *  normalize_positive: NormalizeWithMeanStd_ignore_non_positive (normalize.py:55-66): mean / std over the voxels > 0, y =
+ *             (x - mean) / std there and noise[i] elsewhere (noise: the caller's numpy.random.normal(0, 1) draw, as fp32);
+ *             y may alias x
  *  pad_reflect: numpy.pad(mode='reflect') with lower margins lo_* (pad.py:126-163); elem_bytes 4 (fp32) or 1 (uint8)
  *  crop_flip: crop box [c*, c*+o*) then flip of the cropped patch, flip_mask bit0 = W, bit1 = H, bit2 = D
  *             (crop.py:27-49, flip.py:34-62)
@@ -364,6 +367,8 @@ int fplx_pixel_weight(const uint8_t* a, const uint8_t* b, int64_t v, int apply_s
  *  set_weight: in place pw = (pw < 1 ? 0 : pw) * image_weight (PyMIC/pymic/io/nifty_dataset.py:165-168) */
 size_t fplx_normalize_ws_bytes(void);
 int fplx_normalize_mean_std(const float* x, float* y, int64_t n, const float* mean_std, void* ws, size_t ws_bytes,
+                            float* out_mean_std, fplx_stream_t stream);
+int fplx_normalize_positive(const float* x, const float* noise, float* y, int64_t n, void* ws, size_t ws_bytes,
                             float* out_mean_std, fplx_stream_t stream);
 int fplx_pad_reflect(const void* x, void* y, int elem_bytes, int c, int d, int h, int w, int lo_d, int lo_h, int lo_w,
                      int od, int oh, int ow, fplx_stream_t stream);

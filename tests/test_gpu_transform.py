@@ -323,3 +323,29 @@ def test_pseudo_label_stage_files_in_files_out(tmp_path):
     got = s["pixel_weight"].cpu().numpy()[0]
     assert np.array_equal(got, np.where(want < 1, 0, want) * np.float32(0.9))
     assert tuple(s["label"].shape) == (1,) + shapes[0]
+
+
+@pytest.mark.parametrize("case", ["auto", "given"])
+def test_normalize_ignore_non_positive_matches_reference_fixture(golden_dir, case):
+    """NormalizeWithMeanStd_ignore_non_positive (normalize.py:39, 55-66) against the reference's own output
+    (tests/golden/make_golden_normalize_np.py): moments over the voxels > 0 (or the given ones), the non-positive voxels
+    replaced by numpy.random.normal(0, 1) drawn from numpy's global generator in the reference's order - bit-exact there, the
+    normalised voxels within the float32 rounding of the moments (numpy sums pairwise in float32, the kernel in float64)."""
+    from fplx import transform as T
+    g = np.load(os.path.join(golden_dir, "normalize_np.npz"))
+    given = case == "given"
+    p = {"task": "segmentation", "normalizewithmeanstd_channels": [0, 1],
+         "normalizewithmeanstd_mean": [float(v) for v in g["given_mean"]] if given else None,
+         "normalizewithmeanstd_std": [float(v) for v in g["given_std"]] if given else None,
+         "normalizewithmeanstd_ignore_non_positive": True}
+    np.random.seed(int(g["seed"]))
+    got = T.NormalizeWithMeanStd(p)({"image": _dev(g["image"])})["image"].cpu().numpy()
+    want, bg = g["out_" + case], g["image"] <= 0
+    assert bg.any() and (~bg).any()
+    assert np.array_equal(got[bg], want[bg])                                  # the host draw, cast to float32
+    np.testing.assert_allclose(got[~bg], want[~bg], rtol=NORM_RTOL, atol=NORM_ATOL)
+    # the moments really are those of the positive voxels (a whole-image mean would shift every value by > 0.5)
+    if not given:
+        x = g["image"][0].astype(np.float64)
+        m, sd = x[x > 0].mean(), x[x > 0].std()
+        np.testing.assert_allclose(got[0][~bg[0]], ((x - m) / sd)[~bg[0]], rtol=1e-5, atol=1e-5)
