@@ -242,8 +242,8 @@ bn_act_fwd_g_k(const T* __restrict__ y, int64_t ldy, T* __restrict__ out, int64_
   }
 }
 
-template <typename T, int VEC>
-__global__ void __launch_bounds__(EW_THREADS)
+template <typename T, int VEC, int U = 4, bool DROP = true>
+__global__ void __launch_bounds__(EW_THREADS, (U == 1 ? 7 : 1))
 bn_act_bwd_apply_g_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dout, int64_t ldd, T* __restrict__ dy,
                      int64_t ldo, const float* __restrict__ mean, const float* __restrict__ rstd,
                      const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ slope_p,
@@ -259,11 +259,12 @@ bn_act_bwd_apply_g_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__
   }
   auto one = [&](int64_t v, float (&a)[VEC], float (&d)[VEC]) {
     bool keep[VEC];
-    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+    const bool on = DROP && dc.on;                       // DROP = false: the host saw p == 0 (no Philox code, fewer registers)
+    if (on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float z;
-      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, dc.on ? keep[j] : true, dc.inv_keep, z);
+      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, on, on ? keep[j] : true, dc.inv_keep, z);
       const float xh = (a[j] - m[j]) * rs[j];
       d[j] = sc[j] * (dz - k0[j] - xh * k1[j]);
     }
@@ -271,15 +272,15 @@ bn_act_bwd_apply_g_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__
   };
   const int64_t st = (int64_t)gridDim.x * VL;
   int64_t v = (int64_t)blockIdx.x * VL + vl;
-  for (; v + 3 * st < voxels; v += 4 * st) {               // four voxels (8 loads) in flight per lane
-    float a[4][VEC], d[4][VEC];
+  for (; v + (U - 1) * st < voxels; v += U * st) {         // U voxels (2 U loads) in flight per lane
+    float a[U][VEC], d[U][VEC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       ldv_nt<T, VEC>(y + (v + u * st) * ldy + c0, a[u]);
       ldv_nt<T, VEC>(dout + (v + u * st) * ldd + c0, d[u]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) one(v + u * st, a[u], d[u]);
+    for (int u = 0; u < U; ++u) one(v + u * st, a[u], d[u]);
   }
   for (; v < voxels; v += st) {
     float a[VEC], d[VEC];
@@ -290,7 +291,7 @@ bn_act_bwd_apply_g_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__
 }
 
 // stage 1 of backward: per-channel sums of dz and dz*xhat, and the slope gradient
-template <typename T, int VEC>
+template <typename T, int VEC, int U = 4, bool DROP = true>
 __global__ void __launch_bounds__(EW_THREADS)
 bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ dout, int64_t ldd,
                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -311,14 +312,15 @@ bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ 
   }
   auto consume = [&](int64_t v, const float (&a)[VEC], const float (&d)[VEC]) {
     bool keep[VEC];
-    if (dc.on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
+    const bool on = DROP && dc.on;
+    if (on) keep_flags<VEC>(v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float z;
-      const bool kp = dc.on ? keep[j] : true;
-      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, dc.on, kp, dc.inv_keep, z);
+      const bool kp = on ? keep[j] : true;
+      const float dz = dz_of(a[j], d[j], sc[j], sh[j], slope, on, kp, dc.inv_keep, z);
       float da = d[j];
-      if (dc.on) da = kp ? d[j] * dc.inv_keep : 0.f;
+      if (on) da = kp ? d[j] * dc.inv_keep : 0.f;
       sds += z > 0.f ? 0.f : da * z;
       sdz[j] += dz;
       sdx[j] = fmaf(dz, (a[j] - m[j]) * rs[j], sdx[j]);
@@ -328,15 +330,15 @@ bn_act_bwd_reduce_k(const T* __restrict__ y, int64_t ldy, const T* __restrict__ 
     // four voxels (8 x 16-byte loads) in flight per lane: the pass is pure HBM streaming
     const int64_t st = (int64_t)gridDim.x * VL;
     int64_t v = (int64_t)blockIdx.x * VL + vl;
-    for (; v + 3 * st < voxels; v += 4 * st) {
-      float a[4][VEC], d[4][VEC];
+    for (; v + (U - 1) * st < voxels; v += U * st) {
+      float a[U][VEC], d[U][VEC];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         ldv<T, VEC>(y + (v + u * st) * ldy + c0, a[u]);
         ldv<T, VEC>(dout + (v + u * st) * ldd + c0, d[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) consume(v + u * st, a[u], d[u]);
+      for (int u = 0; u < U; ++u) consume(v + u * st, a[u], d[u]);
     }
     for (; v < voxels; v += st) {
       float a[VEC], d[VEC];
@@ -1055,10 +1057,17 @@ int fplx_bn_act_bwd_reduce(const void* y, int64_t ldy, const void* dout, int64_t
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, nullptr, 0, c) && c / 8 <= EW_THREADS;
     FPLX_REQUIRE(ok || c <= EW_THREADS, FPLX_E_BADSHAPE, "bn_act_bwd_reduce: C=%d unsupported", c);
+    const int infl = (int)fplx_knob(FPLX_K_EW_INFLIGHT);
+#define REDUCE_U(U_, D_) bn_act_bwd_reduce_k<bf16_t, 8, U_, D_><<<rows, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, \
+                         ldd, mean, rstd, scale, shift, slope, dc, voxels, c, part)
+    if (ok && dc.on) { if (infl >= 4) REDUCE_U(4, true); else if (infl >= 2) REDUCE_U(2, true); else REDUCE_U(1, true); }
+    else if (ok) { if (infl >= 4) REDUCE_U(4, false); else if (infl >= 2) REDUCE_U(2, false); else REDUCE_U(1, false); }
+    else
     DISPATCH_VEC(bf16_t, ok, bn_act_bwd_reduce_k, <<<rows, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy,
                                                                                 (const bf16_t*)dout, ldd, mean, rstd,
                                                                                 scale, shift, slope, dc, voxels, c,
                                                                                 part));
+#undef REDUCE_U
   } else
     return fplx_fail(FPLX_E_BADDTYPE, "bn_act_bwd_reduce: dtype %d", dt);
   return fplx_check_launch("bn_act_bwd_reduce");
@@ -1092,8 +1101,14 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
     const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, dy, ldo, c);
     const int g = ew_grid(voxels * (ok ? c / 8 : c));
     if (ok && c / 8 <= EW_THREADS && EW_THREADS % (c / 8) == 0 && ew_group_form())
-      bn_act_bwd_apply_g_k<bf16_t, 8><<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, ldd, (bf16_t*)dy,
-                                                                ldo, mean, rstd, scale, shift, slope, coef, dc, voxels, c);
+    {
+      const int infl = (int)fplx_knob(FPLX_K_EW_INFLIGHT);
+#define APPLY_G(U_, D_) bn_act_bwd_apply_g_k<bf16_t, 8, U_, D_><<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, \
+                        ldd, (bf16_t*)dy, ldo, mean, rstd, scale, shift, slope, coef, dc, voxels, c)
+      if (dc.on) { if (infl >= 4) APPLY_G(4, true); else if (infl >= 2) APPLY_G(2, true); else APPLY_G(1, true); }
+      else if (infl >= 4) APPLY_G(4, false); else if (infl >= 2) APPLY_G(2, false); else APPLY_G(1, false);
+#undef APPLY_G
+    }
     else
       DISPATCH_VEC(bf16_t, ok, bn_act_bwd_apply_k, <<<g, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout,
                                                                               ldd, (bf16_t*)dy, ldo, mean, rstd, scale,
