@@ -235,6 +235,8 @@ class SegmentationAgent(object):
                 y = self.convert_tensor_type(datas[k]['label_prob']).to(self.device)
                 if not dual:
                     self.optimizer.zero_grad()
+                if dual and k > 0 and isinstance(self.net, UNet2D5_dsbn):
+                    self.net.parameters_unchanged_since_last_forward()     # one optimiser step per iteration: same weight packs
                 out = self.net(x, domain_label=k * torch.ones(x.shape[0], dtype=torch.long))
                 lk = self.get_loss_value(datas[k], out, y, self.fpl_uda)
                 dice_lists[k].append(self.loss_calculator.last_out[4:4 + class_num])   # hard Dice of this pass

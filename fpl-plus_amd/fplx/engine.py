@@ -35,6 +35,8 @@ class Engine(object):
         self.ws = None
         self.ws_side = None
         self._pack_cache = None
+        self._train_packs = None                         # packs of the last train-mode forward (reuse_packs)
+        self.allow_pack_reuse = os.environ.get("FPLX_PACK_REUSE", "1") != "0"      # A/B switch
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
         # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
         self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
@@ -93,6 +95,7 @@ class Engine(object):
 
     def invalidate(self):
         self._pack_cache = None
+        self._train_packs = None
         self._fold_cache = {}
 
     def _folded(self, adt, domain, key, conv, bn):
@@ -118,7 +121,7 @@ class Engine(object):
         return tab[key]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1, out=None):
+    def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1, out=None, reuse_packs=False):
         """x: fp32 [N, Cin, D, H, W] contiguous on the GPU -> logits fp32 [N, class_num, D, H, W].
         train: BatchNorm uses batch statistics (and updates the running ones);
         drop_on: list of 9 bools - dropout active per ConvBlockND.
@@ -127,7 +130,10 @@ class Engine(object):
         masks are keyed by the element index of the mc * N batch - but the encoder levels above the first active dropout see
         the same input in every pass and are computed ONCE (the shipped configs drop out at levels 2-4 only: levels 0 and 1,
         the two most expensive, run once instead of `mc` times; reference: agent_seg.py:898-909 runs the whole net per pass).
-        out: where the logits go (fp32 [mc * N, class_num, D, H, W], contiguous) instead of a new tensor."""
+        out: where the logits go (fp32 [mc * N, class_num, D, H, W], contiguous) instead of a new tensor.
+        reuse_packs: the caller guarantees that no parameter changed since the previous train-mode forward (the second domain
+        of one training_all iteration: both losses are formed before the one optimiser step, agent_seg.py:462-486) - the
+        weight packs of that forward are used again instead of being rebuilt."""
         net = self.net
         logits_out = out
         ops.require_gpu(x)
@@ -149,9 +155,12 @@ class Engine(object):
         dev, adt = x.device, net.act_dtype
         a_dt = ops._DT[adt]
         ft = net.ft_chns
-        if train or self._pack_cache is None or self._pack_cache[0] != adt:
+        if train and reuse_packs and self.allow_pack_reuse and self._train_packs is not None and self._train_packs[0] == adt:
+            packs = self._train_packs[1]
+        elif train or self._pack_cache is None or self._pack_cache[0] != adt:
             packs = self._pack(adt)
             self._pack_cache = None if train else (adt, packs)
+            self._train_packs = (adt, packs) if train else None
         else:
             packs = self._pack_cache[1]
         if train:

@@ -101,7 +101,8 @@ class _UNetFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, domain, train, drop_on, seed, step, keep, *params):
-        logits, sv = net.engine.forward(x, domain, train, drop_on, seed, step, keep=keep)
+        reuse, net._reuse_packs_once = getattr(net, "_reuse_packs_once", False), False
+        logits, sv = net.engine.forward(x, domain, train, drop_on, seed, step, keep=keep, reuse_packs=reuse)
         ctx.net, ctx.sv, ctx.n_params = net, sv, len(params)
         return logits
 
@@ -284,6 +285,12 @@ class UNet2D5_dsbn(nn.Module):
     def train(self, mode=True):
         self.engine.invalidate()
         return super(UNet2D5_dsbn, self).train(mode)
+
+    def parameters_unchanged_since_last_forward(self):
+        """A promise by the caller, consumed by the NEXT train-mode forward: no parameter was touched since the previous
+        forward (the second domain of a `training_all` iteration, agent_seg.py:462-486) - that forward then uses the
+        previous one's weight packs instead of rebuilding them."""
+        self._reuse_packs_once = True
 
     def dropout_active(self):
         """per ConvBlockND: the nn.Dropout child's own training flag decides (this is what the

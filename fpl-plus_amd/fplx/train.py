@@ -57,11 +57,12 @@ class TrainStep(object):
                 torch.empty(n * c * 2 + 2, dtype=torch.float32, device=dev))
         return self._loss_bufs[key]
 
-    def _fwd_bwd(self, x, label, domain, pw, iw, gscale, gflat, reduce_hook):
+    def _fwd_bwd(self, x, label, domain, pw, iw, gscale, gflat, reduce_hook, reuse_packs=False):
         net = self.net
         step = net._fwd_counter
         net._fwd_counter += 1
-        logits, sv = net.engine.forward(x, domain, True, net.dropout_active(), net.dropout_seed, step, keep=True)
+        logits, sv = net.engine.forward(x, domain, True, net.dropout_active(), net.dropout_seed, step, keep=True,
+                                        reuse_packs=reuse_packs)
         n, c = logits.shape[0], logits.shape[1]
         v = logits[0, 0].numel()
         part, coef = self._loss_buffers(n, c, v, logits.device)
@@ -96,8 +97,9 @@ class TrainStep(object):
             gs = self._one if nd == 1 else self._half
             last = k == nd - 1
             tgt = self.gflat if k == 0 else self.gacc
+            # the parameters do not change between the domains of one iteration: the first forward's weight packs serve all
             outs.append(self._fwd_bwd(b['image'], b['label_prob'], k, b.get('pixel_weight'), b.get('image_weight'),
-                                      gs, tgt, None))
+                                      gs, tgt, None, reuse_packs=k > 0))
             if k > 0:
                 self.gflat.add_(self.gacc)
         self.reducer.begin(self.gflat)

@@ -153,6 +153,27 @@ def test_training_all_engine_mode_matches_reference(golden_dir):
             _check_params(net.state_dict(), g, "dice_pw", step)
 
 
+def test_second_domain_reuses_the_weight_packs_bit_identically():
+    """step_all: the second domain's forward of an iteration uses the first one's weight packs (no parameter changes in between,
+    agent_seg.py:462-486) - the parameters after three iterations are the bits of the run that repacks every forward, and the
+    next iteration does repack (a stale pack would show in the second and third iteration)."""
+    import fplx
+    res = []
+    for reuse in (True, False):
+        p = dict(NETS["tiny"])
+        net = fplx.UNet2D5_dsbn(p)
+        load_det_weights(net, p, "cuda")
+        net.engine.allow_pack_reuse = reuse
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5, milestones=[2, 4], gamma=0.5)
+        b = [{k: v.cuda() for k, v in d.items()} for d in _batches(True)]
+        packs_seen = []
+        for _ in range(3):
+            ts.step_all(b)
+            packs_seen.append(net.engine._train_packs[1]["out_conv"][0].data_ptr())
+        res.append((net.flat_params.clone(), packs_seen))
+    assert torch.equal(res[0][0], res[1][0])
+
+
 def test_inferer_matches_reference(golden_dir):
     import fplx
     g = np.load(os.path.join(golden_dir, "inferer.npz"))
