@@ -272,10 +272,116 @@ mc_filter_k(const float* __restrict__ logits, int T, int64_t V, float thr, uint8
   }
 }
 
+// The same filter, four consecutive voxels per thread: 16-byte loads of the logits, one 4-byte store of the four hard labels
+// per pass (mc_filter_k's byte stores and its one-voxel-at-a-time dependent loads kept it at 0.7 TB/s).  Per voxel the
+// arithmetic - and so every mask, mean and uncertainty - is mc_filter_k's; V % 4 == 0 and 16-byte-aligned pointers (host).
+template <int C>
+__global__ void __launch_bounds__(LT)
+mc_filter_v4_k(const float* __restrict__ logits, int T, int64_t V, float thr, uint8_t* __restrict__ hards,
+               float* __restrict__ mean_out, float* __restrict__ unc_out, double* __restrict__ part) {
+  const bool exact_cut = thr == 0.01f;
+  double var_acc = 0.0;
+  long long bnd = 0;
+  for (int64_t v = ((int64_t)blockIdx.x * LT + threadIdx.x) * 4; v < V; v += (int64_t)gridDim.x * LT * 4) {
+    float sum_c[4][C];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < C; ++c) sum_c[j][c] = 0.f;
+    constexpr int TB = 3;                                 // passes loaded together (their loads in flight before the first exp)
+    for (int t0 = 0; t0 < T; t0 += TB) {
+      float4 lv[TB][C];
+#pragma unroll
+      for (int k = 0; k < TB; ++k) {
+        const int t = t0 + k < T ? t0 + k : T - 1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) lv[k][c] = *reinterpret_cast<const float4*>(logits + ((int64_t)t * C + c) * V + v);
+      }
+#pragma unroll
+      for (int k = 0; k < TB; ++k) {
+        if (t0 + k >= T) break;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float l[MAXC], q[MAXC];
+#pragma unroll
+          for (int c = 0; c < C; ++c) l[c] = j == 0 ? lv[k][c].x : j == 1 ? lv[k][c].y : j == 2 ? lv[k][c].z : lv[k][c].w;
+          const int a = softmax_argmax<C>(l, q, true);
+          packed |= (uint32_t)a << (8 * j);
+#pragma unroll
+          for (int c = 0; c < C; ++c) sum_c[j][c] += q[c];
+        }
+        if (hards) *reinterpret_cast<uint32_t*>(hards + (int64_t)(t0 + k) * V + v) = packed;
+      }
+    }
+    const float invT = (float)T;
+    float mc[4][C], s2[4][C];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < C; ++c) { mc[j][c] = sum_c[j][c] / invT; s2[j][c] = 0.f; }
+    for (int t0 = 0; t0 < T; t0 += TB) {                 // second sweep: L2 resident
+      float4 lv[TB][C];
+#pragma unroll
+      for (int k = 0; k < TB; ++k) {
+        const int t = t0 + k < T ? t0 + k : T - 1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) lv[k][c] = *reinterpret_cast<const float4*>(logits + ((int64_t)t * C + c) * V + v);
+      }
+#pragma unroll
+      for (int k = 0; k < TB; ++k) {
+        if (t0 + k >= T) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float l[MAXC], q[MAXC];
+#pragma unroll
+          for (int c = 0; c < C; ++c) l[c] = j == 0 ? lv[k][c].x : j == 1 ? lv[k][c].y : j == 2 ? lv[k][c].z : lv[k][c].w;
+          softmax_argmax<C>(l, q, true);
+#pragma unroll
+          for (int c = 0; c < C; ++c) { const float d = q[c] - mc[j][c]; s2[j][c] += d * d; }
+        }
+      }
+    }
+    float m4[4], u4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vsum = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) vsum += s2[j][c] / invT;
+      var_acc += (double)vsum;
+      const float m1 = sum_c[j][C > 1 ? 1 : 0] / invT;
+      const float u = -1.0f * (m1 * logf(m1 + 1e-6f));
+      m4[j] = m1; u4[j] = u;
+      const uint32_t mb = __float_as_uint(m1);
+      const bool over = exact_cut ? (mb >= FPL_CUT_LO && mb <= FPL_CUT_HI) : (u > thr);
+      bnd += over ? 1 : 0;
+    }
+    if (mean_out) *reinterpret_cast<float4*>(mean_out + v) = make_float4(m4[0], m4[1], m4[2], m4[3]);
+    if (unc_out) *reinterpret_cast<float4*>(unc_out + v) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+  }
+  __shared__ double red[LT / 64][2];
+  const double a = wave_sum_d(var_acc), b = wave_sum_d((double)bnd);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s0 = 0, s1 = 0;
+    for (int i = 0; i < LT / 64; ++i) { s0 += red[i][0]; s1 += red[i][1]; }
+    part[(int64_t)blockIdx.x * 2 + 0] = s0;
+    part[(int64_t)blockIdx.x * 2 + 1] = s1;
+  }
+}
+
 __global__ void mc_filter_finalize_k(const double* __restrict__ part, int rows, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane l adds rows l, l + 64, ... in order, then the 64 lane sums are added in lane order (fixed order; a single
+  // thread walking the <= 512 rows took 40-50 us of dependent loads - a third of the whole filter)
+  __shared__ double red[64][2];
   double v = 0, b = 0;
-  for (int r = 0; r < rows; ++r) { v += part[r * 2]; b += part[r * 2 + 1]; }
+  for (int r = threadIdx.x; r < rows; r += 64) { v += part[r * 2]; b += part[r * 2 + 1]; }
+  red[threadIdx.x][0] = v; red[threadIdx.x][1] = b;
+  __syncthreads();
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  v = 0; b = 0;
+  for (int l = 0; l < 64; ++l) { v += red[l][0]; b += red[l][1]; }
   out[0] = v;
   out[1] = b;
   // `vars` is a float32 scalar in the reference (maps is float32), boundary an int64
@@ -412,6 +518,17 @@ int fplx_mc_filter(const float* logits, int t, int c, int64_t v, float thr, uint
                "mc_filter: t=%d (<=%d) c=%d (2..%d)", t, MAXT, c, MAXC);
   hipStream_t st = (hipStream_t)stream;
   const int rows = fplx_rows_for(v);
+  const bool v4 = v % 4 == 0 && ((uintptr_t)logits % 16) == 0 && ((uintptr_t)hards % 4) == 0 && ((uintptr_t)mean_out % 16) == 0 &&
+                  ((uintptr_t)unc_out % 16) == 0;
+  if (v4 && c <= 4) {
+    switch (c) {
+      case 2: mc_filter_v4_k<2><<<rows, LT, 0, st>>>(logits, t, v, thr, hards, mean_out, unc_out, part); break;
+      case 3: mc_filter_v4_k<3><<<rows, LT, 0, st>>>(logits, t, v, thr, hards, mean_out, unc_out, part); break;
+      default: mc_filter_v4_k<4><<<rows, LT, 0, st>>>(logits, t, v, thr, hards, mean_out, unc_out, part); break;
+    }
+    mc_filter_finalize_k<<<1, 64, 0, st>>>(part, rows, out);
+    return fplx_check_launch("mc_filter");
+  }
   switch (c) {
     case 2: mc_filter_k<2><<<rows, LT, 0, st>>>(logits, t, v, thr, hards, mean_out, unc_out, part); break;
     case 3: mc_filter_k<3><<<rows, LT, 0, st>>>(logits, t, v, thr, hards, mean_out, unc_out, part); break;

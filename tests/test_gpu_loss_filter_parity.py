@@ -231,6 +231,36 @@ def test_fpl_filter_matches_reference_run_and_oracle(golden_dir):
     assert np.array_equal(fplx.filter.hard_label(_cuda(lg)).cpu().numpy(), N.hard_label(lg))
 
 
+@pytest.mark.parametrize("classes,T", [(2, 6), (3, 4), (4, 5)])
+def test_mc_filter_vector_form_equals_the_scalar_form(classes, T):
+    """mc_filter's four-voxels-per-thread kernel (16-byte loads, packed label stores; taken when V % 4 == 0 and the pointers are
+    16-byte aligned) against the one-voxel kernel (forced by an odd volume / a misaligned view of the same numbers): hard labels,
+    means and uncertainties bit for bit, the boundary count exactly, the variance sum to double rounding; and both against numpy."""
+    from fplx import ops
+    from oracle import np_ref as N
+    vol = (6, 10, 12)
+    v = vol[0] * vol[1] * vol[2]
+    lg = detdata.normal("mcf4.%d.%d" % (classes, T), (T, classes) + vol, 2.5).astype(np.float32)
+    lg[:, 1, 0, 0, ::3] = lg[:, 0, 0, 0, ::3]                         # ties: first maximum
+    a = ops.mc_filter(torch.from_numpy(lg).cuda(), 0.01, True, True)                     # aligned, V % 4 == 0: vector kernel
+    # the same numbers at a pointer that is 4 bytes off a 16-byte boundary: scalar kernel
+    flat = torch.zeros(lg.size + 1, dtype=torch.float32, device="cuda")
+    flat[1:] = torch.from_numpy(lg).cuda().reshape(-1)
+    b = ops.mc_filter(flat[1:].view((T, classes) + vol), 0.01, True, True)
+    assert flat[1:].data_ptr() % 16 == 4
+    for k in ("hards", "means", "uncertainty"):
+        assert torch.equal(a[k], b[k]), k
+    sa, sb = a["stats"].cpu().numpy(), b["stats"].cpu().numpy()
+    assert sa[1] == sb[1] and abs(sa[0] - sb[0]) <= 1e-12 * abs(sb[0])
+    if classes == 2:
+        ref = N.fpl_filter(lg)
+        assert np.array_equal(a["hards"].cpu().numpy(), ref["hards"])
+    # an odd volume goes through the scalar kernel as well and agrees voxel by voxel on the common part
+    odd = ops.mc_filter(torch.from_numpy(np.ascontiguousarray(lg.reshape(T, classes, v)[:, :, :v - 1])).cuda(), 0.01, True, True)
+    assert torch.equal(odd["hards"].reshape(T, -1), a["hards"].reshape(T, -1)[:, :v - 1])
+    assert torch.equal(odd["means"].reshape(-1), a["means"].reshape(-1)[:v - 1])
+
+
 def test_pixel_weight_bit_exact(golden_dir):
     import fplx
     from oracle import np_ref as N

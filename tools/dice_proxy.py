@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--held-out", type=int, default=8, help="held-out volumes per domain")
     ap.add_argument("--control", type=float, default=0.0, help="> 0: third arm = fp32 from an init perturbed by this relative noise (e.g. 1e-6)")
     ap.add_argument("--dropout", default="0,0,0,0,0", help="e.g. 0,0,0.3,0.4,0.5 (then the CPU oracle trajectory is not comparable)")
+    ap.add_argument("--reference-arm", default=None,
+                    help="json written by tools/dice_proxy_refarm.py (the reference's own training_all on the CPU, same init / "
+                         "batches / held-out volumes): adds the paired reports fplx - reference")
     ap.add_argument("--out", default=None, help="write the report (text) here as well")
     a = ap.parse_args()
     shape = tuple(int(t) for t in a.shape.split(","))
@@ -178,6 +181,24 @@ def main():
                       np.std(stc["per_order"], ddof=1) if a.seeds > 1 else float("nan")))
     verdict = "MET" if st["bound"] < 0.5 else "NOT RESOLVED at this number of orders"
     out.append("north_star +-0.5 Dice points on this proxy: |mean| + 2 SE = %.3f -> %s" % (st["bound"], verdict))
+    if a.reference_arm:
+        import json
+        ra = json.load(open(a.reference_arm))
+        rc = ra["config"]
+        same = (rc["base"] == b and rc["dims"] == a.dims and tuple(rc["shape"]) == shape and rc["iters"] == a.iters and
+                rc["held_out"] == a.held_out and [float(t) for t in a.dropout.split(",")] == [float(t) for t in rc["dropout"]])
+        seeds = [s_ for s_ in range(a.seeds) if str(s_) in ra["orders"]]
+        if not same or not seeds:
+            out.append("reference arm %s: configuration differs or no common batch order - not compared" % a.reference_arm)
+        else:
+            ref = np.asarray([ra["orders"][str(s_)]["dice_percent"] for s_ in seeds])
+            out.append("REFERENCE arm (%s): Dice %% over orders: %s (mean %.2f, std %.2f)"
+                       % (ra["what"], " ".join("%.2f" % v for v in ref.mean(1)), ref.mean(), ref.mean(1).std()))
+            for k in ("fp32", "bf16"):
+                lines, sr = paired_report("fplx %s - REFERENCE" % k, ref, res[k][seeds])
+                out += lines
+                out.append("north_star +-0.5 Dice points, fplx %s against the reference's own training on this proxy: |mean| + 2 SE = "
+                           "%.3f -> %s" % (k, sr["bound"], "MET" if sr["bound"] < 0.5 else "NOT RESOLVED at this number of orders"))
     text = "\n".join(out)
     print(text)
     if a.out:
