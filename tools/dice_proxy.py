@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--reference-arm", default=None,
                     help="json written by tools/dice_proxy_refarm.py (the reference's own training_all on the CPU, same init / "
                          "batches / held-out volumes): adds the paired reports fplx - reference")
+    ap.add_argument("--arms", default=None, help="comma list out of fp32,bf16,fp32c (default: fp32,bf16 and fp32c with --control)")
+    ap.add_argument("--save-json", default=None, help="per-order, per-volume Dice of every arm (for merging runs)")
     ap.add_argument("--out", default=None, help="write the report (text) here as well")
     a = ap.parse_args()
     shape = tuple(int(t) for t in a.shape.split(","))
@@ -129,6 +131,9 @@ def main():
     train = [[make_case(rs, shape, d) for _ in range(13)] for d in (0, 1)]          # 13 cases per domain, like the sample data
     test = [[make_case(rs, shape, d) for _ in range(a.held_out)] for d in (0, 1)]
     arms = ["fp32", "bf16"] + (["fp32c"] if a.control > 0 else [])
+    if a.arms:
+        arms = [k for k in a.arms.split(",") if k]
+        assert all(k in ("fp32", "bf16", "fp32c") for k in arms) and ("fp32c" not in arms or a.control > 0)
     res = {k: [] for k in arms}
     traj, order0, init0 = {}, None, None
     for seed in range(a.seeds):
@@ -145,6 +150,12 @@ def main():
                 traj[k] = t
         print("order %d: %s" % (seed, "  ".join("%s %.2f" % (k, res[k][-1].mean()) for k in arms)), flush=True)
     res = {k: np.asarray(v) for k, v in res.items()}
+    if a.save_json:
+        import json
+        os.makedirs(os.path.dirname(os.path.abspath(a.save_json)), exist_ok=True)
+        json.dump({"config": {"base": b, "dims": a.dims, "shape": list(shape), "iters": a.iters, "held_out": a.held_out,
+                              "dropout": a.dropout, "control": a.control},
+                   "dice_percent": {k: v.tolist() for k, v in res.items()}}, open(a.save_json, "w"))
     if a.oracle_iters > 0:
         from oracle import torch_ref as R
         torch.set_num_threads(max(1, min(os.cpu_count() or 1, 32)))
@@ -170,17 +181,20 @@ def main():
     if "oracle" in traj:
         out.append("oracle (CPU restatement of the reference, dropout off) loss of the first iterations: %s"
                    % ["%.4f" % v for v in traj["oracle"]])
-    lines, st = paired_report("bf16 - fp32", res["fp32"], res["bf16"])
-    out += lines
-    if a.control > 0:
+    st = None
+    if "fp32" in res and "bf16" in res:
+        lines, st = paired_report("bf16 - fp32", res["fp32"], res["bf16"])
+        out += lines
+    if a.control > 0 and "fp32c" in res and st is not None:
         lines, stc = paired_report("CONTROL fp32(init x (1 + %.0e N(0,1))) - fp32" % a.control, res["fp32"], res["fp32c"])
         out += lines
         out.append("reading: the bf16 arm differs from fp32 by bf16 rounding (2^-9 relative) at every stored activation; the control "
                    "differs by %.0e in the initial weights only.  Spread of the per-order differences: bf16 %.2f, control %.2f points."
                    % (a.control, np.std(st["per_order"], ddof=1) if a.seeds > 1 else float("nan"),
                       np.std(stc["per_order"], ddof=1) if a.seeds > 1 else float("nan")))
-    verdict = "MET" if st["bound"] < 0.5 else "NOT RESOLVED at this number of orders"
-    out.append("north_star +-0.5 Dice points on this proxy: |mean| + 2 SE = %.3f -> %s" % (st["bound"], verdict))
+    if st is not None:
+        verdict = "MET" if st["bound"] < 0.5 else "NOT RESOLVED at this number of orders"
+        out.append("north_star +-0.5 Dice points on this proxy: |mean| + 2 SE = %.3f -> %s" % (st["bound"], verdict))
     if a.reference_arm:
         import json
         ra = json.load(open(a.reference_arm))
@@ -194,7 +208,7 @@ def main():
             ref = np.asarray([ra["orders"][str(s_)]["dice_percent"] for s_ in seeds])
             out.append("REFERENCE arm (%s): Dice %% over orders: %s (mean %.2f, std %.2f)"
                        % (ra["what"], " ".join("%.2f" % v for v in ref.mean(1)), ref.mean(), ref.mean(1).std()))
-            for k in ("fp32", "bf16"):
+            for k in [k_ for k_ in ("fp32", "bf16") if k_ in res]:
                 lines, sr = paired_report("fplx %s - REFERENCE" % k, ref, res[k][seeds])
                 out += lines
                 out.append("north_star +-0.5 Dice points, fplx %s against the reference's own training on this proxy: |mean| + 2 SE = "
