@@ -152,7 +152,8 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(DECONV_DGRAD_ROWS, "deconv_dgrad_rows", 1)  /* 0: conv_fwd_direct for the shallow transposed-convolution data gradients */ \
   X(EW_GROUP, "ew_group", 1)                                                                                           \
   X(POOL_COL, "pool_col", 1)               /* 0: the fused DownBlock-tail passes with a thread per pooled voxel */          \
-  X(EW_INFLIGHT, "ew_inflight", 2)         /* voxels (pairs of 16-byte loads) in flight per lane of the BatchNorm backward passes: 4, 2, 1 */
+  X(EW_INFLIGHT, "ew_inflight", 2)         /* voxels (pairs of 16-byte loads) in flight per lane of bn_act_bwd_apply: 4, 2, 1 (131 / 99 / 72 registers) */ \
+  X(EW_INFLIGHT_REDUCE, "ew_inflight_reduce", 2) /* the same for bn_act_bwd_reduce: 4, 2, 1 */
 enum FplxKnobId {
 #define FPLX_KNOB_ENUM(id, key, def) FPLX_K_##id,
   FPLX_KNOB_LIST(FPLX_KNOB_ENUM)

@@ -1057,7 +1057,7 @@ int fplx_bn_act_bwd_reduce(const void* y, int64_t ldy, const void* dout, int64_t
   } else if (dt == FPLX_BF16) {
     const bool ok = vec_ok<bf16_t>(y, ldy, dout, ldd, nullptr, 0, c) && c / 8 <= EW_THREADS;
     FPLX_REQUIRE(ok || c <= EW_THREADS, FPLX_E_BADSHAPE, "bn_act_bwd_reduce: C=%d unsupported", c);
-    const int infl = (int)fplx_knob(FPLX_K_EW_INFLIGHT);
+    const int infl = (int)fplx_knob(FPLX_K_EW_INFLIGHT_REDUCE);
 #define REDUCE_U(U_, D_) bn_act_bwd_reduce_k<bf16_t, 8, U_, D_><<<rows, EW_THREADS, 0, st>>>((const bf16_t*)y, ldy, (const bf16_t*)dout, \
                          ldd, mean, rstd, scale, shift, slope, dc, voxels, c, part)
     if (ok && dc.on) { if (infl >= 4) REDUCE_U(4, true); else if (infl >= 2) REDUCE_U(2, true); else REDUCE_U(1, true); }
