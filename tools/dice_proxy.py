@@ -120,6 +120,7 @@ def main():
                     help="json written by tools/dice_proxy_refarm.py (the reference's own training_all on the CPU, same init / "
                          "batches / held-out volumes): adds the paired reports fplx - reference")
     ap.add_argument("--arms", default=None, help="comma list out of fp32,bf16,fp32c (default: fp32,bf16 and fp32c with --control)")
+    ap.add_argument("--first-seed", type=int, default=0, help="first batch order (with --seeds: orders first .. first + seeds - 1)")
     ap.add_argument("--save-json", default=None, help="per-order, per-volume Dice of every arm (for merging runs)")
     ap.add_argument("--out", default=None, help="write the report (text) here as well")
     a = ap.parse_args()
@@ -136,17 +137,17 @@ def main():
         assert all(k in ("fp32", "bf16", "fp32c") for k in arms) and ("fp32c" not in arms or a.control > 0)
     res = {k: [] for k in arms}
     traj, order0, init0 = {}, None, None
-    for seed in range(a.seeds):
+    for seed in range(a.first_seed, a.first_seed + a.seeds):
         ors = np.random.RandomState(100 + seed)
         order = [[ors.permutation(13)[:2] for _ in range(a.iters)] for _ in (0, 1)]      # the same batches for every arm
         torch.manual_seed(1 + seed)
         init = fplx.UNet2D5_dsbn(dict(p)).state_dict()
-        if seed == 0:
+        if seed == a.first_seed:
             order0, init0 = order, init
         for k in arms:
             t, dice = run_arm(p, "bf16" if k == "bf16" else "fp32", init, train, test, order, a.iters, a.control if k == "fp32c" else 0.0)
             res[k].append(100 * dice)
-            if seed == 0:
+            if seed == a.first_seed:
                 traj[k] = t
         print("order %d: %s" % (seed, "  ".join("%s %.2f" % (k, res[k][-1].mean()) for k in arms)), flush=True)
     res = {k: np.asarray(v) for k, v in res.items()}
@@ -154,7 +155,7 @@ def main():
         import json
         os.makedirs(os.path.dirname(os.path.abspath(a.save_json)), exist_ok=True)
         json.dump({"config": {"base": b, "dims": a.dims, "shape": list(shape), "iters": a.iters, "held_out": a.held_out,
-                              "dropout": a.dropout, "control": a.control},
+                              "dropout": a.dropout, "control": a.control, "first_seed": a.first_seed},
                    "dice_percent": {k: v.tolist() for k, v in res.items()}}, open(a.save_json, "w"))
     if a.oracle_iters > 0:
         from oracle import torch_ref as R
@@ -201,11 +202,11 @@ def main():
         rc = ra["config"]
         same = (rc["base"] == b and rc["dims"] == a.dims and tuple(rc["shape"]) == shape and rc["iters"] == a.iters and
                 rc["held_out"] == a.held_out and [float(t) for t in a.dropout.split(",")] == [float(t) for t in rc["dropout"]])
-        seeds = [s_ for s_ in range(a.seeds) if str(s_) in ra["orders"]]
+        seeds = [s_ for s_ in range(a.seeds) if str(a.first_seed + s_) in ra["orders"]]
         if not same or not seeds:
             out.append("reference arm %s: configuration differs or no common batch order - not compared" % a.reference_arm)
         else:
-            ref = np.asarray([ra["orders"][str(s_)]["dice_percent"] for s_ in seeds])
+            ref = np.asarray([ra["orders"][str(a.first_seed + s_)]["dice_percent"] for s_ in seeds])
             out.append("REFERENCE arm (%s): Dice %% over orders: %s (mean %.2f, std %.2f)"
                        % (ra["what"], " ".join("%.2f" % v for v in ref.mean(1)), ref.mean(), ref.mean(1).std()))
             for k in [k_ for k_ in ("fp32", "bf16") if k_ in res]:

@@ -2,7 +2,7 @@
 arm (tools/dice_proxy_refarm.py, the reference's own training on the CPU of the build container) over the batch orders both
 hold.  Runs anywhere (no GPU, no reference).
 
-    python tools/dice_proxy_merge.py <fplx arms json> <reference arm json> [arm=bf16] [out.txt]"""
+    python tools/dice_proxy_merge.py <fplx arms json>[,<more json of later orders>] <reference arm json> [arm=bf16] [out.txt]"""
 import json
 import os
 import sys
@@ -27,14 +27,22 @@ def report(name, a, b):
 
 
 def main():
-    fx, rf = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+    rf = json.load(open(sys.argv[2]))
     arm = sys.argv[3] if len(sys.argv) > 3 else "bf16"
-    fc, rc = fx["config"], rf["config"]
-    assert (fc["base"], fc["dims"], list(fc["shape"]), fc["iters"], fc["held_out"]) == \
-           (rc["base"], rc["dims"], list(rc["shape"]), rc["iters"], rc["held_out"]), (fc, rc)
-    got = np.asarray(fx["dice_percent"][arm])
-    seeds = [s for s in range(len(got)) if str(s) in rf["orders"]]
+    rc = rf["config"]
+    by_seed = {}
+    for path in sys.argv[1].split(","):
+        fx = json.load(open(path))
+        fc = fx["config"]
+        assert (fc["base"], fc["dims"], list(fc["shape"]), fc["iters"], fc["held_out"]) == \
+               (rc["base"], rc["dims"], list(rc["shape"]), rc["iters"], rc["held_out"]), (fc, rc)
+        for i, row in enumerate(fx["dice_percent"][arm]):
+            by_seed[fc.get("first_seed", 0) + i] = row
+    seeds = sorted(s for s in by_seed if str(s) in rf["orders"])
+    got = {s: by_seed[s] for s in seeds}
     ref = np.asarray([rf["orders"][str(s)]["dice_percent"] for s in seeds])
+    got = np.asarray([got[s] for s in seeds])
+    seeds = list(range(len(seeds)))
     out = ["config: %s" % json.dumps(rc),
            "REFERENCE arm: %s" % rf["what"],
            "  Dice %% over orders: %s (mean %.2f, std %.2f)" % (" ".join("%.2f" % v for v in ref.mean(1)), ref.mean(), ref.mean(1).std()),
