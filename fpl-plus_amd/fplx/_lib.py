@@ -100,7 +100,7 @@ def tuning_keys():
 
 
 def set_tuning(key, value):
-    """fplx_set_tuning: A/B knob of the kernel dispatchers (benchmarks and tests only; no knob changes a result)"""
+    """fplx_set_tuning: A/B knob of the kernel dispatchers (benchmarks and tests only; every knob selects among kernels computing the same function - some in another order of fp32 additions)"""
     check(lib().fplx_set_tuning(key.encode(), int(value)))
 
 

@@ -11,7 +11,7 @@
  *  - plain C: raw device pointers + sizes.  The CALLER owns every buffer (including
  *    workspaces); the library allocates nothing.  Its only mutable state is the table of
  *    integer tuning knobs behind fplx_set_tuning (A/B measurements; the defaults are the shipped
- *    configuration and no knob changes a result, only which kernel computes it) and the calling
+ *    configuration and every knob selects among kernels computing the same function - some in another order of fp32 additions, only which kernel computes it) and the calling
  *    thread's last error message.  The library never reads the environment.
  *  - only the functions declared here are exported (the library is built with
  *    -fvisibility=hidden; tests/test_host_cpu.py compares `nm -D` with this file).
