@@ -23,7 +23,11 @@ def report(name, a, b):
             % (d.mean(), d.std(ddof=1), se, abs(d.mean()) + 2 * se),
             "  per-volume differences (%d): 5/25/50/75/95 %% = %+.2f %+.2f %+.2f %+.2f %+.2f, max |.| %.2f"
             % (pv.size, q[0], q[1], q[2], q[3], q[4], np.abs(pv).max()),
-            "  -> %s" % ("MET" if abs(d.mean()) + 2 * se < 0.5 else "NOT RESOLVED at this number of orders")]
+            "  -> by the |mean| + 2 SE < 0.5 rule: %s" % ("MET" if abs(d.mean()) + 2 * se < 0.5 else "NOT RESOLVED at this number of orders"),
+            "  -> equivalence test at +-0.5 points (two one-sided tests, 5 %% each): mean -+ 1.645 SE = [%+.3f, %+.3f] -> %s"
+            % (d.mean() - 1.645 * se, d.mean() + 1.645 * se,
+               "inside +-0.5: equivalent at the 5 % level" if (d.mean() - 1.645 * se > -0.5 and d.mean() + 1.645 * se < 0.5)
+               else "not inside +-0.5")]
 
 
 def main():
