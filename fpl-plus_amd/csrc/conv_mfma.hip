@@ -2170,6 +2170,18 @@ extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* 
   return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, nullptr, ws, ws_bytes, mid, st, slope);
 }
 
+// conv_wgrad.hip (rolling-window weight gradient): same partial-tile format, reduced by wgrad_stream_reduce
+extern "C" int fplx_wgroll_ok(int n, int d, int h, int w, int cin, int cout, int64_t ldx, int64_t ldy);
+extern "C" size_t fplx_wgroll_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d, int h,
+                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1);
+extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
+                                        hipStream_t st) {
+  const int64_t total = (int64_t)npairs * 27 * 1024;
+  wgrad_stream_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw, mid);
+  return fplx_check_launch("wgrad_stream_reduce");
+}
+
 extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 32 != 0 || cout % 32 != 0) return 0;
   return wg_cfg(n, d, h, w, cin, cout).cit;
@@ -2178,8 +2190,10 @@ extern "C" int fplx_mfma_conv3d_wgrad_cit(int n, int d, int h, int w, int cin, i
 extern "C" size_t fplx_mfma_conv3d_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
   if (cin % 32 != 0 || cout % 32 != 0) return 0;
   const size_t a = wg_cfg(n, d, h, w, cin, cout).ws;
-  const VoxCfg v = vox_cfg(n, d, h, w, cin, cout);          // the larger of the two: the 2.5D form of a layer never takes vox
-  return (v.ok && v.ws > a) ? v.ws : a;
+  const VoxCfg v = vox_cfg(n, d, h, w, cin, cout);          // the largest of the three: the 2.5D form of a layer never takes vox
+  size_t m = (v.ok && v.ws > a) ? v.ws : a;                 // or the rolling-window kernel, and a knob may switch kernels
+  if (fplx_wgroll_ok(n, d, h, w, cin, cout, cin, cout)) { const size_t r = fplx_wgroll_ws_bytes(n, d, h, w, cin, cout); if (r > m) m = r; }
+  return m;
 }
 
 // returns 1 if handled, 0 if not applicable, <0 on error.  dw fp32 [Cout][Cin][27]
@@ -2206,6 +2220,10 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
       int rcv = fplx_check_launch("mfma_conv3d_wgrad_vox");
       return rcv < 0 ? rcv : 1;
     }
+  }
+  if (!mid) {                                               // the rolling-window kernel (conv_wgrad.hip) where it applies
+    const int rr = fplx_wgroll_conv3d_wgrad(x, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, st, x1);
+    if (rr != 0) return rr;
   }
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);
   if (x1 && (c.cit != 2 || cin != 64 || ((uintptr_t)x1 % 16))) return 0;   // split x: one group of two ci tiles

@@ -1,0 +1,321 @@
+// Rolling-window weight gradient of the 3x3x3 convolution for gfx950 (bf16 NDHWC operands, fp32 accumulate).
+//
+//   dW[tap][ci][co] = sum over voxels v of x[v + tap][ci] * dy[v][co]          (autograd of nn.Conv3d,
+//   reference PyMIC/pymic/net/net3d/unet2d5_dsbn.py:54-55,75,79 - ConvolutionLayer inside ConvBlockND)
+//
+// conv_wgrad_roll replaces conv_wgrad_stream (conv_mfma.hip) on the large levels.  Same decomposition - a block owns a
+// TH x TW footprint in (h, w) of one 32 x 32 (ci, co) tile pair and marches along d; voxels are the K dimension; both MFMA
+// operands are transposes of the NDHWC image and come out of LDS through ds_read_b64_tr_b16; per-block partial tiles in the
+// same [tap][co][ci] format, summed in a fixed order by wgrad_stream_reduce - but:
+//   * ROLLING WINDOW over the kernel row.  The x fragment (slab kd, slab row rx, column offset kw) is the A operand of the
+//     three taps (kd, kh, kw), kh = 0..2, paired with the dy rows rx - kh.  A wave owns whole kh-triples, walks rx over the
+//     TH + 2 slab rows, loads that fragment ONCE and keeps the last three dy fragments in registers: 4 fragments per 7 MFMAs
+//     (1.3 transposed reads per MFMA with the edge rows) where the tap-per-fragment form reads 8 (2.3).  The 9 triples
+//     (kd, kw) are dealt 2 + 2 + 2 + 2 to the four waves and the ninth is split into its three taps: 7 / 7 / 7 / 6 tiles.
+//   * <= 256 REGISTERS per lane (7 accumulator tiles + 10 fragments + 10 DMA offsets), one wave per SIMD: half of every
+//     SIMD's register file stays free, so the HBM-bound BatchNorm passes of the main stream co-reside on every CU while the
+//     weight gradients run on the second stream (profiles/r03_coresidency_probe.txt: beside the 504-register form the
+//     level-0 apply pass took 361-522 us instead of 128).
+//   * LDS-DMA staging through buffer descriptors (buffer_load_dwordx4 ... offen lds): halo, padding and ragged footprints are
+//     the hardware's out-of-range zeros, the per-lane offsets are constants of the march, the depth is the scalar offset;
+//     no staging registers, no commit phase, a 4-slot x ring + 2-slot dy ring.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
+                                        hipStream_t st);      // conv_mfma.hip
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int TH_, int TW_>
+struct WR {
+  static constexpr int TH = TH_, TW = TW_, SH = TH + 2, SW = TW + 2, SLAB = SH * SW;
+  static constexpr int XP = (SLAB * 4 + 63) / 64;          // 1-KiB DMA pieces per x slab (64-byte voxel rows)
+  static constexpr int XSLOT = XP * 1024;
+  static constexpr int YP = TH * TW * 4 / 64;              // ... per dy slab
+  static constexpr int YSLOT = YP * 1024;
+  static constexpr int NXS = 4, NYS = 2;
+  static constexpr int LDS = NXS * XSLOT + NYS * YSLOT;
+  static constexpr int NCH = TW / 16;                      // 16-voxel K chunks per row
+  static constexpr int NCELL = NCH * SH;                   // (chunk, slab row) cells per depth step
+  static constexpr int XPW = (XP + 3) / 4, YPW = (YP + 3) / 4;   // pieces per wave
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
+  // two transposed 4 x 16 block reads: voxels +0..3 and +4..7 of a lane group's 8 (64 bytes per voxel row)
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo + 4 * 64));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// Tap ownership of wave WV: triples (kd, kw) = 2 WV, 2 WV + 1 of the row-major (kd, kw) enumeration, each with its three kh;
+// waves 0-2 also own tap (kd 2, kh WV, kw 2) of the ninth triple.  Local tile j * 3 + kh (triple j), 6 = the single.
+template <int WV> struct RollTaps {
+  static constexpr int NT = WV < 3 ? 7 : 6;
+  static constexpr int kd(int j) { return j < 2 ? (2 * WV + j) / 3 : 2; }
+  static constexpr int kw(int j) { return j < 2 ? (2 * WV + j) % 3 : 2; }
+  static constexpr int tap(int i) { return i < 6 ? kd(i / 3) * 9 + (i % 3) * 3 + kw(i / 3) : 18 + WV * 3 + 2; }
+};
+
+template <class G, int WV>
+__device__ __forceinline__ void roll_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                           int64_t ldy, float* __restrict__ part, int D, int H, int W, int Cin, int Cout,
+                                           int tilesH, int tilesW, int dsegs, int dlen, const bf16_t* __restrict__ x1,
+                                           const FplxBlock bid) {
+  using T = RollTaps<WV>;
+  constexpr int TH = G::TH, TW = G::TW, SH = G::SH, SW = G::SW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;
+  char* ys = smem + G::NXS * G::XSLOT;
+  const int lane = threadIdx.x & 63;
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int ncg = Cin / 32;
+  const int cot = bid.y / ncg, cg = bid.y % ncg;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+
+  // ---- DMA geometry: per-lane byte offsets inside a depth slice (constants of the march), 0x40000000 = out of range
+  unsigned xvo[G::XPW], yvo[G::YPW];
+#pragma unroll
+  for (int k = 0; k < G::XPW; ++k) {
+    const int i = (WV + 4 * k) * 64 + lane;
+    const int vox = i >> 2, c = i & 3;
+    const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
+    const bool in = vox < G::SLAB && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    xvo[k] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
+  }
+#pragma unroll
+  for (int k = 0; k < G::YPW; ++k) {
+    const int i = (WV + 4 * k) * 64 + lane;
+    const int vox = i >> 2, c = i & 3;
+    const int hh = vox / TW + h0, ww = vox % TW + w0;
+    yvo[k] = (hh < H && ww < W) ? (unsigned)((((int64_t)hh * W + ww) * ldy + c * 8) * 2) : 0x40000000u;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2, yslice = (int64_t)H * W * ldy * 2;
+  // the two ci tiles of a split concatenation (x1 != NULL, Cin = 64) come from two tensors
+  const char* xn = reinterpret_cast<const char*>((x1 && cg == 1) ? x1 : x + cg * 32) + (int64_t)n * D * xslice;
+  const char* yn = reinterpret_cast<const char*>(dy + cot * 32) + (int64_t)n * D * yslice;
+  u32x4 xr, yr;
+  xr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  xr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  xr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * xslice - (ldx - 32) * 2));
+  xr[3] = 0x00020000u;
+  yr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)yn);
+  yr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)yn >> 32) & 0xFFFFu);
+  yr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * yslice - (ldy - 32) * 2));
+  yr[3] = 0x00020000u;
+  const unsigned xslice32 = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+  const unsigned yslice32 = __builtin_amdgcn_readfirstlane((unsigned)yslice);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  auto dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst) {    // dst: LDS byte address of the 1-KiB piece
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so), "s"(dst) : "memory");
+  };
+  // x slab of depth d0 - 1 + m lives in slot m & 3, the dy slab of depth d0 + t in slot t & 1
+  // on = false (nothing follows this block's last depth): the scalar offset is out of range, the slot - a free one - gets zeros
+  auto dma_x = [&](int m, int k, bool on) {            // piece WV + 4 k of slab m
+    if (WV + 4 * k < G::XP) {
+      const int s = d0 - 1 + m;
+      const unsigned so = __builtin_amdgcn_readfirstlane((on && s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
+      dma(xr, xvo[k], so, lds0 + (unsigned)((m & 3) * G::XSLOT + (WV + 4 * k) * 1024));
+    }
+  };
+  auto dma_y = [&](int t, int k, bool on) {
+    if (WV + 4 * k < G::YP) {
+      const int s = d0 + t;
+      const unsigned so = __builtin_amdgcn_readfirstlane((on && s < D) ? (unsigned)s * yslice32 : 0x40000000u);
+      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + (t & 1) * G::YSLOT + (WV + 4 * k) * 1024));
+    }
+  };
+
+  // transposed-read lane geometry: group g = lane / 16 reads voxel rows 8 (g >> 1) + q, channels 16 (g & 1) + 4 p ..
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+
+  f32x16 acc[T::NT];
+#pragma unroll
+  for (int i = 0; i < T::NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // prologue: slabs d0 - 1, d0, d0 + 1 and dy(d0)
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, true);
+#pragma unroll
+  for (int k = 0; k < G::YPW; ++k) dma_y(0, k, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 fx[2][3];       // [cell parity][triple 0, triple 1, single]
+  bf16x8 fy[4];          // dy rows, ring by row & 3
+  const int nd = d1 - d0;
+#pragma unroll 1
+  for (int t = 0; t < nd; ++t) {
+    const char* sb[3] = {xs + ((t + 0) & 3) * G::XSLOT + lane_off, xs + ((t + 1) & 3) * G::XSLOT + lane_off,
+                         xs + ((t + 2) & 3) * G::XSLOT + lane_off};
+    const char* yb = ys + (t & 1) * G::YSLOT + lane_off;
+    const bool more = t + 1 < nd;
+    // load item i of cell k: 0 / 1 = the triples' x fragments, 2 = the single's, 3 = the dy row entering the window
+    auto load_item = [&](int k, int i) {
+      const int c = k / SH, rx = k % SH;
+      if (i < 2) fx[k & 1][i] = tr_frag(sb[T::kd(i)] + ((rx * SW + c * 16 + T::kw(i)) * 64));
+      else if (i == 2) { if (WV < 3 && rx - WV >= 0 && rx - WV < TH) fx[k & 1][2] = tr_frag(sb[2] + ((rx * SW + c * 16 + 2) * 64)); }
+      else if (rx < TH) fy[rx & 3] = tr_frag(yb + ((rx * TW + c * 16) * 64));
+    };
+    auto mfma_item = [&](int k, int i) {
+      const int rx = k % SH;
+      const int r = i < 6 ? rx - i % 3 : rx - WV;        // dy row of this tap
+      if (i < T::NT && r >= 0 && r < TH)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[k & 1][i < 6 ? i / 3 : 2], fy[r & 3], acc[i], 0, 0, 0);
+    };
+    load_item(0, 3); load_item(0, 0); load_item(0, 1); load_item(0, 2);
+#pragma unroll
+    for (int k = 0; k < G::NCELL; ++k) {
+      // the fragments of cell k + 1 are requested one at a time in the gaps between the MFMAs of cell k; one DMA piece of
+      // the next depth's slabs per cell while there are any
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        if (k + 1 < G::NCELL) {
+          if (i == 0) load_item(k + 1, 3);
+          if (i == 2) load_item(k + 1, 0);
+          if (i == 4) load_item(k + 1, 1);
+          if (i == 5) load_item(k + 1, 2);
+        }
+        if (i == 3) {
+          if (k < G::XPW) dma_x(t + 3, k, more);
+          else if (k - G::XPW < G::YPW) dma_y(t + 1, k - G::XPW, more);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_item(k, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // partial tiles: part[block][pair][tap][co][ci] - a lane owns 4 consecutive ci per register quad: 16-byte stores
+  const int co = lane & 31, rbase = (lane >> 5) * 4;
+  const int pair = cot * ncg + cg;
+  float* out = part + ((int64_t)bid.x * (ncg * (Cout / 32)) + pair) * (27 * 1024);
+#pragma unroll
+  for (int i = 0; i < T::NT; ++i) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<float4*>(out + (T::tap(i) * 32 + co) * 32 + 8 * g4 + rbase) =
+          make_float4(acc[i][4 * g4 + 0], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
+  }
+}
+
+template <int TH, int TW>
+__global__ void __launch_bounds__(256, 2)
+conv_wgrad_roll(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                float* __restrict__ part, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW, int dsegs, int dlen,
+                const bf16_t* __restrict__ x1, int xcd) {
+  using G = WR<TH, TW>;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform: four copies of the march
+    case 0: roll_march<G, 0>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 1: roll_march<G, 1>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 2: roll_march<G, 2>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    default: roll_march<G, 3>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+  }
+}
+
+struct RollCfg { int th, tw, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
+
+inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
+  RollCfg c;
+  // footprint: the one that pads the (h, w) plane least; 16 x 16 on a tie (fewer slab rows per dy row, smaller halo)
+  const int geo = (int)fplx_knob(FPLX_K_WG_ROLL_GEO);
+  auto area = [&](int th, int tw) { return (int64_t)((h + th - 1) / th) * th * ((w + tw - 1) / tw) * tw; };
+  c.th = 16; c.tw = 16;
+  if (area(8, 32) < area(c.th, c.tw)) { c.th = 8; c.tw = 32; }
+  if (area(8, 16) < area(c.th, c.tw)) { c.th = 8; c.tw = 16; }
+  if (geo == 1) { c.th = 8; c.tw = 32; } else if (geo == 2) { c.th = 16; c.tw = 16; } else if (geo == 3) { c.th = 8; c.tw = 16; }
+  c.tilesH = (h + c.th - 1) / c.th;
+  c.tilesW = (w + c.tw - 1) / c.tw;
+  c.npairs = (cin / 32) * (cout / 32);
+  const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * c.npairs;
+  // one block per CU at a time: the depth split that minimises rounds x (depths per block + per-block overhead)
+  const double ovh = (double)fplx_knob(FPLX_K_WG_ROLL_OVH);
+  int ds = 1;
+  double best = 1e30;
+  for (int cand = 1; cand <= d; ++cand) {
+    const int dl = (d + cand - 1) / cand;
+    if (dl < 4 && cand > 1) break;
+    const int segs = (d + dl - 1) / dl;
+    const int64_t rounds = (tiles * segs + 255) / 256;
+    const double cost = (double)rounds * (dl + ovh);
+    if (cost < best - 1e-9) { best = cost; ds = segs; }
+  }
+  {
+    const int e = (int)fplx_knob(FPLX_K_WG_DS);
+    if (e > 0) ds = e;
+  }
+  c.dlen = (d + ds - 1) / ds;
+  c.dsegs = (d + c.dlen - 1) / c.dlen;
+  c.nblk = n * c.tilesH * c.tilesW * c.dsegs;
+  c.ws = (size_t)c.nblk * c.npairs * 27 * 1024 * sizeof(float);
+  return c;
+}
+
+}  // namespace
+
+// 1 if the rolling-window kernel takes the layer (3D, both channel counts multiples of 32, a sample below 1 GiB so that the
+// out-of-range marker 0x40000000 cannot alias a voxel)
+extern "C" int fplx_wgroll_ok(int n, int d, int h, int w, int cin, int cout, int64_t ldx, int64_t ldy) {
+  if (!fplx_knob(FPLX_K_WG_ROLL)) return 0;
+  if (cin % 32 != 0 || cout % 32 != 0) return 0;
+  if ((int64_t)d * h * w < fplx_knob(FPLX_K_WG_ROLL_MINVOX)) return 0;
+  if (h < 8 || w < 16) return 0;
+  if ((int64_t)d * h * w * ldx * 2 > ((int64_t)1 << 30) || (int64_t)d * h * w * ldy * 2 > ((int64_t)1 << 30)) return 0;
+  return 1;
+}
+
+extern "C" size_t fplx_wgroll_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
+  return roll_cfg(n, d, h, w, cin, cout).ws;
+}
+
+// returns 1 if launched, 0 if not applicable, < 0 on error.  dw fp32 [Cout][Cin][27]; x1: second ci tile of a split Cin = 64
+extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d, int h,
+                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1) {
+  if (!fplx_wgroll_ok(n, d, h, w, cin, cout, ldx, ldy)) return 0;
+  if (ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)x1 % 16)) return 0;
+  if (x1 && cin != 64) return 0;
+  const RollCfg c = roll_cfg(n, d, h, w, cin, cout);
+  if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "wgroll_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
+  dim3 grid(c.nblk, c.npairs);
+#define LAUNCH_ROLL(TH_, TW_)                                                                                        \
+  do {                                                                                                              \
+    using G_ = WR<TH_, TW_>;                                                                                        \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll<TH_, TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_wgrad_roll<TH_, TW_><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, \
+                                                         cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, \
+                                                         fplx_xcd_on());                                            \
+  } while (0)
+  if (c.th == 16) LAUNCH_ROLL(16, 16); else if (c.tw == 32) LAUNCH_ROLL(8, 32); else LAUNCH_ROLL(8, 16);
+#undef LAUNCH_ROLL
+  int rc = fplx_check_launch("wgroll_conv3d_wgrad");
+  if (rc < 0) return rc;
+  rc = fplx_wgrad_reduce_launch((const float*)ws, c.nblk, c.npairs, cin, cout, dw, 0, st);
+  return rc < 0 ? rc : 1;
+}

@@ -607,6 +607,56 @@ def test_conv3d_wgrad_vox_kernel(shape):
     assert float((got[2] - got[0]).abs().max()) < 1e-4 * scale + 1e-6
 
 
+@pytest.mark.parametrize("shape,geo", [
+    ((1, 32, 32, 9, 16, 64), 1),         # 8 x 32 footprints, exact fit, one depth segment
+    ((2, 32, 64, 7, 20, 70), 1),         # ... ragged in h and w, n = 2, two co tiles
+    ((1, 64, 32, 37, 24, 64), 1),        # ... several depth segments, two ci tiles
+    ((1, 32, 32, 12, 32, 48), 2),        # 16 x 16 footprints, exact fit
+    ((3, 32, 96, 6, 17, 65), 2),         # ... ragged, n = 3, three co tiles
+    ((1, 64, 64, 20, 40, 40), 2),        # ... level-2-like
+    ((2, 64, 128, 20, 40, 40), 3),       # 8 x 16 footprints: level 2 of the benchmark
+    ((1, 96, 32, 5, 9, 17), 3),          # ... ragged, short volume
+    ((2, 32, 32, 40, 48, 64), 0),        # the dispatcher's own choice
+    ((1, 128, 64, 10, 20, 20), 0)])
+def test_conv3d_wgrad_roll_kernel(shape, geo):
+    """conv_wgrad_roll (rolling-window weight gradient, conv_wgrad.hip): against torch autograd, bf16 operands given as channel
+    slices of wider buffers, every footprint forced by the tuning knob wg_roll_geo; and the same numbers as the footprint
+    march it replaces (wg_roll = 0) up to the order of the fp32 additions.  Reference: autograd of nn.Conv3d,
+    unet2d5_dsbn.py:54-55."""
+    from fplx import ops
+    _lib = ops._lib
+    n, cin, cout, d, h, w = shape
+    q = lambda t: t.bfloat16().float()
+    x = q(torch.from_numpy(detdata.normal("rl.x%s" % (shape,), (n, cin, d, h, w))))
+    dy = q(torch.from_numpy(detdata.normal("rl.dy%s" % (shape,), (n, cout, d, h, w))))
+    wr = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, wr, None, padding=1).backward(dy)
+    bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
+    xw = torch.full((n * d * h * w, cin + 32), 3.0, dtype=bf, device="cuda")
+    xw[:, 8:8 + cin] = cl(x).to(bf).cuda()
+    dyw = torch.full((n * d * h * w, cout + 16), 5.0, dtype=bf, device="cuda")
+    dyw[:, 16:] = cl(dy).to(bf).cuda()
+    xg, dyg = xw[:, 8:8 + cin], dyw[:, 16:]
+    got = {}
+    for roll in (1, 0):
+        _lib.set_tuning("wg_roll", roll)
+        _lib.set_tuning("wg_roll_geo", geo)
+        _lib.set_tuning("wg_vox", 0)
+        try:
+            ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+            dw = torch.full((cout, cin, 3, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+            ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin + 32), dt, dyg, ops.cl_strides(d, h, w, cout + 16), dt, dw, None,
+                             dims, cin, cout, (3, 3, 3), ws)
+            got[roll] = dw.cpu()
+        finally:
+            _lib.set_tuning("wg_roll", 1)
+            _lib.set_tuning("wg_roll_geo", 0)
+            _lib.set_tuning("wg_vox", 1)
+    scale = float(wr.grad.abs().max())
+    assert float((got[1] - wr.grad).abs().max()) < 1e-4 * scale + 1e-6, float((got[1] - wr.grad).abs().max()) / scale
+    assert float((got[1] - got[0]).abs().max()) < 1e-4 * scale + 1e-6
+
+
 @pytest.mark.parametrize("shape", [
     (4, 64, 32, 16, 32, 64),       # the depth march on two 32-channel half-slabs (level 0), x0 shared by 2 passes
     (4, 128, 64, 16, 32, 44),      # the brick kernel's two-tensor form (level 1: 64 || 64 -> 64), ragged bricks in W

@@ -1,6 +1,9 @@
-"""Weight-gradient kernels of the deep levels, isolated: the footprint march (wg_vox = 0) against the voxel GEMM (wg_vox = 2) on
-the benchmark's level 2-4 layers (2 x 20 x 40 x 40, 2 x 10 x 20 x 20, 2 x 5 x 10 x 10), interleaved rounds in one process.
-usage: python tools/wgrad_bench.py"""
+"""Weight-gradient kernels, isolated (HIP events, interleaved rounds in one process): the benchmark's 3x3x3 layers under a list of
+tuning-knob settings, e.g. the footprint march (wg_roll = 0) against the rolling-window kernel (wg_roll = 1) and its footprints.
+Every setting's result is compared with the first one's (relative to the largest gradient entry).
+
+    python tools/wgrad_bench.py [level ...]            levels 0-4 of the benchmark shape (default: 0 1 2)
+    FPLX_WGB_SETTINGS="wg_roll=0;wg_roll=1;wg_roll=1,wg_roll_geo=1" python tools/wgrad_bench.py 0"""
 import os
 import sys
 
@@ -9,46 +12,70 @@ import torch  # noqa: E402
 
 from fplx import ops, _lib  # noqa: E402
 
-LAYERS = [((2, 20, 40, 40), 64, 128), ((2, 20, 40, 40), 128, 128), ((2, 20, 40, 40), 256, 128),
-          ((2, 10, 20, 20), 128, 256), ((2, 10, 20, 20), 256, 256), ((2, 10, 20, 20), 512, 256),
-          ((2, 5, 10, 10), 256, 512), ((2, 5, 10, 10), 512, 512),
-          ((4, 28, 32, 32), 64, 128), ((4, 28, 32, 32), 128, 128)]       # + level 2 of the shipped 2.5D config
+LEVELS = {0: [((2, 80, 160, 160), 32, 32), ((2, 80, 160, 160), 64, 32)],
+          1: [((2, 40, 80, 80), 32, 64), ((2, 40, 80, 80), 64, 64), ((2, 40, 80, 80), 128, 64)],
+          2: [((2, 20, 40, 40), 64, 128), ((2, 20, 40, 40), 128, 128), ((2, 20, 40, 40), 256, 128)],
+          3: [((2, 10, 20, 20), 128, 256), ((2, 10, 20, 20), 256, 256), ((2, 10, 20, 20), 512, 256)],
+          4: [((2, 5, 10, 10), 256, 512), ((2, 5, 10, 10), 512, 512)],
+          25: [((4, 28, 32, 32), 64, 128), ((4, 28, 32, 32), 128, 128)]}     # level 2 of the shipped 2.5D config
+
+
+def parse_settings():
+    txt = os.environ.get("FPLX_WGB_SETTINGS", "wg_roll=0;wg_roll=1")
+    out = []
+    for s in txt.split(";"):
+        kv = {}
+        for item in s.split(","):
+            k, v = item.split("=")
+            kv[k.strip()] = int(v)
+        out.append((s.strip(), kv))
+    return out
 
 
 def main():
+    levels = [int(a) for a in sys.argv[1:]] or [0, 1, 2]
+    settings = parse_settings()
+    keys = sorted({k for _, kv in settings for k in kv})
+    defaults = {k: _lib.get_tuning(k) for k in keys}
     bf, dt = torch.bfloat16, ops.BF16
-    print("%-28s %10s %10s %8s   (us per launch incl. the reduction, median of 5 rounds x 20 launches)" % ("layer", "march", "vox", "ratio"))
-    tot = [0.0, 0.0]
-    for dims, cin, cout in LAYERS:
-        n, d, h, w = dims
-        v = n * d * h * w
-        x = torch.randn(v, cin, device="cuda").to(bf)
-        dy = (torch.randn(v, cout, device="cuda") * 0.01).to(bf)
-        dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device="cuda")
-        res = {0: [], 2: []}
-        for rnd in range(5):
-            for mode in (0, 2):
-                _lib.set_tuning("wg_vox", mode)
-                ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
-                f = lambda: ops.conv3d_wgrad(x, ops.cl_strides(d, h, w, cin), dt, dy, ops.cl_strides(d, h, w, cout), dt, dw, None,
-                                             dims, cin, cout, (3, 3, 3), ws)
-                for _ in range(3):
-                    f()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    f()
-                e1.record()
-                torch.cuda.synchronize()
-                res[mode].append(e0.elapsed_time(e1) * 50.0)
-        _lib.set_tuning("wg_vox", 1)
-        a, b = sorted(res[0])[2], sorted(res[2])[2]
-        fl = 2.0 * v * 27 * cin * cout
-        print("%-28s %10.1f %10.1f %8.2f   vox: %.3f of 2.5 PFLOP/s" % ("%s %d->%d" % (dims, cin, cout), a, b, a / b, fl / (b * 1e-6) / 2.5e15))
-        if dims[0] == 2:
-            tot[0] += a
-            tot[1] += b
-    print("benchmark layers (once each): march %.0f us, vox %.0f us" % (tot[0], tot[1]))
+    print("us per launch incl. the reduction, median of 5 rounds x 10 launches; fraction of 2.5 PFLOP/s; max |diff| vs the first "
+          "setting / max |dw|")
+    for lv in levels:
+        for dims, cin, cout in LEVELS[lv]:
+            n, d, h, w = dims
+            v = n * d * h * w
+            x = torch.randn(v, cin, device="cuda").to(bf)
+            dy = (torch.randn(v, cout, device="cuda") * 0.01).to(bf)
+            res = {name: [] for name, _ in settings}
+            outs = {}
+            for rnd in range(5):
+                for name, kv in settings:
+                    for k in keys:
+                        _lib.set_tuning(k, kv.get(k, defaults[k]))
+                    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+                    dw = torch.empty((cout, cin, 3, 3, 3), dtype=torch.float32, device="cuda")
+                    f = lambda: ops.conv3d_wgrad(x, ops.cl_strides(d, h, w, cin), dt, dy, ops.cl_strides(d, h, w, cout), dt, dw,
+                                                 None, dims, cin, cout, (3, 3, 3), ws)
+                    for _ in range(2):
+                        f()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        f()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    res[name].append(e0.elapsed_time(e1) * 100.0)
+                    if rnd == 0:
+                        outs[name] = dw.clone()
+            for k in keys:
+                _lib.set_tuning(k, defaults[k])
+            fl = 2.0 * v * 27 * cin * cout
+            ref = outs[settings[0][0]]
+            for name, _ in settings:
+                t = sorted(res[name])[2]
+                err = float((outs[name] - ref).abs().max() / ref.abs().max())
+                print("%-26s %-34s %8.1f us  %.3f   diff %.2e" % ("%s %d->%d" % (dims, cin, cout), name, t, fl / (t * 1e-6) / 2.5e15, err),
+                      flush=True)
 
 
 if __name__ == "__main__":
