@@ -1396,6 +1396,15 @@ extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout) {
   return 0;
 }
 
+// which depth march a layer takes (fplx_conv3d_plan_query's geometry for FPLX_KERNEL_MARCH): Cin = 32: 2 = the one-wave-per-SIMD
+// kernels for footprints inside the volume (conv_fwd_march32v2 with statistics, conv_fwd_march32v3 without, for operands
+// with ld = channels), 0 = the 8-wave conv_fwd_march32; Cin >= 64: the footprint width of conv_fwd_march64 (16 | 32)
+extern "C" int fplx_march_variant(int n, int d, int h, int w, int cin, int cout) {
+  if (cin == 32)
+    return (fplx_knob(FPLX_K_MARCH32_V2) && h % MG2::FH == 0 && w % MG2::FW == 0 && (int64_t)d * h * w * cin * 2 <= ((int64_t)1 << 30)) ? 2 : 0;
+  return march_cfg(n, d, h, w, cin, cout).fw;
+}
+
 extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout) {
   return march_cfg(n, d, h, w, cin, cout).nblk;
 }

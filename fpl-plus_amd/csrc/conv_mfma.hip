@@ -1951,6 +1951,7 @@ inline bool mfma_applicable(int64_t ldx, int64_t ldy, int cin, int cout, const v
 // conv_march.hip
 extern "C" int fplx_march_ok(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_rows(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_march_variant(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_march_conv3d_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy,
                                      int n, int d, int h, int w, int cin, int cout, float* stats, hipStream_t st,
                                      const void* x1, void* y1, int twod);
@@ -2020,7 +2021,7 @@ extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int co
   if (cin % 16 != 0 || cout % 32 != 0 || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   auto brick = [&]() { int b; fplx_brick_plan(n, d, h, w, cin, cout, geo, ksplit, &b); *kernel = FPLX_KERNEL_BRICK; return 1; };
   if (!mid && fplx_brick_first(n, d, h, w, cin, cout)) return brick();
-  if (fplx_march_ok(n, d, h, w, cin, cout)) { *kernel = FPLX_KERNEL_MARCH; return 1; }
+  if (fplx_march_ok(n, d, h, w, cin, cout)) { *kernel = FPLX_KERNEL_MARCH; *geo = fplx_march_variant(n, d, h, w, cin, cout); return 1; }
   if (stream_ok(d, h, w, cin, cout)) { *kernel = FPLX_KERNEL_STREAM; return 1; }
   if (!mid && fplx_brick_ok(n, d, h, w, cin, cout)) return brick();
   const DirectCfg c = direct_cfg((int64_t)n * d * h * w, cin, cout, mid_tile(mid, n, d, h, w, cin, cout) ? 9 : 27);

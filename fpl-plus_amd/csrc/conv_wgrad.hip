@@ -225,6 +225,216 @@ __device__ __forceinline__ void roll_march(const bf16_t* __restrict__ x, int64_t
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// roll16_march: the same march on v_mfma_f32_16x16x32_bf16 (TW = 32: one K = 32-voxel chunk per footprint row).  These kernels
+// run against the chip's power limit, and the 16 x 16 x 32 shape moves the same FLOPs for less (MI355X_MICROARCH.md, DVFS
+// give-back item 7).  A 32 x 32 tile is four 16 x 16 blocks (ci half a, co half b); per tap and row 2 + 2 fragments feed 4 MFMAs
+// - the LDS traffic per FLOP of the 32 x 32 x 16 form.  The LDS image is two PLANES per slab, one per 16-channel half, with
+// 32-byte voxel rows: a fragment's 8 voxels x 16 channels per 32 lanes are then 256 contiguous bytes - conflict-free for every
+// tap shift without a swizzle - and the lane offset of a transposed read is simply lane * 8.  MFMA k-slot 8 g + j (g = lane / 16)
+// holds voxel 4 g + (j & 3) + 16 (j >> 2) of the chunk, for x and dy alike (any bijection serves, both operands use this one).
+// A DMA piece is 32 voxels of one plane: lane i fetches 16-byte chunk 2 cb + (i & 1) of voxel i / 2.
+template <int TH_>
+struct WR16 {
+  static constexpr int TH = TH_, TW = 32, SH = TH + 2, SW = TW + 2, SLAB = SH * SW;
+  static constexpr int XPP = (SLAB * 2 + 63) / 64;         // 1-KiB pieces per x plane (32-byte rows)
+  static constexpr int XPLANE = XPP * 1024, XP = 2 * XPP, XSLOT = 2 * XPLANE;
+  static constexpr int YPP = TH * TW * 2 / 64;
+  static constexpr int YPLANE = YPP * 1024, YP = 2 * YPP, YSLOT = 2 * YPLANE;
+  static constexpr int NXS = 4, NYS = 2;
+  static constexpr int LDS = NXS * XSLOT + NYS * YSLOT;
+  static constexpr int NCELL = SH;
+  static constexpr int XPW = (XP + 3) / 4, YPW = (YP + 3) / 4;
+};
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <class G, int WV>
+__device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                             int64_t ldy, float* __restrict__ part, int D, int H, int W, int Cin, int Cout,
+                                             int tilesH, int tilesW, int dsegs, int dlen, const bf16_t* __restrict__ x1,
+                                             const FplxBlock bid) {
+  using T = RollTaps<WV>;
+  constexpr int TH = G::TH, TW = G::TW, SH = G::SH, SW = G::SW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int ncg = Cin / 32;
+  const int cot = bid.y / ncg, cg = bid.y % ncg;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+
+  // ---- DMA geometry.  Piece P = 2 p + cb (p-th KiB of plane cb): the two halves of a voxel row are fetched by neighbouring
+  // waves in the same cell, i.e. close in time (the second request for the line hits in L2)
+  unsigned xvo[G::XPW], yvo[G::YPW];
+#pragma unroll
+  for (int k = 0; k < G::XPW; ++k) {
+    const int P = WV + 4 * k, pp = P >> 1, cb = P & 1;
+    const int vox = pp * 32 + (lane >> 1), c = 2 * cb + (lane & 1);
+    const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
+    const bool in = vox < G::SLAB && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    xvo[k] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
+  }
+#pragma unroll
+  for (int k = 0; k < G::YPW; ++k) {
+    const int P = WV + 4 * k, pp = P >> 1, cb = P & 1;
+    const int vox = pp * 32 + (lane >> 1), c = 2 * cb + (lane & 1);
+    const int hh = vox / TW + h0, ww = vox % TW + w0;
+    yvo[k] = (hh < H && ww < W) ? (unsigned)((((int64_t)hh * W + ww) * ldy + c * 8) * 2) : 0x40000000u;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2, yslice = (int64_t)H * W * ldy * 2;
+  const char* xn = reinterpret_cast<const char*>((x1 && cg == 1) ? x1 : x + cg * 32) + (int64_t)n * D * xslice;
+  const char* yn = reinterpret_cast<const char*>(dy + cot * 32) + (int64_t)n * D * yslice;
+  u32x4 xr, yr;
+  xr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  xr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  xr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * xslice - (ldx - 32) * 2));
+  xr[3] = 0x00020000u;
+  yr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)yn);
+  yr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)yn >> 32) & 0xFFFFu);
+  yr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * yslice - (ldy - 32) * 2));
+  yr[3] = 0x00020000u;
+  const unsigned xslice32 = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+  const unsigned yslice32 = __builtin_amdgcn_readfirstlane((unsigned)yslice);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  auto dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so), "s"(dst) : "memory");
+  };
+  auto dma_x = [&](int m, int k, bool on) {
+    if (WV + 4 * k < G::XP) {
+      constexpr int dummy = 0; (void)dummy;
+      const int P = WV + 4 * k;
+      const int s = d0 - 1 + m;
+      const unsigned so = __builtin_amdgcn_readfirstlane((on && s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
+      dma(xr, xvo[k], so, lds0 + (unsigned)((m & 3) * G::XSLOT + (P & 1) * G::XPLANE + (P >> 1) * 1024));
+    }
+  };
+  auto dma_y = [&](int t, int k, bool on) {
+    if (WV + 4 * k < G::YP) {
+      const int P = WV + 4 * k;
+      const int s = d0 + t;
+      const unsigned so = __builtin_amdgcn_readfirstlane((on && s < D) ? (unsigned)s * yslice32 : 0x40000000u);
+      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + (t & 1) * G::YSLOT + (P & 1) * G::YPLANE + (P >> 1) * 1024));
+    }
+  };
+
+  f32x4 acc[T::NT][4];                                   // [tap][2 a + b]: ci half a x co half b
+#pragma unroll
+  for (int i = 0; i < T::NT; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][q][r] = 0.f;
+
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, true);
+#pragma unroll
+  for (int k = 0; k < G::YPW; ++k) dma_y(0, k, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // a fragment = 16 channels x 32 voxels: two transposed reads of 512 contiguous bytes (voxels +0..15 and +16..31 of the plane)
+  auto frag = [&](const char* pl) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pl));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pl + 16 * 32));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  };
+  bf16x8 fx[2][3][2];    // [cell parity][triple 0, triple 1, single][ci half]
+  bf16x8 fy[4][2];       // dy rows (ring by row & 3) x co half
+  const int nd = d1 - d0;
+  const int lane8 = lane * 8;
+#pragma unroll 1
+  for (int t = 0; t < nd; ++t) {
+    const char* sb[3] = {smem + ((t + 0) & 3) * G::XSLOT + lane8, smem + ((t + 1) & 3) * G::XSLOT + lane8,
+                         smem + ((t + 2) & 3) * G::XSLOT + lane8};
+    const char* yb = smem + G::NXS * G::XSLOT + (t & 1) * G::YSLOT + lane8;
+    const bool more = t + 1 < nd;
+    // load item i of cell rx: 2 j + a = x fragment of triple j (2: the single), ci half a; 6 + b = the entering dy row, co half b
+    auto load_item = [&](int rx, int i) {
+      if (i < 6) {
+        const int j = i >> 1, a = i & 1;
+        if (j < 2 || (WV < 3 && rx - WV >= 0 && rx - WV < TH))
+          fx[rx & 1][j][a] = frag(sb[T::kd(j)] + a * G::XPLANE + (rx * SW + T::kw(j)) * 32);
+      } else if (rx < TH) fy[rx & 3][i - 6] = frag(yb + (i - 6) * G::YPLANE + (rx * TW) * 32);
+    };
+    // MFMA item i of cell rx: tap i / 4 (local index), block i % 4 = 2 a + b
+    auto mfma_item = [&](int rx, int i) {
+      const int tp = i >> 2, a = (i >> 1) & 1, bb = i & 1;
+      const int r = tp < 6 ? rx - tp % 3 : rx - WV;
+      if (tp < T::NT && r >= 0 && r < TH)
+        acc[tp][2 * a + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[rx & 1][tp < 6 ? tp / 3 : 2][a], fy[r & 3][bb],
+                                                                     acc[tp][2 * a + bb], 0, 0, 0);
+    };
+    load_item(0, 6); load_item(0, 7);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) load_item(0, i);
+#pragma unroll
+    for (int rx = 0; rx < SH; ++rx) {
+#pragma unroll
+      for (int i = 0; i < 28; ++i) {
+        if (rx + 1 < SH) {                              // 8 fragments of the next cell spread over the 28 gaps
+          if (i == 0) load_item(rx + 1, 6);
+          if (i == 3) load_item(rx + 1, 7);
+          if (i == 6) load_item(rx + 1, 0);
+          if (i == 9) load_item(rx + 1, 1);
+          if (i == 12) load_item(rx + 1, 2);
+          if (i == 15) load_item(rx + 1, 3);
+          if (i == 18) load_item(rx + 1, 4);
+          if (i == 21) load_item(rx + 1, 5);
+        }
+        if (i == 13) {
+          if (rx < G::XPW) dma_x(t + 3, rx, more);
+        }
+        if (i == 25) {
+          if (rx < G::YPW) dma_y(t + 1, rx, more);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_item(rx, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // partial tiles [tap][co][ci]: block (a, b) of a lane = ci 16 a + 4 (lane / 16) .. + 3 at co 16 b + lane % 16: one 16-byte store
+  const int pair = cot * ncg + cg;
+  float* out = part + ((int64_t)bid.x * (ncg * (Cout / 32)) + pair) * (27 * 1024);
+#pragma unroll
+  for (int i = 0; i < T::NT; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(out + (T::tap(i) * 32 + 16 * (q & 1) + (lane & 15)) * 32 + 16 * (q >> 1) + 4 * (lane >> 4)) =
+          make_float4(acc[i][q][0], acc[i][q][1], acc[i][q][2], acc[i][q][3]);
+}
+
+template <int TH>
+__global__ void __launch_bounds__(256, 2)
+conv_wgrad_roll16(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW, int dsegs, int dlen,
+                  const bf16_t* __restrict__ x1, int xcd) {
+  using G = WR16<TH>;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: roll16_march<G, 0>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 1: roll16_march<G, 1>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 2: roll16_march<G, 2>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    default: roll16_march<G, 3>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+  }
+}
+
 template <int TH, int TW>
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_roll(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
@@ -312,7 +522,13 @@ extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* 
                                                          cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, \
                                                          fplx_xcd_on());                                            \
   } while (0)
-  if (c.th == 16) LAUNCH_ROLL(16, 16); else if (c.tw == 32) LAUNCH_ROLL(8, 32); else LAUNCH_ROLL(8, 16);
+  if (c.th == 8 && c.tw == 32 && fplx_knob(FPLX_K_WG_ROLL_M16)) {          // the 16 x 16 x 32 form of the 8 x 32 footprint
+    using G_ = WR16<8>;
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);
+    conv_wgrad_roll16<8><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, cin, cout,
+                                                    c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on());
+  }
+  else if (c.th == 16) LAUNCH_ROLL(16, 16); else if (c.tw == 32) LAUNCH_ROLL(8, 32); else LAUNCH_ROLL(8, 16);
 #undef LAUNCH_ROLL
   int rc = fplx_check_launch("wgroll_conv3d_wgrad");
   if (rc < 0) return rc;

@@ -62,8 +62,10 @@ int fplx_num_partials(int64_t voxels);
  *   ("xcd", "brick", "march", "march32_v2", "wg_cot", "tile_ks", ...; fplx_tuning_key enumerates them: returns the key's
  *   length and copies it, or -1 past the end).  Unknown key: FPLX_E_BADSHAPE.  Benchmarks and tests only.
  * fplx_conv3d_plan_query: which kernel family fplx_conv3d_fwd dispatches this layer to (for 16-byte aligned NDHWC bf16
- *   operands; FPLX_KERNEL_*), the brick geometry (0: 4x8x8, 1: 5x4x8; -1 for other families), the split of the reduction
- *   dimension (1 = none) and the statistics rows - pure host code, no launch. */
+ *   operands; FPLX_KERNEL_*), the geometry (brick: 0 = 4x8x8, 1 = 5x4x8; depth march: Cin = 32: 2 = the one-wave-per-SIMD
+ *   kernels for footprints inside the volume [statistics form / statistics-free form], 0 = the 8-wave kernel; Cin >= 64: the
+ *   footprint width 16 | 32; -1 for other families), the split of the reduction dimension (1 = none) and the statistics
+ *   rows - pure host code, no launch. */
 enum {
   FPLX_KERNEL_GENERIC = 0, FPLX_KERNEL_DIRECT = 1, FPLX_KERNEL_TILE = 2, FPLX_KERNEL_STREAM = 3, FPLX_KERNEL_MARCH = 4,
   FPLX_KERNEL_BRICK = 5, FPLX_KERNEL_STEM = 6, FPLX_KERNEL_OUTCONV = 7

@@ -95,7 +95,10 @@ def test_conv3d_fwd_wgrad_dgrad_generic(dtype, tol, shape):
     # Cin = 64, 8 x 32 footprint; Cin = 32
     (1, 64, 32, 7, 24, 64), (1, 32, 64, 9, 20, 96),
     # Cin = 128: the streamed-weight form (four channel quarters per slab), both footprints, ragged, depth segments
-    (1, 128, 64, 6, 16, 80), (2, 128, 32, 5, 9, 70), (1, 128, 96, 21, 24, 64), (1, 128, 64, 4, 17, 65)])
+    (1, 128, 64, 6, 16, 80), (2, 128, 32, 5, 9, 70), (1, 128, 96, 21, 24, 64), (1, 128, 64, 4, 17, 65),
+    # Cin = 32, footprints inside the volume (H % 16 = W % 32 = 0): conv_fwd_march32v2<true>, the forward + statistics kernel
+    # of the benchmark's level 0 (2 of its 4 dominant launches per step); one / two co blocks, several depth segments
+    (1, 32, 32, 9, 16, 64), (2, 32, 64, 12, 32, 96), (2, 32, 32, 40, 48, 64)])
 def test_conv3d_march_kernels_aligned_output(shape):
     """the depth-marching kernels need 16-byte aligned rows (the generic test writes into an odd channel slice and so
     exercises them only through the data gradient): forward + BN statistics on a dense output, bf16, against torch"""
@@ -108,6 +111,8 @@ def test_conv3d_march_kernels_aligned_output(shape):
     yr = F.conv3d(x, wt, b, padding=1)
     bf, dt, dims = torch.bfloat16, ops._DT[torch.bfloat16], (n, d, h, w)
     assert plan_kernel(n, d, h, w, cin, cout) == 4                # FPLX_KERNEL_MARCH
+    if cin == 32:       # the one-wave-per-SIMD kernel (v2 with statistics) exactly on the footprints inside the volume
+        assert plan_kernel(n, d, h, w, cin, cout, full=True)[1] == (2 if h % 16 == 0 and w % 32 == 0 else 0)
     xg = cl(x).to(bf).cuda()
     wf, _ = ops.pack_conv_weight(wt.cuda(), bf, want_wb=False)
     y = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
@@ -121,6 +126,12 @@ def test_conv3d_march_kernels_aligned_output(shape):
     yf = cl(yr)
     np.testing.assert_allclose(s[0].numpy(), yf.sum(0).numpy(), atol=2e-2 * scale * yf.shape[0] ** 0.5 + 1e-3)
     np.testing.assert_allclose(s[1].numpy(), (yf * yf).sum(0).numpy(), rtol=8e-2)
+    if cin == 32 and h % 16 == 0 and w % 32 == 0:
+        # the statistics-free form of the same layer (conv_fwd_march32v3<false>, what a data gradient runs) against torch too
+        y3 = torch.full((xg.shape[0], cout), 7.0, dtype=bf, device="cuda")
+        ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y3, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout,
+                       (3, 3, 3), None)
+        assert float((uncl(y3.float().cpu(), n, d, h, w) - yr).abs().max()) < 2e-2 * scale
 
 
 @pytest.mark.parametrize("shape,geo,ks", [
@@ -196,7 +207,9 @@ def test_conv3d_brick_kernel(shape, geo, ks):
         assert float((uncl(dx.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < 2e-2 * float(xr.grad.abs().max())
 
 
-@pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70)])
+@pytest.mark.parametrize("shape", [(1, 20, 40, 64), (2, 21, 24, 70),
+                                   # H % 16 = W % 32 = 0: the split data gradient is conv_fwd_march32v3 with two output tensors (y1)
+                                   (1, 16, 32, 64), (2, 12, 48, 96)])
 def test_conv3d_cat2_split_concat(shape):
     """conv3x3x3 on cat([x0, x1], channel) with the concatenation never built (reference unet2d5_dsbn.py:182-183):
     forward + statistics, data gradient into two tensors, weight gradient - against torch on the explicit cat"""
@@ -237,6 +250,7 @@ def test_conv3d_cat2_split_concat(shape):
     assert torch.equal(y, y2)
     dx0 = torch.empty_like(g0)
     dx1 = torch.empty_like(g1)
+    assert plan_kernel(n, d, h, w, cout, cin, full=True)[:2] == (4, 2 if h % 16 == 0 and w % 32 == 0 else 0)
     ops.conv3d_dgrad_split2(dyg, wb, dx0, dx1, dims, cin, cout)
     gmax = float(xr.grad.abs().max())
     assert float((uncl(dx0.float().cpu(), n, d, h, w) - xr.grad[:, :32]).abs().max()) < tol * gmax

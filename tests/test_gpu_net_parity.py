@@ -417,3 +417,92 @@ def test_eval_fusion_matches_the_separate_batchnorm_passes(dims, shape):
         assert float((mc - rep).abs().max()) <= 2e-2 * rng, float((mc - rep).abs().max()) / rng
         assert float((fplx.filter.hard_label(mc) == fplx.filter.hard_label(rep)).float().mean()) >= 0.995
         assert float((mc[:shape[0]] - mc[shape[0]:2 * shape[0]]).abs().max()) > 1e-3 * rng       # the passes differ
+
+
+EVAL_CASES = {
+    # the benchmark's kernel families in inference: level-0 / level-1 depth marches (m1), bricks from level 1 down (b2), and
+    # the shipped 2.5D pattern (Conv2d levels 0-1 as middle-plane packs, 3D levels 2-4)
+    "m1": ([3, 3, 3, 3, 3], (1, 1, 32, 64, 128)),
+    "b2": ([3, 3, 3, 3, 3], (2, 1, 32, 64, 128)),
+    "s25": ([2, 2, 3, 3, 3], (2, 1, 12, 64, 64)),
+}
+
+
+def _philox_masks(seed, step, p, in_shape):
+    """the keep masks of one forward as the engine numbers them (stream = step * 16 + block, element index of the NDHWC
+    tensor): oracle/np_ref.py:dropout_masks_ncdhw with the depth of a level following conv_dims (a dim-2 level pools h, w only)"""
+    from oracle import np_ref as N
+    from oracle import torch_ref as R
+    n, _, D, H, W = in_shape
+    dims, ft, ps = list(p["conv_dims"]), p["feature_chns"], R.block_dropout_p(p)
+    depth = [D]
+    for i in range(4):
+        depth.append(depth[-1] // 2 if dims[i] == 3 else depth[-1])
+    lv, out = [0, 1, 2, 3, 4, 3, 2, 1, 0], []
+    for b in range(9):
+        if ps[b] <= 0:
+            out.append(None)
+            continue
+        L = lv[b]
+        d, h, w, c = depth[L], H >> L, W >> L, ft[L]
+        keep = N.philox_keep_mask(seed, step * 16 + b, n * d * h * w * c, ps[b])
+        out.append(torch.from_numpy(np.ascontiguousarray(keep.reshape(n, d, h, w, c).transpose(0, 4, 1, 2, 3))))
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("case", ["m1", "b2", "s25"])
+def test_bf16_eval_inference_against_oracle(case, fused):
+    """bf16 EVAL-mode inference (config 4's path: BatchNorm on running statistics, agent_seg.py:843-852, 897-909) against
+    the oracle rounding to bf16 at the same points, with the eval-mode BatchNorm folded into the packs and PReLU in the
+    convolution write-out (fplx_conv3d_fwd_act; fused) and with the separate passes: both domains, logits within 3e-2 of
+    their range of the bf16 oracle AND no further from an oracle (bf16 or fp32: the fused form skips a rounding point, the
+    pre-BatchNorm tensor is never stored) than the oracle's own fp32-vs-bf16 gap; then the Monte-Carlo forward with the
+    SUPPLIED Philox masks (test_dropout_stream_matches_oracle_philox does this in fp32 only)."""
+    import fplx
+    from oracle import torch_ref as R
+    dims, shape = EVAL_CASES[case]
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=dims, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    n = shape[0]
+    x = torch.from_numpy(detdata.normal("x.eval." + case, shape))
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")        # non-trivial running statistics and BatchNorm affine parameters (detdata.state_dict_3d)
+    net.eval()
+    net.engine.use_eval_fusion = fused
+    net.engine.invalidate()
+    sd, _ = R.split_state(detdata.state_dict_3d(p), requires_grad=False)
+    os.makedirs("gpurun_out", exist_ok=True)
+    rep = open(os.path.join("gpurun_out", "parity_bf16_eval_%s_%s.txt" % (case, "fused" if fused else "unfused")), "w")
+    with torch.no_grad():
+        for dom in (0, 1):
+            got = net(x.cuda(), domain_label=dom * torch.ones(n, dtype=torch.long)).float().cpu()
+            ref = R.unet_forward(sd, p, x, dom, train=False, act_dtype=torch.bfloat16)
+            ref32 = R.unet_forward(sd, p, x, dom, train=False)
+            rng, gap = float(ref.abs().max()), float((ref32 - ref).abs().max())
+            e16, e32 = float((got - ref).abs().max()), float((got - ref32).abs().max())
+            # hard labels (random weights: many voxels sit near a tie): as often equal to an oracle's as the two oracles' are
+            agree = max(float((got.argmax(1) == ref.argmax(1)).float().mean()), float((got.argmax(1) == ref32.argmax(1)).float().mean()))
+            agree_o = float((ref.argmax(1) == ref32.argmax(1)).float().mean())
+            rep.write("domain %d: max err vs bf16 oracle %.4g, vs fp32 oracle %.4g, range %.4g, oracle gap %.4g, labels agree %.5f "
+                      "(bf16 oracle vs fp32 oracle %.5f)\n" % (dom, e16, e32, rng, gap, agree, agree_o))
+            assert e16 < 3e-2 * rng and e32 < 3e-2 * rng, (dom, e16, e32, rng)
+            assert min(e16, e32) <= gap + 1e-3 * rng, (dom, e16, e32, gap)
+            assert agree >= min(0.995, agree_o - 1e-3), (agree, agree_o)
+        # Monte-Carlo forward, two passes of the batch in one call, masks supplied by the oracle's Philox
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.train()
+        net.dropout_seed, net._fwd_counter, passes = 77, 3, 2
+        mc = net.forward_mc(x.cuda(), torch.ones(n, dtype=torch.long), passes).float().cpu()
+        xr = x.repeat(passes, 1, 1, 1, 1)
+        masks = _philox_masks(77, 3, p, tuple(xr.shape))
+        ref = R.unet_forward(sd, p, xr, 1, train=False, dropout_masks=masks, dropout_on=True, act_dtype=torch.bfloat16)
+        ref32 = R.unet_forward(sd, p, xr, 1, train=False, dropout_masks=masks, dropout_on=True)
+        rng, gap = float(ref.abs().max()), float((ref32 - ref).abs().max())
+        e16, e32 = float((mc - ref).abs().max()), float((mc - ref32).abs().max())
+        rep.write("forward_mc x %d: max err vs bf16 oracle %.4g, vs fp32 oracle %.4g, range %.4g, oracle gap %.4g\n" % (passes, e16, e32, rng, gap))
+        rep.close()
+        assert e16 < 3e-2 * rng and e32 < 3e-2 * rng, (e16, e32, rng)
+        assert min(e16, e32) <= gap + 1e-3 * rng, (e16, e32, gap)
+        assert float((mc[:n] - mc[n:]).abs().max()) > 1e-3 * rng          # the passes differ
