@@ -240,26 +240,163 @@ def cpu_baseline():
             "sample": "32-base UNet-DSBN, DiceLoss + Adam, oracle/torch_ref.py, %d threads: %s" % (cores, sample)}
 
 
-def launch_ranks(n):
+SECONDARY_PARTS = ("plugin_path", "config4", "config5_one_gpu")
+
+
+def _timed(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def secondary_part(name, dev):
+    """One of the measurements reported beside the headline (`secondary`, OUTSIDE the timed region; SURVEY 8d asks for configs 4
+    and 5, VERDICT r03 for the plugin path), run in a process of its own - see secondary().  ms per unit on this GPU.
+      plugin_path     : SegmentationAgent.training_all (agent_seg.py:415-508) at the headline shape - one iteration = both
+                        domains + one Adam step, iter_valid = 8 iterations per call as a training round has many - as the agent
+                        runs it (routed through fplx.TrainStep), in its autograd route (net(x), loss module, loss.backward(),
+                        FusedAdam.step()), and TrainStep.step_all on the same batches
+      config4         : pseudo-label selection on one 1 x 1 x 48 x 160 x 272 volume (eval-mode BatchNorm, test-time dropout):
+                        T = 4 Monte-Carlo forwards + filter, the reference-literal 6 passes x 4-flip TTA (24 forwards), and the
+                        filter kernel's rate on the T = 6 stack
+      config5_one_gpu : one training_all iteration of the 4-channel 2 x 4 x 128^3-per-domain network, 0.5 Dice + 0.5 CE with
+                        pixel weights, ONE GPU (the 8-GPU half needs a node)"""
+    import fplx
+    from fplx import ops
+    from fplx.infer import Inferer
+    if name == "plugin_path":
+        batches = [synth_batch(SHAPE, 7 + d, dev) for d in (0, 1)]
+        iv = 8
+        tcfg = {"dis": False, "train_fpl_uda": True, "loss_type": "DiceLoss", "optimizer": "Adam", "learning_rate": 1e-4,
+                "momentum": 0.9, "weight_decay": 1e-5, "lr_scheduler": "MultiStepLR", "lr_gamma": 0.5,
+                "lr_milestones": [10000, 20000], "iter_valid": iv, "gpus": [dev.index or 0]}
+        agent = fplx.SegmentationAgent({"dataset": {"tensor_type": "float"}, "network": dict(NET), "training": tcfg, "testing": {}},
+                                       "train")
+        torch.manual_seed(1)
+        agent.create_network()
+        agent.create_optimizer()
+        agent.create_loss_calculator()
+        agent.set_loaders([{"image": batches[0][0], "label_prob": batches[0][1]}], [{"image": batches[1][0], "label_prob": batches[1][1]}])
+        t_agent = _timed(agent.training_all, 1, 2) / iv
+        agent.engine_mode = False
+        t_autograd = _timed(agent.training_all, 1, 2) / iv
+        ts = fplx.TrainStep(agent.net, (1.0, 0.0, 0.0, 0.0), True, optimizer=agent.optimizer)
+        bl = [{"image": b[0], "label_prob": b[1]} for b in batches]
+        t_engine = _timed(lambda: ts.step_all(bl), 4, 2 * iv)
+        return {"shape": list(SHAPE), "unit": "ms per training_all iteration (two domains, one Adam step)",
+                "SegmentationAgent.training_all": round(t_agent, 3),
+                "SegmentationAgent.training_all, autograd route (engine_mode = False)": round(t_autograd, 3),
+                "TrainStep.step_all": round(t_engine, 3), "agent_over_engine": round(t_agent / t_engine, 4)}
+    if name == "config4":
+        net = fplx.UNet2D5_dsbn(dict(NET)).to(dev)
+        net.eval()
+        for m in net.modules():
+            if type(m) == torch.nn.Dropout:
+                m.train()
+        x = torch.randn(1, 1, 48, 160, 272, device=dev)
+        dl = torch.ones(1, dtype=torch.long)
+        c4 = {"volume": [1, 1, 48, 160, 272]}
+        stack = None
+        for T, tta, key in ((4, 0, "T4_ms_per_volume"), (6, 1, "T6x4flip_24_forwards_ms_per_volume")):
+            inf = Inferer(dict(class_num=2, tta_mode=tta, infer_batch_voxels=1 << 23))
+
+            def mc():
+                with torch.no_grad():
+                    st = inf.run_mc(net, x, dl, T)[:, 0]
+                return st, ops.mc_filter(st, 0.01)
+            c4[key] = round(_timed(mc, 2, 4), 3)
+            stack = mc()[0]
+        ms = _timed(lambda: ops.mc_filter(stack, 0.01), 3, 20)
+        c4["mc_filter_ms"] = round(ms, 4)
+        c4["mc_filter_GBps_of_logits"] = round(stack.numel() * 4 / ms / 1e6, 1)
+        return c4
+    if name == "config5_one_gpu":
+        torch.manual_seed(1)
+        net = fplx.UNet2D5_dsbn(dict(NET, in_chns=4)).to(dev)
+        loss = fplx.make_loss({"loss_type": ["DiceLoss", "CrossEntropyLoss"], "loss_weight": [0.5, 0.5]})
+        ts = fplx.TrainStep(net, loss.terms, True, lr=1e-4, weight_decay=1e-5)
+        g = torch.Generator().manual_seed(0)
+        b5 = []
+        for d in range(2):
+            xx = torch.randn(2, 4, 128, 128, 128, generator=g)
+            lab = torch.zeros(2, 2, 128, 128, 128)
+            lab[:, 0] = 1.0
+            lab[:, 0, 40:90, 30:100, 50:110] = 0.0
+            lab[:, 1, 40:90, 30:100, 50:110] = 1.0
+            w_img = torch.rand(2, generator=g) + 0.01
+            pw = (torch.rand(2, 1, 128, 128, 128, generator=g) > 0.1).float() * w_img.view(2, 1, 1, 1, 1)
+            b5.append({"image": xx.to(dev), "label_prob": lab.to(dev), "pixel_weight": pw.to(dev), "image_weight": w_img.to(dev)})
+        t5 = _timed(lambda: ts.step_all(b5), 4, 10)
+        return {"batch": "2 x 4 x 128^3 per domain, two domains", "ms_per_training_all_iteration": round(t5, 3),
+                "crops_per_s": round(4 / t5 * 1e3, 2)}
+    raise ValueError(name)
+
+
+def secondary():
+    """The `secondary` object of the bench line: every part in a CHILD process of its own, after the headline (measured in THIS
+    process's fresh address space: a network built after others were freed ran up to 35 % slower here whatever its kernels -
+    tools/step_ab.py saw the same with a fourth live network - so the parts do not share a process either).  A failing part
+    leaves an `error` entry; the headline is never affected."""
+    import subprocess
+    out = {}
+    for name in SECONDARY_PARTS:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-part", name], stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, text=True, timeout=180)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            out[name] = json.loads(lines[-1]) if r.returncode == 0 and lines else {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def launch_ranks(n, timeout_s=1500.0, attempts=3):
     """`bench.py --gpus N` without a launcher: start N ranks as a child `python -m torch.distributed.run` (this process has
-    not initialised the GPU and never will), relay rank 0's JSON line, return the child's exit code."""
+    not initialised the GPU and never will), relay rank 0's JSON line, return the child's exit code.  The child runs in a
+    process group of its own: when it exceeds `timeout_s` (a rank hung in RCCL initialisation, say) the whole group is
+    killed and the exit code is non-zero.  A rendezvous port that was taken between the probe and the bind gets a FRESH
+    child on a fresh port (never a re-exec of a process that touched the GPU)."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
-    if proc.returncode == 0 and len(lines) == 1:
-        print(lines[0])
+    rc, out = 1, ""
+    for attempt in range(attempts):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            out, err = proc.communicate()
+            sys.stderr.write("bench.py: the %d-rank child exceeded %.0f s and was killed (process group %d)\n%s\n"
+                             % (n, timeout_s, proc.pid, (err or "")[-2000:]))
+            return 124
+        rc = proc.returncode
+        sys.stderr.write(err or "")
+        if rc != 0 and ("EADDRINUSE" in (err or "") or "address already in use" in (err or "").lower()):
+            continue                                     # the port was taken after the probe: a fresh child, a fresh port
+        break
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    if rc == 0 and lines:
+        print(lines[-1])                                 # rank 0 prints the line once; the last one if a rank echoed it
         return 0
     sys.stderr.write("bench.py: the %d-rank child exited with code %d and printed %d result line(s)\n%s\n"
-                     % (n, proc.returncode, len(lines), proc.stdout[-2000:]))
-    return proc.returncode or 1
+                     % (n, rc, len(lines), out[-2000:]))
+    return rc or 1
 
 
 def main():
@@ -271,7 +408,14 @@ def main():
     ap.add_argument("--launch", action="store_true", help="start the ranks as a child torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` measurements (plugin path, configs 4 and 5)")
+    ap.add_argument("--secondary-part", choices=SECONDARY_PARTS, help="(internal) run ONE secondary measurement and print its JSON")
     args = ap.parse_args()
+    if args.secondary_part:
+        dev0 = torch.device("cuda", 0)
+        torch.cuda.set_device(dev0)
+        print(json.dumps(secondary_part(args.secondary_part, dev0)))
+        return
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1 or args.warmup < 0:
         ap.error("--gpus, --steps, --repeats must be >= 1 and --warmup >= 0")
 
@@ -388,6 +532,8 @@ def main():
             res["roofline"] = roof
         if ktable:
             res["kernels"] = ktable[:30]
+        if world == 1 and not args.no_secondary:
+            res["secondary"] = secondary()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

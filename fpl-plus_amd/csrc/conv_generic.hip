@@ -818,7 +818,9 @@ int fplx_conv3d_fwd_act(const void* x0, const void* x1, int64_t ldx, const void*
                                       (hipStream_t)stream);
   else r = fplx_mfma_conv3d_fwd_act(x0, ldx, wp, bias, prelu_slope, y, ldy, n, d, h, w, cin, cout, ws, ws_bytes, mid ? 1 : 0,
                                     (hipStream_t)stream);
-  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_act: pointers / leading dimensions not 16-byte aligned");
+  if (r == 0)
+    return fplx_fail(FPLX_E_BADSHAPE, "conv3d_fwd_act: the kernel's launcher declined (pointers / leading dimensions not 16-byte "
+                     "aligned, or a sample of 1 GiB and more: d h w ldx 2 >= 2^30)");
   return r < 0 ? r : FPLX_OK;
 }
 

@@ -246,7 +246,7 @@ conv_fwd_march32(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
       // a VALU write of those registers needs 2 wait states on gfx940+); hipcc's hazard recognizer does not look inside
       // inline asm, and the register allocator reuses v0 / v1 at once.  Without the nop the first dword of the store's
       // last lanes picked up the next instruction's result whenever another kernel's waves shared the SIMD
-      // (tools/race25c.py: the 2.5D stream-order hazard of round 1)
+      // (profiles/r02_race25_hazard_location.txt: the 2.5D stream-order hazard of round 1)
       if (sok0) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
       if (sok1) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + 16u * l2 + soffb), "v"(v1) : "memory");
     }

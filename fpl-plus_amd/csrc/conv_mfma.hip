@@ -2145,8 +2145,15 @@ extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* 
 }
 
 // 1 if the layer's forward kernel has the PReLU write-out (or finishes through splitk_finish_k)
+// The launchers decline samples of 1 GiB and more (32-bit buffer offsets, the out-of-range marker 0x40000000) - a limit on
+// d h w ldx the plan cannot see; mirrored here for every leading dimension the engine uses (ldx <= 2 cin: a half of a
+// concatenation buffer), so that a caller who committed to the fused form on this answer is never refused at launch.
+static inline bool act_sample_fits(int d, int h, int w, int cin) {
+  return (int64_t)d * h * w * (2 * cin) * 2 < ((int64_t)1 << 30);
+}
 extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int cout, int mid) {
   int kernel, geo, ks;
+  if (!act_sample_fits(d, h, w, cin)) return 0;
   if (!fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
   return kernel == FPLX_KERNEL_BRICK || kernel == FPLX_KERNEL_MARCH || ((kernel == FPLX_KERNEL_TILE || kernel == FPLX_KERNEL_DIRECT) && ks > 1);
 }
@@ -2154,7 +2161,7 @@ extern "C" int fplx_mfma_conv3d_act_ok(int n, int d, int h, int w, int cin, int 
 // kernel's activation form: the 3D layers it takes first, unsplit in Cin
 extern "C" int fplx_mfma_conv3d_act_cat2_ok(int n, int d, int h, int w, int cin, int cout, int mid) {
   int kernel, geo, ks;
-  if (mid || cin % 64 != 0 || !fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
+  if (mid || cin % 64 != 0 || !act_sample_fits(d, h, w, cin) || !fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
   return kernel == FPLX_KERNEL_BRICK && ks == 1;
 }
 extern "C" int fplx_mfma_conv3d_fwd_act_cat2(const void* x0, const void* x1, int64_t ldx, const void* wp, const float* bias,

@@ -22,6 +22,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"      // LDS pointers are 32 bits wide: they are formed from 32-bit addresses
 
 extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
                                         hipStream_t st);      // conv_mfma.hip
@@ -34,21 +35,28 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-template <int TH_, int TW_>
+// MB: the step's one barrier sits in the MIDDLE of the step and the rings get one x slot and one dy slot more (5 + 3): the DMA
+// of a slab is issued behind the barrier of the step BEFORE the one whose barrier publishes it, into a slot nobody has read
+// since the step before that - so the first fragments of step t + 1 are requested during the last MFMAs of step t and no
+// step begins with an empty pipe (with the barrier at the end of the step they can only be requested behind it).
+template <int TH_, int TW_, bool MB_>
 struct WR {
+  static constexpr bool MB = MB_;
   static constexpr int TH = TH_, TW = TW_, SH = TH + 2, SW = TW + 2, SLAB = SH * SW;
   static constexpr int XP = (SLAB * 4 + 63) / 64;          // 1-KiB DMA pieces per x slab (64-byte voxel rows)
   static constexpr int XSLOT = XP * 1024;
   static constexpr int YP = TH * TW * 4 / 64;              // ... per dy slab
   static constexpr int YSLOT = YP * 1024;
-  static constexpr int NXS = 4, NYS = 2;
+  static constexpr int NXS = MB ? 5 : 4, NYS = MB ? 3 : 2;
   static constexpr int LDS = NXS * XSLOT + NYS * YSLOT;
   static constexpr int NCH = TW / 16;                      // 16-voxel K chunks per row
   static constexpr int NCELL = NCH * SH;                   // (chunk, slab row) cells per depth step
   static constexpr int XPW = (XP + 3) / 4, YPW = (YP + 3) / 4;   // pieces per wave
 };
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
+// fragment reads take 32-bit LDS byte addresses: an opaque per-step base (one VGPR per slab, see lds_base) + a compile-time
+// offset that lands in the instruction's 16-bit offset field
+__device__ __forceinline__ bf16x8 tr_frag(unsigned base_lo) {
   // two transposed 4 x 16 block reads: voxels +0..3 and +4..7 of a lane group's 8 (64 bytes per voxel row)
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo));
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base_lo + 4 * 64));
@@ -56,6 +64,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base_lo) {
   r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
   r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
   return r;
+}
+// hipcc must not take a base apart and hoist base + constant sums out of the depth loop (it did: 30 address registers)
+__device__ __forceinline__ unsigned lds_base(unsigned a) {
+  asm volatile("" : "+v"(a));
+  return a;
 }
 
 // Tap ownership of wave WV: triples (kd, kw) = 2 WV, 2 WV + 1 of the row-major (kd, kw) enumeration, each with its three kh;
@@ -133,14 +146,14 @@ __device__ __forceinline__ void roll_march(const bf16_t* __restrict__ x, int64_t
     if (WV + 4 * k < G::XP) {
       const int s = d0 - 1 + m;
       const unsigned so = __builtin_amdgcn_readfirstlane((on && s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
-      dma(xr, xvo[k], so, lds0 + (unsigned)((m & 3) * G::XSLOT + (WV + 4 * k) * 1024));
+      dma(xr, xvo[k], so, lds0 + (unsigned)(((unsigned)m % G::NXS) * G::XSLOT + (WV + 4 * k) * 1024));
     }
   };
   auto dma_y = [&](int t, int k, bool on) {
     if (WV + 4 * k < G::YP) {
       const int s = d0 + t;
       const unsigned so = __builtin_amdgcn_readfirstlane((on && s < D) ? (unsigned)s * yslice32 : 0x40000000u);
-      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + (t & 1) * G::YSLOT + (WV + 4 * k) * 1024));
+      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + ((unsigned)t % G::NYS) * G::YSLOT + (WV + 4 * k) * 1024));
     }
   };
 
@@ -154,63 +167,91 @@ __device__ __forceinline__ void roll_march(const bf16_t* __restrict__ x, int64_t
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // prologue: slabs d0 - 1, d0, d0 + 1 and dy(d0)
+  // prologue: slabs d0 - 1, d0, d0 + 1 and dy(d0) (MB: also the slab and dy of the second step)
+  const int nd = d1 - d0;
 #pragma unroll
-  for (int m = 0; m < 3; ++m)
+  for (int m = 0; m < (G::MB ? 4 : 3); ++m)
 #pragma unroll
-    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, true);
+    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, m < 3 || nd > 1);
 #pragma unroll
   for (int k = 0; k < G::YPW; ++k) dma_y(0, k, true);
+  if (G::MB) {
+#pragma unroll
+    for (int k = 0; k < G::YPW; ++k) dma_y(1, k, nd > 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   bf16x8 fx[2][3];       // [cell parity][triple 0, triple 1, single]
   bf16x8 fy[4];          // dy rows, ring by row & 3
-  const int nd = d1 - d0;
+  constexpr int PB = G::NCELL / 2;                        // MB: the barrier sits behind cell PB - 1
+  static_assert(!G::MB || 2 * (G::NCELL - PB) >= G::XPW + G::YPW, "DMA pieces must fit behind the barrier");
+  // load item i of cell k: 0 / 1 = the triples' x fragments, 2 = the single's, 3 = the dy row entering the window
+  auto load_item = [&](const unsigned (&sb)[3], unsigned yb, int k, int i) {
+    const int c = k / SH, rx = k % SH;
+    if (i < 2) fx[k & 1][i] = tr_frag(sb[T::kd(i)] + ((rx * SW + c * 16 + T::kw(i)) * 64));
+    else if (i == 2) { if (WV < 3 && rx - WV >= 0 && rx - WV < TH) fx[k & 1][2] = tr_frag(sb[2] + ((rx * SW + c * 16 + 2) * 64)); }
+    else if (rx < TH) fy[rx & 3] = tr_frag(yb + ((rx * TW + c * 16) * 64));
+  };
+  auto mfma_item = [&](int k, int i) {
+    const int rx = k % SH;
+    const int r = i < 6 ? rx - i % 3 : rx - WV;        // dy row of this tap
+    if (i < T::NT && r >= 0 && r < TH)
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[k & 1][i < 6 ? i / 3 : 2], fy[r & 3], acc[i], 0, 0, 0);
+  };
+  auto bases = [&](int t, unsigned (&sb)[3], unsigned& yb) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sb[k] = lds_base(lds0 + ((unsigned)(t + k) % G::NXS) * G::XSLOT + lane_off);
+    yb = lds_base(lds0 + G::NXS * G::XSLOT + ((unsigned)t % G::NYS) * G::YSLOT + lane_off);
+  };
+  if (G::MB) {                                            // the first cell of the first step
+    unsigned sb0[3], yb0;
+    bases(0, sb0, yb0);
+    load_item(sb0, yb0, 0, 3); load_item(sb0, yb0, 0, 0); load_item(sb0, yb0, 0, 1); load_item(sb0, yb0, 0, 2);
+  }
 #pragma unroll 1
   for (int t = 0; t < nd; ++t) {
-    const char* sb[3] = {xs + ((t + 0) & 3) * G::XSLOT + lane_off, xs + ((t + 1) & 3) * G::XSLOT + lane_off,
-                         xs + ((t + 2) & 3) * G::XSLOT + lane_off};
-    const char* yb = ys + (t & 1) * G::YSLOT + lane_off;
-    const bool more = t + 1 < nd;
-    // load item i of cell k: 0 / 1 = the triples' x fragments, 2 = the single's, 3 = the dy row entering the window
-    auto load_item = [&](int k, int i) {
-      const int c = k / SH, rx = k % SH;
-      if (i < 2) fx[k & 1][i] = tr_frag(sb[T::kd(i)] + ((rx * SW + c * 16 + T::kw(i)) * 64));
-      else if (i == 2) { if (WV < 3 && rx - WV >= 0 && rx - WV < TH) fx[k & 1][2] = tr_frag(sb[2] + ((rx * SW + c * 16 + 2) * 64)); }
-      else if (rx < TH) fy[rx & 3] = tr_frag(yb + ((rx * TW + c * 16) * 64));
-    };
-    auto mfma_item = [&](int k, int i) {
-      const int rx = k % SH;
-      const int r = i < 6 ? rx - i % 3 : rx - WV;        // dy row of this tap
-      if (i < T::NT && r >= 0 && r < TH)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[k & 1][i < 6 ? i / 3 : 2], fy[r & 3], acc[i], 0, 0, 0);
-    };
-    load_item(0, 3); load_item(0, 0); load_item(0, 1); load_item(0, 2);
+    unsigned sb[3], yb, sn[3], yn;
+    bases(t, sb, yb);
+    bases(t + 1, sn, yn);
+    const bool more = t + 1 < nd, more2 = t + 2 < nd;
+    if (!G::MB) { load_item(sb, yb, 0, 3); load_item(sb, yb, 0, 0); load_item(sb, yb, 0, 1); load_item(sb, yb, 0, 2); }
 #pragma unroll
     for (int k = 0; k < G::NCELL; ++k) {
-      // the fragments of cell k + 1 are requested one at a time in the gaps between the MFMAs of cell k; one DMA piece of
-      // the next depth's slabs per cell while there are any
+      // the fragments of cell k + 1 (MB: of the next step's first cell behind the last one) are requested one at a time in
+      // the gaps between the MFMAs of cell k; the DMA pieces of the coming slabs ride in the gaps as well
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
-        if (k + 1 < G::NCELL) {
-          if (i == 0) load_item(k + 1, 3);
-          if (i == 2) load_item(k + 1, 0);
-          if (i == 4) load_item(k + 1, 1);
-          if (i == 5) load_item(k + 1, 2);
+        const int li = i == 0 ? 3 : (i == 2 ? 0 : (i == 4 ? 1 : (i == 5 ? 2 : -1)));
+        if (li >= 0) {
+          if (k + 1 < G::NCELL) load_item(sb, yb, k + 1, li);
+          else if (G::MB) load_item(sn, yn, 0, li);
         }
-        if (i == 3) {
-          if (k < G::XPW) dma_x(t + 3, k, more);
-          else if (k - G::XPW < G::YPW) dma_y(t + 1, k - G::XPW, more);
+        if (!G::MB) {
+          if (i == 3) {
+            if (k < G::XPW) dma_x(t + 3, k, more);
+            else if (k - G::XPW < G::YPW) dma_y(t + 1, k - G::XPW, more);
+          }
+        } else if ((i == 1 || i == 3) && k >= PB) {       // behind this step's barrier: slab t + 4 and dy(t + 2), two pieces per cell
+          const int q = 2 * (k - PB) + (i == 3);
+          if (q < G::XPW) dma_x(t + 4, q, more2);
+          else if (q - G::XPW < G::YPW) dma_y(t + 2, q - G::XPW, more2);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_item(k, i);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (G::MB && k == PB - 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!G::MB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // partial tiles: part[block][pair][tap][co][ci] - a lane owns 4 consecutive ci per register quad: 16-byte stores
   const int co = lane & 31, rbase = (lane >> 5) * 4;
@@ -234,14 +275,15 @@ __device__ __forceinline__ void roll_march(const bf16_t* __restrict__ x, int64_t
 // tap shift without a swizzle - and the lane offset of a transposed read is simply lane * 8.  MFMA k-slot 8 g + j (g = lane / 16)
 // holds voxel 4 g + (j & 3) + 16 (j >> 2) of the chunk, for x and dy alike (any bijection serves, both operands use this one).
 // A DMA piece is 32 voxels of one plane: lane i fetches 16-byte chunk 2 cb + (i & 1) of voxel i / 2.
-template <int TH_>
+template <int TH_, bool MB_>
 struct WR16 {
+  static constexpr bool MB = MB_;
   static constexpr int TH = TH_, TW = 32, SH = TH + 2, SW = TW + 2, SLAB = SH * SW;
   static constexpr int XPP = (SLAB * 2 + 63) / 64;         // 1-KiB pieces per x plane (32-byte rows)
   static constexpr int XPLANE = XPP * 1024, XP = 2 * XPP, XSLOT = 2 * XPLANE;
   static constexpr int YPP = TH * TW * 2 / 64;
   static constexpr int YPLANE = YPP * 1024, YP = 2 * YPP, YSLOT = 2 * YPLANE;
-  static constexpr int NXS = 4, NYS = 2;
+  static constexpr int NXS = MB ? 5 : 4, NYS = MB ? 3 : 2;
   static constexpr int LDS = NXS * XSLOT + NYS * YSLOT;
   static constexpr int NCELL = SH;
   static constexpr int XPW = (XP + 3) / 4, YPW = (YP + 3) / 4;
@@ -313,7 +355,7 @@ __device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64
       const int P = WV + 4 * k;
       const int s = d0 - 1 + m;
       const unsigned so = __builtin_amdgcn_readfirstlane((on && s >= 0 && s < D) ? (unsigned)s * xslice32 : 0x40000000u);
-      dma(xr, xvo[k], so, lds0 + (unsigned)((m & 3) * G::XSLOT + (P & 1) * G::XPLANE + (P >> 1) * 1024));
+      dma(xr, xvo[k], so, lds0 + (unsigned)(((unsigned)m % G::NXS) * G::XSLOT + (P & 1) * G::XPLANE + (P >> 1) * 1024));
     }
   };
   auto dma_y = [&](int t, int k, bool on) {
@@ -321,7 +363,7 @@ __device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64
       const int P = WV + 4 * k;
       const int s = d0 + t;
       const unsigned so = __builtin_amdgcn_readfirstlane((on && s < D) ? (unsigned)s * yslice32 : 0x40000000u);
-      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + (t & 1) * G::YSLOT + (P & 1) * G::YPLANE + (P >> 1) * 1024));
+      dma(yr, yvo[k], so, lds0 + (unsigned)(G::NXS * G::XSLOT + ((unsigned)t % G::NYS) * G::YSLOT + (P & 1) * G::YPLANE + (P >> 1) * 1024));
     }
   };
 
@@ -333,17 +375,22 @@ __device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[i][q][r] = 0.f;
 
+  const int nd = d1 - d0;
 #pragma unroll
-  for (int m = 0; m < 3; ++m)
+  for (int m = 0; m < (G::MB ? 4 : 3); ++m)
 #pragma unroll
-    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, true);
+    for (int k = 0; k < G::XPW; ++k) dma_x(m, k, m < 3 || nd > 1);
 #pragma unroll
   for (int k = 0; k < G::YPW; ++k) dma_y(0, k, true);
+  if (G::MB) {
+#pragma unroll
+    for (int k = 0; k < G::YPW; ++k) dma_y(1, k, nd > 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // a fragment = 16 channels x 32 voxels: two transposed reads of 512 contiguous bytes (voxels +0..15 and +16..31 of the plane)
-  auto frag = [&](const char* pl) {
+  auto frag = [&](unsigned pl) {
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pl));
     const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(pl + 16 * 32));
     bf16x8 r;
@@ -353,61 +400,79 @@ __device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64
   };
   bf16x8 fx[2][3][2];    // [cell parity][triple 0, triple 1, single][ci half]
   bf16x8 fy[4][2];       // dy rows (ring by row & 3) x co half
-  const int nd = d1 - d0;
   const int lane8 = lane * 8;
+  constexpr int PB = SH / 2;                              // MB: the barrier sits behind cell PB - 1
+  static_assert(!G::MB || 2 * (SH - PB) >= (G::XPW > G::YPW ? G::XPW : G::YPW), "DMA pieces must fit behind the barrier");
+  // load item i of cell rx: 2 j + a = x fragment of triple j (2: the single), ci half a; 6 + b = the entering dy row, co half b
+  auto load_item = [&](const unsigned (&sb)[3], unsigned yb, int rx, int i) {
+    if (i < 6) {
+      const int j = i >> 1, a = i & 1;
+      if (j < 2 || (WV < 3 && rx - WV >= 0 && rx - WV < TH))
+        fx[rx & 1][j][a] = frag(sb[T::kd(j)] + a * G::XPLANE + (rx * SW + T::kw(j)) * 32);
+    } else if (rx < TH) fy[rx & 3][i - 6] = frag(yb + (i - 6) * G::YPLANE + (rx * TW) * 32);
+  };
+  // MFMA item i of cell rx: tap i / 4 (local index), block i % 4 = 2 a + b
+  auto mfma_item = [&](int rx, int i) {
+    const int tp = i >> 2, a = (i >> 1) & 1, bb = i & 1;
+    const int r = tp < 6 ? rx - tp % 3 : rx - WV;
+    if (tp < T::NT && r >= 0 && r < TH)
+      acc[tp][2 * a + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[rx & 1][tp < 6 ? tp / 3 : 2][a], fy[r & 3][bb],
+                                                                   acc[tp][2 * a + bb], 0, 0, 0);
+  };
+  auto bases = [&](int t, unsigned (&sb)[3], unsigned& yb) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sb[k] = lds_base(lds0 + ((unsigned)(t + k) % G::NXS) * G::XSLOT + lane8);
+    yb = lds_base(lds0 + G::NXS * G::XSLOT + ((unsigned)t % G::NYS) * G::YSLOT + lane8);
+  };
+  auto first_cell = [&](const unsigned (&sb)[3], unsigned yb) {
+    load_item(sb, yb, 0, 6); load_item(sb, yb, 0, 7);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) load_item(sb, yb, 0, i);
+  };
+  if (G::MB) {
+    unsigned sb0[3], yb0;
+    bases(0, sb0, yb0);
+    first_cell(sb0, yb0);
+  }
 #pragma unroll 1
   for (int t = 0; t < nd; ++t) {
-    const char* sb[3] = {smem + ((t + 0) & 3) * G::XSLOT + lane8, smem + ((t + 1) & 3) * G::XSLOT + lane8,
-                         smem + ((t + 2) & 3) * G::XSLOT + lane8};
-    const char* yb = smem + G::NXS * G::XSLOT + (t & 1) * G::YSLOT + lane8;
-    const bool more = t + 1 < nd;
-    // load item i of cell rx: 2 j + a = x fragment of triple j (2: the single), ci half a; 6 + b = the entering dy row, co half b
-    auto load_item = [&](int rx, int i) {
-      if (i < 6) {
-        const int j = i >> 1, a = i & 1;
-        if (j < 2 || (WV < 3 && rx - WV >= 0 && rx - WV < TH))
-          fx[rx & 1][j][a] = frag(sb[T::kd(j)] + a * G::XPLANE + (rx * SW + T::kw(j)) * 32);
-      } else if (rx < TH) fy[rx & 3][i - 6] = frag(yb + (i - 6) * G::YPLANE + (rx * TW) * 32);
-    };
-    // MFMA item i of cell rx: tap i / 4 (local index), block i % 4 = 2 a + b
-    auto mfma_item = [&](int rx, int i) {
-      const int tp = i >> 2, a = (i >> 1) & 1, bb = i & 1;
-      const int r = tp < 6 ? rx - tp % 3 : rx - WV;
-      if (tp < T::NT && r >= 0 && r < TH)
-        acc[tp][2 * a + bb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[rx & 1][tp < 6 ? tp / 3 : 2][a], fy[r & 3][bb],
-                                                                     acc[tp][2 * a + bb], 0, 0, 0);
-    };
-    load_item(0, 6); load_item(0, 7);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) load_item(0, i);
+    unsigned sb[3], yb, sn[3], yn;
+    bases(t, sb, yb);
+    bases(t + 1, sn, yn);
+    const bool more = t + 1 < nd, more2 = t + 2 < nd;
+    if (!G::MB) first_cell(sb, yb);
 #pragma unroll
     for (int rx = 0; rx < SH; ++rx) {
 #pragma unroll
       for (int i = 0; i < 28; ++i) {
-        if (rx + 1 < SH) {                              // 8 fragments of the next cell spread over the 28 gaps
-          if (i == 0) load_item(rx + 1, 6);
-          if (i == 3) load_item(rx + 1, 7);
-          if (i == 6) load_item(rx + 1, 0);
-          if (i == 9) load_item(rx + 1, 1);
-          if (i == 12) load_item(rx + 1, 2);
-          if (i == 15) load_item(rx + 1, 3);
-          if (i == 18) load_item(rx + 1, 4);
-          if (i == 21) load_item(rx + 1, 5);
+        // 8 fragments of the next cell (MB: of the next step's first cell behind the last one) spread over the 28 gaps
+        const int li = i == 0 ? 6 : (i == 3 ? 7 : ((i >= 6 && i <= 21 && i % 3 == 0) ? (i - 6) / 3 : -1));
+        if (li >= 0) {
+          if (rx + 1 < SH) load_item(sb, yb, rx + 1, li);
+          else if (G::MB) load_item(sn, yn, 0, li);
         }
-        if (i == 13) {
-          if (rx < G::XPW) dma_x(t + 3, rx, more);
-        }
-        if (i == 25) {
-          if (rx < G::YPW) dma_y(t + 1, rx, more);
+        if (!G::MB) {
+          if (i == 13 && rx < G::XPW) dma_x(t + 3, rx, more);
+          if (i == 25 && rx < G::YPW) dma_y(t + 1, rx, more);
+        } else if (rx >= PB) {                            // behind this step's barrier: slab t + 4 and dy(t + 2)
+          if ((i == 7 || i == 19) && 2 * (rx - PB) + (i == 19) < G::XPW) dma_x(t + 4, 2 * (rx - PB) + (i == 19), more2);
+          if ((i == 13 || i == 25) && 2 * (rx - PB) + (i == 25) < G::YPW) dma_y(t + 2, 2 * (rx - PB) + (i == 25), more2);
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_item(rx, i);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (G::MB && rx == PB - 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!G::MB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // partial tiles [tap][co][ci]: block (a, b) of a lane = ci 16 a + 4 (lane / 16) .. + 3 at co 16 b + lane % 16: one 16-byte store
   const int pair = cot * ncg + cg;
@@ -420,12 +485,12 @@ __device__ __forceinline__ void roll16_march(const bf16_t* __restrict__ x, int64
           make_float4(acc[i][q][0], acc[i][q][1], acc[i][q][2], acc[i][q][3]);
 }
 
-template <int TH>
+template <int TH, bool MB>
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_roll16(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                   float* __restrict__ part, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW, int dsegs, int dlen,
                   const bf16_t* __restrict__ x1, int xcd) {
-  using G = WR16<TH>;
+  using G = WR16<TH, MB>;
   const FplxBlock bid = fplx_xcd_block(xcd);
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
     case 0: roll16_march<G, 0>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
@@ -435,12 +500,12 @@ conv_wgrad_roll16(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   }
 }
 
-template <int TH, int TW>
+template <int TH, int TW, bool MB>
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_roll(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
                 float* __restrict__ part, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW, int dsegs, int dlen,
                 const bf16_t* __restrict__ x1, int xcd) {
-  using G = WR<TH, TW>;
+  using G = WR<TH, TW, MB>;
   const FplxBlock bid = fplx_xcd_block(xcd);
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {            // wave-uniform: four copies of the march
     case 0: roll_march<G, 0>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
@@ -457,8 +522,12 @@ inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
   // footprint: the one that pads the (h, w) plane least; 16 x 16 on a tie (fewer slab rows per dy row, smaller halo)
   const int geo = (int)fplx_knob(FPLX_K_WG_ROLL_GEO);
   auto area = [&](int th, int tw) { return (int64_t)((h + th - 1) / th) * th * ((w + tw - 1) / tw) * tw; };
+  // on a tie 8 x 32 where it runs on the 16 x 16 x 32 MFMA (less energy per FLOP: in the train step, beside the main stream's
+  // kernels, that form measured -0.6 % against 16 x 16 footprints and -1.2 % against 8 x 32 on 32 x 32 x 16), else 16 x 16
+  // (fewer slab rows per dy row, smaller halo)
+  const bool m16 = fplx_knob(FPLX_K_WG_ROLL_M16) != 0;
   c.th = 16; c.tw = 16;
-  if (area(8, 32) < area(c.th, c.tw)) { c.th = 8; c.tw = 32; }
+  if (area(8, 32) < area(c.th, c.tw) || (m16 && area(8, 32) == area(c.th, c.tw))) { c.th = 8; c.tw = 32; }
   if (area(8, 16) < area(c.th, c.tw)) { c.th = 8; c.tw = 16; }
   if (geo == 1) { c.th = 8; c.tw = 32; } else if (geo == 2) { c.th = 16; c.tw = 16; } else if (geo == 3) { c.th = 8; c.tw = 16; }
   c.tilesH = (h + c.th - 1) / c.th;
@@ -514,21 +583,28 @@ extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* 
   const RollCfg c = roll_cfg(n, d, h, w, cin, cout);
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "wgroll_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
   dim3 grid(c.nblk, c.npairs);
-#define LAUNCH_ROLL(TH_, TW_)                                                                                        \
+#define LAUNCH_ROLL(TH_, TW_, MB_)                                                                                   \
   do {                                                                                                              \
-    using G_ = WR<TH_, TW_>;                                                                                        \
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll<TH_, TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
-    conv_wgrad_roll<TH_, TW_><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, \
-                                                         cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, \
-                                                         fplx_xcd_on());                                            \
+    using G_ = WR<TH_, TW_, MB_>;                                                                                   \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll<TH_, TW_, MB_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_wgrad_roll<TH_, TW_, MB_><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, \
+                                                              cin, cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, \
+                                                              fplx_xcd_on());                                       \
   } while (0)
-  if (c.th == 8 && c.tw == 32 && fplx_knob(FPLX_K_WG_ROLL_M16)) {          // the 16 x 16 x 32 form of the 8 x 32 footprint
-    using G_ = WR16<8>;
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);
-    conv_wgrad_roll16<8><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, cin, cout,
-                                                    c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on());
-  }
-  else if (c.th == 16) LAUNCH_ROLL(16, 16); else if (c.tw == 32) LAUNCH_ROLL(8, 32); else LAUNCH_ROLL(8, 16);
+#define LAUNCH_ROLL16(MB_)                                                                                          \
+  do {                                                                                                              \
+    using G_ = WR16<8, MB_>;                                                                                        \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll16<8, MB_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_wgrad_roll16<8, MB_><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, cin, \
+                                                         cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
+  } while (0)
+  // mb: the mid-step barrier form (5 + 3 ring slots); the 8 x 16 footprint keeps the 4 + 2 rings (two blocks per CU) unless mb = 2
+  const int mb = (int)fplx_knob(FPLX_K_WG_ROLL_MB);
+  if (c.th == 8 && c.tw == 32 && fplx_knob(FPLX_K_WG_ROLL_M16)) { if (mb) LAUNCH_ROLL16(true); else LAUNCH_ROLL16(false); }
+  else if (c.th == 16) { if (mb) LAUNCH_ROLL(16, 16, true); else LAUNCH_ROLL(16, 16, false); }
+  else if (c.tw == 32) { if (mb) LAUNCH_ROLL(8, 32, true); else LAUNCH_ROLL(8, 32, false); }
+  else { if (mb == 2) LAUNCH_ROLL(8, 16, true); else LAUNCH_ROLL(8, 16, false); }
+#undef LAUNCH_ROLL16
 #undef LAUNCH_ROLL
   int rc = fplx_check_launch("wgroll_conv3d_wgrad");
   if (rc < 0) return rc;

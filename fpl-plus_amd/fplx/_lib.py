@@ -112,17 +112,53 @@ def get_tuning(key):
 
 def _apply_env_tuning():
     """The library itself never reads the environment; the benchmark tools' FPLX_<KEY>=<int> variables (FPLX_BRICK=0,
-    FPLX_MARCH32_V2=1, ...) are translated here, once, when the library is loaded."""
+    FPLX_MARCH32_V2=1, ...) are translated here, once, when the library is loaded.  A bad value leaves NO half-configured
+    library behind: the handle is dropped before the error is raised."""
+    global _lib
     buf, i = ctypes.create_string_buffer(64), 0
-    while _lib.fplx_tuning_key(i, buf, 64) >= 0:
-        key = buf.value.decode()
+    try:
+        while _lib.fplx_tuning_key(i, buf, 64) >= 0:
+            key = buf.value.decode()
+            env = os.environ.get("FPLX_" + key.upper())
+            if env is not None:
+                try:
+                    val = int(env)
+                except ValueError:
+                    raise ValueError("fplx: FPLX_%s=%r is not an integer" % (key.upper(), env))
+                rc = _lib.fplx_set_tuning(key.encode(), val)
+                if rc != 0:
+                    raise FplxError("fplx (%d): fplx_set_tuning(%s, %d) failed" % (rc, key, val))
+            i += 1
+    except Exception:
+        _lib = None
+        raise
+
+
+# ---- host-side A/B switches (benchmarks and bisection tools only).  The ONE place product Python translates FPLX_<KEY>
+# environment variables: Engine / TrainStep read their defaults from here, tools flip the attributes they set.
+_HOST_KNOBS = {
+    "pack_reuse": 1,        # Engine.allow_pack_reuse: the second domain's forward of an iteration reuses the first one's packs
+    "side_stream": 1,       # Engine.use_side_stream: weight gradients on a second HIP stream (0: one stream, clean profiles)
+    "split_cat": 1,         # Engine.use_split_cat: level-0 skip || up as two tensors
+    "fused_pool": 1,        # Engine.use_fused_pool: DownBlock tails in one pass each way
+    "eval_fuse": 1,         # Engine.use_eval_fusion: eval-mode BatchNorm folded into the packs
+    "stem_wg_main": 1,      # Engine.stem_wgrad_on_main
+    "bucket_elems": 1 << 21,    # TrainStep: gradient all-reduce bucket size (elements)
+}
+_host_vals = {}
+
+
+def host_knob(key):
+    """value of a host-side A/B switch: FPLX_<KEY> from the environment (read once), else the shipped default"""
+    if key not in _HOST_KNOBS:
+        raise ValueError("fplx: unknown host knob %r" % (key,))
+    if key not in _host_vals:
         env = os.environ.get("FPLX_" + key.upper())
-        if env is not None:
-            try:
-                _lib.fplx_set_tuning(key.encode(), int(env))
-            except ValueError:
-                raise ValueError("fplx: FPLX_%s=%r is not an integer" % (key.upper(), env))
-        i += 1
+        try:
+            _host_vals[key] = _HOST_KNOBS[key] if env is None else int(env)
+        except ValueError:
+            raise ValueError("fplx: FPLX_%s=%r is not an integer" % (key.upper(), env))
+    return _host_vals[key]
 
 
 def last_error():

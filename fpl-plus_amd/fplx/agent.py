@@ -57,6 +57,8 @@ class SegmentationAgent(object):
         self.inferer = None
         self.checkpoint = None
         self.train_loader_1 = self.train_loader_2 = self.test_loader = None
+        self.engine_mode = True            # training loops through fplx.TrainStep where network, loss and optimiser are fplx's own
+        self._ts = None
         self.tensor_type = config['dataset'].get('tensor_type', 'float')
         self.fpl_uda = config['training'].get('train_fpl_uda', False) if 'training' in config else False
         # one process per GPU: the process group comes up BEFORE anything touches the device
@@ -213,6 +215,30 @@ class SegmentationAgent(object):
             it = iter(loader)
             return next(it), it
 
+    def _engine_step(self):
+        """fplx.TrainStep over THIS agent's network, loss terms and optimiser when all three are fplx's own (and the agent is
+        not data parallel): the training loops below then run the engine step - flat gradient buffer, fused loss, one Adam
+        launch per segment, no autograd bookkeeping - instead of net(x) / loss.backward() / optimizer.step().  Same kernels,
+        same numbers (tests/test_gpu_loss_filter_parity.py runs the reference's training_all fixtures through both); measured
+        at the benchmark shape the autograd route was 9 % slower (bench.py `secondary.plugin_path`, round 4).  Anything
+        foreign - a network / loss / optimiser registered through set_network / set_loss_dict / set_optimizer, more than two
+        domains, engine_mode = False - keeps the autograd route."""
+        from .loss import AbstractSegLoss
+        from .optim import FusedAdam
+        from .train import TrainStep
+        lc, opt, net = self.loss_calculator, self.optimizer, self.net
+        ok = (self.engine_mode and not self.distributed and type(net) is UNet2D5_dsbn and
+              isinstance(lc, AbstractSegLoss) and type(lc).forward is AbstractSegLoss.forward and type(lc)._run is AbstractSegLoss._run
+              and type(opt) is FusedAdam and opt.net is net and int(self.config['network']['num_domains']) <= 2)
+        if not ok:
+            self._ts = None
+            return None
+        key = (id(net), id(opt), tuple(lc.terms), bool(lc.softmax))
+        if self._ts is None or self._ts_key != key:
+            self._ts = TrainStep(net, lc.terms, lc.softmax, optimizer=opt)
+            self._ts_key = key
+        return self._ts
+
     def _train_loop(self, dual):
         class_num = self.config['network']['class_num']
         iter_valid = self.config['training']['iter_valid']
@@ -222,11 +248,42 @@ class SegmentationAgent(object):
         self.net.train()
         train_loss = None
         dice_lists = [[] for _ in range(nd)]
+        ts = self._engine_step()
         for _ in range(iter_valid):
             datas = []
             for k in range(nd):
                 d, iters[k] = self._next(iters[k], loaders[k])
                 datas.append(d)
+            if ts is not None:
+                # engine route: the same iteration (agent_seg.py:459-495 / 336-357) on flat buffers
+                bl = []
+                for k in range(nd):
+                    b = {'image': self.convert_tensor_type(datas[k]['image']).to(self.device),
+                         'label_prob': self.convert_tensor_type(datas[k]['label_prob']).to(self.device)}
+                    if self.fpl_uda and datas[k].get('pixel_weight', None) is not None:      # get_loss_value, agent_seg.py:134-142
+                        b['pixel_weight'] = datas[k]['pixel_weight'].to(self.device)
+                        if datas[k].get('image_weight', None) is not None:
+                            b['image_weight'] = datas[k]['image_weight'].to(self.device)
+                    bl.append(b)
+                step_sched = self.scheduler is not None and not isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau)
+                if dual:
+                    outs = ts.step_all(bl)
+                    loss = outs[0][0] if nd == 1 else (outs[0][0] + outs[1][0]) / 2           # agent_seg.py:468,482
+                    if step_sched:
+                        self.scheduler.step()
+                    train_loss = loss if train_loss is None else train_loss + loss
+                else:
+                    outs = []
+                    for k in range(nd):
+                        o = ts.step(bl[k]['image'], bl[k]['label_prob'], k, bl[k].get('pixel_weight'), bl[k].get('image_weight'))
+                        outs.append(o)
+                        if step_sched:
+                            self.scheduler.step()                                              # agent_seg.py:355-357
+                        train_loss = o[0] if train_loss is None else train_loss + o[0]
+                for k in range(nd):
+                    dice_lists[k].append(outs[k][4:4 + class_num])
+                    self.loss_calculator.last_out = outs[k]
+                continue
             if dual:
                 self.optimizer.zero_grad()
             loss = None

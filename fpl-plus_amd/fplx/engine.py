@@ -14,10 +14,9 @@ Reference semantics implemented here (paths under /root/reference/PyMIC/pymic):
   DownBlock / UpBlock             net/net3d/unet2d5_dsbn.py:108-129 / 156-188
   DomainSpecificBatchNorm3d       net_run_dsbn/dsbn.py:54-57 (bns[domain_label[0]] for the batch)
 """
-import os
 
 import torch
-from . import ops
+from . import ops, _lib
 from ._lib import F32, BF16
 
 LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
@@ -36,21 +35,26 @@ class Engine(object):
         self.ws_side = None
         self._pack_cache = None
         self._train_packs = None                         # packs of the last train-mode forward (reuse_packs)
-        self.allow_pack_reuse = os.environ.get("FPLX_PACK_REUSE", "1") != "0"      # A/B switch
+        self.allow_pack_reuse = _lib.host_knob("pack_reuse") != 0      # A/B switches: fplx/_lib.py:_HOST_KNOBS
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
-        # FPLX_SIDE_STREAM=0 serialises all kernels on one stream (clean per-kernel profiles)
-        self.use_side_stream = os.environ.get("FPLX_SIDE_STREAM", "1") != "0"
-        self.use_split_cat = os.environ.get("FPLX_SPLIT_CAT", "1") != "0"     # A/B knob (benchmarks only)
-        self.use_fused_pool = os.environ.get("FPLX_FUSED_POOL", "1") != "0"   # A/B knob (benchmarks only)
+        # side_stream = 0 serialises all kernels on one stream (clean per-kernel profiles)
+        self.use_side_stream = _lib.host_knob("side_stream") != 0
+        self.use_split_cat = _lib.host_knob("split_cat") != 0
+        self.use_fused_pool = _lib.host_knob("fused_pool") != 0
         # inference (eval-mode BatchNorm, nothing kept for a backward, bf16): BatchNorm folded into the packs, PReLU in the
         # convolution's write-out - the BN-apply passes of the sites without active dropout disappear (FPLX_EVAL_FUSE=0: off)
-        self.use_eval_fusion = os.environ.get("FPLX_EVAL_FUSE", "1") != "0"
-        self.stem_wgrad_on_main = os.environ.get("FPLX_STEM_WG_MAIN", "1") != "0"   # A/B knob (benchmarks only)
+        self.use_eval_fusion = _lib.host_knob("eval_fuse") != 0
+        self.stem_wgrad_on_main = _lib.host_knob("stem_wg_main") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
+        # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
+        # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
+        # zeroing, so training is wrong; what is measured is the step time a pipelined optimiser step could reach
+        self.defer_probe = False
+        self._deferred = []
         # block_joins: the main stream waits for the weight-gradient stream at every block boundary of backward.
-        # None = decide per network (see backward()); tools/race25.py sets it to bisect.
+        # None = decide per network (see backward()); a bisection tool may set it (round 2's tools/race25.py, git history).
         self.block_joins = None
-        self.debug_tap = None              # tools/race25.py: callable(name, tensor) on intermediate gradients of backward
+        self.debug_tap = None              # callable(name, tensor) on intermediate gradients of backward (bisection tools)
 
     # ------------------------------------------------------------------ helpers
     def _workspace(self, nbytes, dev):
@@ -90,7 +94,7 @@ class Engine(object):
     def default_block_joins(self):
         """No joins at block boundaries: backward's main stream never waits for the weight-gradient stream until the end.
         (Round 1 needed them for networks with 2D levels; the cause was a store-data hazard inside the march kernels'
-        inline-asm 16-byte stores, fixed there - DESIGN section 7, tools/race25.py / race25c.py.)"""
+        inline-asm 16-byte stores, fixed there - DESIGN section 7, profiles/r02_race25_hazard_location.txt.)"""
         return False
 
     def invalidate(self):
@@ -101,11 +105,18 @@ class Engine(object):
     def _folded(self, adt, domain, key, conv, bn):
         """forward pack and bias of a convolution with its eval-mode BatchNorm folded in (dsbn.py:54-57 on running statistics:
         z = scale (conv(x; w) + b) + shift = conv(x; scale w) + (scale b + shift)); cached until the parameters or the
-        running statistics change (invalidate(), any train-mode forward)"""
+        running statistics change: invalidate(), any train-mode forward, an optimiser step, or a version-counter change of
+        one of the six source tensors"""
         ck = (adt, domain)
         tab = self._fold_cache.setdefault(ck, {})
-        if key not in tab:
-            bnm = bn.bns[domain]
+        bnm = bn.bns[domain]
+        # the fold bakes in six tensors; torch-side in-place edits made while the net stays in eval mode (running_mean.copy_, an
+        # EMA / SWA weight swap, a stock torch optimiser) bump their version counters - a stale fold would give silently wrong
+        # logits.  (Writes through raw pointers - the engine's own Adam, the train-mode statistics kernels - do not; those
+        # paths call invalidate(): FusedAdam.step_flat / step, every train-mode forward.)
+        src = (conv.weight, conv.bias, bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var)
+        ver = tuple(-1 if t is None else (t.data_ptr(), t._version) for t in src)
+        if key not in tab or tab[key][2] != ver:
             with torch.no_grad():
                 scale = bnm.weight.detach().float() * torch.rsqrt(bnm.running_var.float() + bnm.eps)
                 shift = bnm.bias.detach().float() - bnm.running_mean.float() * scale
@@ -117,8 +128,8 @@ class Engine(object):
                     wf, _ = ops.pack_conv2d_weight(wf_, adt, False)
                 else:
                     wf, _ = ops.pack_conv_weight(wf_, adt, False)
-            tab[key] = (wf, biasf)
-        return tab[key]
+            tab[key] = (wf, biasf, ver)
+        return tab[key][:2]
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, domain, train, drop_on, seed=0, step=0, keep=True, mc=1, out=None, reuse_packs=False):
@@ -157,14 +168,30 @@ class Engine(object):
         ft = net.ft_chns
         if train and reuse_packs and self.allow_pack_reuse and self._train_packs is not None and self._train_packs[0] == adt:
             packs = self._train_packs[1]
-        elif train or self._pack_cache is None or self._pack_cache[0] != adt:
+        elif train or self._pack_cache is None or self._pack_cache[0] != (adt, net.flat_params.data_ptr(), net.flat_params._version):
             packs = self._pack(adt)
-            self._pack_cache = None if train else (adt, packs)
+            # eval-mode packs are kept until the parameters change: invalidate() (the engine's own raw-pointer writers call it)
+            # or a version-counter change of the flat parameter buffer (torch-side in-place edits of any parameter view)
+            self._pack_cache = None if train else ((adt, net.flat_params.data_ptr(), net.flat_params._version), packs)
             self._train_packs = (adt, packs) if train else None
         else:
             packs = self._pack_cache[1]
         if train:
             self._fold_cache = {}                        # the running statistics are about to change
+        deferred_join = None
+        if train and self._deferred and self._side is not None:
+            # timing probe (defer_probe): the previous step's decoder weight gradients run beside this forward
+            main_ = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main_)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                for fn_, _ in self._deferred:
+                    fn_()
+                deferred_join = torch.cuda.Event()
+                deferred_join.record(self._side)
+            self._deferred_keep = self._deferred
+            self._deferred = []
         fuse = self.use_eval_fusion and not train and not keep and adt == torch.bfloat16
         if mc > 1 and (train or keep):
             raise ValueError("fplx: Monte-Carlo replication (mc > 1) is an inference mode: eval-mode BatchNorm, keep=False")
@@ -343,6 +370,9 @@ class Engine(object):
             raise ValueError("fplx: out must be a contiguous fp32 tensor of shape %s on %s" % ((NM, ncls, D, H, W), dev))
         ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
                        ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
+        if deferred_join is not None:
+            torch.cuda.current_stream().wait_event(deferred_join)
+            self._deferred_keep = None
         return logits, (sv if keep else None)
 
     # ------------------------------------------------------------------ backward
@@ -397,7 +427,12 @@ class Engine(object):
             block_joins = self.default_block_joins()
         ws_w = self.ws_side if side_on else ws
 
+        decoder_phase = [True]
+
         def on_side(fn, *tensors):
+            if self.defer_probe and side_on and decoder_phase[0]:
+                self._deferred.append((fn, tensors))
+                return
             if not side_on:
                 fn()
                 return
@@ -562,6 +597,7 @@ class Engine(object):
             if tap is not None:
                 tap(name + ".dx", d_cur)
         # ---- encoder, block4 .. block0
+        decoder_phase[0] = False
         d_pool = block_bwd(4, d_cur, True)                            # grad w.r.t. pooled3 [V_4, ft_3]
         ready("block4.conv.relu_1.weight")
         for i in range(3, -1, -1):

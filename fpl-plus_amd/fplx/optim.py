@@ -75,6 +75,7 @@ class FusedAdam(Optimizer):
     def step(self, closure=None):
         net = self.net
         net._ensure_flat()
+        net.engine.invalidate()                 # raw-pointer update below: packs and eval-mode folds are stale afterwards
         group = self.param_groups[0]
         lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
         for si, (start, end) in enumerate(self.seg_ranges):
@@ -111,6 +112,8 @@ class FusedAdam(Optimizer):
         """engine-mode update: gflat is laid out like net.flat_params; only the shared segment and
         the listed domains' BN segments are updated."""
         net = self.net
+        net.engine.invalidate()                 # the update goes through raw pointers: packs and eval-mode folds are stale now
+        self._opt_called = True                 # torch's lr schedulers check that an optimiser step preceded theirs
         group = self.param_groups[0]
         lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
         for si, (start, end) in enumerate(self.seg_ranges):

@@ -7,41 +7,39 @@ backward + optimizer.step the published loop forgot (it exists in training_all, 
 the vanilla agent, net_run/agent_seg.py:153-159).  `step_all()` = one iteration of training_all
 (agent_seg.py:459-495): every domain forward, loss (l0 + l1)/2, ONE Adam step.
 """
-import os
-
 import torch
 
-from . import ops
+from . import ops, _lib
 from .ddp import GradAllReducer
 from .optim import FusedAdam
 
 
 class TrainStep(object):
     def __init__(self, net, loss_terms=(1.0, 0.0, 0.0, 0.0), softmax=True, lr=1e-4, weight_decay=1e-5,
-                 milestones=(), gamma=0.5, group=None, bucket_elems=1 << 21):
+                 milestones=(), gamma=0.5, group=None, bucket_elems=1 << 21, optimizer=None):
+        """optimizer: an existing fplx.FusedAdam over `net` (SegmentationAgent routes its training loops through this class and
+        keeps ITS optimiser - state, param_groups, the torch lr scheduler stepping it); its learning rate is then whatever the
+        param_group says at the time of the step, `lr` / `milestones` / `gamma` are not used."""
         net._ensure_flat()
         net.train()
         self.net = net
         self.terms = tuple(float(t) for t in loss_terms)
         self.softmax = bool(softmax)
-        self.opt = FusedAdam(net, lr, weight_decay=weight_decay)
+        self.external_lr = optimizer is not None
+        self.opt = optimizer if optimizer is not None else FusedAdam(net, lr, weight_decay=weight_decay)
         self.base_lr, self.milestones, self.gamma = lr, sorted(milestones), gamma
         self.iteration = 0
         self.gflat = torch.zeros_like(net.flat_params)
         self.gacc = None
         shared, doms = net.segments()
-        bucket_elems = int(os.environ.get("FPLX_BUCKET_ELEMS", bucket_elems))      # tuning knob (benchmarks only)
+        if bucket_elems == 1 << 21:
+            bucket_elems = int(_lib.host_knob("bucket_elems"))          # A/B switch (fplx/_lib.py:_HOST_KNOBS)
         self.reducer = GradAllReducer(net.bucket_ranges(bucket_elems), doms, group)
         # the loss is evaluated over the FULL batch of all ranks (reference: nn.DataParallel gathers the logits, one loss):
         # the ranks' gradients add up to its gradient, nothing is divided by the world size
         self.group = group
         self.opt.grad_scale = 1.0
         self.dist_loss = self.reducer.enabled
-        dbg = os.environ.get("FPLX_DDP_DEBUG", "")        # measurement knob (tools/gpu_job6.sh): which part costs what
-        if "noloss" in dbg:
-            self.dist_loss = False
-        if "nogr" in dbg:
-            self.reducer.enabled = False
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
         self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
         self._loss_bufs = {}
@@ -65,6 +63,20 @@ class TrainStep(object):
                                         reuse_packs=reuse_packs)
         n, c = logits.shape[0], logits.shape[1]
         v = logits[0, 0].numel()
+        if logits.shape != label.shape:                                       # as fplx.loss._FusedSegLoss.forward
+            raise ValueError("fplx loss: prediction {0:} and ground_truth {1:} differ in shape".format(
+                tuple(logits.shape), tuple(label.shape)))
+        if self.terms[2] != 0.0 and (pw is None or iw is None):
+            raise KeyError('pixel_weight')                                    # dice.py:109-110 index the dict
+        if self.terms[2] == 0.0:
+            iw = None
+        label = label.float().contiguous()
+        if pw is not None:
+            pw = pw.float().contiguous()
+            if pw.numel() != n * v:
+                raise ValueError("fplx loss: pixel_weight must be [N,1,D,H,W]")
+        if iw is not None:
+            iw = iw.float().contiguous()
         part, coef = self._loss_buffers(n, c, v, logits.device)
         out = torch.empty(4 + c, dtype=torch.float32, device=logits.device)
         if self.dist_loss:
@@ -81,7 +93,8 @@ class TrainStep(object):
         self.reducer.begin(self.gflat)
         out = self._fwd_bwd(x, label, domain, pixel_weight, image_weight, self._one, self.gflat, self.reducer.ready)
         self.reducer.finish([domain])
-        self.opt.param_groups[0]['lr'] = self._lr()
+        if not self.external_lr:
+            self.opt.param_groups[0]['lr'] = self._lr()
         self.opt.step_flat(self.gflat, [domain])
         self.iteration += 1
         return out
@@ -104,7 +117,8 @@ class TrainStep(object):
                 self.gflat.add_(self.gacc)
         self.reducer.begin(self.gflat)
         self.reducer.finish(list(range(nd)))
-        self.opt.param_groups[0]['lr'] = self._lr()
+        if not self.external_lr:
+            self.opt.param_groups[0]['lr'] = self._lr()
         self.opt.step_flat(self.gflat, list(range(nd)))
         self.iteration += 1
         return outs
