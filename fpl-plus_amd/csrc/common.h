@@ -123,7 +123,6 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
 #define FPLX_KNOB_LIST(X)                                                                                              \
   X(XCD, "xcd", 1)                         /* 0: hardware block order (fplx_xcd_block off) */                           \
   X(BRICK, "brick", 1)                     /* 0: no brick kernel; 3: only layers no march kernel takes */               \
-  X(BRICK_M16, "brick_m16", 0)             /* 1: conv_fwd_brick16 (v_mfma_f32_16x16x32_bf16; measured 1-5 % slower alone, +0.3 % step) */ \
   X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \

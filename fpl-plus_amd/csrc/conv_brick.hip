@@ -395,384 +395,6 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// conv_fwd_brick16: conv_fwd_brick on v_mfma_f32_16x16x32_bf16.  The kernels of this file run against the chip's power limit
-// (DESIGN 5.2), and the train step as a whole is bounded by the energy it spends rather than by any one pipe (round 4: the
-// 16 x 16 x 32 form of the weight gradient is no faster alone and makes the step 0.6-1.2 % faster): the 16 x 16 x 32 shape moves
-// the same FLOPs for less (MI355X_MICROARCH.md, DVFS give-back item 7).  Same bricks, rings, DMA, barrier protocol and write-out
-// as conv_fwd_brick; what changes:
-//   * a stage (one (kh, kw) of a 32-channel chunk) is ONE K step: an A fragment = 16 voxels x all 32 channels (lane = voxel
-//     l & 15, 8-channel group l >> 4), a B fragment = 16 output channels x 32 input channels; the wave's 4 x 8 patch is two
-//     voxel halves (rows {0, 2} | {1, 3}: m16_row / m16_col), its 32 NTW channels 2 NTW blocks of 16: per plane and depth tap
-//     4 NTW MFMAs on 2 + 2 NTW fragments - the same LDS reads per FLOP as the 32 x 32 x 16 form;
-//   * the stage's two halves are the two VOXEL halves: the B fragments of a stage serve both, and the next stage's are
-//     requested depth tap by depth tap behind the second half's MFMAs that last read the registers;
-//   * LDS images: 16-byte chunk c of voxel / weight row L sits at chunk c ^ (2 ((L >> 2) & 1)) - with the lane maps above every
-//     ds_read_b128 lane group touches 16 distinct 16-byte slots for every tap shift (exhaustive search over the groups).
-__device__ __forceinline__ int m16_row(int m) { return 2 * ((m & 15) >> 3) + (m >> 4); }     // tile row m = 16 half + v
-__device__ __forceinline__ int m16_col(int m) { return m & 7; }
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-// ACT (inference, eval-mode BatchNorm folded into the pack): PReLU(slope) in the write-out (STATS must be false)
-// CAT2 (inference forms only): the input is the channel concatenation of TWO tensors of Cin / 2 channels and one leading
-// dimension - chunks below Cin / 2 come from x, sample n % nmod0 (nmod0 > 0: the skip tensor that the Monte-Carlo passes
-// share, one copy for all of them), the rest from x1
-template <bool STATS, int NTW, int TD, int WH, bool ACT = false, bool CAT2 = false>
-__global__ void __launch_bounds__(BK::THREADS)
-conv_fwd_brick16(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
-               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr,
-               const bf16_t* __restrict__ x1 = nullptr, int nmod0 = 0) {
-  using G = BKG<TD, WH, NTW>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* bricks = smem;
-  char* wring = smem + 2 * G::BRICK_BYTES;
-  float* bias_s = reinterpret_cast<float*>(wring + 2 * G::WST_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, kg = lane >> 4;            // fragment lane = (voxel | output channel r16, 8-channel group kg)
-  const int hhalf = wave / G::WN, wn = wave % G::WN;
-  // Which (output-channel tile, Cin split) = weight slice and which part of the brick list this block takes.  The dispatcher
-  // deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own 4-MB L2 (common.h):
-  //   xcd == 1: XCD j sweeps its contiguous eighth of the brick list for every slice (fplx_xcd_tiles) - neighbouring bricks,
-  //             shared halos, one L2: the levels whose weights fit an L2 beside the activations (levels 1-2);
-  //   xcd == 2: (the launcher made grid.x * U a multiple of 8, U = grid.y * grid.z slices) every XCD works on ONE slice (U
-  //             divides 8) or on U / 8 of them: the slice - 27 x NT x Cin / grid.z weights, streamed once per brick - stays
-  //             in that XCD's L2.  The deep levels' packs are 3.5-14 MB: dealt the other way every L2 streams all of it for
-  //             every brick (level 3, 256 -> 512: 122 -> 75 us).
-  int by = blockIdx.y, bz = blockIdx.z;
-  FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd == 1);
-  if (xcd == 2) {
-    const unsigned gx = gridDim.x, U = gridDim.y * gridDim.z;
-    const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x, xc = L & 7u, idx = L >> 3;
-    unsigned u, stripe;
-    if (8 % U == 0) { u = xc % U; stripe = idx * (8 / U) + xc / U; }
-    else { u = xc + 8 * (idx % (U / 8)); stripe = idx / (U / 8); }
-    by = __builtin_amdgcn_readfirstlane((int)(u % gridDim.y));
-    bz = __builtin_amdgcn_readfirstlane((int)(u / gridDim.y));
-    tr.first = __builtin_amdgcn_readfirstlane((int)stripe);
-    tr.step = gx;
-  }
-  const int n0 = by * G::NT;
-  // persistent: the next brick's first chunk is fetched during the current brick's last one, the weight ring never stops
-  if (tr.first >= tr.end) return;
-
-  // blockIdx.z deals the 32-channel chunks of Cin (split-K for the small deep volumes): fp32 partial tiles, summed by
-  // splitk_finish_k (conv_mfma.hip)
-  const int c_lo = (int)((int64_t)(Cin / G::KC) * bz / gridDim.z);
-  const int nch = (int)((int64_t)(Cin / G::KC) * (bz + 1) / gridDim.z) - c_lo;
-
-  // ---- DMA plumbing (see conv_fwd_march32v2): out-of-range lanes of a buffer load to LDS write zeros
-  const int64_t xsample = (int64_t)D * H * W * ldx * 2;
-  u32x4 rw;
-  rw[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wp);
-  rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
-  rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
-  rw[3] = 0x00020000u;
-  auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, char* l) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
-    const unsigned so_ = __builtin_amdgcn_readfirstlane(so);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so_), "s"(dst) : "memory");
-  };
-  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  // a brick's coordinates, its descriptor (the sample's volume) and its DMA lane offsets: piece p = wave + 4 k covers LDS
-  // bytes [p * 1024, +1024) of the slot, lane -> 16-byte chunk
-  struct Brick { int n, n0, d0, h0, w0; unsigned vo[G::NPB]; };
-  auto setup = [&](int64_t tile, Brick& B) {
-    int b = (int)tile;
-    const int bw = b % bW; b /= bW;
-    const int bh = b % bH; b /= bH;
-    const int bd = b % bD; b /= bD;
-    B.n = __builtin_amdgcn_readfirstlane(b);
-    B.n0 = (CAT2 && nmod0 > 0) ? __builtin_amdgcn_readfirstlane(b % nmod0) : B.n;
-    B.d0 = __builtin_amdgcn_readfirstlane(bd * G::TD);
-    B.h0 = __builtin_amdgcn_readfirstlane(bh * G::TH);
-    B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
-#pragma unroll
-    for (int k = 0; k < G::NPB; ++k) {
-      const int ci = (wave + 4 * k) * 64 + lane;
-      const int L = ci >> 2, cc = (ci & 3) ^ (2 * ((L >> 2) & 1));
-      const int q = L / G::PL, rem = L % G::PL, hh = rem / G::SWP, ww = rem % G::SWP;
-      const int gd = B.d0 - 1 + q, gh = B.h0 - 1 + hh, gw = B.w0 - 1 + ww;
-      const bool in = q < G::SD && rem < G::SH * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-      B.vo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
-    }
-  };
-  // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][NT couts], swizzle 2 ((row >> 2) & 1)
-  const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ (2 * ((lane >> 4) & 1))) * 8) * 2);
-  const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
-  auto brick_pieces = [&](const Brick& B, int ch, int slot, int k0, int cnt) {     // pieces k0 .. k0 + cnt - 1 of chunk ch
-    int c = c_lo + ch;                                                            // uniform
-    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
-    if (CAT2) {
-      const int half = Cin / (2 * G::KC);
-      if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
-      else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
-    }
-    u32x4 rx;
-    rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
-    rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
-    rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
-    rx[3] = 0x00020000u;
-#pragma unroll
-    for (int k = k0; k < k0 + cnt; ++k)
-      if (k < G::NPB && wave + 4 * k < G::NP_TOT)            // uniform
-        buf_dma(rx, B.vo[k], (unsigned)(c * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
-  };
-  auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
-#pragma unroll
-    for (int k = 0; k < G::NPW; ++k) {
-      const int j = wave + 4 * k, kd = j / (G::NT / 16);
-      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
-      buf_dma(rw, wvo, so, wring + slot * G::WST_BYTES + j * 1024);
-    }
-  };
-
-  f32x4 acc[TD][NTW][4];                                      // [plane][N-tile][2 vh + cb]: voxel half vh x 16-channel block cb
-#pragma unroll
-  for (int p = 0; p < TD; ++p)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int bq = 0; bq < 4; ++bq)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[p][j][bq][i] = 0.f;
-
-  Brick cur, nxt;
-  int64_t tile = tr.first;
-  setup(tile, cur);
-  // prologue: brick chunk 0 -> brick slot 0, weight stages 0 and 1
-  brick_pieces(cur, 0, 0, 0, G::NPB);
-  weight_stage(0, 0, 0);
-  weight_stage(0, 1, 1);
-  if (tid < G::NT) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
-  dma_wait();
-  block_sync();
-
-  // fragment addresses: A lane base (slot of the patch's tap (0, 0, 0) corner voxel for voxel half 0; half 1 is one row down),
-  // B lane base (row r16 of a 16-channel block, chunk kg swizzled by the row)
-  const int L0 = (hhalf * 4 + 2 * (r16 >> 3)) * G::SWP + (r16 & 7);
-  const int bb = (wn * (32 * NTW) + r16) * G::ROWB + ((kg ^ (2 * ((r16 >> 2) & 1))) << 4);
-  bf16x8 fa[2][G::SD], fb[3][2 * NTW];
-  auto load_a = [&](const char* brick, int kh, int kw, int vh) {
-    int a0 = L0 + (kh + vh) * G::SWP + kw;
-    asm volatile("" : "+v"(a0));
-    const char* p = brick + a0 * G::ROWB + ((kg ^ (2 * ((a0 >> 2) & 1))) << 4);
-#pragma unroll
-    for (int q = 0; q < G::SD; ++q) fa[vh][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
-  };
-  auto load_b = [&](const char* wslot, int kd) {
-    int b0 = bb;
-    asm volatile("" : "+v"(b0));
-    const char* p = wslot + b0;
-#pragma unroll
-    for (int c = 0; c < 2 * NTW; ++c)
-      fb[kd][c] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + c * 16) * G::ROWB);
-  };
-  auto mfmas = [&](int vh, int kd) {
-#pragma unroll
-    for (int p = 0; p < TD; ++p)
-#pragma unroll
-      for (int c = 0; c < 2 * NTW; ++c)
-        acc[p][c >> 1][2 * vh + (c & 1)] =
-            __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[vh][p + kd], fb[kd][c], acc[p][c >> 1][2 * vh + (c & 1)], 0, 0, 0);
-  };
-
-  load_a(bricks, 0, 0, 0);
-  load_b(wring, 0); load_b(wring, 1); load_b(wring, 2);
-  int cc = 0;                                               // chunks done so far (all bricks): brick slot = cc & 1
-  int gs = 0;                                               // stages done so far: weight slot = gs & 1
-  for (;;) {
-    const int64_t tile_nx = tile + tr.step;
-    const bool has_next = tile_nx < tr.end;                  // uniform
-    if (has_next) setup(tile_nx, nxt);
-    for (int ch = 0; ch < nch; ++ch, ++cc) {
-      const char* brick = bricks + (cc & 1) * G::BRICK_BYTES;
-      const char* brick_nx = bricks + ((cc + 1) & 1) * G::BRICK_BYTES;
-      const bool last_ch = ch + 1 == nch;
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9, ++gs) {
-        const int kh = t9 / 3, kw = t9 % 3;
-        const char* wslot_nx = wring + ((gs + 1) & 1) * G::WST_BYTES;
-        // ---- first half (voxel rows 0, 2 of the patch): prefetch the second half's A fragments
-        load_a(brick, kh, kw, 1);
-        mfmas(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // the next stage's weights (issued in the second half of the stage before this one) and, at t9 == 8, the next
-        // chunk of the brick / the next brick's first chunk have landed; nobody reads this stage's weight slot (its B
-        // fragments are in registers since the previous stage) / (at t9 == 8) this chunk's brick slot any more once past this
-        // barrier
-        dma_wait();
-        block_sync();
-        // ---- second half: the stage after next's weights -> this stage's slot, two pieces of the next chunk, next stage's
-        // fragments - its B fragments depth tap by depth tap, each behind the MFMAs that read the registers last
-        {
-          int ch2 = ch, t92 = t9 + 2;
-          if (t92 >= 9) { t92 -= 9; ++ch2; }
-          if (ch2 < nch) weight_stage(ch2, t92, gs & 1);
-          else if (has_next) weight_stage(0, t92, gs & 1);
-        }
-        if (2 * t9 < G::NPB) {
-          if (!last_ch) brick_pieces(cur, ch + 1, (cc + 1) & 1, 2 * t9, 2);
-          else if (has_next) brick_pieces(nxt, 0, (cc + 1) & 1, 2 * t9, 2);
-        }
-        if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0); else load_a(brick_nx, 0, 0, 0);
-        mfmas(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(wslot_nx, 0);
-        mfmas(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(wslot_nx, 1);
-        mfmas(1, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(wslot_nx, 2);
-      }
-    }
-
-    // ---- write-out of this brick: bias, statistics, bf16 through 2-KiB per-wave LDS tiles, 16-byte stores.  The tiles
-    // live in the brick slot of the chunk just finished: nobody has read it since the last stage's barrier, and the next
-    // DMA into it is issued behind the next stage's barrier, i.e. after every wave has left this write-out.
-    // Tile row m = 16 vh + v <-> patch voxel (m16_row(m), m16_col(m)); accumulator block (vh, cb), register i of a lane =
-    // tile row 16 vh + 4 kg + i, tile column 16 cb + r16.
-    char* dead = bricks + ((cc - 1) & 1) * G::BRICK_BYTES;
-    char* stg = dead + wave * 4096;
-    const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
-    const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
-    unsigned vmask = 0xFFu;                                    // bit 4 vh + i: accumulator row (vh, i) of this lane is inside
-    if (!full) {
-      vmask = 0;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int m = 16 * (t >> 2) + 4 * kg + (t & 3);
-        if (h0 + hhalf * 4 + m16_row(m) < H && w0 + m16_col(m) < W) vmask |= 1u << t;
-      }
-    }
-    f32x2 s1[NTW][2], s2[NTW][2];                              // per (N-tile, 16-channel block): this lane's channel
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) { s1[j][c] = f32x2{0.f, 0.f}; s2[j][c] = f32x2{0.f, 0.f}; }
-    const int mrow = lane >> 2;                                // this lane stores tile rows mrow and mrow + 16
-    const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + m16_row(mrow)) * W + w0 + m16_col(mrow)) * ldy;
-    const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + m16_row(mrow + 16)) * W + w0 + m16_col(mrow + 16)) * ldy;
-    const bool ok0 = h0 + hhalf * 4 + m16_row(mrow) < H && w0 + m16_col(mrow) < W;
-    const bool ok1 = h0 + hhalf * 4 + m16_row(mrow + 16) < H && w0 + m16_col(mrow + 16) < W;
-    bf16_t* ycol = y + n0 + wn * (32 * NTW) + (lane & 3) * 8;
-    const float slope_v = ACT ? *slope_p : 0.f;
-    auto write_out = [&](auto full_c) {
-      constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-      for (int p = 0; p < TD; ++p) {
-        const int dd = d0 + p;
-        if (FULL || dd < D) {                                  // uniform
-          bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            char* tile_ = stg + ((p * NTW + j) & 1) * 2048;    // two tiles per wave, used alternately
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              const float bv = bias_s[wn * (32 * NTW) + j * 32 + c * 16 + r16];
-#pragma unroll
-              for (int vh = 0; vh < 2; ++vh)
-#pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                  const int m = 16 * vh + 4 * kg + i;          // rows m, m + 1
-                  f32x2 o = f32x2{acc[p][j][2 * vh + c][i], acc[p][j][2 * vh + c][i + 1]} + f32x2{bv, bv};
-                  if (ACT) { o[0] = o[0] > 0.f ? o[0] : o[0] * slope_v; o[1] = o[1] > 0.f ? o[1] : o[1] * slope_v; }
-                  *reinterpret_cast<bf16_t*>(tile_ + m * 64 + (c * 16 + r16) * 2) = (bf16_t)o[0];
-                  *reinterpret_cast<bf16_t*>(tile_ + (m + 1) * 64 + (c * 16 + r16) * 2) = (bf16_t)o[1];
-                  if (STATS) {
-                    if (!FULL) {
-                      if (!((vmask >> (4 * vh + i)) & 1u)) o[0] = 0.f;
-                      if (!((vmask >> (4 * vh + i + 1)) & 1u)) o[1] = 0.f;
-                    }
-                    s1[j][c] += o;
-                    s2[j][c] = __builtin_elementwise_fma(o, o, s2[j][c]);
-                  }
-                }
-            }
-            const uint4 pk0 = *reinterpret_cast<const uint4*>(tile_ + mrow * 64 + (lane & 3) * 16);
-            const uint4 pk1 = *reinterpret_cast<const uint4*>(tile_ + (mrow + 16) * 64 + (lane & 3) * 16);
-            if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
-            if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-          for (int bq = 0; bq < 4; ++bq)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[p][j][bq][i] = 0.f;
-      }
-    };
-    // split-K: the fp32 tile of (plane p, N-tile j) goes through the wave's 4 KiB as [tile row m][32 channels] and leaves as
-    // 16-byte stores into partial[z][voxel][Cout]; bias, bf16 and statistics are splitk_finish_k's
-    auto write_partial = [&]() {
-      float* pz = partial + (int64_t)bz * ((int64_t)N * D * H * W) * Cout + n0 + wn * (32 * NTW) + (lane & 7) * 4;
-      float* stf = reinterpret_cast<float*>(stg);
-#pragma unroll
-      for (int p = 0; p < TD; ++p) {
-        const int dd = d0 + p;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-          for (int bq = 0; bq < 4; ++bq)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              stf[(16 * (bq >> 1) + 4 * kg + i) * 32 + (bq & 1) * 16 + r16] = acc[p][j][bq][i];
-              acc[p][j][bq][i] = 0.f;
-            }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int m = (lane >> 3) + 8 * q;
-            const int hh = h0 + hhalf * 4 + m16_row(m), ww = w0 + m16_col(m);
-            const float4 pk = *reinterpret_cast<const float4*>(stf + m * 32 + (lane & 7) * 4);
-            if (dd < D && hh < H && ww < W)
-              *reinterpret_cast<float4*>(pz + ((((int64_t)n * D + dd) * H + hh) * W + ww) * Cout + j * 32) = pk;
-          }
-        }
-      }
-    };
-    if (partial) write_partial();
-    else if (full) write_out(std::true_type{});
-    else write_out(std::false_type{});
-    if (STATS && stats) {
-      float* red = reinterpret_cast<float*>(dead + 16384);     // [WH (hhalf)][2][NT]
-#pragma unroll
-      for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          // this lane's channel is shared by the lanes 16, 32 and 48 away (the other voxel rows of the block)
-          float a_ = s1[j][c][0] + s1[j][c][1], q_ = s2[j][c][0] + s2[j][c][1];
-          a_ += __shfl_xor(a_, 16, 64); q_ += __shfl_xor(q_, 16, 64);
-          a_ += __shfl_xor(a_, 32, 64); q_ += __shfl_xor(q_, 32, 64);
-          if (lane < 16) {
-            red[(hhalf * 2 + 0) * G::NT + wn * (32 * NTW) + j * 32 + c * 16 + r16] = a_;
-            red[(hhalf * 2 + 1) * G::NT + wn * (32 * NTW) + j * 32 + c * 16 + r16] = q_;
-          }
-        }
-      block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
-      if (tid < 2 * G::NT) {
-        const int which = tid / G::NT, c = tid % G::NT;
-        float t_ = red[(0 * 2 + which) * G::NT + c];
-        if (WH == 2) t_ += red[(1 * 2 + which) * G::NT + c];
-        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = t_;
-      }
-    }
-    if (!has_next) break;
-    tile = tile_nx;
-    cur = nxt;
-  }
-}
-
 inline int brick_enabled() {
   return (int)fplx_knob(FPLX_K_BRICK);              // A/B knob (benchmarks only)
 }
@@ -879,7 +501,6 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
   }
   dim3 grid((unsigned)gx, gy, ksplit);
   float* part = ksplit > 1 ? partial : nullptr;
-  const bool m16 = fplx_knob(FPLX_K_BRICK_M16) != 0;          // the 16 x 16 x 32 form (conv_fwd_brick16) of the training kernels
 #define LAUNCH_BRICK_K(KERNEL_, STATS_, NTW_, TD_, WH_)                                                              \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
@@ -889,8 +510,7 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
         (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
         bW, xcd_on);                                                                                                 \
   } while (0)
-#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_)                                                                         \
-  do { if (m16) LAUNCH_BRICK_K(conv_fwd_brick16, STATS_, NTW_, TD_, WH_); else LAUNCH_BRICK_K(conv_fwd_brick, STATS_, NTW_, TD_, WH_); } while (0)
+#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_) LAUNCH_BRICK_K(conv_fwd_brick, STATS_, NTW_, TD_, WH_)
   const bool st_ = stats && !part;
 #define LAUNCH_BRICK_ACT(NTW_, TD_, WH_)                                                                              \
   do {                                                                                                               \
