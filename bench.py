@@ -123,11 +123,11 @@ def roofline_of(key, n_avg_ms):
     return flops, nbytes, flops / sec / 1e12, nbytes / sec / 1e9
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r03_pmc_hbm_traffic.json,
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r04_pmc_hbm_traffic.json,
     made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of THIS command with the gfx950
     x2 FETCH correction).  The summary records the sha256 of the kernel sources it was measured on: if conv_march.hip or
     common.h have changed since, the figure is stale and None is reported.  None also if there is no matching entry."""
