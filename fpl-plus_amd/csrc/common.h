@@ -123,6 +123,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
 #define FPLX_KNOB_LIST(X)                                                                                              \
   X(XCD, "xcd", 1)                         /* 0: hardware block order (fplx_xcd_block off) */                           \
   X(BRICK, "brick", 1)                     /* 0: no brick kernel; 3: only layers no march kernel takes */               \
+  X(BRICK_FILL, "brick_fill", 192)         /* the Cin split of the brick kernel grows until the launch has this many blocks */  \
   X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \

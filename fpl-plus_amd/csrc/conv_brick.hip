@@ -438,8 +438,9 @@ inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
     return c;
   }
   if ((c.geo ? p1 : p0) * 4 > V * 5) return c;
-  while (blocks * c.ksplit < 192 && nch / (c.ksplit + 1) >= 2) ++c.ksplit;
-  if (blocks * c.ksplit < 192) return c;
+  const int64_t fill = fplx_knob(FPLX_K_BRICK_FILL);          // blocks the launch should have before the Cin split stops growing
+  while (blocks * c.ksplit < fill && nch / (c.ksplit + 1) >= 2) ++c.ksplit;
+  if (blocks * c.ksplit < (fill < 192 ? fill : 192)) return c;
   c.ok = 1;
   return c;
 }
