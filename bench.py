@@ -65,7 +65,7 @@ class KernelTimer(object):
         self._orig = {}
         for name in ("conv3d_fwd", "conv3d_wgrad", "conv3d_fwd_cat2", "conv3d_dgrad_split2", "conv3d_wgrad_cat2",
                      "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad", "maxpool2_fwd",
-                     "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step"):
+                     "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "outconv_fwd_bn", "outconv_dgrad_bn_bwd"):
             self._wrap(name)
 
     def _key(self, name, a):

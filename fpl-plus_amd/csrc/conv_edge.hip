@@ -555,11 +555,25 @@ outconv_fwd_mfma(const bf16_t* __restrict__ x, int64_t ldx, const float* __restr
 // LDS traffic of a tile is one 16-byte read per (tap, 16 voxels), and the result comes out voxel-contiguous: lanes 0-15 hold
 // class 0 / 1 (registers 0 / 1) of 16 consecutive voxels = 64-byte stores into the planar logits.
 typedef __attribute__((ext_vector_type(4))) float f32x4e;
-template <int KS32>      // Cin / 32
-__global__ void __launch_bounds__(256, KS32 == 1 ? 3 : 1)     // Cin = 32: three blocks per CU (the per-tile chain is latency, occupancy hides it)
+// BN (round 4, Cin = 32): the input is the PRE-BatchNorm output y of the network's last 3x3x3 convolution; the BatchNorm
+// apply + PReLU pass of that site (fplx_bn_act_fwd, dropout-free) happens HERE, on the staged registers on their way into LDS,
+// and the activation a = PReLU(scale y + shift) - the tensor backward needs - is written out for the tile's own voxels: the
+// separate pass's read of y and this kernel's read of a (262 MB at the benchmark shape) become one.  Same arithmetic on the same
+// values: a and the logits are the bits of the two-kernel path.
+template <int KS32, bool BN = false>      // Cin / 32
+__global__ void __launch_bounds__(256, KS32 == 1 ? (BN ? 2 : 3) : 1)     // Cin = 32: three blocks per CU (the per-tile chain is latency, occupancy hides it); two with the BatchNorm constants in registers
 outconv_fwd_t(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ wf, const float* __restrict__ bias,
-              float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
+              float* __restrict__ out, int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd,
+              const float* __restrict__ bn_scale = nullptr, const float* __restrict__ bn_shift = nullptr,
+              const float* __restrict__ slope_p = nullptr, bf16_t* __restrict__ aout = nullptr, int64_t lda = 0) {
+  static_assert(!BN || KS32 == 1, "the fused BatchNorm form exists for Cin = 32");
   constexpr int CIN = KS32 * 32, ROWB = CIN * 2, CH = ROWB / 16;
+  float bsc[8], bsh[8], bslope = 0.f;                   // BN: this thread always stages chunk threadIdx.x % CH = channels 8 c ..
+  if (BN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { bsc[j] = bn_scale[(threadIdx.x % CH) * 8 + j]; bsh[j] = bn_shift[(threadIdx.x % CH) * 8 + j]; }
+    bslope = *slope_p;
+  }
   __shared__ __attribute__((aligned(16))) char xs[SH * SW * ROWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;
@@ -602,6 +616,22 @@ outconv_fwd_t(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict
     for (int k = 0; k < NLD; ++k) {
       const int i = threadIdx.x + 256 * k;
       const int vox = i / CH, c = i % CH;
+      if (BN && i < SH * SW * CH) {
+        // BatchNorm apply + PReLU on the staged chunk (voxels outside the volume stay the convolution's zero padding)
+        const int hh = vox / SW, ww = vox % SW, h = t.h0 + hh - 1, w = t.w0 + ww - 1;
+        if (h >= 0 && h < H && w >= 0 && w < W) {
+          bf16x8 v8 = *reinterpret_cast<bf16x8*>(&xreg[k]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = fmaf((float)v8[j], bsc[j], bsh[j]);
+            z = z > 0.f ? z : z * bslope;
+            v8[j] = (bf16_t)z;
+          }
+          xreg[k] = *reinterpret_cast<uint4*>(&v8);
+          if (hh >= 1 && hh <= TH && ww >= 1 && ww <= TW)          // the tile's own voxel: its activation goes to memory
+            *reinterpret_cast<uint4*>(aout + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * lda + c * 8) = xreg[k];
+        }
+      }
       if (i < SH * SW * CH) *reinterpret_cast<uint4*>(xs + vox * ROWB + ((c ^ swz(vox)) * 16)) = xreg[k];
     }
     __syncthreads();
@@ -695,10 +725,23 @@ outconv_dgrad_valu(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 // rounded to bf16 (8 bits) at the end.  One 8 x 32 in-plane tile at a time (grid-strided): the fp32 dlogit planes with
 // their in-plane halo sit in LDS (next tile prefetched into registers), a wave owns two rows of the tile, the B fragments
 // (weights) stay in registers, the result leaves through the per-wave LDS transpose as 16-byte stores.
-template <int NT>                 // C0 / 32
-__global__ void __launch_bounds__(256)
+// MODE 1 / 2 (round 4, C0 = 32): the data gradient is not stored at all.  The site it feeds - the last 3x3x3 convolution's
+// BatchNorm + PReLU (dropout-free) - needs it twice, in the reduction and in the apply pass of its backward, and the dlogits it
+// is formed from are 1 / 8 of its size: both passes RECOMPUTE it here (rounded to bf16 where the stored tensor was) and run
+// their arithmetic on the registers that would have been stored:
+//   MODE 1  reads y, accumulates sum dz, sum dz x-hat, sum d min(z, 0) -> one partial row [2 C0 + 1] per block (fixed order),
+//           for fplx_bn_act_bwd_finalize;
+//   MODE 2  reads y and the finalize's coefficients, writes dy = scale (dz - k0 - x-hat k1).
+// Against data gradient + reduction + apply (33 + 262 | 524 | 786 MB) the pair moves 295 + 557 MB.
+template <int NT, int MODE = 0>                 // C0 / 32
+__global__ void __launch_bounds__(256, (NT == 1 ? (MODE == 0 ? 3 : 2) : 1))      // fused forms: two blocks per CU without spills (three with: measured slower)
 outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx,
-                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd) {
+                   int N, int D, int H, int W, int ncls, int64_t ntiles, int tilesH, int tilesW, int xcd,
+                   const bf16_t* __restrict__ yv = nullptr, int64_t ldy = 0, const float* __restrict__ bn_mean = nullptr,
+                   const float* __restrict__ bn_rstd = nullptr, const float* __restrict__ bn_scale = nullptr,
+                   const float* __restrict__ bn_shift = nullptr, const float* __restrict__ slope_p = nullptr,
+                   const float* __restrict__ coef = nullptr, float* __restrict__ part = nullptr) {
+  static_assert(MODE == 0 || NT == 1, "the fused BatchNorm forms exist for C0 = 32");
   constexpr int C0 = NT * 32, MAXK = 5;              // k-steps of 16: 8 (tap, class) pairs x (hi, lo) each; ncls <= 4 -> <= 5
   __shared__ float gs[4 * SH * SW];                  // [class][SH][SW]
   __shared__ __attribute__((aligned(16))) char stg_all[4][32 * 64];
@@ -732,6 +775,34 @@ outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
     }
   constexpr int NLD = (4 * SH * SW + 255) / 256;
   float greg[NLD];
+  // MODE 1 / 2: the lane's 8 channels at the store point are 8 (lane & 3) ..: their BatchNorm constants live in registers, the
+  // four 16-byte pieces of y the lane will meet in a tile (rows 2 wave + m, voxels (lane >> 2) + 16 half) travel with the
+  // next tile's dlogits
+  // per channel: z = fma(y, bsc, bsh); MODE 1: x-hat = fma(y, bxa, bxb) (= (y - mean) rstd); MODE 2: dy = scale (dz - k0 -
+  // x-hat k1) = fma(dz, bsc, fma(y, bxa, bxb)) with the finalize's coefficients folded into bxa / bxb
+  float bsc[8], bsh[8], bxa[8], bxb[8], sdz[8], sdx[8], sds = 0.f, bslope = 0.f;
+  uint4 ycur[4];
+  if (MODE != 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (lane & 3) * 8 + j;
+      const float m_ = bn_mean[c], rs_ = bn_rstd[c];
+      bsc[j] = bn_scale[c]; bsh[j] = bn_shift[c];
+      if (MODE == 1) { bxa[j] = rs_; bxb[j] = -m_ * rs_; }
+      else { const float k0 = coef[c], k1 = coef[C0 + c]; bxa[j] = -bsc[j] * k1 * rs_; bxb[j] = -bsc[j] * (k0 - k1 * m_ * rs_); }
+      sdz[j] = 0.f; sdx[j] = 0.f;
+    }
+    bslope = *slope_p;
+  }
+  auto fetch_y = [&](const Tile& t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = t.h0 + wave * 2 + (q >> 1), w = t.w0 + (lane >> 2) + 16 * (q & 1);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (h < H && w < W) v = *reinterpret_cast<const uint4*>(yv + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldy + (lane & 3) * 8);
+      ycur[q] = v;
+    }
+  };
   auto fetch = [&](const Tile& t) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -757,6 +828,7 @@ outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
       const int i = threadIdx.x + 256 * k;
       if (i < 4 * SH * SW) gs[i] = greg[k];
     }
+    if (MODE != 0) fetch_y(t);                         // this tile's y: in flight during the commit barrier and the MFMAs
     __syncthreads();
     if (tt + tr.step < tr.end) {
       tn = tile_of(tt + tr.step, D, tilesH, tilesW);
@@ -797,11 +869,62 @@ outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             const int wu = (lane >> 2) + 16 * half;
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + wu * 64 + (lane & 3) * 16);
-            if (t.w0 + wu < W) *reinterpret_cast<uint4*>(dx + (vrow + wu) * ldx + j * 32 + (lane & 3) * 8) = v;
+            uint4 v = *reinterpret_cast<const uint4*>(stg + wu * 64 + (lane & 3) * 16);
+            if (MODE == 0) {
+              if (t.w0 + wu < W) *reinterpret_cast<uint4*>(dx + (vrow + wu) * ldx + j * 32 + (lane & 3) * 8) = v;
+            } else if (t.w0 + wu < W) {
+              // the BatchNorm + PReLU backward of fplx_bn_act_bwd_reduce / _apply (elementwise.hip: dz_of, dropout-free) on
+              // the eight bf16 values that would have been stored and the y values of the same voxel
+              bf16x8 d8 = *reinterpret_cast<bf16x8*>(&v);
+              const bf16x8 y8 = *reinterpret_cast<const bf16x8*>(&ycur[m * 2 + half]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float a = (float)y8[e], d = (float)d8[e];
+                const float z = fmaf(a, bsc[e], bsh[e]);
+                const float dz = z > 0.f ? d : d * bslope;
+                const float t_ = fmaf(a, bxa[e], bxb[e]);
+                if (MODE == 1) {
+                  sds += z > 0.f ? 0.f : d * z;
+                  sdz[e] += dz;
+                  sdx[e] = fmaf(dz, t_, sdx[e]);
+                } else d8[e] = (bf16_t)fmaf(dz, bsc[e], t_);
+              }
+              if (MODE == 2) *reinterpret_cast<uint4*>(dx + (vrow + wu) * ldx + (lane & 3) * 8) = *reinterpret_cast<uint4*>(&d8);
+            }
           }
         }
       }
+    }
+  }
+  if (MODE == 1) {
+    // the block's partial row: lanes that share a channel group sit 4 apart - butterfly inside the wave, then the four waves
+    // through LDS, every addition in a fixed order
+    for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sdz[e] += __shfl_xor(sdz[e], o, 64); sdx[e] += __shfl_xor(sdx[e], o, 64); }
+      sds += __shfl_xor(sds, o, 64);
+    }
+    __syncthreads();
+    float* red = gs;                                     // [wave][group 0..3][17]; the dlogit tile is dead
+    if (lane < 4) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[(wave * 4 + lane) * 17 + e] = sdz[e]; red[(wave * 4 + lane) * 17 + 8 + e] = sdx[e]; }
+      red[(wave * 4 + lane) * 17 + 16] = sds;
+    }
+    __syncthreads();
+    float* row = part + (int64_t)blockIdx.x * (2 * C0 + 1);
+    if (threadIdx.x < 64) {                              // thread = (which sum 0 | 1, channel 0..31)
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31, g4 = c >> 3, e = c & 7;
+      float t_ = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) t_ += red[(wv * 4 + g4) * 17 + which * 8 + e];
+      row[which * C0 + c] = t_;
+    }
+    if (threadIdx.x == 64) {
+      float t_ = 0.f;
+      for (int wv = 0; wv < 4; ++wv)
+        for (int g4 = 0; g4 < 4; ++g4) t_ += red[(wv * 4 + g4) * 17 + 16];
+      row[2 * C0] = t_;
     }
   }
 }
@@ -1068,6 +1191,50 @@ extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx
   else if (c0 == 32) outconv_dgrad_valu<32><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
   else outconv_dgrad_valu<64><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dx, ldx, n, d, h, w, ncls);
   int rc = fplx_check_launch("edge_outconv_dgrad");
+  return rc < 0 ? rc : 1;
+}
+
+// ---- out_conv fused with the BatchNorm + PReLU passes of the convolution site in front of it (round 4)
+extern "C" int fplx_edge_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls) {
+  return c0 == 32 && ncls >= 1 && ncls <= 4 && (int64_t)n * d * h * w < ((int64_t)1 << 31);
+}
+// blocks of the fused data-gradient kernels = partial rows the reduction form writes
+extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w) {
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  return (int)(nt < 2048 ? nt : 2048);
+}
+extern "C" int fplx_edge_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* slope,
+                                        void* a, int64_t lda, const float* wf, const float* bias, float* out, int n, int d,
+                                        int h, int w, int c0, int ncls, hipStream_t st) {
+  if (!fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls) || ldy % 8 != 0 || lda % 8 != 0 || ((uintptr_t)y % 16) || ((uintptr_t)a % 16))
+    return 0;
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = (int)(nt < 2048 ? nt : 2048);
+  outconv_fwd_t<1, true><<<nb, 256, 0, st>>>((const bf16_t*)y, ldy, wf, bias, out, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on(),
+                                             scale, shift, slope, (bf16_t*)a, lda);
+  const int rc = fplx_check_launch("edge_outconv_fwd_bn");
+  return rc < 0 ? rc : 1;
+}
+// mode 1: reduction (part: fplx_edge_outconv_bn_rows rows of 2 c0 + 1 floats), mode 2: apply (coef from the finalize, dy out)
+extern "C" int fplx_edge_outconv_dgrad_bn(int mode, const float* dl, const void* wb, const void* y, int64_t ldy,
+                                          const float* mean, const float* rstd, const float* scale, const float* shift,
+                                          const float* slope, const float* coef, float* part, void* dy, int64_t lddy, int n,
+                                          int d, int h, int w, int c0, int ncls, hipStream_t st) {
+  if (!fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls) || ldy % 8 != 0 || ((uintptr_t)y % 16)) return 0;
+  if (mode == 2 && (lddy % 8 != 0 || ((uintptr_t)dy % 16))) return 0;
+  int th, tw;
+  const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
+  const int nb = (int)(nt < 2048 ? nt : 2048);
+  if (mode == 1)
+    outconv_dgrad_mfma<1, 1><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, nullptr, 0, n, d, h, w, ncls, nt, th, tw, fplx_xcd_on(),
+                                                 (const bf16_t*)y, ldy, mean, rstd, scale, shift, slope, nullptr, part);
+  else
+    outconv_dgrad_mfma<1, 2><<<nb, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dy, lddy, n, d, h, w, ncls, nt, th, tw,
+                                                 fplx_xcd_on(), (const bf16_t*)y, ldy, mean, rstd, scale, shift, slope, coef,
+                                                 nullptr);
+  const int rc = fplx_check_launch("edge_outconv_dgrad_bn");
   return rc < 0 ? rc : 1;
 }
 

@@ -433,6 +433,15 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
                                     int cin, int cout, void* ws, hipStream_t st);
 extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
                                      int d, int h, int w, int cin, int ncls, hipStream_t st);
+extern "C" int fplx_edge_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls);
+extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w);
+extern "C" int fplx_edge_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* slope,
+                                        void* a, int64_t lda, const float* wf, const float* bias, float* out, int n, int d,
+                                        int h, int w, int c0, int ncls, hipStream_t st);
+extern "C" int fplx_edge_outconv_dgrad_bn(int mode, const float* dl, const void* wb, const void* y, int64_t ldy,
+                                          const float* mean, const float* rstd, const float* scale, const float* shift,
+                                          const float* slope, const float* coef, float* part, void* dy, int64_t lddy, int n,
+                                          int d, int h, int w, int c0, int ncls, hipStream_t st);
 extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
                                        int c0, int ncls, hipStream_t st);
 extern "C" size_t fplx_edge_outconv_wgrad_ws_bytes(int n, int d, int h, int w, int c0, int ncls);
@@ -863,6 +872,42 @@ int fplx_conv3d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const vo
 int fplx_conv2d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
                            int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
   return wgrad_cat2_impl(x0, x1, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, 1, stream);
+}
+
+/* ---- out_conv (C0 -> classes, 1x3x3) fused with the BatchNorm + PReLU passes of the convolution site in front of it ---- */
+int fplx_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls) {
+  return n > 0 && d > 0 && h > 0 && w > 0 && fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls);
+}
+int fplx_outconv_bn_rows(int n, int d, int h, int w) { return fplx_edge_outconv_bn_rows(n, d, h, w); }
+int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
+                        int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,
+                        int ncls, fplx_stream_t stream) {
+  FPLX_REQUIRE(y && scale && shift && prelu_slope && a && wf && logits, FPLX_E_NULL, "outconv_fwd_bn: null pointer");
+  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_fwd_bn: c0 = %d, classes = %d not supported (fplx_outconv_bn_ok)", c0, ncls);
+  const int r = fplx_edge_outconv_fwd_bn(y, ldy, scale, shift, prelu_slope, a, lda, wf, bias, logits, n, d, h, w, c0, ncls, (hipStream_t)stream);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_fwd_bn: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+int fplx_outconv_dgrad_bn_reduce(const float* dlogits, const void* wb, const void* y, int64_t ldy, const float* mean,
+                                 const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
+                                 float* part, int n, int d, int h, int w, int c0, int ncls, fplx_stream_t stream) {
+  FPLX_REQUIRE(dlogits && wb && y && mean && rstd && scale && shift && prelu_slope && part, FPLX_E_NULL, "outconv_dgrad_bn_reduce: null pointer");
+  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_reduce: shape not supported (fplx_outconv_bn_ok)");
+  const int r = fplx_edge_outconv_dgrad_bn(1, dlogits, wb, y, ldy, mean, rstd, scale, shift, prelu_slope, nullptr, part, nullptr, 0,
+                                           n, d, h, w, c0, ncls, (hipStream_t)stream);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_reduce: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void* y, int64_t ldy, const float* mean,
+                                const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
+                                const float* coef, void* dy, int64_t lddy, int n, int d, int h, int w, int c0, int ncls,
+                                fplx_stream_t stream) {
+  FPLX_REQUIRE(dlogits && wb && y && mean && rstd && scale && shift && prelu_slope && coef && dy, FPLX_E_NULL, "outconv_dgrad_bn_apply: null pointer");
+  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: shape not supported (fplx_outconv_bn_ok)");
+  const int r = fplx_edge_outconv_dgrad_bn(2, dlogits, wb, y, ldy, mean, rstd, scale, shift, prelu_slope, coef, nullptr, dy, lddy,
+                                           n, d, h, w, c0, ncls, (hipStream_t)stream);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
 }
 
 int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,

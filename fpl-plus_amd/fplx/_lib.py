@@ -143,6 +143,7 @@ _HOST_KNOBS = {
     "fused_pool": 1,        # Engine.use_fused_pool: DownBlock tails in one pass each way
     "eval_fuse": 1,         # Engine.use_eval_fusion: eval-mode BatchNorm folded into the packs
     "stem_wg_main": 1,      # Engine.stem_wgrad_on_main
+    "outconv_fuse": 1,      # Engine.use_outconv_fusion: out_conv fused with the last site's BatchNorm + PReLU passes
     "bucket_elems": 1 << 21,    # TrainStep: gradient all-reduce bucket size (elements)
 }
 _host_vals = {}

@@ -25,7 +25,7 @@ LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
 class Saved(object):
     """what one forward leaves behind for its backward"""
     __slots__ = ("x", "dims", "domain", "train", "seed", "step", "blocks", "cats", "pooled", "packs",
-                 "drop_on", "deconv_in", "skips", "split")
+                 "drop_on", "deconv_in", "skips", "split", "oc_fused")
 
 
 class Engine(object):
@@ -45,6 +45,9 @@ class Engine(object):
         # convolution's write-out - the BN-apply passes of the sites without active dropout disappear (FPLX_EVAL_FUSE=0: off)
         self.use_eval_fusion = _lib.host_knob("eval_fuse") != 0
         self.stem_wgrad_on_main = _lib.host_knob("stem_wg_main") != 0
+        # out_conv fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn / _dgrad_bn_*):
+        # one pass over that site's tensor forward, two instead of three (+ the data gradient's write) backward
+        self.use_outconv_fusion = _lib.host_knob("outconv_fuse") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
         # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
@@ -193,6 +196,9 @@ class Engine(object):
             self._deferred_keep = self._deferred
             self._deferred = []
         fuse = self.use_eval_fusion and not train and not keep and adt == torch.bfloat16
+        # the last site's BatchNorm + PReLU inside the out_conv kernel (not where that site runs the folded inference form)
+        oc_fuse = (self.use_outconv_fusion and not fuse and mc == 1 and adt == torch.bfloat16 and
+                   ops.outconv_bn_ok((N, D, H, W), net.ft_chns[0], net.n_class))
         if mc > 1 and (train or keep):
             raise ValueError("fplx: Monte-Carlo replication (mc > 1) is an inference mode: eval-mode BatchNorm, keep=False")
         # first encoder level whose input differs between Monte-Carlo passes (the level after the first active dropout)
@@ -263,7 +269,8 @@ class Engine(object):
                         ops.conv3d_fwd_act_ok(dims[l], 2 * ft[l], ft[l], blk.conv_of(1).weight.dim() == 4, True)):
                     skip_mod[l] = edims[l][0]
 
-        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None, dims=dims, vox=vox, n_x0=0):
+        def conv_site(xin, xs, x_dt, cin, key, site, l, out_view, p, sid, dropout_active, pool=None, dims=dims, vox=vox, n_x0=0,
+                      defer_act=False):
             """conv3x3x3 (+stats) -> DSBN finalize -> BN-apply + PReLU (+dropout) into out_view; pool = (pooled, pd): the
             MaxPool of out_view is produced by the same pass (tail of a DownBlock)"""
             conv, bn, prelu = site
@@ -302,7 +309,7 @@ class Engine(object):
                 ops.bn_eval_prepare(bnm.weight, bnm.bias, bnm.running_mean, bnm.running_var, bnbuf, bnm.eps)
             if pool is not None:
                 ops.bn_act_pool_fwd(y, out_view, pool[0], bnbuf, prelu.weight, dims[l], cout, pool[1])
-            else:
+            elif not defer_act:                          # defer_act: the out_conv kernel applies BatchNorm + PReLU (oc_fuse)
                 ops.bn_act_fwd(y, out_view, bnbuf, prelu.weight, pp, seed, sid, cout)
             return y, bnbuf, pp
 
@@ -317,7 +324,7 @@ class Engine(object):
                                     dims=dims, vox=vox, n_x0=n_x0)
             y2, bn2, _ = conv_site(a1, ops.cl_strides(*dims[l][1:], c), a_dt, c, key + "." + blk.cname(2),
                                    (blk.conv_of(2), blk.bn_of(2), blk.relu_2), l, out_view, 0.0, 0, False, pool,
-                                   dims=dims, vox=vox)
+                                   dims=dims, vox=vox, defer_act=(b == 8 and oc_fuse))
             sv.blocks.append(dict(xin=xin, xs=xs, x_dt=x_dt, cin=cin, l=l, y1=y1, bn1=bn1, p1=p1, sid=sid, a1=a1,
                                   y2=y2, bn2=bn2, out=out_view))
 
@@ -368,8 +375,14 @@ class Engine(object):
         elif (tuple(logits.shape) != (NM, ncls, D, H, W) or logits.dtype != torch.float32 or logits.device != dev
               or not logits.is_contiguous()):
             raise ValueError("fplx: out must be a contiguous fp32 tensor of shape %s on %s" % ((NM, ncls, D, H, W), dev))
-        ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
-                       ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
+        if oc_fuse:
+            blk8, mod8 = sv.blocks[8], net.block_modules[8]
+            ops.outconv_fwd_bn(blk8["y2"], blk8["bn2"], mod8.relu_2.weight, cur, packs["out_conv"][0], net.out_conv.bias, logits,
+                               dims[0], ft[0], ncls)
+        else:
+            ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
+                           ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
+        sv.oc_fused = oc_fuse
         if deferred_join is not None:
             torch.cuda.current_stream().wait_event(deferred_join)
             self._deferred_keep = None
@@ -488,21 +501,28 @@ class Engine(object):
             on_ready(end)
 
         d_cur = empty(vox[0], ft[0])
-        ops.conv3d_fwd(dlogits, ops.planar_strides(ncls, D, H, W), F32, packs["out_conv"][1], None, d_cur,
-                       ops.cl_strides(D, H, W, ft[0]), a_dt, dims[0], ncls, ft[0], (1, 3, 3), None)
+        oc_fused = bool(sv.oc_fused)
+        if not oc_fused:       # (fused: out_conv's data gradient is never stored - site_bwd of the last site recomputes it twice)
+            ops.conv3d_fwd(dlogits, ops.planar_strides(ncls, D, H, W), F32, packs["out_conv"][1], None, d_cur,
+                           ops.cl_strides(D, H, W, ft[0]), a_dt, dims[0], ncls, ft[0], (1, 3, 3), None)
         # the weight gradient BEHIND the data gradient, as at every 3x3x3 site (either order measures the same step time,
         # 9.64-9.78 ms on one box: the two queues are scheduled dynamically; one convention is kept)
         outconv_wgrad()
         ready("out_conv.bias")
 
         def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view, reduced=False,
-                     wgrad_here=False):
+                     wgrad_here=False, from_logits=False):
             """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy.
             reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)"""
             c = ft[l]
             gkey = "%s.bns.%d" % (bnkey, domain)
-            ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
-                           gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced)
+            if from_logits:     # d_out is not given: it is out_conv's data gradient, recomputed inside the two BatchNorm passes
+                ops.outconv_dgrad_bn_bwd(dlogits, packs["out_conv"][1], y, bnbuf, net.get_param(relukey + ".weight"), sv.train,
+                                         gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, d_out,
+                                         dims[l], c, ncls)
+            else:
+                ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
+                               gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced)
             if tap is not None:
                 tap(key + ".dy", d_out)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly
@@ -551,7 +571,8 @@ class Engine(object):
             l, c, cin = blk["l"], ft[blk["l"]], blk["cin"]
             d_a1 = empty(vox[l], c)
             site_bwd(key + "." + mod.cname(2), key + "." + mod.bname(2), key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0,
-                     d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1, reduced)
+                     d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1, reduced,
+                     from_logits=(b == 8 and oc_fused))
             if isinstance(blk["xin"], tuple):
                 d_in = (empty(vox[l], cin // 2), empty(vox[l], cin // 2)) if want_dx else None
             else:

@@ -273,6 +273,41 @@ def num_partials(voxels):
     return _lib.lib().fplx_num_partials(voxels)
 
 
+def outconv_bn_ok(dims, c0, ncls):
+    """True if out_conv can be fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn,
+    fplx_outconv_dgrad_bn_reduce / _apply: bf16, C0 = 32, classes <= 4)"""
+    n, d, h, w = dims
+    return _lib.lib().fplx_outconv_bn_ok(n, d, h, w, int(c0), int(ncls)) == 1
+
+
+def outconv_bn_rows(dims):
+    n, d, h, w = dims
+    return _lib.lib().fplx_outconv_bn_rows(n, d, h, w)
+
+
+def outconv_fwd_bn(y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls):
+    """a = PReLU(BN(y)) (bnbuf rows 2 / 3 = scale / shift) and logits = out_conv(a) in one pass over y"""
+    n, d, h, w = dims
+    call("fplx_outconv_fwd_bn", ptr(y), ld_of(y), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(a), ld_of(a), ptr(wf), ptr(bias),
+         ptr(logits), n, d, h, w, int(c0), int(ncls), stream())
+
+
+def outconv_dgrad_bn_bwd(dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls):
+    """backward of [BN + PReLU -> out_conv] without ever storing out_conv's data gradient: reduction (recomputing it from
+    dlogits), the usual finalize, apply (recomputing it again) -> dy.  part must hold outconv_bn_rows(dims) x (2 c0 + 1) floats."""
+    n, d, h, w = dims
+    rows = outconv_bn_rows(dims)
+    if part.numel() < rows * (2 * c0 + 1):
+        raise ValueError("fplx: partial-row buffer too small for the fused out_conv backward (%d < %d floats)" % (part.numel(), rows * (2 * c0 + 1)))
+    bn = [ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3])]
+    call("fplx_outconv_dgrad_bn_reduce", ptr(dlogits), ptr(wb), ptr(y), ld_of(y), bn[0], bn[1], bn[2], bn[3], ptr(slope), ptr(part),
+         n, d, h, w, int(c0), int(ncls), stream())
+    call("fplx_bn_act_bwd_finalize", ptr(part), rows, int(c0), y.shape[0], 1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope),
+         ptr(coef), stream())
+    call("fplx_outconv_dgrad_bn_apply", ptr(dlogits), ptr(wb), ptr(y), ld_of(y), bn[0], bn[1], bn[2], bn[3], ptr(slope), ptr(coef),
+         ptr(dy), ld_of(dy), n, d, h, w, int(c0), int(ncls), stream())
+
+
 def bn_pool_fused_ok(c, dtype):
     return _lib.lib().fplx_bn_pool_fused_ok(int(c), _DT[dtype]) == 1
 

@@ -281,6 +281,30 @@ int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t 
                             const float* slope, int n, int d, int h, int w, int c, int dt, int pd, float* part,
                             fplx_stream_t stream);
 
+/* out_conv (Conv3d C0 -> classes, kernel (1,3,3), unet2d5_dsbn.py:293-294, 307) fused with the BatchNorm + PReLU passes of the
+ * convolution site in front of it (ConvBlockND's second site of the last UpBlock, unet2d5_dsbn.py:79-81; dropout-free, bf16
+ * NDHWC, C0 = 32, classes <= 4: fplx_outconv_bn_ok).  The out_conv operands are 1 / 8 the size of that site's tensors, so
+ *   fplx_outconv_fwd_bn          reads the site's PRE-BatchNorm output y, applies a = PReLU(scale y + shift) on the way into its
+ *                                tiles, writes a (what backward keeps) and the fp32 planar logits: fplx_bn_act_fwd + fplx_conv3d_fwd
+ *                                in one pass over y; a and the logits are the bits of the two-call path;
+ *   fplx_outconv_dgrad_bn_reduce / _apply   never store out_conv's data gradient: both RECOMPUTE it from dlogits (fp32 planar)
+ *                                and the mirrored pack wb and run fplx_bn_act_bwd_reduce / _apply on it - _reduce writes
+ *                                fplx_outconv_bn_rows(n, d, h, w) partial rows of 2 C0 + 1 floats for fplx_bn_act_bwd_finalize,
+ *                                _apply takes the finalize's coef and writes dy (gradient w.r.t. y).
+ * mean / rstd / scale / shift: the site's BatchNorm constants (fplx_bn_train_finalize / fplx_bn_eval_prepare). */
+int fplx_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls);
+int fplx_outconv_bn_rows(int n, int d, int h, int w);
+int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
+                        int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,
+                        int ncls, fplx_stream_t stream);
+int fplx_outconv_dgrad_bn_reduce(const float* dlogits, const void* wb, const void* y, int64_t ldy, const float* mean,
+                                 const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
+                                 float* part, int n, int d, int h, int w, int c0, int ncls, fplx_stream_t stream);
+int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void* y, int64_t ldy, const float* mean,
+                                const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
+                                const float* coef, void* dy, int64_t lddy, int n, int d, int h, int w, int c0, int ncls,
+                                fplx_stream_t stream);
+
 /* (Tri / bi)linear x2 upsampling, align_corners = True - UpBlock with bilinear = True (unet2d5_dsbn.py:148-150, 172-176:
  * nn.Upsample(scale_factor=2, mode='trilinear' | 'bilinear', align_corners=True) behind a kernel-1 convolution, which runs
  * through fplx_conv3d_fwd / _wgrad with kd = kh = kw = 1).  x [n][d][h][w][ldx] -> y [n][sd*d][2h][2w][ldy]; sd = 2:

@@ -707,3 +707,91 @@ def test_conv3d_fwd_act_two_tensor_form(shape):
                 assert torch.equal(y1, y2[:, :cout]), n0
             else:
                 assert float((y1.float() - y2[:, :cout].float()).abs().max()) < 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (1, 2, 16, 64, 2), (1, 4, 24, 40, 3)])
+def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape):
+    """fplx_outconv_fwd_bn / fplx_outconv_dgrad_bn_reduce / _apply (out_conv fused with the BatchNorm + PReLU passes of the
+    convolution site in front of it; reference unet2d5_dsbn.py:79-81 + 293-294, 307) against the calls they replace: forward -
+    fplx_bn_act_fwd then fplx_conv3d_fwd (1,3,3): the activation and the logits bit for bit; backward - fplx_conv3d_fwd with the
+    mirrored pack (out_conv's data gradient), then fplx_bn_act_bwd: the BatchNorm / PReLU gradients to 1e-4 (another order of
+    additions), dy equal on >= 99 % of the elements and within bf16 rounding elsewhere.  Ragged tiles, n = 2, 2 and 3 classes."""
+    from fplx import ops
+    n, d, h, w, ncls = shape
+    c0, v, bf = 32, n * d * h * w, torch.bfloat16
+    dims = (n, d, h, w)
+    assert ops.outconv_bn_ok(dims, c0, ncls) and not ops.outconv_bn_ok(dims, 64, ncls)
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(v, c0, generator=g).to(bf).cuda()
+    gamma, beta = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    mean, var = torch.randn(c0, generator=g) * 0.3, torch.rand(c0, generator=g) + 0.5
+    rstd = torch.rsqrt(var + 1e-5)
+    bnbuf = torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd]).cuda()
+    slope = torch.tensor([0.25]).cuda()
+    wo = torch.randn(ncls, c0, 1, 3, 3, generator=g) * 0.1
+    wof, _ = ops.pack_conv_weight(wo.cuda(), torch.float32, False)
+    _, wob = ops.pack_conv_weight(wo.cuda(), bf, True)
+    bias = torch.randn(ncls, generator=g).cuda()
+    cl, pl = ops.cl_strides, ops.planar_strides
+    # ---- forward
+    a_ref = torch.empty(v, c0, dtype=bf, device="cuda")
+    ops.bn_act_fwd(y, a_ref, bnbuf, slope, 0.0, 0, 0, c0)
+    lg_ref = torch.empty(n, ncls, d, h, w, device="cuda")
+    ops.conv3d_fwd(a_ref, cl(d, h, w, c0), ops.BF16, wof, bias, lg_ref, pl(ncls, d, h, w), ops.F32, dims, c0, ncls, (1, 3, 3), None)
+    a = torch.full((v, c0), 7.0, dtype=bf, device="cuda")
+    lg = torch.full((n, ncls, d, h, w), 7.0, device="cuda")
+    ops.outconv_fwd_bn(y, bnbuf, slope, a, wof, bias, lg, dims, c0, ncls)
+    assert torch.equal(a, a_ref) and torch.equal(lg, lg_ref)
+    # ---- backward
+    dl = (torch.randn(n, ncls, d, h, w, generator=g) * 0.05).cuda()
+    d_ref = torch.empty(v, c0, dtype=bf, device="cuda")
+    ops.conv3d_fwd(dl, pl(ncls, d, h, w), ops.F32, wob, None, d_ref, cl(d, h, w, c0), ops.BF16, dims, ncls, c0, (1, 3, 3), None)
+    maxc = 64
+    part = torch.empty((max(ops.num_partials(v), ops.outconv_bn_rows(dims)), 2 * maxc + 1), device="cuda")
+    coef = torch.empty((2, maxc), device="cuda")
+    gr = [torch.zeros(c0, device="cuda"), torch.zeros(c0, device="cuda"), torch.zeros(1, device="cuda")]
+    ops.bn_act_bwd(y, d_ref, d_ref, bnbuf, slope, 0.0, 0, 0, c0, True, gr[0], gr[1], gr[2], part, coef)
+    gf = [torch.zeros(c0, device="cuda"), torch.zeros(c0, device="cuda"), torch.zeros(1, device="cuda")]
+    dy = torch.full((v, c0), 7.0, dtype=bf, device="cuda")
+    ops.outconv_dgrad_bn_bwd(dl, wob, y, bnbuf, slope, True, gf[0], gf[1], gf[2], part, coef, dy, dims, c0, ncls)
+    for a_, b_ in zip(gf, gr):
+        assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max()) + 1e-7, (a_, b_)
+    diff = (dy.float() - d_ref.float()).abs()
+    assert float(diff.max()) <= 1e-2 * float(d_ref.float().abs().max())
+    assert float((diff == 0).float().mean()) >= 0.99
+    with pytest.raises(ValueError):
+        ops.outconv_dgrad_bn_bwd(dl, wob, y, bnbuf, slope, True, gf[0], gf[1], gf[2], part.view(-1)[:8], coef, dy, dims, c0, ncls)
+
+
+def test_network_step_with_and_without_the_out_conv_fusion():
+    """the engine with out_conv fused into the last site's BatchNorm passes (Engine.use_outconv_fusion, the default) against the
+    separate passes: same logits bit for bit, the parameters after one Adam step within the noise of another order of
+    additions in three BatchNorm sums"""
+    import fplx
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
+    lab = torch.zeros(2, 2, 16, 32, 64)
+    lab[:, 0] = 1.0
+    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
+    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
+    lab = lab.cuda()
+    res = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        net.engine.use_outconv_fusion = fuse
+        net.train()
+        with torch.no_grad():
+            net.dropout_seed, net._fwd_counter = 9, 0
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+        logits, sv = net.engine.forward(x, 1, True, net.dropout_active(), 9, 0, keep=True)
+        assert bool(sv.oc_fused) == fuse
+        out = ts.step(x, lab, 1)
+        res.append((logits.clone(), net.flat_params.detach().clone(), float(out[0])))
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][2] - res[1][2]) < 1e-6
+    rel = float((res[0][1] - res[1][1]).abs().max()) / float(res[1][1].abs().max())
+    assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr
+
