@@ -147,8 +147,10 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(WG_ROLL_GEO, "wg_roll_geo", 0)         /* footprint of conv_wgrad_roll: 0 least padding, 1: 8 x 32, 2: 16 x 16, 3: 8 x 16 */ \
   X(WG_ROLL_M16, "wg_roll_m16", 1)         /* 0: the 8 x 32 footprint on v_mfma_f32_32x32x16_bf16 instead of 16x16x32 */        \
   X(WG_ROLL_MB, "wg_roll_mb", 1)           /* 0: barrier at the end of a depth step (4 + 2 ring slots); 2: mid-step form for 8 x 16 too */ \
+  X(WG_ROLL_CUS, "wg_roll_cus", 256)       /* CUs the rolling-window kernel's depth split plans for */                         \
   X(WG_ROLL_OVH, "wg_roll_ovh", 9)         /* per-block overhead of its depth-split cost model, in depth steps */            \
   X(WG_ROLL_MINVOX, "wg_roll_minvox", 0)   /* smallest d x h x w it takes */                                                \
+  X(WG_VOX_CUS, "wg_vox_cus", 128)         /* blocks the voxel-GEMM weight gradient aims at: HALF the CUs - the main stream's deep-level kernels are small latency-bound grids that need free CUs at once (step -0.9 % against 256) */ \
   X(WG_VOX_MAXV, "wg_vox_maxv", 10000)     /* largest voxel count (whole batch) the voxel-GEMM weight gradient takes */    \
   X(STREAM_MIN_W, "stream_min_w", 64)                                                                                  \
   X(TILE_MT, "tile_mt", 0)                                                                                             \

@@ -835,7 +835,8 @@ inline VoxCfg vox_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.npairs = (cin / 32) * (cout / 32);
   const int groups = c.npairs / c.cot;
   const int chunks = (int)((V + VX_KC - 1) / VX_KC);
-  int S = (256 + groups - 1) / groups;                       // just enough voxel ranges to give every CU a block
+  const int cus = (int)fplx_knob(FPLX_K_WG_VOX_CUS);         // blocks the launch aims at (256: every CU one)
+  int S = (cus + groups - 1) / groups;                       // just enough voxel ranges to give every CU a block
   if (S > chunks) S = chunks;
   if (S < 1) S = 1;
   const int cper = (chunks + S - 1) / S;

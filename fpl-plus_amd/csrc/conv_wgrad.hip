@@ -536,13 +536,14 @@ inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
   const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * c.npairs;
   // one block per CU at a time: the depth split that minimises rounds x (depths per block + per-block overhead)
   const double ovh = (double)fplx_knob(FPLX_K_WG_ROLL_OVH);
+  const int64_t cus = fplx_knob(FPLX_K_WG_ROLL_CUS);          // CUs the depth split plans for
   int ds = 1;
   double best = 1e30;
   for (int cand = 1; cand <= d; ++cand) {
     const int dl = (d + cand - 1) / cand;
     if (dl < 4 && cand > 1) break;
     const int segs = (d + dl - 1) / dl;
-    const int64_t rounds = (tiles * segs + 255) / 256;
+    const int64_t rounds = (tiles * segs + cus - 1) / cus;
     const double cost = (double)rounds * (dl + ovh);
     if (cost < best - 1e-9) { best = cost; ds = segs; }
   }
