@@ -40,6 +40,9 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     opts = dict(a[2:].split("=") for a in sys.argv[1:] if a.startswith("--") and "=" in a)
     steps, rounds = int(opts.get("steps", 20)), int(opts.get("rounds", 5))
+    hi = None
+    if int(opts.get("main-prio", 0)):           # --main-prio=1: the step runs on a high-priority stream (the second stream stays normal)
+        hi = torch.cuda.Stream(priority=-1)
     settings = [(a, ) + parse(a) for a in args] or [("default", {}, {})]
     keys = sorted({k for _, kn, _ in settings for k in kn})
     defaults = {k: _lib.get_tuning(k) for k in keys}
@@ -58,20 +61,23 @@ def main():
     attr_keys = sorted({k for _, _, at in settings for k in at})
     attr_def = {k: getattr(net.engine, k) for k in attr_keys}
     runs = [(name, kn, at, []) for name, kn, at in settings]
-    for r in range(rounds):
-        for name, kn, at, res in runs:
-            apply(kn)
-            net.engine.invalidate()                     # packs / plans cached under the previous knobs
-            for k in attr_keys:
-                setattr(net.engine, k, type(attr_def[k])(at[k]) if k in at else attr_def[k])
-            for i in range(3 if r else 6):
-                ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps):
-                ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
-            torch.cuda.synchronize()
-            res.append((time.perf_counter() - t0) / steps * 1e3)
+    import contextlib
+    ctx = torch.cuda.stream(hi) if hi is not None else contextlib.nullcontext()
+    with ctx:
+      for r in range(rounds):
+          for name, kn, at, res in runs:
+              apply(kn)
+              net.engine.invalidate()                     # packs / plans cached under the previous knobs
+              for k in attr_keys:
+                  setattr(net.engine, k, type(attr_def[k])(at[k]) if k in at else attr_def[k])
+              for i in range(3 if r else 6):
+                  ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
+              torch.cuda.synchronize()
+              t0 = time.perf_counter()
+              for i in range(steps):
+                  ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
+              torch.cuda.synchronize()
+              res.append((time.perf_counter() - t0) / steps * 1e3)
     apply({})
     for name, kn, at, res in runs:
         print("%-48s %7.3f ms/step (min %.3f, max %.3f over %d rounds of %d steps)  %.1f vol/s" %
