@@ -440,42 +440,48 @@ conv_wgrad_stream(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   }
 }
 
-// dw[co][ci][tap] = sum_b part[b][pair][tap][co%32][ci%32]; 256 outputs (four consecutive ci per thread, 16-byte loads) x 4
-// partial-lanes per block.  Per output the additions run in a fixed order: lane pl adds the blocks b = pl, pl + 4, ... one
-// after the other, then ((lane 0 + lane 1) + lane 2) + lane 3 - the order of the 4-byte form this replaces (same bits).
+// dw[co][ci][tap] = sum_b part[b][pair][tap][co%32][ci%32].  A block = 16 outputs (four consecutive ci each, 16-byte loads) x 16
+// partial lanes: lane pl adds the blocks b = pl, pl + 16, ... one after the other (four loads in flight), then the 16 lane sums
+// are added in index order through LDS - a fixed order for every output.  (Round 3's form had 4 partial lanes: with the
+// 200-500 partial tiles of the large levels each lane walked 50-128 dependent rounds of loads - 22-36 us of pure latency per
+// launch, 6.5 % of the shipped 2.5D configuration's kernel time.)
 __global__ void __launch_bounds__(256)
 wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw,
                     int mid) {       // mid: only taps 9..17 were produced; dw is the 9-tap tensor [Cout][Cin][3][3]
   __shared__ float4 red[256];
   const int64_t total = (int64_t)npairs * 27 * 1024;
-  const int64_t i = ((int64_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-  const int pl = threadIdx.x >> 6, o = threadIdx.x & 63;
+  const int o = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int64_t i = ((int64_t)blockIdx.x * 16 + o) * 4;
   const int tap0 = i < total ? (int)((i >> 10) % 27) : 0;
-  const bool live = i < total && (!mid || (tap0 >= 9 && tap0 < 18));     // uniform per 1024-element tile (= per block)
+  const bool live = i < total && (!mid || (tap0 >= 9 && tap0 < 18));     // uniform per 64-element run (= per block)
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     const float* p = part + i;
     int b = pl;
-    for (; b + 12 < nblk; b += 16) {                 // four loads in flight, added in order
+    for (; b + 48 < nblk; b += 64) {                 // four loads in flight, added in order
       const float4 v0 = *reinterpret_cast<const float4*>(p + (int64_t)b * total);
-      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 4) * total);
-      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 8) * total);
-      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 12) * total);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 16) * total);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 32) * total);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (int64_t)(b + 48) * total);
       t.x += v0.x; t.y += v0.y; t.z += v0.z; t.w += v0.w;
       t.x += v1.x; t.y += v1.y; t.z += v1.z; t.w += v1.w;
       t.x += v2.x; t.y += v2.y; t.z += v2.z; t.w += v2.w;
       t.x += v3.x; t.y += v3.y; t.z += v3.z; t.w += v3.w;
     }
-    for (; b < nblk; b += 4) {
+    for (; b < nblk; b += 16) {
       const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)b * total);
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
   }
-  red[pl * 64 + o] = t;
+  red[pl * 16 + o] = t;
   __syncthreads();
   if (pl != 0 || !live) return;
-  const float4 r1 = red[64 + o], r2 = red[128 + o], r3 = red[192 + o];
-  const float out[4] = {t.x + r1.x + r2.x + r3.x, t.y + r1.y + r2.y + r3.y, t.z + r1.z + r2.z + r3.z, t.w + r1.w + r2.w + r3.w};
+  float out[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const float4 r = red[k * 16 + o];
+    out[0] += r.x; out[1] += r.y; out[2] += r.z; out[3] += r.w;
+  }
   const int ci_l = i & 31, co_l = (i >> 5) & 31, tap = (int)((i >> 10) % 27), pair = (int)(i / (27 * 1024));
   const int ncit = Cin / 32;
   const int co = (pair / ncit) * 32 + co_l, ci = (pair % ncit) * 32 + ci_l;
@@ -2187,7 +2193,7 @@ extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* 
 extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
                                         hipStream_t st) {
   const int64_t total = (int64_t)npairs * 27 * 1024;
-  wgrad_stream_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw, mid);
+  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw, mid);
   return fplx_check_launch("wgrad_stream_reduce");
 }
 
@@ -2225,7 +2231,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
         conv_wgrad_vox<1><<<grid, 256, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
       }
       const int64_t total = (int64_t)v.npairs * 27 * 1024;
-      wgrad_stream_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float*)ws, v.g.S, v.npairs, cin, cout, dw, 0);
+      wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, v.g.S, v.npairs, cin, cout, dw, 0);
       int rcv = fplx_check_launch("mfma_conv3d_wgrad_vox");
       return rcv < 0 ? rcv : 1;
     }
@@ -2251,7 +2257,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
 #undef LAUNCH_WG
 #undef LAUNCH_WG2
   const int64_t total = (int64_t)c.npairs * 27 * 1024;
-  wgrad_stream_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw, mid);
+  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw, mid);
   int rc = fplx_check_launch("mfma_conv3d_wgrad");
   return rc < 0 ? rc : 1;
 }
