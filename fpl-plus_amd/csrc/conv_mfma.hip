@@ -2189,7 +2189,7 @@ extern "C" int fplx_mfma_conv3d_fwd_act(const void* x, int64_t ldx, const void* 
 extern "C" int fplx_wgroll_ok(int n, int d, int h, int w, int cin, int cout, int64_t ldx, int64_t ldy);
 extern "C" size_t fplx_wgroll_ws_bytes(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d, int h,
-                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1);
+                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1, int mid);
 extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
                                         hipStream_t st) {
   const int64_t total = (int64_t)npairs * 27 * 1024;
@@ -2236,8 +2236,8 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
       return rcv < 0 ? rcv : 1;
     }
   }
-  if (!mid) {                                               // the rolling-window kernel (conv_wgrad.hip) where it applies
-    const int rr = fplx_wgroll_conv3d_wgrad(x, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, st, x1);
+  {                                                         // the rolling-window kernels (conv_wgrad.hip) where they apply
+    const int rr = fplx_wgroll_conv3d_wgrad(x, ldx, dy, ldy, dw, n, d, h, w, cin, cout, ws, ws_bytes, st, x1, mid);
     if (rr != 0) return rr;
   }
   const WgCfg c = wg_cfg(n, d, h, w, cin, cout);

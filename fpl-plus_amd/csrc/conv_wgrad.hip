@@ -515,9 +515,185 @@ conv_wgrad_roll(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// roll2d_march: the weight gradient of a Conv2d per depth slice (the 2.5D levels: dW[kh][kw] sums over ALL depths, a tap
+// never crosses a slice).  A depth step needs one x slab and one dy slab and runs 9 taps on them - a third of the 3D form's
+// MFMAs on the same bytes, so the kernel is bound by the slab stream, not the matrix pipe: waves 0-2 own the kernel column
+// kw = WV (the rolling window over kh: one x fragment per cell, three MFMAs against the last three dy rows), wave 3 only
+// fetches.  Three ring slots per operand: the slabs of depth t + 2 are requested during step t, and the step's closing wait
+// is COUNTED - every wave issues the same number of pieces per step (a piece index past the end repeats the last piece:
+// same bytes, same place), so vmcnt(NPW) leaves exactly the newest slab pair in flight and a fetch has a whole step to land.
+// Partial tiles go to the taps 9..17 of the usual [block][pair][27][co][ci] layout (wgrad_stream_reduce, mid form).
+template <int TH_, int TW_>
+struct WR2 {
+  static constexpr int TH = TH_, TW = TW_, SH = TH + 2, SW = TW + 2, SLAB = SH * SW;
+  static constexpr int XP = (SLAB * 4 + 63) / 64, XSLOT = XP * 1024;
+  static constexpr int YP = TH * TW * 4 / 64, YSLOT = YP * 1024;
+  static constexpr int NS = 3;
+  static constexpr int LDS = NS * (XSLOT + YSLOT);
+  static constexpr int NCH = TW / 16, NCELL = NCH * SH;
+  static constexpr int XPW = (XP + 3) / 4, YPW = (YP + 3) / 4, NPW = XPW + YPW;
+  static_assert(NPW <= NCELL, "one DMA piece per cell");
+};
+
+template <class G, int WV>
+__device__ __forceinline__ void roll2d_march(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy,
+                                             int64_t ldy, float* __restrict__ part, int D, int H, int W, int Cin, int Cout,
+                                             int tilesH, int tilesW, int dsegs, int dlen, const bf16_t* __restrict__ x1,
+                                             const FplxBlock bid) {
+  constexpr int TH = G::TH, TW = G::TW, SH = G::SH, SW = G::SW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int ncg = Cin / 32;
+  const int cot = bid.y / ncg, cg = bid.y % ncg;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+
+  unsigned xvo[G::XPW], yvo[G::YPW];
+#pragma unroll
+  for (int k = 0; k < G::XPW; ++k) {
+    const int piece = WV + 4 * k < G::XP ? WV + 4 * k : G::XP - 1;
+    const int i = piece * 64 + lane;
+    const int vox = i >> 2, c = i & 3;
+    const int hh = vox / SW + h0 - 1, ww = vox % SW + w0 - 1;
+    const bool in = vox < G::SLAB && hh >= 0 && hh < H && ww >= 0 && ww < W;
+    xvo[k] = in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u;
+  }
+#pragma unroll
+  for (int k = 0; k < G::YPW; ++k) {
+    const int piece = WV + 4 * k < G::YP ? WV + 4 * k : G::YP - 1;
+    const int i = piece * 64 + lane;
+    const int vox = i >> 2, c = i & 3;
+    const int hh = vox / TW + h0, ww = vox % TW + w0;
+    yvo[k] = (hh < H && ww < W) ? (unsigned)((((int64_t)hh * W + ww) * ldy + c * 8) * 2) : 0x40000000u;
+  }
+  const int64_t xslice = (int64_t)H * W * ldx * 2, yslice = (int64_t)H * W * ldy * 2;
+  const char* xn = reinterpret_cast<const char*>((x1 && cg == 1) ? x1 : x + cg * 32) + (int64_t)n * D * xslice;
+  const char* yn = reinterpret_cast<const char*>(dy + cot * 32) + (int64_t)n * D * yslice;
+  u32x4 xr, yr;
+  xr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+  xr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+  xr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * xslice - (ldx - 32) * 2));
+  xr[3] = 0x00020000u;
+  yr[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)yn);
+  yr[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)yn >> 32) & 0xFFFFu);
+  yr[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)D * yslice - (ldy - 32) * 2));
+  yr[3] = 0x00020000u;
+  const unsigned xslice32 = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+  const unsigned yslice32 = __builtin_amdgcn_readfirstlane((unsigned)yslice);
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  auto dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so), "s"(dst) : "memory");
+  };
+  const int nd = d1 - d0;
+  // piece j of this wave for the slabs of depth d0 + t (ring slot t % 3); off (t >= nd): out of range, the free slot gets zeros
+  auto issue = [&](int t, int j) {
+    const bool on = t < nd;
+    const unsigned slot = (unsigned)t % G::NS;
+    if (j < G::XPW) {
+      const int piece = WV + 4 * j < G::XP ? WV + 4 * j : G::XP - 1;
+      const unsigned so = __builtin_amdgcn_readfirstlane(on ? (unsigned)(d0 + t) * xslice32 : 0x40000000u);
+      dma(xr, xvo[j], so, lds0 + slot * G::XSLOT + piece * 1024);
+    } else {
+      const int jj = j - G::XPW;
+      const int piece = WV + 4 * jj < G::YP ? WV + 4 * jj : G::YP - 1;
+      const unsigned so = __builtin_amdgcn_readfirstlane(on ? (unsigned)(d0 + t) * yslice32 : 0x40000000u);
+      dma(yr, yvo[jj], so, lds0 + G::NS * G::XSLOT + slot * G::YSLOT + piece * 1024);
+    }
+  };
+  auto wait_newest = [&]() {                               // all but the NPW pieces issued last have landed
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(G::NPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (8 * (g >> 1) + q) * 64 + (16 * (g & 1) + 4 * p) * 2;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+  for (int j = 0; j < G::NPW; ++j) issue(0, j);
+#pragma unroll
+  for (int j = 0; j < G::NPW; ++j) issue(1, j);
+  wait_newest();
+
+  bf16x8 fx[2], fy[4];
+#pragma unroll 1
+  for (int t = 0; t < nd; ++t) {
+    const unsigned slot = (unsigned)t % G::NS;
+    const unsigned xb = lds_base(lds0 + slot * G::XSLOT + lane_off);
+    const unsigned yb = lds_base(lds0 + G::NS * G::XSLOT + slot * G::YSLOT + lane_off);
+    if (WV < 3) {
+      fy[0] = tr_frag(yb);
+      fx[0] = tr_frag(xb + WV * 64);
+    }
+#pragma unroll
+    for (int k = 0; k < G::NCELL; ++k) {
+      const int rx = k % SH;
+      if (WV < 3 && k + 1 < G::NCELL) {                     // the next cell's fragments behind this cell's MFMAs
+        const int c1 = (k + 1) / SH, r1 = (k + 1) % SH;
+        if (r1 < TH) fy[r1 & 3] = tr_frag(yb + ((r1 * TW + c1 * 16) * 64));
+        fx[(k + 1) & 1] = tr_frag(xb + ((r1 * SW + c1 * 16 + WV) * 64));
+      }
+      if (k < G::NPW) issue(t + 2, k);
+      __builtin_amdgcn_sched_barrier(0);
+      if (WV < 3) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int r = rx - kh;
+          if (r >= 0 && r < TH) acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[k & 1], fy[r & 3], acc[kh], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wait_newest();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (WV < 3) {
+    const int co = lane & 31, rbase = (lane >> 5) * 4;
+    const int pair = cot * ncg + cg;
+    float* out = part + ((int64_t)bid.x * (ncg * (Cout / 32)) + pair) * (27 * 1024);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(out + ((9 + kh * 3 + WV) * 32 + co) * 32 + 8 * g4 + rbase) =
+            make_float4(acc[kh][4 * g4 + 0], acc[kh][4 * g4 + 1], acc[kh][4 * g4 + 2], acc[kh][4 * g4 + 3]);
+    }
+  }
+}
+
+template <int TH, int TW>
+__global__ void __launch_bounds__(256)
+conv_wgrad_roll2d(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int D, int H, int W, int Cin, int Cout, int tilesH, int tilesW, int dsegs, int dlen,
+                  const bf16_t* __restrict__ x1, int xcd) {
+  using G = WR2<TH, TW>;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: roll2d_march<G, 0>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 1: roll2d_march<G, 1>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    case 2: roll2d_march<G, 2>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+    default: roll2d_march<G, 3>(x, ldx, dy, ldy, part, D, H, W, Cin, Cout, tilesH, tilesW, dsegs, dlen, x1, bid); break;
+  }
+}
+
 struct RollCfg { int th, tw, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
 
-inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
+inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout, bool twod = false) {
   RollCfg c;
   // footprint: the one that pads the (h, w) plane least; 16 x 16 on a tie (fewer slab rows per dy row, smaller halo)
   const int geo = (int)fplx_knob(FPLX_K_WG_ROLL_GEO);
@@ -525,7 +701,7 @@ inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
   // on a tie 8 x 32 where it runs on the 16 x 16 x 32 MFMA (less energy per FLOP: in the train step, beside the main stream's
   // kernels, that form measured -0.6 % against 16 x 16 footprints and -1.2 % against 8 x 32 on 32 x 32 x 16), else 16 x 16
   // (fewer slab rows per dy row, smaller halo)
-  const bool m16 = fplx_knob(FPLX_K_WG_ROLL_M16) != 0;
+  const bool m16 = !twod && fplx_knob(FPLX_K_WG_ROLL_M16) != 0;          // (the 2D form has no 16 x 16 x 32 kernel)
   c.th = 16; c.tw = 16;
   if (area(8, 32) < area(c.th, c.tw) || (m16 && area(8, 32) == area(c.th, c.tw))) { c.th = 8; c.tw = 32; }
   if (area(8, 16) < area(c.th, c.tw)) { c.th = 8; c.tw = 16; }
@@ -535,7 +711,8 @@ inline RollCfg roll_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.npairs = (cin / 32) * (cout / 32);
   const int64_t tiles = (int64_t)n * c.tilesH * c.tilesW * c.npairs;
   // one block per CU at a time: the depth split that minimises rounds x (depths per block + per-block overhead)
-  const double ovh = (double)fplx_knob(FPLX_K_WG_ROLL_OVH);
+  // (a block of the 2D form has no depth halo to fetch: its overhead is the prologue's fetch latency and 9 partial tiles)
+  const double ovh = (double)fplx_knob(twod ? FPLX_K_WG_ROLL2D_OVH : FPLX_K_WG_ROLL_OVH);
   const int64_t cus = fplx_knob(FPLX_K_WG_ROLL_CUS);          // CUs the depth split plans for
   int ds = 1;
   double best = 1e30;
@@ -571,19 +748,38 @@ extern "C" int fplx_wgroll_ok(int n, int d, int h, int w, int cin, int cout, int
   return 1;
 }
 
-extern "C" size_t fplx_wgroll_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
-  return roll_cfg(n, d, h, w, cin, cout).ws;
+extern "C" size_t fplx_wgroll_ws_bytes(int n, int d, int h, int w, int cin, int cout) {      // the larger of the 3D and the 2D form's
+  const size_t a = roll_cfg(n, d, h, w, cin, cout).ws, b = roll_cfg(n, d, h, w, cin, cout, true).ws;
+  return a > b ? a : b;
 }
 
 // returns 1 if launched, 0 if not applicable, < 0 on error.  dw fp32 [Cout][Cin][27]; x1: second ci tile of a split Cin = 64
+// mid != 0: a Conv2d per depth slice (conv_wgrad_roll2d), dw fp32 [Cout][Cin][3][3]
 extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n, int d, int h,
-                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1) {
+                                        int w, int cin, int cout, void* ws, size_t ws_bytes, hipStream_t st, const void* x1,
+                                        int mid) {
   if (!fplx_wgroll_ok(n, d, h, w, cin, cout, ldx, ldy)) return 0;
+  if (mid && !fplx_knob(FPLX_K_WG_ROLL2D)) return 0;
   if (ldx % 8 != 0 || ldy % 8 != 0 || ((uintptr_t)x % 16) || ((uintptr_t)dy % 16) || ((uintptr_t)x1 % 16)) return 0;
   if (x1 && cin != 64) return 0;
-  const RollCfg c = roll_cfg(n, d, h, w, cin, cout);
+  const RollCfg c = roll_cfg(n, d, h, w, cin, cout, mid != 0);
   if (ws_bytes < c.ws) return fplx_fail(FPLX_E_WORKSPACE, "wgroll_conv3d_wgrad: workspace %zu < %zu", ws_bytes, c.ws);
   dim3 grid(c.nblk, c.npairs);
+  if (mid) {
+#define LAUNCH_ROLL2D(TH_, TW_)                                                                                     \
+  do {                                                                                                              \
+    using G_ = WR2<TH_, TW_>;                                                                                       \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_roll2d<TH_, TW_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_wgrad_roll2d<TH_, TW_><<<grid, 256, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, d, h, w, cin, \
+                                                           cout, c.tilesH, c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
+  } while (0)
+    if (c.th == 16) LAUNCH_ROLL2D(16, 16); else if (c.tw == 32) LAUNCH_ROLL2D(8, 32); else LAUNCH_ROLL2D(8, 16);
+#undef LAUNCH_ROLL2D
+    int rc2 = fplx_check_launch("wgroll_conv2d_wgrad");
+    if (rc2 < 0) return rc2;
+    rc2 = fplx_wgrad_reduce_launch((const float*)ws, c.nblk, c.npairs, cin, cout, dw, 1, st);
+    return rc2 < 0 ? rc2 : 1;
+  }
 #define LAUNCH_ROLL(TH_, TW_, MB_)                                                                                   \
   do {                                                                                                              \
     using G_ = WR<TH_, TW_, MB_>;                                                                                   \
