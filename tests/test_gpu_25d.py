@@ -141,6 +141,44 @@ def test_conv2d_through_the_3d_kernels(dtype, shape):
     assert float((db.cpu() - cl(dy).sum(0)).abs().max()) < max(tol, 1e-4) * float(cl(dy).sum(0).abs().max())
 
 
+# (fplx_conv3d_cat2_ok: 32 + 32 -> 32 channels, W >= 64, at least 32000 voxels per sample)
+@pytest.mark.parametrize("shape", [(1, 32, 16, 32, 64), (2, 32, 12, 48, 96), (1, 32, 9, 56, 72), (3, 32, 5, 88, 80)])
+def test_conv2d_wgrad_two_tensors_and_depth_segments(shape):
+    """the 2.5D decoder's weight gradient on the two halves of a concatenation (x0 | x1, never materialised) and the 9-tap
+    rolling-window kernel over several depth segments and ragged footprints - against autograd of the Conv2d
+    applied per depth slice; the 9-tap result equals the middle plane of the 27-tap kernel's result on the same operands"""
+    from fplx import ops
+    n, cout, d, h, w = shape
+    cin, tol = 64, 2e-2
+    dims = (n, d, h, w)
+    q = lambda t: t.bfloat16().float()
+    x0 = q(torch.from_numpy(detdata.normal("c2d2.x0%s" % (shape,), (n, 32, d, h, w))))
+    x1 = q(torch.from_numpy(detdata.normal("c2d2.x1%s" % (shape,), (n, 32, d, h, w))))
+    dy = q(torch.from_numpy(detdata.normal("c2d2.dy%s" % (shape,), (n, cout, d, h, w))))
+    wr = torch.zeros(cout, cin, 3, 3).requires_grad_(True)
+    F.conv3d(torch.cat([x0, x1], 1), wr.unsqueeze(2), None, padding=(0, 1, 1)).backward(dy)
+    bf = torch.bfloat16
+    g0, g1, dyg = cl(x0).to(bf).cuda(), cl(x1).to(bf).cuda(), cl(dy).to(bf).cuda()
+    ws = torch.empty(max(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), 16), dtype=torch.uint8, device="cuda")
+    dw9 = torch.full((cout, cin, 3, 3), 7.0, dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad_cat2(g0, g1, dyg, dw9, dims, cin, cout, ws, mid=True)
+    gmax = float(wr.grad.abs().max())
+    assert float((dw9.cpu() - wr.grad).abs().max()) < tol * gmax
+    # the same layer through the single-tensor entry point on the materialised concatenation: the same kernel, the same bits
+    cat = torch.cat([g0, g1], 1).contiguous()
+    dt = ops._DT[bf]
+    dw9b = torch.empty_like(dw9)
+    ws2 = torch.empty(max(ops.conv2d_wgrad_ws_bytes(dims, cin, cout), 16), dtype=torch.uint8, device="cuda")
+    ops.conv2d_wgrad(cat, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw9b, None, dims, cin, cout,
+                     ws2)
+    assert torch.equal(dw9, dw9b)
+    # and the 27-tap kernel's middle plane (another kernel, another order of additions)
+    dw27 = torch.empty((cout, cin, 27), dtype=torch.float32, device="cuda")
+    ops.conv3d_wgrad_cat2(g0, g1, dyg, dw27, dims, cin, cout, ws)
+    mid = dw27.view(cout, cin, 3, 3, 3)[:, :, 1]
+    assert float((mid - dw9).abs().max()) < 1e-3 * gmax
+
+
 def test_25d_training_all_matches_reference(golden_dir):
     """five iterations of SegmentationAgent.training_all (pixel / image weights on domain 1) in the shipped
     dimensionality pattern: loss, class Dice, lr schedule, parameters after 1 and 3 Adam steps."""
