@@ -99,9 +99,17 @@ def tuning_keys():
     return keys
 
 
+tuning_epoch = 0            # bumped by every set_tuning: host-side caches built under the old knob values (Engine's packs, folds and
+                            # split plans) are dropped when they see a new epoch
+
+
 def set_tuning(key, value):
-    """fplx_set_tuning: A/B knob of the kernel dispatchers (benchmarks and tests only; every knob selects among kernels computing the same function - some in another order of fp32 additions)"""
+    """fplx_set_tuning: A/B knob of the kernel dispatchers (benchmarks and tests only; every knob selects among kernels computing the same function - some in another order of fp32 additions).
+    The knob table is process-wide and read by the size queries and the launches independently: flip knobs between steps,
+    never between a query (fplx_*_stats_rows, fplx_*_ws_bytes, plan queries) and the launch it sizes."""
+    global tuning_epoch
     check(lib().fplx_set_tuning(key.encode(), int(value)))
+    tuning_epoch += 1
 
 
 def get_tuning(key):

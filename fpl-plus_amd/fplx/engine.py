@@ -100,6 +100,8 @@ class Engine(object):
         inline-asm 16-byte stores, fixed there - DESIGN section 7, profiles/r02_race25_hazard_location.txt.)"""
         return False
 
+    _tuning_epoch = -1
+
     def invalidate(self):
         self._pack_cache = None
         self._train_packs = None
@@ -169,6 +171,9 @@ class Engine(object):
         dev, adt = x.device, net.act_dtype
         a_dt = ops._DT[adt]
         ft = net.ft_chns
+        if self._tuning_epoch != _lib.tuning_epoch:      # a kernel knob was flipped: packs / folds may have been laid out for another kernel
+            self.invalidate()
+            self._tuning_epoch = _lib.tuning_epoch
         if train and reuse_packs and self.allow_pack_reuse and self._train_packs is not None and self._train_packs[0] == adt:
             packs = self._train_packs[1]
         elif train or self._pack_cache is None or self._pack_cache[0] != (adt, net.flat_params.data_ptr(), net.flat_params._version):

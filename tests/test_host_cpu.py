@@ -37,13 +37,16 @@ def test_tuning_table_round_trip_and_env_translation():
     keys = _lib.tuning_keys()
     assert "brick" in keys and "march32_v2" in keys and "xcd" in keys and len(set(keys)) == len(keys) >= 20
     assert _lib.get_tuning("brick") == 1 and _lib.get_tuning("march32_v2") == 4
+    e0 = _lib.tuning_epoch
     _lib.set_tuning("brick", 3)
     try:
         assert _lib.get_tuning("brick") == 3
     finally:
         _lib.set_tuning("brick", 1)
+    assert _lib.tuning_epoch == e0 + 2           # what Engine.forward compares its caches' epoch with (packs, folds, plans)
     with pytest.raises(ValueError):
         _lib.set_tuning("no_such_knob", 1)
+    assert _lib.tuning_epoch == e0 + 2           # a refused knob changes nothing
     code = "import sys; sys.path.insert(0, %r); from fplx import _lib; print(_lib.get_tuning('brick'), _lib.get_tuning('tile_ks'))" % (
         os.path.dirname(os.path.dirname(_lib.__file__)),)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
