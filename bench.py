@@ -68,7 +68,7 @@ class KernelTimer(object):
                      "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "outconv_fwd_bn", "outconv_dgrad_bn_bwd"):
             self._wrap(name)
 
-    def _key(self, name, a):
+    def _key(self, name, a, kw={}):
         if name in ("conv3d_fwd",):
             dims, cin, cout, k = a[8], a[9], a[10], a[11]
             return (name, dims, cin, cout, k)
@@ -82,6 +82,11 @@ class KernelTimer(object):
             return ("conv3d_fwd", a[4], a[6], a[5], (3, 3, 3))
         if name == "conv3d_wgrad_cat2":         # (x0, x1, dy, dw, dims, cin, cout, ws)
             return ("conv3d_wgrad", a[4], a[5], a[6], (3, 3, 3))
+        if name == "bn_act_bwd":                # (y, dout, dy, bnbuf, slope, p, seed, sid, c, ...): voxels x channels of the site
+            red = bool(kw.get("reduced", a[15] if len(a) > 15 else False))      # the DownBlock tails: the reduction was fused elsewhere
+            return (name + "(apply only)" if red else name, int(a[0].shape[0]), int(a[8]))
+        if name == "bn_act_fwd":                # (y, out, bnbuf, slope, p, seed, sid, c)
+            return (name, int(a[0].shape[0]), int(a[7]))
         return (name,)
 
     def _wrap(self, name):
@@ -95,7 +100,7 @@ class KernelTimer(object):
             e0.record()
             r = orig(*a, **kw)
             e1.record()
-            self.records.setdefault(self._key(name, a), []).append((e0, e1))
+            self.records.setdefault(self._key(name, a, kw), []).append((e0, e1))
             return r
         setattr(self.ops, name, f)
 
@@ -479,6 +484,7 @@ def main():
 
     # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
     roof = None
+    roof_hbm = None
     ktable = []
     if timer is not None:
         timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
@@ -493,6 +499,18 @@ def main():
         tot = sum(v[2] for v in summ.values())
         for k, (cnt, avg, s) in sorted(summ.items(), key=lambda kv: -kv[1][2]):
             ktable.append({"kernel": str(k), "launches": cnt, "avg_ms": round(avg, 4), "share": round(s / tot, 4)})
+        # the largest HBM-bound consumer beside the dominant convolution (the BatchNorm backward passes are the
+        # biggest group of the table): bn_act_bwd = reduce (reads d(out), y) + finalize + apply (reads both, writes dy) =
+        # 5 tensors of voxels x C bf16; bn_act_fwd = 2
+        bns = {k: v for k, v in summ.items() if k[0] in ("bn_act_bwd", "bn_act_fwd")}       # (not the apply-only form)
+        if bns:
+            kb = max(bns, key=lambda kk: bns[kk][2])
+            nb = (5.0 if kb[0] == "bn_act_bwd" else 2.0) * kb[1] * kb[2] * 2.0
+            gb = nb / (bns[kb][1] * 1e-3) / 1e9
+            roof_hbm = {"bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gb / HBM_PEAK_GBS, 5), "kernel": str(kb), "avg_ms": round(bns[kb][1], 4),
+                        "launches_timed": bns[kb][0], "algorithmic_bytes": nb, "time_share": round(bns[kb][2] / tot, 4),
+                        "note": "three launches (reduce, finalize, apply) timed as one op, second stream off"}
         convs = {k: v for k, v in summ.items() if k[0] in ("conv3d_fwd", "conv3d_wgrad")}
         if convs:
             k = max(convs, key=lambda kk: convs[kk][2])
@@ -530,6 +548,8 @@ def main():
         }
         if roof is not None:
             res["roofline"] = roof
+        if roof_hbm is not None:
+            res["roofline_hbm"] = roof_hbm
         if ktable:
             res["kernels"] = ktable[:30]
         if world == 1 and not args.no_secondary:
