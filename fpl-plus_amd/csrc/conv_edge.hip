@@ -202,7 +202,10 @@ stem_fwd_mfma(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2e;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
 
-__global__ void __launch_bounds__(256, 4)
+// CIN = 4 (round 4, config 5): the same two MFMAs per input channel - the planar input makes a channel just another base
+// offset, the tap -> k-slot map and the padding selects are shared - 64 loads in flight per lane, two blocks per CU.
+template <int CIN>
+__global__ void __launch_bounds__(256, CIN == 1 ? 4 : 2)
 stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
               float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd) {
@@ -212,14 +215,16 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   // k-slot p = 8 s + j of lane half khalf: combo = p / 3 + 5 khalf (kd = combo / 3, kh = combo % 3), kw = p % 3
   // (low half: slots 0-14 = combos 0-4, slot 15 spare; high half: slots 0-11 = combos 5-8, slots 12-15 spare)
   auto slot_tap = [&](int p, int kh_) { return p < (kh_ ? 12 : 15) ? (p / 3 + 5 * kh_) * 3 + p % 3 : -1; };
-  bf16x8 afr[2];                                     // A: row = output channel r, the lane's 8 k-slots of step s
+  bf16x8 afr[CIN][2];                                // A: row = output channel r, the lane's 8 k-slots of step s, per input channel
 #pragma unroll
-  for (int s_ = 0; s_ < 2; ++s_)
+  for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int tap = slot_tap(8 * s_ + j, khalf);
-      afr[s_][j] = tap >= 0 ? wf[((int64_t)tap * Cout + co0 + r)] : (bf16_t)0.f;      // pack [tap][Cout][Cin = 1]
-    }
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tap = slot_tap(8 * s_ + j, khalf);
+        afr[ci][s_][j] = tap >= 0 ? wf[((int64_t)tap * Cout + co0 + r) * CIN + ci] : (bf16_t)0.f;      // pack [tap][Cout][Cin]
+      }
   f32x16 cinit;                                      // D[row = channel (i & 3) + 8 (i >> 2) + 4 khalf][col = voxel r]
 #pragma unroll
   for (int i = 0; i < 16; ++i) cinit[i] = bias ? bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf] : 0.f;
@@ -230,7 +235,7 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
     const int cb = c + 5 * khalf;
     roff[c] = cb < 9 ? ((cb / 3 - 1) * H + (cb % 3 - 1)) * W : 0;
   }
-  const int64_t xbytes = (int64_t)N * D * H * W * 4;
+  const int64_t xbytes = (int64_t)N * CIN * D * H * W * 4;
   // (the launcher keeps the input below 2 GiB; raw buffer, no stride: out-of-range offsets read as zeros)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
   float ssum[16], qsum[16];
@@ -251,16 +256,21 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   // the segment's 16 loads per lane.  Byte offset of (row c, kw): a VECTOR offset that is negative (= huge, out of range -> 0)
   // exactly when the element lies before the tensor.  (A scalar offset must not carry the kw shift: the range check sees the
   // vector offset alone, and a row that starts one element before the tensor would lose its two valid taps.)
-  auto issue = [&](const Seg& g, float (&xv)[16]) {
-    const int vidx = ((g.n * D + g.d) * H + g.h) * W + g.w0 + r;
+  auto issue = [&](const Seg& g, float (&xv)[CIN][16]) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int c = p / 3, kw = p % 3;
-      const unsigned off = g.n < N ? (unsigned)(vidx + roff[c < 6 ? c : 5] + kw - 1) * 4u : 0x80000000u;
-      xv[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+    for (int ci = 0; ci < CIN; ++ci) {
+      const int vidx = (((g.n * CIN + ci) * D + g.d) * H + g.h) * W + g.w0 + r;
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int c = p / 3, kw = p % 3;
+        // a row before the tensor: a negative = huge offset, out of range -> 0.  For ci > 0 such an offset lands in the previous
+        // channel's plane instead - inside the tensor - and is cleared by the padding selects below like any other halo value
+        const unsigned off = g.n < N ? (unsigned)(vidx + roff[c < 6 ? c : 5] + kw - 1) * 4u : 0x80000000u;
+        xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+      }
     }
   };
-  auto consume = [&](const Seg& g, const float (&xv)[16]) {
+  auto consume = [&](const Seg& g, const float (&xv)[CIN][16]) {
     if (g.n >= N) return;                            // wave-uniform
     const int n = g.n, d = g.d, h = g.h;
     // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
@@ -273,15 +283,19 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
     const unsigned dhl = dh >> (5 * khalf);
     const int wv = g.w0 + r;
     const bool wl = wv - 1 >= 0 && wv - 1 < W, wc = wv < W, wr = wv + 1 < W;
-    bf16x8 bfr[2];
+    f32x16 acc = cinit;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int c = p / 3, kw = p % 3;
-      const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
-      bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[p] : 0.f);
+    for (int ci = 0; ci < CIN; ++ci) {
+      bf16x8 bfr[2];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const int c = p / 3, kw = p % 3;
+        const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
+        bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[ci][p] : 0.f);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
     }
-    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bfr[0], cinit, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[1], bfr[1], acc, 0, 0, 0);
     if (wc) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
@@ -311,7 +325,7 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   };
   // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured: 134 us
   // against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
-  float xa[16];
+  float xa[CIN][16];
   for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
     const Seg ga = seg_of(tt);
     issue(ga, xa);
@@ -1108,12 +1122,15 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
-  if (cin == 1 && vec_ok && fplx_knob(FPLX_K_STEM_ROWS) && (int64_t)n * d * h * w < ((int64_t)1 << 29)) {
-    // in_chns = 1: the LDS-free row kernel; the same number of blocks (= statistics rows) as the tile kernel
+  if (vec_ok && fplx_knob(FPLX_K_STEM_ROWS) && (cin == 1 || fplx_knob(FPLX_K_STEM_ROWS) != 2) &&
+      (int64_t)n * cin * d * h * w < ((int64_t)1 << 29)) {
+    // the LDS-free row kernel; the same number of blocks (= statistics rows) as the tile kernel  (knob 2: in_chns = 1 only)
     const int tilesW = (w + 31) / 32;
     const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
-    for (int co0 = 0; co0 < cout; co0 += 32)
-      stem_fwd_rows<<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+    for (int co0 = 0; co0 < cout; co0 += 32) {
+      if (cin == 1) stem_fwd_rows<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+      else stem_fwd_rows<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+    }
     int rc0 = fplx_check_launch("edge_stem_fwd_rows");
     return rc0 < 0 ? rc0 : 1;
   }

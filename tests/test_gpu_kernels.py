@@ -350,7 +350,10 @@ def test_fused_adam_matches_torch():
 @pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32),
                                    # in_chns = 1 runs the LDS-free row kernel (stem_fwd_rows): a volume of one row, a width
                                    # one past a segment, a single voxel, several samples
-                                   (1, 1, 32, 1, 1, 40), (3, 1, 32, 5, 7, 161), (1, 1, 32, 1, 1, 1), (2, 1, 64, 6, 20, 96)])
+                                   (1, 1, 32, 1, 1, 40), (3, 1, 32, 5, 7, 161), (1, 1, 32, 1, 1, 1), (2, 1, 64, 6, 20, 96),
+                                   # in_chns = 4 (config 5) on the same kernel: the channels' planes sit back to back, a halo
+                                   # offset of channel ci > 0 lands in channel ci - 1 and must be cleared by the padding selects
+                                   (2, 4, 32, 3, 9, 35), (3, 4, 64, 2, 5, 70), (1, 4, 32, 1, 1, 1)])
 def test_stem_kernels_bf16(shape):
     """fp32 NCDHW network input -> bf16 NDHWC (MFMA stem kernels): forward + statistics, weight gradient"""
     from fplx import ops
