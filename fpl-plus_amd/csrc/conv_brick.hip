@@ -20,6 +20,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifdef FPLX_STAMP
+__device__ long long* fplx_brick_stamp_buf;      // set by tools/micro/brick_bench.hip: 8 counters per wave
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -45,7 +49,12 @@ struct BKG : BK {
   static constexpr int NPB = (NP_TOT + 3) / 4;                // ... per wave (12 / 9)
   static constexpr int WST_BYTES = 3 * NT * ROWB;             // one weight stage: 24576 / 12288
   static constexpr int NPW = WST_BYTES / 1024 / 4;            // 6 / 3
-  static constexpr int LDS = 2 * BRICK_BYTES + 2 * WST_BYTES + NT * 4;
+  // weight ring: THREE slots where they fit the 160 KB beside the two brick slots (<4,2,1>: 132 KB, <5,1,1>: 144 KB; <4,2,2>
+  // would need 168 KB and keeps two).  With three, the slot of stage s + 2 is free during ALL of stage s, so its DMA pieces are
+  // spread over both halves of the stage, one every few MFMAs; with two, only behind the stage's barrier (see the stage loop)
+  static constexpr int NWS = (2 * BRICK_BYTES + 3 * WST_BYTES + NT * 4 <= 160 * 1024) ? 3 : 2;
+  static constexpr int LDS = 2 * BRICK_BYTES + NWS * WST_BYTES + NT * 4;
+  static constexpr int M1 = 3 * TD * NTW;                     // MFMAs per half-stage and wave
 };
 
 // M-tile row m (0..31, = lane & 31 of an A fragment) -> (row 0..3, col 0..7) of the wave's 4 x 8 patch
@@ -66,7 +75,7 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* bricks = smem;
   char* wring = smem + 2 * G::BRICK_BYTES;
-  float* bias_s = reinterpret_cast<float*>(wring + 2 * G::WST_BYTES);
+  float* bias_s = reinterpret_cast<float*>(wring + G::NWS * G::WST_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, khalf = lane >> 5;
@@ -108,8 +117,10 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
   rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
   rw[3] = 0x00020000u;
-  auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, char* l) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)l));
+  // (LDS destinations as plain integers: a pointer cast per piece costs a null check and a branch)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst_off) {        // dst_off: byte offset inside smem
+    const unsigned dst = lds0 + dst_off;
     const unsigned so_ = __builtin_amdgcn_readfirstlane(so);
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
@@ -133,7 +144,9 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
     B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
 #pragma unroll
     for (int k = 0; k < G::NPB; ++k) {
-      const int ci = (wave + 4 * k) * 64 + lane;
+      // (a piece index past the slot's end repeats the slot's last piece - same bytes, same place: every wave issues NPB pieces)
+      const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
+      const int ci = pidx * 64 + lane;
       const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
       const int q = L / G::PL, rem = L % G::PL, hh = rem / G::SWP, ww = rem % G::SWP;
       const int gd = B.d0 - 1 + q, gh = B.h0 - 1 + hh, gw = B.w0 - 1 + ww;
@@ -160,15 +173,51 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #pragma unroll
     for (int k = k0; k < k0 + cnt; ++k)
       if (k < G::NPB && wave + 4 * k < G::NP_TOT)            // uniform
-        buf_dma(rx, B.vo[k], (unsigned)(c * G::KC * 2), bricks + slot * G::BRICK_BYTES + (wave + 4 * k) * 1024);
+        buf_dma(rx, B.vo[k], (unsigned)(c * G::KC * 2), (unsigned)(slot * G::BRICK_BYTES + (wave + 4 * k) * 1024));
+  };
+  // the stage loop's form: every wave issues the SAME number of pieces per stage (the stage's closing wait counts them; see
+  // setup for the piece past the slot's end); on = false (nothing follows): the scalar offset is out of the descriptor's range,
+  // the free slot gets zeros.  brick_rsrc: the descriptor and channel offset of (brick, chunk), made once per stage.
+  struct BrickSrc { u32x4 rx; unsigned so; };
+  auto brick_rsrc = [&](const Brick& B, int ch, bool on) {
+    int c = c_lo + ch;
+    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
+    if (CAT2) {
+      const int half = Cin / (2 * G::KC);
+      if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
+      else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
+    }
+    BrickSrc r;
+    r.rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+    r.rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+    r.rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
+    r.rx[3] = 0x00020000u;
+    r.so = __builtin_amdgcn_readfirstlane(on ? (unsigned)(c * G::KC * 2) : 0x40000000u);
+    return r;
+  };
+  auto brick_piece = [&](const BrickSrc& src, const Brick& B, int slot, int k) {
+    const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
+    buf_dma(src.rx, B.vo[k], src.so, (unsigned)(slot * G::BRICK_BYTES + pidx * 1024));
   };
   auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
 #pragma unroll
     for (int k = 0; k < G::NPW; ++k) {
       const int j = wave + 4 * k, kd = j / (G::NT / 16);
       const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
-      buf_dma(rw, wvo, so, wring + slot * G::WST_BYTES + j * 1024);
+      buf_dma(rw, wvo, so, (unsigned)(2 * G::BRICK_BYTES + slot * G::WST_BYTES + j * 1024));
     }
+  };
+
+  // one DMA piece at a time, for the second half of a stage where the pieces ride between the MFMAs.  Cycle stamps (tools/micro/
+  // brick_bench.hip, -DFPLX_STAMP), level 1 64 -> 64: a half without DMA runs its 12 MFMAs in 435-450 cycles (384 of issue); the 5
+  // pieces of a wave issued as a block behind the barrier cost 520 cycles with the matrix pipe idle (790 for 8 pieces at level 2).
+  // Between the MFMAs the half takes 1090 cycles instead of 483 + 523: a piece still holds the issuing wave for about 120 cycles
+  // wherever it sits (2 pieces 6 MFMAs apart: +235 cycles; without the M0 save / restore: the same) - only the surrounding scalar
+  // work is hidden.  Alone -5..-10 % per launch, the train step -0.9 %.
+  auto weight_piece = [&](int ch, int t9, int slot, int k, bool on) {
+    const int j = wave + 4 * k, kd = j / (G::NT / 16);
+    const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
+    buf_dma(rw, wvo, on ? so : 0x40000000u, (unsigned)(2 * G::BRICK_BYTES + slot * G::WST_BYTES + j * 1024));
   };
 
   f32x16 acc[TD][NTW];
@@ -223,7 +272,16 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   load_a(bricks, 0, 0, 0, 0);
   load_b(wring, 0, 0);
   int cc = 0;                                               // chunks done so far (all bricks): brick slot = cc & 1
-  int gs = 0;                                               // stages done so far: weight slot = gs & 1
+  int gs = 0;                                               // stages done so far
+  int ws = 0;                                               // ... modulo the ring: this stage's weight slot
+#ifdef FPLX_STAMP
+  long long st_h1 = 0, st_wait = 0, st_bar = 0, st_dma = 0, st_h2 = 0, st_wo = 0, st_n = 0;
+  const long long st_begin = __builtin_amdgcn_s_memtime();
+  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#define STAMP(var_) do { const long long t__ = __builtin_amdgcn_s_memtime(); var_ += t__ - st_t; st_t = t__; } while (0)
+#else
+#define STAMP(var_) do { } while (0)
+#endif
   for (;;) {
     const int64_t tile_nx = tile + tr.step;
     const bool has_next = tile_nx < tr.end;                  // uniform
@@ -235,44 +293,89 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9, ++gs) {
         const int kh = t9 / 3, kw = t9 % 3;
-        const char* wslot = wring + (gs & 1) * G::WST_BYTES;
-        const char* wslot_nx = wring + ((gs + 1) & 1) * G::WST_BYTES;
-        // ---- first half (input channels 0-15 of the chunk): prefetch the second half's fragments
+        const int s1 = ws + 1 == G::NWS ? 0 : ws + 1, s2 = s1 + 1 == G::NWS ? 0 : s1 + 1;      // slots of stages gs + 1, gs + 2
+        const char* wslot = wring + ws * G::WST_BYTES;
+        const char* wslot_nx = wring + s1 * G::WST_BYTES;
+        // ---- this stage's DMA work: the NPW pieces of stage gs + 2's weights and up to two pieces of the next chunk of the
+        // brick (the next brick's first chunk behind the last one).  Every wave issues ALL of them in every stage - nothing
+        // follows: out of range, zeros into a free slot - so that the stage's closing wait can count.
+        int ch2 = ch, t92 = t9 + 2;
+        if (t92 >= 9) { t92 -= 9; ++ch2; }
+        const bool w_on = ch2 < nch || has_next;             // uniform
+        if (ch2 >= nch) ch2 = 0;
+        const bool b_on = !last_ch || has_next;
+        const int nbp = 2 * t9 + 1 < G::NPB ? 2 : (2 * t9 < G::NPB ? 1 : 0);      // brick pieces of this stage (compile-time)
+        const int nps = G::NPW + nbp;
+        BrickSrc bsrc;
+        if (nbp > 0) bsrc = last_ch ? brick_rsrc(nxt, 0, b_on) : brick_rsrc(cur, ch + 1, true);
+        auto piece = [&](int i) {
+          if (i < G::NPW) weight_piece(ch2, t92, s2, i, w_on);
+          else brick_piece(bsrc, last_ch ? nxt : cur, (cc + 1) & 1, 2 * t9 + (i - G::NPW));
+        };
+        // Where the pieces sit (cycle stamps, tools/micro/brick_bench.hip and lds_dma_issue.hip: a piece of 16 separate 64-byte
+        // rows takes the issuing wave's memory path about 130-160 cycles; closer together they queue and the wave cannot issue
+        // its MFMAs): three weight slots - the slot of stage gs + 2 is free all stage long, one piece every 2 M1 / nps MFMAs
+        // over BOTH halves; two slots - that slot is this stage's own until the barrier: the pieces share the second half.
+        const int gap = G::NWS == 3 ? 2 * G::M1 / nps : G::M1 / nps;
+        const int first = G::NWS == 3 ? 0 : G::M1;            // MFMA index behind which piece 0 goes
+        auto half = [&](int hf) {                             // hf: 0 = input channels 0-15 of the chunk, 1 = 16-31
+          int mi = hf * G::M1;
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            if (kd == 1) { if (hf == 0) load_b(wslot, 1, 1); else load_b(wslot_nx, 0, 0); }
+#pragma unroll
+            for (int p = 0; p < TD; ++p)
+#pragma unroll
+              for (int j = 0; j < NTW; ++j) {
+                acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
+                const int rel = mi - first;
+                if (rel >= 0 && rel % gap == 0 && rel / gap < nps) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  piece(rel / gap);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+                ++mi;
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        // ---- first half: prefetch the second half's fragments
+#ifdef FPLX_STAMP
+        long long st_t = __builtin_amdgcn_s_memtime();
+        ++st_n;
+#endif
         load_a(brick, kh, kw, 1, 1);
-        mfmas(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(wslot, 1, 1);
-        mfmas(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        // the next stage's weights (issued in the second half of the stage before this one) and, at t9 == 8, the next
-        // chunk of the brick / the next brick's first chunk have landed; nobody reads this stage's weight slot / (at
-        // t9 == 8) this chunk's brick slot any more once past this barrier
-        dma_wait();
-        block_sync();
-        // ---- second half: the stage after next's weights -> this stage's slot, two pieces of the next chunk, next stage's
-        // fragments
+        half(0);
+        STAMP(st_h1);
+        // the next stage's weights and, at t9 == 8, the next chunk of the brick / the next brick's first chunk have landed -
+        // everything but what THIS stage's first half requested; nobody reads the stage before's weight slot / (at t9 == 8)
+        // this chunk's brick slot any more once past this barrier
         {
-          int ch2 = ch, t92 = t9 + 2;
-          if (t92 >= 9) { t92 -= 9; ++ch2; }
-          if (ch2 < nch) weight_stage(ch2, t92, gs & 1);
-          else if (has_next) weight_stage(0, t92, gs & 1);
+          int nfirst = 0;                                     // pieces issued in the first half (compile-time)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) if (i < nps && first + i * gap < G::M1) ++nfirst;
+          if (nfirst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (nfirst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else if (nfirst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else if (nfirst == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          else if (nfirst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if (nfirst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (2 * t9 < G::NPB) {
-          if (!last_ch) brick_pieces(cur, ch + 1, (cc + 1) & 1, 2 * t9, 2);
-          else if (has_next) brick_pieces(nxt, 0, (cc + 1) & 1, 2 * t9, 2);
-        }
+        STAMP(st_wait);
+        block_sync();
+        STAMP(st_bar);
+        // ---- second half: next stage's fragments
+        STAMP(st_dma);
         if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
-        mfmas(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(wslot_nx, 0, 0);
-        mfmas(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfmas(1, 2);
-        __builtin_amdgcn_sched_barrier(0);
+        half(1);
+        STAMP(st_h2);
+        ws = s1;
       }
     }
+#ifdef FPLX_STAMP
+    const long long st_wo0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- write-out of this brick: bias, statistics, bf16 through 2-KiB per-wave LDS tiles, 16-byte stores.  The tiles
     // live in the brick slot of the chunk just finished: nobody has read it since the last stage's barrier, and the next
@@ -389,10 +492,23 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
         stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = t_;
       }
     }
+#ifdef FPLX_STAMP
+    st_wo += __builtin_amdgcn_s_memtime() - st_wo0;
+#endif
     if (!has_next) break;
+    // three weight slots: the next stage's FIRST half already requests brick pieces - into the slot the write-out tiles live in
+    if (G::NWS == 3) block_sync();
     tile = tile_nx;
     cur = nxt;
   }
+#ifdef FPLX_STAMP
+  if (lane == 0 && fplx_brick_stamp_buf) {
+    long long* o_ = fplx_brick_stamp_buf + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 10;
+    o_[0] = st_h1; o_[1] = st_wait; o_[2] = st_bar; o_[3] = st_dma; o_[4] = st_h2; o_[5] = st_wo; o_[6] = st_n;
+    o_[7] = __builtin_amdgcn_s_memtime() - st_begin; o_[8] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o_[9] = 1;
+  }
+#endif
+#undef STAMP
 }
 
 inline int brick_enabled() {
