@@ -542,7 +542,7 @@ inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
   c.bD = c.geo ? (d + 4) / 5 : (d + 3) / 4;
   c.bH = c.geo ? (h + 3) / 4 : (h + 7) / 8;
   c.bW = bw;
-  // more than 25 % padding: the tile kernel's (level 4 of the benchmark, 5 x 10 x 10, pads 1.9x: measured 47 against 48 us)
+  // more than 25 % padding: the tile kernel's, except for tiny volumes (below)
   if (c.bricks >= ((int64_t)1 << 24) || cout % 8 != 0 || cout > 2048) return c;
   const int64_t blocks = c.bricks * (cout / c.nt);
   const int nch = cin / BK::KC;
@@ -553,7 +553,10 @@ inline BrickCfg brick_cfg(int n, int d, int h, int w, int cin, int cout) {
     c.ok = 1;
     return c;
   }
-  if ((c.geo ? p1 : p0) * 4 > V * 5) return c;
+  // (tiny volumes - level 4 of the benchmark, 5 x 10 x 10, pads 1.9x as 5 x 4 x 8 bricks - still beat the tile kernel since the
+  // brick kernel spreads its DMA pieces: 512 -> 512 53 -> 45 us, 256 -> 512 39 -> 34, 512 -> 256 37 -> 33 with the split below)
+  const bool tiny = c.geo == 1 && V <= 2048 && p1 <= 2 * V;
+  if ((c.geo ? p1 : p0) * 4 > V * 5 && !tiny) return c;
   const int64_t fill = fplx_knob(FPLX_K_BRICK_FILL);          // blocks the launch should have before the Cin split stops growing
   while (blocks * c.ksplit < fill && nch / (c.ksplit + 1) >= 2) ++c.ksplit;
   if (blocks * c.ksplit < (fill < 192 ? fill : 192)) return c;

@@ -146,7 +146,9 @@ def test_conv3d_march_kernels_aligned_output(shape):
     ((1, 160, 64, 6, 12, 16), 0, 3),          # ... 5 chunks over 3 splits (2 / 1 / 2), 4 x 8 x 8 bricks
     ((2, 128, 128, 20, 40, 40), -1, 0),       # through the dispatcher: a level-2 layer of the benchmark
     ((2, 128, 64, 12, 32, 64), -1, 0),        # ... a layer a march kernel would take as well
-    ((2, 256, 256, 10, 20, 20), -1, 0)])      # ... a level-3 layer: 5 x 4 x 8 bricks, split-K + finish
+    ((2, 256, 256, 10, 20, 20), -1, 0),       # ... a level-3 layer: 5 x 4 x 8 bricks, split-K + finish
+    ((2, 512, 512, 5, 10, 10), -1, 0),        # ... level 4 (round 4: bricks padded 1.9x, 4-way Cin split) and its data gradient's shape
+    ((2, 512, 256, 5, 10, 10), -1, 0)])
 def test_conv3d_brick_kernel(shape, geo, ks):
     """conv_fwd_brick (input-stationary bricks, conv_brick.hip): forward + BN statistics against torch, bf16;
     geo >= 0: the tuning knobs "brick_geo" / "brick_ksplit" force that geometry / Cin split (+ its split-K finish) on shapes

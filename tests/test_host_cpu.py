@@ -73,7 +73,9 @@ def test_brick_kernel_plan_for_the_benchmark_layers():
     assert plan(2, 20, 40, 40, 128, 128)[:4] == (1, 0, 1, 250)     # level 2
     assert plan(2, 10, 20, 20, 256, 256)[:4] == (1, 1, 2, 512)     # level 3: 5 x 4 x 8 bricks, Cin split in two: the finish kernel's rows
     assert plan(2, 10, 20, 20, 256, 512)[:4] == (1, 1, 1, 60)
-    assert plan(2, 5, 10, 10, 512, 512)[4] == TILE                 # level 4 pads 1.9x: the tile kernel's
+    assert plan(2, 5, 10, 10, 512, 512)[:4] == (1, 1, 4, 125)      # level 4 pads 1.9x as 5 x 4 x 8 bricks and still beats the tile kernel (round 4)
+    assert plan(2, 5, 10, 10, 512, 256)[:4] == (1, 1, 8, 125)
+    assert plan(2, 8, 8, 8, 512, 512)[4] == TILE                   # too few blocks even with the deepest Cin split
     assert plan(2, 80, 160, 160, 32, 32)[4] == MARCH and plan(2, 80, 160, 160, 64, 32)[4] == MARCH   # level 0: the march kernels'
     assert plan(2, 80, 160, 160, 48, 48)[4] == GENERIC
     # the rows the dispatcher promises: bricks, or the split-K finish kernel's blocks
