@@ -102,6 +102,10 @@ class Engine(object):
 
     _tuning_epoch = -1
 
+    def _pack_key(self, adt):
+        net = self.net
+        return (adt, net.flat_params.data_ptr(), net.flat_params._version) + tuple(p._version for p in net._named.values())
+
     def invalidate(self):
         self._pack_cache = None
         self._train_packs = None
@@ -176,11 +180,13 @@ class Engine(object):
             self._tuning_epoch = _lib.tuning_epoch
         if train and reuse_packs and self.allow_pack_reuse and self._train_packs is not None and self._train_packs[0] == adt:
             packs = self._train_packs[1]
-        elif train or self._pack_cache is None or self._pack_cache[0] != (adt, net.flat_params.data_ptr(), net.flat_params._version):
+        elif train or self._pack_cache is None or self._pack_cache[0] != self._pack_key(adt):
             packs = self._pack(adt)
             # eval-mode packs are kept until the parameters change: invalidate() (the engine's own raw-pointer writers call it)
-            # or a version-counter change of the flat parameter buffer (torch-side in-place edits of any parameter view)
-            self._pack_cache = None if train else ((adt, net.flat_params.data_ptr(), net.flat_params._version), packs)
+            # or a version-counter change of ANY parameter (torch-side in-place edits under no_grad: p.mul_(), p.copy_() - each
+            # parameter is attached as p.data = flat[...] and owns its counter; the flat buffer's own does not move then).
+            # Edits through `.data` (p.data.add_()) or raw pointers bump no counter: such writers call engine.invalidate().
+            self._pack_cache = None if train else (self._pack_key(adt), packs)
             self._train_packs = (adt, packs) if train else None
         else:
             packs = self._pack_cache[1]
@@ -468,7 +474,10 @@ class Engine(object):
                 main.wait_event(ev)
 
         maxc = max(ft) * 2
-        part = torch.empty((ops.num_partials(vox[0]), 2 * maxc + 1), dtype=torch.float32, device=dev)
+        part_floats = ops.num_partials(vox[0]) * (2 * maxc + 1)
+        if sv.oc_fused:        # the fused out_conv backward writes one partial row per tile block: up to 2048 rows of 2 ft[0] + 1
+            part_floats = max(part_floats, ops.outconv_bn_rows(dims[0]) * (2 * ft[0] + 1))
+        part = torch.empty(part_floats, dtype=torch.float32, device=dev)
         coef = torch.empty((2, maxc), dtype=torch.float32, device=dev)
 
         # ---- out_conv

@@ -200,8 +200,17 @@ def test_second_domain_reuses_the_weight_packs_bit_identically():
         net.engine.allow_pack_reuse = reuse
         ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5, milestones=[2, 4], gamma=0.5)
         b = [{k: v.cuda() for k, v in d.items()} for d in _batches(True)]
+        calls = [0]
+        inner = net.engine._pack
+
+        def counting_pack(adt, _inner=inner, _calls=calls):
+            _calls[0] += 1
+            return _inner(adt)
+        net.engine._pack = counting_pack
         for _ in range(3):
+            calls[0] = 0
             ts.step_all(b)
+            assert calls[0] == (1 if reuse else 2), (reuse, calls[0])     # ONE set of weight packs per iteration when reused
             assert net.engine._train_packs is None        # the optimiser step drops every pack (FusedAdam.step_flat)
         res.append(net.flat_params.clone())
     assert torch.equal(res[0], res[1])
