@@ -216,18 +216,22 @@ class SegmentationAgent(object):
             return next(it), it
 
     def _engine_step(self):
-        """fplx.TrainStep over THIS agent's network, loss terms and optimiser when all three are fplx's own (and the agent is
-        not data parallel): the training loops below then run the engine step - flat gradient buffer, fused loss, one Adam
-        launch per segment, no autograd bookkeeping - instead of net(x) / loss.backward() / optimizer.step().  Same kernels,
-        same numbers (tests/test_gpu_loss_filter_parity.py runs the reference's training_all fixtures through both); measured
-        at the benchmark shape the autograd route was 9 % slower (bench.py `secondary.plugin_path`, round 4).  Anything
-        foreign - a network / loss / optimiser registered through set_network / set_loss_dict / set_optimizer, more than two
-        domains, engine_mode = False - keeps the autograd route."""
+        """fplx.TrainStep over THIS agent's network, loss terms and optimiser when all three are fplx's own: the training
+        loops below then run the engine step - flat gradient buffer, fused loss, one Adam launch per segment, no autograd
+        bookkeeping - instead of net(x) / loss.backward() / optimizer.step().  Same kernels, same numbers
+        (tests/test_gpu_loss_filter_parity.py runs the reference's training_all fixtures through both); measured at the
+        benchmark shape the autograd route was 9 % slower (bench.py `secondary.plugin_path`, round 4).  Under data
+        parallelism (one process per GPU, round 5) the engine step is the route as well: the full-batch loss through
+        ops.seg_loss_fwd_dist, the gradients through GradAllReducer on the default group, bucket by bucket DURING backward
+        (training_all: during the last domain's backward, TrainStep.step_all) - the autograd route all-reduces the whole
+        90 MB inside FusedAdam.step(), behind the last kernel.  Anything foreign - a network / loss / optimiser registered
+        through set_network / set_loss_dict / set_optimizer, more than two domains, engine_mode = False - keeps the
+        autograd route."""
         from .loss import AbstractSegLoss
         from .optim import FusedAdam
         from .train import TrainStep
         lc, opt, net = self.loss_calculator, self.optimizer, self.net
-        ok = (self.engine_mode and not self.distributed and type(net) is UNet2D5_dsbn and
+        ok = (self.engine_mode and type(net) is UNet2D5_dsbn and
               isinstance(lc, AbstractSegLoss) and type(lc).forward is AbstractSegLoss.forward and type(lc)._run is AbstractSegLoss._run
               and type(opt) is FusedAdam and opt.net is net and int(self.config['network']['num_domains']) <= 2)
         if not ok:

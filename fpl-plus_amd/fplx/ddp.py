@@ -28,14 +28,30 @@ class GradAllReducer(object):
         forced = os.environ.get("FPLX_DDP_FORCE", "0") == "1"
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or forced)
         self.world = dist.get_world_size(group) if self.enabled else 1
-        self._works, self._next, self._gflat = [], 0, None
+        self._works, self._next, self._gflat, self._acc = [], 0, None, None
+        self.launched = []                      # (start, end) of every collective of the current step, in launch order (tests)
 
-    def begin(self, gflat):
-        self._works, self._next, self._gflat = [], 0, gflat
+    def begin(self, gflat, acc=None):
+        """gflat: the buffer that is all-reduced (and that Adam reads).
+        acc: the buffer the CURRENT backward writes into when it is not gflat itself (the later domains of a training_all
+        iteration, agent_seg.py:459-495: gflat already holds the earlier domains' sum): a range is then first added,
+        gflat[s:e] += acc[s:e], on the stream the hook runs on, and all-reduced behind that - bucket by bucket while the
+        backward still runs, instead of one add of the whole buffer and all collectives behind the last kernel."""
+        self._works, self._next, self._gflat, self._acc = [], 0, gflat, acc
+        self.launched = []
+
+    def set_acc(self, acc):
+        self._acc = acc
 
     def pending(self, end):
         """would ready(end) launch a collective?  (the engine joins its weight-gradient stream only then)"""
         return self.enabled and self._next < len(self.buckets) and self.buckets[self._next][1] <= end
+
+    def _reduce(self, s, e):
+        if self._acc is not None:
+            self._gflat[s:e].add_(self._acc[s:e])
+        self._works.append(dist.all_reduce(self._gflat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append((s, e))
 
     def ready(self, end):
         """gradients of flat elements [0, end) are final: launch every bucket that is complete"""
@@ -43,19 +59,29 @@ class GradAllReducer(object):
             return
         while self._next < len(self.buckets) and self.buckets[self._next][1] <= end:
             s, e = self.buckets[self._next]
-            self._works.append(dist.all_reduce(self._gflat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            self._reduce(s, e)
             self._next += 1
 
+    def reduce_domain(self, d):
+        """the BatchNorm segment of domain d is final (its pass is over; no other pass writes it): all-reduce it now.
+        Always from gflat itself - the caller has already folded a non-first pass's buffer in."""
+        if not self.enabled:
+            return
+        s, e = self.domain_ranges[d]
+        acc, self._acc = self._acc, None
+        try:
+            self._reduce(s, e)
+        finally:
+            self._acc = acc
+
     def finish(self, active_domains):
-        """flush remaining buckets + the BN segments of the domains used in this step; wait."""
+        """flush remaining buckets + the BN segments of the listed domains (those not yet sent by reduce_domain); wait."""
         if not self.enabled:
             return
         self.ready(self.buckets[-1][1])
         for d in active_domains:
             s, e = self.domain_ranges[d]
-            self._works.append(dist.all_reduce(self._gflat[s:e], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            self._reduce(s, e)
         for w in self._works:
             w.wait()
         self._works = []

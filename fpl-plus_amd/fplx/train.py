@@ -40,6 +40,7 @@ class TrainStep(object):
         self.group = group
         self.opt.grad_scale = 1.0
         self.dist_loss = self.reducer.enabled
+        self.overlap_all = _lib.host_knob("ddp_overlap_all") != 0      # A/B switch: step_all's collectives behind the last backward
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
         self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
         self._loss_bufs = {}
@@ -100,23 +101,44 @@ class TrainStep(object):
         return out
 
     def step_all(self, batches):
-        """batches: one dict per domain with 'image', 'label_prob' (+ 'pixel_weight', 'image_weight')."""
+        """batches: one dict per domain with 'image', 'label_prob' (+ 'pixel_weight', 'image_weight').
+
+        Data parallel (agent_seg.py:459-495 + 692-698): the gradient exchange overlaps the LAST domain's backward.
+        Domain 0 leaves its gradients in gflat, a later domain writes into gacc; a non-last domain's BatchNorm segment is
+        final when its pass ends and travels during the next pass; during the last domain's backward every completed bucket
+        is folded (gflat[s:e] += gacc[s:e]) and all-reduced from the weight-gradient stream at once (GradAllReducer.ready),
+        so only the last bucket and the last domain's BatchNorm segment are exposed behind the last kernel.  The sums are
+        the same additions as the single-rank path's (one add per element: domain 0 + domain 1), only cut into ranges."""
         nd = len(batches)
         outs = []
-        if self.gacc is None:
+        red = self.reducer
+        overlap = red.enabled and self.overlap_all
+        if self.gacc is None and nd > 1:
             self.gacc = torch.zeros_like(self.gflat)
+        red.begin(self.gflat)
         for k, b in enumerate(batches):
             # loss = (l0 + l1) / 2  (agent_seg.py:482): both terms carry 1/2; a single domain carries 1
             gs = self._one if nd == 1 else self._half
             last = k == nd - 1
             tgt = self.gflat if k == 0 else self.gacc
+            hook = None
+            if overlap and last:
+                red.set_acc(None if k == 0 else self.gacc)
+                hook = red.ready
             # the parameters do not change between the domains of one iteration: the first forward's weight packs serve all
             outs.append(self._fwd_bwd(b['image'], b['label_prob'], k, b.get('pixel_weight'), b.get('image_weight'),
-                                      gs, tgt, None, reuse_packs=k > 0))
+                                      gs, tgt, hook, reuse_packs=k > 0))
+            if overlap and last:
+                break
             if k > 0:
                 self.gflat.add_(self.gacc)
-        self.reducer.begin(self.gflat)
-        self.reducer.finish(list(range(nd)))
+            if overlap:
+                red.reduce_domain(k)               # final now: travels beside the next domain's forward + backward
+        if overlap:
+            red.finish([nd - 1])                   # remaining buckets + the last domain's BatchNorm segment (folded from gacc)
+            red.set_acc(None)
+        else:
+            red.finish(list(range(nd)))
         if not self.external_lr:
             self.opt.param_groups[0]['lr'] = self._lr()
         self.opt.step_flat(self.gflat, list(range(nd)))

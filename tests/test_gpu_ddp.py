@@ -120,6 +120,190 @@ def test_two_rank_train_step_equals_dataparallel_emulation(tmp_path):
     assert np.abs(r0["flat"] - ref).max() <= 0.05 * 2e-3
 
 
+_WORKER_ALL = r"""
+import os, sys
+root, out, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+for p in (root, os.path.join(root, "fpl-plus_amd"), os.path.join(root, "tests", "golden"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import fplx, detdata
+from fplx import ddp
+from make_golden_cfg import NETS
+from util import load_det_weights
+p = dict(NETS["tiny"])
+N = 4
+data = []
+for dom in (0, 1):
+    xs = torch.from_numpy(detdata.normal("ddp.all.x%d" % dom, (N, 1, 16, 32, 32)))
+    ys = torch.from_numpy(detdata.ball_label((16, 32, 32), 6.0, n=N, offsets=[(0, 1, -2), (1, -3, 2), (-2, 0, 3), (2, 2, -1)][dom:] +
+                                             [(0, 1, -2)][:dom]))
+    data.append((xs, ys))
+terms = (0.5, 0.5, 0.0, 0.0)
+launched_before_finish, n_buckets = [], 0
+if mode == "ts":
+    assert ddp.init_from_env()
+    rank, world = ddp.rank(), ddp.world_size()
+    torch.cuda.set_device(0)
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    net._ensure_flat()
+    ddp.broadcast_params_from_rank0(net)
+    ts = fplx.TrainStep(net, terms, True, lr=1e-3, weight_decay=1e-5, bucket_elems=1 << 14)
+else:
+    tcfg = {"dis": False, "train_fpl_uda": True, "loss_type": ["DiceLoss", "CrossEntropyLoss"], "loss_weight": [0.5, 0.5],
+            "optimizer": "Adam", "learning_rate": 1e-3, "momentum": 0.9, "weight_decay": 1e-5, "lr_scheduler": "MultiStepLR",
+            "lr_gamma": 0.5, "lr_milestones": [100], "iter_valid": 1, "gpus": [0, 0]}
+    cfg = {"dataset": {"tensor_type": "float"}, "network": dict(p), "training": tcfg, "testing": {}}
+    agent = fplx.SegmentationAgent(cfg, "train")
+    assert agent.distributed and agent.world == 2
+    rank, world = agent.rank, agent.world
+    agent.create_network()
+    load_det_weights(agent.net, cfg["network"], "cuda")
+    agent.net._ensure_flat()
+    ddp.broadcast_params_from_rank0(agent.net)
+    agent.create_optimizer()
+    agent.create_loss_calculator()
+    agent.engine_mode = mode == "agent_engine"
+    ts = agent._engine_step()
+    assert (ts is not None) == (mode == "agent_engine")       # the distributed agent runs the engine step (round 5)
+    net = agent.net
+per = N // world
+b = [{"image": data[d][0][rank * per:(rank + 1) * per].cuda(), "label_prob": data[d][1][rank * per:(rank + 1) * per].cuda()}
+     for d in (0, 1)]
+if ts is not None:
+    assert ts.reducer.enabled and ts.reducer.world == 2
+    n_buckets = len(ts.reducer.buckets)
+    inner = ts.reducer.finish
+    def finish(active, _inner=inner):
+        launched_before_finish.append(list(ts.reducer.launched))
+        return _inner(active)
+    ts.reducer.finish = finish
+losses = []
+for it in range(2):
+    if mode == "ts":
+        outs = ts.step_all(b)
+        losses.append(0.5 * (float(outs[0][0].item()) + float(outs[1][0].item())))
+    else:
+        agent.set_loaders([b[0]], [b[1]])
+        losses.append(agent.training_all()["loss"] * 2)       # the agent reports loss / num_domains (train_avg_loss)
+torch.cuda.synchronize()
+np.savez(out + ".%d.npz" % rank, flat=net.flat_params.detach().cpu().numpy(), losses=np.array(losses),
+         before=np.array([len(l) for l in launched_before_finish]), n_buckets=n_buckets,
+         first=np.array(launched_before_finish[0][0] if launched_before_finish and launched_before_finish[0] else (-1, -1)),
+         dom0=np.array(ts.reducer.domain_ranges[0] if ts is not None else (-1, -1)))
+ddp.barrier()
+print("OK", rank)
+"""
+
+
+def _emulate_step_all(terms, iters=2):
+    """single process = the reference's nn.DataParallel on a training_all iteration (agent_seg.py:459-495, 692-698): per domain
+    the replica forwards on the chunks (per-chunk BatchNorm statistics), ONE loss over the gathered batch, loss = (l0 + l1) / 2,
+    the replicas' gradients added, one Adam step"""
+    import fplx
+    from fplx import ops
+    p = dict(NETS["tiny"])
+    net = fplx.UNet2D5_dsbn(p)
+    load_det_weights(net, p, "cuda")
+    net._ensure_flat()
+    net.train()
+    opt = fplx.FusedAdam(net, 1e-3, weight_decay=1e-5)
+    N = 4
+    data = []
+    for dom in (0, 1):
+        xs = torch.from_numpy(detdata.normal("ddp.all.x%d" % dom, (N, 1, 16, 32, 32))).cuda()
+        ys = torch.from_numpy(detdata.ball_label((16, 32, 32), 6.0, n=N, offsets=[(0, 1, -2), (1, -3, 2), (-2, 0, 3), (2, 2, -1)][dom:] +
+                                                 [(0, 1, -2)][:dom])).cuda()
+        data.append((xs, ys))
+    half = torch.full((1,), 0.5, device="cuda")
+    losses = []
+    step = 0
+    for it in range(iters):
+        g = torch.zeros_like(net.flat_params)
+        tot_loss = 0.0
+        for dom in (0, 1):
+            xs, ys = data[dom]
+            fw = []
+            for c in range(2):
+                x, y = xs[2 * c:2 * c + 2].contiguous(), ys[2 * c:2 * c + 2].contiguous()
+                logits, sv = net.engine.forward(x, dom, True, net.dropout_active(), net.dropout_seed, step, keep=True)
+                step += 1
+                n, cc = logits.shape[0], logits.shape[1]
+                v = logits[0, 0].numel()
+                part = torch.empty((n, ops.loss_rows(v), ops.loss_k(cc)), device="cuda")
+                sums = torch.empty((n + 1, ops.loss_k(cc)), dtype=torch.float64, device="cuda")
+                ops.call("fplx_seg_loss_sums", ops.ptr(logits), ops.ptr(y), 0, n, cc, v, 1, ops.ptr(part), ops.ptr(sums[:n]),
+                         ops.ptr(sums[n]), ops.stream())
+                fw.append((logits, sv, y, sums))
+            tot = fw[0][3][2] + fw[1][3][2]
+            for logits, sv, y, sums in fw:
+                outv = torch.empty(4 + 2, device="cuda")
+                coef = torch.empty(2 * 2 * 2 + 2, device="cuda")
+                ops.call("fplx_seg_loss_from_sums", ops.ptr(sums[:2]), ops.ptr(tot), 0, 2, 4, 2, logits[0, 0].numel(), 0, terms[0],
+                         terms[1], terms[2], terms[3], ops.ptr(outv), ops.ptr(coef), ops.stream())
+                dl = torch.empty_like(logits)
+                ops.seg_loss_bwd(logits, y, None, coef, half, terms, True, dl)
+                gi = torch.empty_like(net.flat_params)
+                net.engine.backward(sv, dl, gi)
+                g += gi
+            tot_loss += 0.5 * float(outv[0].item())
+        losses.append(tot_loss)
+        opt.step_flat(g, [0, 1])
+        net.engine.invalidate()
+    torch.cuda.synchronize()
+    return net.flat_params.cpu().numpy(), losses
+
+
+def test_two_rank_step_all_overlaps_the_exchange_and_equals_dataparallel(tmp_path):
+    """TrainStep.step_all (one training_all iteration, agent_seg.py:459-495) with two ranks - the buckets are
+    folded and all-reduced DURING the last domain's backward (domain 0's BatchNorm segment first, every bucket but the tail
+    before the flush), the result is bit-identical to the run that exchanges everything behind the last kernel
+    (FPLX_DDP_OVERLAP_ALL=0) and equals the single-process DataParallel emulation."""
+    res = {}
+    for ov in ("1", "0"):
+        out = str(tmp_path / ("res" + ov))
+        os.environ["FPLX_DDP_OVERLAP_ALL"] = ov
+        try:
+            _launch(tmp_path, _WORKER_ALL, [out, "ts"])
+        finally:
+            os.environ.pop("FPLX_DDP_OVERLAP_ALL", None)
+        r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+        assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["losses"], r1["losses"])
+        res[ov] = r0
+    on, off = res["1"], res["0"]
+    nb = int(on["n_buckets"])
+    assert nb > 3
+    # overlapped: domain 0's BatchNorm segment + all buckets were launched from inside the backward (the engine's last block
+    # boundary completes the last bucket); not overlapped: nothing before the flush
+    assert list(on["before"]) == [nb + 1, nb + 1] and list(off["before"]) == [0, 0]
+    assert tuple(on["first"]) == tuple(on["dom0"])
+    assert np.array_equal(on["flat"], off["flat"]) and np.array_equal(on["losses"], off["losses"])
+    ref, losses = _emulate_step_all((0.5, 0.5, 0.0, 0.0))
+    np.testing.assert_allclose(on["losses"], losses, rtol=0, atol=2e-6)
+    assert np.abs(on["flat"] - ref).max() <= 0.05 * 2e-3
+
+
+@pytest.mark.parametrize("mode", ["agent_engine", "agent_autograd"])
+def test_two_rank_agent_training_all_equals_dataparallel(tmp_path, mode):
+    """SegmentationAgent.training_all under torch.distributed.run with two ranks: the engine route (the default since round 5:
+    full-batch loss, bucketed exchange during backward) and the autograd route (all-reduce inside FusedAdam.step) against the
+    single-process DataParallel emulation; the engine route gives the bits of TrainStep.step_all."""
+    out = str(tmp_path / "res")
+    _launch(tmp_path, _WORKER_ALL, [out, mode])
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"])
+    ref, losses = _emulate_step_all((0.5, 0.5, 0.0, 0.0))
+    np.testing.assert_allclose(r0["losses"], losses, rtol=0, atol=5e-6)
+    assert np.abs(r0["flat"] - ref).max() <= 0.05 * 2e-3
+    if mode == "agent_engine":
+        assert list(r0["before"]) == [int(r0["n_buckets"]) + 1] * 2
+        out2 = str(tmp_path / "res_ts")
+        _launch(tmp_path, _WORKER_ALL, [out2, "ts"])
+        t0 = np.load(out2 + ".0.npz")
+        # the agent's TrainStep uses the default bucket size, the bare one 1 << 14: other ranges, the same sums (two ranks: one add)
+        assert np.array_equal(r0["flat"], t0["flat"])
+
+
 _AGENT_WORKER = r'''
 import os, sys
 root, cfg = sys.argv[1], sys.argv[2]
