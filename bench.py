@@ -87,6 +87,25 @@ class KernelTimer(object):
             return (name + "(apply only)" if red else name, int(a[0].shape[0]), int(a[8]))
         if name == "bn_act_fwd":                # (y, out, bnbuf, slope, p, seed, sid, c)
             return (name, int(a[0].shape[0]), int(a[7]))
+        # the remaining ops carry what their byte model needs (row_model below)
+        if name == "deconv2_fwd":               # (x, pack, bias, up, dims_in, cin, cout, pd)
+            return (name, tuple(a[4]), int(a[5]), int(a[6]), int(a[7]) if len(a) > 7 else 2)
+        if name == "deconv2_dgrad":             # (d_up, packb, d_x, dims_in, cin, cout, pd)
+            return (name, tuple(a[3]), int(a[4]), int(a[5]), int(a[6]) if len(a) > 6 else 2)
+        if name == "deconv2_wgrad":             # (x, d_up, gw, gb, dims_in, cin, cout, ws, pd)
+            return (name, tuple(a[4]), int(a[5]), int(a[6]), int(a[8]) if len(a) > 8 else 2)
+        if name == "outconv_fwd_bn":            # (y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls)
+            return (name, tuple(a[7]), int(a[8]), int(a[9]))
+        if name == "outconv_dgrad_bn_bwd":      # (dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls)
+            return (name, tuple(a[12]), int(a[13]), int(a[14]))
+        if name in ("maxpool2_fwd",):           # (x, pooled, dims, c, pd)
+            return (name, tuple(a[2]), int(a[3]), int(a[4]) if len(a) > 4 else 2)
+        if name in ("maxpool2_bwd",):           # (skip, d_pool, d_skip, d_x, dims, c, pd)
+            return (name, tuple(a[4]), int(a[5]), int(a[6]) if len(a) > 6 else 2)
+        if name in ("seg_loss_fwd", "seg_loss_bwd"):          # (logits, label, pw, ...)
+            return (name, tuple(a[0].shape), a[2] is not None)
+        if name == "adam_step":                 # (p, g, m, v, ...)
+            return (name, int(a[0].numel()))
         return (name,)
 
     def _wrap(self, name):
@@ -128,11 +147,76 @@ def roofline_of(key, n_avg_ms):
     return flops, nbytes, flops / sec / 1e12, nbytes / sec / 1e9
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_hbm_traffic.json")
+def row_model(key):
+    """-> (bound, algorithmic bytes, algorithmic flops) of one row of the per-kernel table, or None.  Byte models: DESIGN
+    section 4's per-unit figures (SURVEY 8d rule: every input read once, every output written once; bf16 activations 2 B,
+    fp32 network input / logits 4 B); a row is judged against the MFMA peak when its arithmetic intensity exceeds the ridge
+    (peak FLOP/s over peak bytes/s), else against HBM."""
+    name = key[0]
+    flops = 0.0
+    if name in ("conv3d_fwd", "conv3d_wgrad"):
+        _, dims, cin, cout, k = key
+        n, d, h, w = dims
+        vox = n * d * h * w
+        taps = k[0] * k[1] * k[2]
+        flops = 2.0 * vox * cin * cout * taps
+        if tuple(k) == (1, 3, 3):                # out_conv: one side is the fp32 planar logits / their gradient
+            narrow, wide = min(cin, cout), max(cin, cout)
+            nbytes = vox * (wide * 2.0 + narrow * 4.0)
+        elif cin <= 4 and name == "conv3d_fwd":  # stem forward: fp32 network input
+            nbytes = vox * (cin * 4.0 + cout * 2.0)
+        elif cin <= 4:                           # stem weight gradient: fp32 input + bf16 dy
+            nbytes = vox * (cin * 4.0 + cout * 2.0)
+        else:
+            nbytes = vox * (cin + cout) * 2.0
+        if name == "conv3d_wgrad":
+            nbytes += taps * cin * cout * 4.0
+    elif name in ("bn_act_bwd", "bn_act_bwd(apply only)", "bn_act_fwd"):
+        tensors = {"bn_act_bwd": 5.0, "bn_act_bwd(apply only)": 3.0, "bn_act_fwd": 2.0}[name]
+        nbytes = tensors * key[1] * key[2] * 2.0
+    elif name in ("deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad"):
+        _, dims, cin, cout, pd = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        kids = 4 * pd                            # children per input voxel (2 x 2 x 2, or 1 x 2 x 2 per depth slice)
+        flops = 2.0 * vox * kids * cin * cout
+        nbytes = vox * (cin + kids * cout) * 2.0 + (kids * cin * cout * 4.0 if name == "deconv2_wgrad" else 0.0)
+    elif name == "outconv_fwd_bn":
+        _, dims, c0, ncls = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        flops, nbytes = 2.0 * vox * 9 * c0 * ncls, vox * (4.0 * c0 + 4.0 * ncls)
+    elif name == "outconv_dgrad_bn_bwd":
+        _, dims, c0, ncls = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        flops, nbytes = 2.0 * 2.0 * vox * 9 * c0 * ncls, vox * (6.0 * c0 + 8.0 * ncls)       # the data gradient is formed twice
+    elif name == "maxpool2_fwd":
+        _, dims, c, pd = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        nbytes = vox * c * 2.0 * (1.0 + 1.0 / (4 * pd))
+    elif name == "maxpool2_bwd":
+        _, dims, c, pd = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        nbytes = vox * c * 2.0 * (3.0 + 1.0 / (4 * pd))                 # skip tensor, skip gradient in, result out + pooled gradient
+    elif name == "seg_loss_fwd":
+        shp, has_pw = key[1], key[2]
+        vox = shp[0] * shp[2] * shp[3] * shp[4]
+        nbytes = vox * (8.0 * shp[1] + (4.0 if has_pw else 0.0))        # logits + one-hot label (+ pixel weight), fp32
+    elif name == "seg_loss_bwd":
+        shp, has_pw = key[1], key[2]
+        vox = shp[0] * shp[2] * shp[3] * shp[4]
+        nbytes = vox * (12.0 * shp[1] + (4.0 if has_pw else 0.0))
+    elif name == "adam_step":
+        nbytes = 28.0 * key[1]
+    else:
+        return None
+    ridge = MFMA_BF16_PEAK_TF * 1e3 / HBM_PEAK_GBS
+    return ("mfma" if flops / nbytes >= ridge else "hbm"), nbytes, flops
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r04_pmc_hbm_traffic.json,
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r05_pmc_hbm_traffic.json,
     made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of THIS command with the gfx950
     x2 FETCH correction).  The summary records the sha256 of the kernel sources it was measured on: if conv_march.hip or
     common.h have changed since, the figure is stale and None is reported.  None also if there is no matching entry."""
@@ -485,6 +569,7 @@ def main():
     # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
     roof = None
     roof_hbm = None
+    roof_min = None
     ktable = []
     if timer is not None:
         timer.on = rank == 0            # every rank runs the pass (it contains the all-reduce), rank 0 records
@@ -498,7 +583,17 @@ def main():
         summ = timer.summary()
         tot = sum(v[2] for v in summ.values())
         for k, (cnt, avg, s) in sorted(summ.items(), key=lambda kv: -kv[1][2]):
-            ktable.append({"kernel": str(k), "launches": cnt, "avg_ms": round(avg, 4), "share": round(s / tot, 4)})
+            row = {"kernel": str(k), "launches": cnt, "avg_ms": round(avg, 4), "share": round(s / tot, 4)}
+            m = row_model(k)
+            if m is not None:            # every row against the roofline that bounds it
+                bound, nb, fl = m
+                ach = fl / (avg * 1e-3) / 1e12 if bound == "mfma" else nb / (avg * 1e-3) / 1e9
+                row.update({"bound": bound, "frac": round(ach / (MFMA_BF16_PEAK_TF if bound == "mfma" else HBM_PEAK_GBS), 4)})
+            ktable.append(row)
+        fr = [r_ for r_ in ktable if "frac" in r_ and r_["share"] >= 0.01]
+        if fr:
+            roof_min = dict(min(fr, key=lambda r_: r_["frac"]))
+            roof_min["note"] = "the lowest-fraction row with a time share of at least 1 % (kernels alone, second stream off)"
         # the largest HBM-bound consumer beside the dominant convolution (the BatchNorm backward passes are the
         # biggest group of the table): bn_act_bwd = reduce (reads d(out), y) + finalize + apply (reads both, writes dy) =
         # 5 tensors of voxels x C bf16; bn_act_fwd = 2
@@ -550,8 +645,10 @@ def main():
             res["roofline"] = roof
         if roof_hbm is not None:
             res["roofline_hbm"] = roof_hbm
+        if roof_min is not None:
+            res["roofline_min"] = roof_min
         if ktable:
-            res["kernels"] = ktable[:30]
+            res["kernels"] = ktable[:40]
         if world == 1 and not args.no_secondary:
             res["secondary"] = secondary()
         if world == 1 and not args.no_cpu_baseline:

@@ -126,6 +126,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(BRICK_FILL, "brick_fill", 192)         /* the Cin split of the brick kernel grows until the launch has this many blocks */  \
   X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
+  X(BRICK_LW, "brick_lw", 7)               /* loader-wave bricks (conv_fwd_brick_lw): bit 0 <4,2,1>, bit 1 <4,2,2>, bit 2 <5,1,1>; 0: conv_fwd_brick */ \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \
   X(STEM_ROWS, "stem_rows", 1)             /* 0: the tile kernel for in_chns = 1 too */                                 \
   X(OUTCONV_T, "outconv_t", 1)             /* 0: the 32 x 32 out_conv forward (classes as columns) */                    \

@@ -511,6 +511,471 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 #undef STAMP
 }
 
+
+// ------------------------------------------------------------------------------------------
+// conv_fwd_brick_lw (round 5): the same bricks, rings and LDS images with DEDICATED LOADER WAVES.  Cycle stamps of round 4
+// (profiles/r04_brick_stamps_after.txt): a stage's MFMAs are 768-960 cycles of issue, the stage takes 1135-1798 - every LDS-DMA
+// piece holds the wave that issues it for about 120 cycles wherever it is placed, and an in-order wave that waits for its
+// memory path issues no MFMAs.  The stall belongs to the WAVE, not to the SIMD: here a block is 8 waves, two per SIMD -
+//   waves 0-3 (compute): fragment reads + MFMAs + the write-out, no vector-memory instruction in the stage loop at all;
+//   waves 4-7 (loaders): nothing but the stage's DMA pieces (weights of stage s + 2 - s + 1 with two slots - and two pieces of
+//   the next chunk of the brick), a counted s_waitcnt and the stage's barrier: their issue stalls overlap the partner wave's
+//   MFMAs, the matrix pipe of every SIMD sees one uninterrupted MFMA stream.
+// One s_barrier per stage for all 8 waves, at the compute waves' mid-stage point.  What the barrier of stage s orders:
+//   * the loaders' counted wait in front of it has retired every piece issued before this iteration (three weight slots) /
+//     every piece (two): stage s + 1's weights and, at the chunk's last stage, the next chunk of the brick have landed -
+//     the compute waves read them only in the second half of stage s, behind the barrier;
+//   * every fragment read of weight slot s happens before it (first-half fragments in stage s - 1's second half, second-half
+//     fragments in stage s's first half): behind it the loaders may overwrite that slot (stage s + 3 / s + 2);
+//   * the write-out's staging tiles live in the dead brick slot, which is also where the NEXT brick's second chunk goes: the
+//     loaders pass one more barrier (behind the compute waves' write-out) before they issue brick pieces in a brick's first stage.
+// Registers: 2 waves per SIMD = 256 per lane; the accumulators (64-128) and the two fragment sets fit.
+template <bool STATS, int NTW, int TD, int WH, bool ACT = false, bool CAT2 = false>
+__global__ void __launch_bounds__(512)
+conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
+                  bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
+                  float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr,
+                  const bf16_t* __restrict__ x1 = nullptr, int nmod0 = 0) {
+  using G = BKG<TD, WH, NTW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* bricks = smem;
+  char* wring = smem + 2 * G::BRICK_BYTES;
+  float* bias_s = reinterpret_cast<float*>(wring + G::NWS * G::WST_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;                              // uniform per wave
+  const int wave = wave8 & 3;                                  // index inside the role
+  const int r = lane & 31, khalf = lane >> 5;
+  const int hhalf = wave / G::WN, wn = wave % G::WN;
+  int by = blockIdx.y, bz = blockIdx.z;
+  FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd == 1);
+  if (xcd == 2) {                                              // weight slice per XCD (see conv_fwd_brick)
+    const unsigned gx = gridDim.x, U = gridDim.y * gridDim.z;
+    const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x, xc = L & 7u, idx = L >> 3;
+    unsigned u, stripe;
+    if (8 % U == 0) { u = xc % U; stripe = idx * (8 / U) + xc / U; }
+    else { u = xc + 8 * (idx % (U / 8)); stripe = idx / (U / 8); }
+    by = __builtin_amdgcn_readfirstlane((int)(u % gridDim.y));
+    bz = __builtin_amdgcn_readfirstlane((int)(u / gridDim.y));
+    tr.first = __builtin_amdgcn_readfirstlane((int)stripe);
+    tr.step = gx;
+  }
+  const int n0 = by * G::NT;
+  if (tr.first >= tr.end) return;
+  const int c_lo = (int)((int64_t)(Cin / G::KC) * bz / gridDim.z);
+  const int nch = (int)((int64_t)(Cin / G::KC) * (bz + 1) / gridDim.z) - c_lo;
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  struct BrickPos { int n, d0, h0, w0; };
+  auto position = [&](int64_t tile, BrickPos& B) {
+    int b = (int)tile;
+    const int bw = b % bW; b /= bW;
+    const int bh = b % bH; b /= bH;
+    const int bd = b % bD; b /= bD;
+    B.n = __builtin_amdgcn_readfirstlane(b);
+    B.d0 = __builtin_amdgcn_readfirstlane(bd * G::TD);
+    B.h0 = __builtin_amdgcn_readfirstlane(bh * G::TH);
+    B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
+  };
+
+  if (loader) {
+    // ================================================================ loader waves
+    const int64_t xsample = (int64_t)D * H * W * ldx * 2;
+    u32x4 rw;
+    rw[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wp);
+    rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
+    rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
+    rw[3] = 0x00020000u;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+    auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst_off) {
+      const unsigned dst = lds0 + dst_off;
+      const unsigned so_ = __builtin_amdgcn_readfirstlane(so);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so_), "s"(dst) : "memory");
+    };
+    // A brick's DMA lane offsets are NOT tabulated per brick (conv_fwd_brick's setup(): 12 pieces x 64-bit address arithmetic,
+    // about 5 K cycles per brick in front of its first stage - 18 % of a level-1 launch by the stamps): a lane's offset is
+    // brick base + a brick-independent delta, only its validity depends on the brick - the loaders have idle vector slots and
+    // form it when they issue the piece.  dlt[k]: byte offset of the lane's 16 bytes of piece k relative to the voxel
+    // (d0 - 1, h0 - 1, w0 - 1); pos[k]: (q, hh, ww) of that voxel inside the halo, packed, or bit 31 for lanes past the image
+    struct Brick { int n, n0, d0, h0, w0; unsigned base; };
+    unsigned dlt[G::NPB], pos[G::NPB];
+#pragma unroll
+    for (int k = 0; k < G::NPB; ++k) {
+      const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
+      const int ci = pidx * 64 + lane;
+      const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
+      const int q = L / G::PL, rem = L % G::PL, hh = rem / G::SWP, ww = rem % G::SWP;
+      const bool img = q < G::SD && rem < G::SH * G::SWP && ww < 10;
+      dlt[k] = (unsigned)(((((int64_t)q * H + hh) * W + ww) * ldx + cc * 8) * 2);
+      pos[k] = img ? (unsigned)(q | (hh << 8) | (ww << 16)) : 0x80000000u;
+    }
+    auto setup = [&](int64_t tile, Brick& B) {
+      BrickPos P;
+      position(tile, P);
+      B.n = P.n;
+      B.n0 = (CAT2 && nmod0 > 0) ? __builtin_amdgcn_readfirstlane(P.n % nmod0) : P.n;
+      B.d0 = P.d0; B.h0 = P.h0; B.w0 = P.w0;
+      // (the base may be "negative": it only ever meets a delta that brings a valid lane's sum into the sample)
+      B.base = __builtin_amdgcn_readfirstlane((unsigned)(((((int64_t)(P.d0 - 1) * H + (P.h0 - 1)) * W + (P.w0 - 1)) * ldx) * 2));
+    };
+    auto lane_off = [&](const Brick& B, int k) -> unsigned {
+      const unsigned pk = pos[k];
+      const int gd = B.d0 - 1 + (int)(pk & 0xFFu), gh = B.h0 - 1 + (int)((pk >> 8) & 0xFFu), gw = B.w0 - 1 + (int)((pk >> 16) & 0xFFu);
+      const bool in = (int)pk >= 0 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+      return in ? B.base + dlt[k] : 0x40000000u;
+    };
+    const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
+    const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);
+    struct BrickSrc { u32x4 rx; unsigned so; };
+    auto brick_rsrc = [&](const Brick& B, int ch, bool on) {
+      int c = c_lo + ch;
+      const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
+      if (CAT2) {
+        const int half = Cin / (2 * G::KC);
+        if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
+        else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
+      }
+      BrickSrc rs;
+      rs.rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
+      rs.rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
+      rs.rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
+      rs.rx[3] = 0x00020000u;
+      rs.so = __builtin_amdgcn_readfirstlane(on ? (unsigned)(c * G::KC * 2) : 0x40000000u);
+      return rs;
+    };
+    auto brick_piece = [&](const BrickSrc& src, const Brick& B, int slot, int k) {
+      const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
+      buf_dma(src.rx, lane_off(B, k), src.so, (unsigned)(slot * G::BRICK_BYTES + pidx * 1024));
+    };
+    auto weight_piece = [&](int ch, int t9, int slot, int k, bool on) {
+      const int j = wave + 4 * k, kd = j / (G::NT / 16);
+      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
+      buf_dma(rw, wvo, on ? so : 0x40000000u, (unsigned)(2 * G::BRICK_BYTES + slot * G::WST_BYTES + j * 1024));
+    };
+    Brick cur, nxt;
+    int64_t tile = tr.first;
+    setup(tile, cur);
+    nxt = cur;
+    // prologue: brick chunk 0 -> brick slot 0, weight stage 0 (and 1 with three slots) -> slots 0 (, 1)
+    {
+      const BrickSrc s0 = brick_rsrc(cur, 0, true);
+#pragma unroll
+      for (int k = 0; k < G::NPB; ++k) brick_piece(s0, cur, 0, k);
+#pragma unroll
+      for (int k = 0; k < G::NPW; ++k) weight_piece(0, 0, 0, k, true);
+      if (G::NWS == 3) {
+#pragma unroll
+        for (int k = 0; k < G::NPW; ++k) weight_piece(0, 1, 1, k, true);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    block_sync();                                              // P0
+    int cc = 0, ws = 0;
+    bool first_brick = true;
+#ifdef FPLX_STAMP
+    long long st_h1 = 0, st_wait = 0, st_bar = 0, st_n = 0;
+    const long long st_begin = __builtin_amdgcn_s_memtime();
+    const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#define STAMP(var_) do { const long long t__ = __builtin_amdgcn_s_memtime(); var_ += t__ - st_t; st_t = t__; } while (0)
+#else
+#define STAMP(var_) do { } while (0)
+#endif
+    for (;;) {
+      const int64_t tile_nx = tile + tr.step;
+      const bool has_next = tile_nx < tr.end;
+      if (has_next) setup(tile_nx, nxt);
+      for (int ch = 0; ch < nch; ++ch, ++cc) {
+        const bool last_ch = ch + 1 == nch;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+#ifdef FPLX_STAMP
+          long long st_t = __builtin_amdgcn_s_memtime();
+          ++st_n;
+#endif
+          const int s1 = ws + 1 == G::NWS ? 0 : ws + 1, s2 = s1 + 1 == G::NWS ? 0 : s1 + 1;
+          // weights of stage gs + 2 (three slots: its slot was last read in front of the previous stage's barrier) or gs + 1 (two)
+          constexpr int AH = G::NWS == 3 ? 2 : 1;
+          int cha = ch, t9a = t9 + AH;
+          if (t9a >= 9) { t9a -= 9; ++cha; }
+          const bool w_on = cha < nch || has_next;             // uniform
+          if (cha >= nch) cha = 0;
+          const int wslot = G::NWS == 3 ? s2 : s1;
+#pragma unroll
+          for (int k = 0; k < G::NPW; ++k) weight_piece(cha, t9a, wslot, k, w_on);
+          // the brick slot of the next chunk doubles as the previous brick's write-out staging: wait for the compute waves
+          // (their statistics tail has a barrier of its own in front of that one; this brick's first weights are on their way)
+          if (t9 == 0 && ch == 0 && !first_brick) {
+            if (STATS && stats) block_sync();
+            block_sync();
+          }
+          const int nbp = 2 * t9 + 1 < G::NPB ? 2 : (2 * t9 < G::NPB ? 1 : 0);
+          if (nbp > 0) {
+            const bool b_on = !last_ch || has_next;
+            const BrickSrc bsrc = last_ch ? brick_rsrc(nxt, 0, b_on) : brick_rsrc(cur, ch + 1, true);
+#pragma unroll
+            for (int i = 0; i < nbp; ++i) brick_piece(bsrc, last_ch ? nxt : cur, (cc + 1) & 1, 2 * t9 + i);
+          }
+          STAMP(st_h1);
+          // three slots: what was issued before this iteration has landed (this iteration's NPW + nbp pieces may fly on);
+          // two slots: everything has
+          if (G::NWS == 3) {
+            const int nps = G::NPW + nbp;
+            if (nps == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (nps == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (nps == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (nps == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (nps == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (nps == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (nps == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (nps == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          STAMP(st_wait);
+          block_sync();                                        // the stage's barrier
+          STAMP(st_bar);
+          ws = s1;
+        }
+      }
+      if (!has_next) {
+        if (STATS && stats) block_sync();                      // the compute waves' statistics tail has one
+        break;
+      }
+      first_brick = false;
+      tile = tile_nx;
+      cur = nxt;
+    }
+#ifdef FPLX_STAMP
+    if (lane == 0 && fplx_brick_stamp_buf) {
+      long long* o_ = fplx_brick_stamp_buf + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave8) * 10;
+      o_[0] = st_h1; o_[1] = st_wait; o_[2] = st_bar; o_[3] = 0; o_[4] = 0; o_[5] = 0; o_[6] = st_n;
+      o_[7] = __builtin_amdgcn_s_memtime() - st_begin; o_[8] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o_[9] = 2;
+    }
+#endif
+#undef STAMP
+    return;
+  }
+
+  // ================================================================ compute waves
+  f32x16 acc[TD][NTW];
+#pragma unroll
+  for (int p = 0; p < TD; ++p)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
+  BrickPos cur, nxt;
+  int64_t tile = tr.first;
+  position(tile, cur);
+  nxt = cur;
+  if (tid < G::NT) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+  block_sync();                                                // P0
+
+  const int L0 = (hhalf * 4 + bk_row(r)) * G::SWP + bk_col(r);
+  const int bb = (wn * (32 * NTW) + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
+  bf16x8 fa[2][G::SD], fb[2][3 * NTW];
+  auto load_a = [&](const char* brick, int kh, int kw, int ks, int buf) {
+    int a0 = L0 + kh * G::SWP + kw;
+    asm volatile("" : "+v"(a0));
+    const char* p = brick + a0 * G::ROWB + (((2 * ks + khalf) ^ ((a0 >> 2) & 3)) << 4);
+#pragma unroll
+    for (int q = 0; q < G::SD; ++q) fa[buf][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
+  };
+  auto load_b = [&](const char* wslot, int ks, int buf) {
+    int b0 = bb;
+    asm volatile("" : "+v"(b0));
+    const char* p = wslot + (b0 ^ (ks << 5));
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+        fb[buf][kd * NTW + j] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + j * 32) * G::ROWB);
+  };
+  const int rh = khalf * 4;
+  load_a(bricks, 0, 0, 0, 0);
+  load_b(wring, 0, 0);
+  int cc = 0, ws = 0;
+#ifdef FPLX_STAMP
+  long long st_h1 = 0, st_bar = 0, st_h2 = 0, st_wo = 0, st_n = 0;
+  const long long st_begin = __builtin_amdgcn_s_memtime();
+  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
+#define STAMP(var_) do { const long long t__ = __builtin_amdgcn_s_memtime(); var_ += t__ - st_t; st_t = t__; } while (0)
+#else
+#define STAMP(var_) do { } while (0)
+#endif
+  for (;;) {
+    const int64_t tile_nx = tile + tr.step;
+    const bool has_next = tile_nx < tr.end;
+    if (has_next) position(tile_nx, nxt);
+    for (int ch = 0; ch < nch; ++ch, ++cc) {
+      const char* brick = bricks + (cc & 1) * G::BRICK_BYTES;
+      const char* brick_nx = bricks + ((cc + 1) & 1) * G::BRICK_BYTES;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int kh = t9 / 3, kw = t9 % 3;
+        const int s1 = ws + 1 == G::NWS ? 0 : ws + 1;
+        const char* wslot = wring + ws * G::WST_BYTES;
+        const char* wslot_nx = wring + s1 * G::WST_BYTES;
+        auto half = [&](int hf) {
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            if (kd == 1) { if (hf == 0) load_b(wslot, 1, 1); else load_b(wslot_nx, 0, 0); }
+#pragma unroll
+            for (int p = 0; p < TD; ++p)
+#pragma unroll
+              for (int j = 0; j < NTW; ++j)
+                acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+#ifdef FPLX_STAMP
+        long long st_t = __builtin_amdgcn_s_memtime();
+        ++st_n;
+#endif
+        load_a(brick, kh, kw, 1, 1);
+        half(0);
+        STAMP(st_h1);
+        block_sync();                                          // the stage's barrier (see the header)
+        STAMP(st_bar);
+        if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
+        half(1);
+        STAMP(st_h2);
+        ws = s1;
+      }
+    }
+#ifdef FPLX_STAMP
+    const long long st_wo0 = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- write-out (as conv_fwd_brick): per-wave LDS tiles in the dead brick slot, 16-byte stores
+    char* dead = bricks + ((cc - 1) & 1) * G::BRICK_BYTES;
+    char* stg = dead + wave * 4096;
+    const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
+    const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
+    unsigned vmask = 0xFFFFu;
+    if (!full) {
+      vmask = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + rh;
+        if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
+      }
+    }
+    f32x2 s1v[NTW], s2v[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { s1v[j] = f32x2{0.f, 0.f}; s2v[j] = f32x2{0.f, 0.f}; }
+    const int mrow = lane >> 2;
+    const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
+    const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
+    const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
+    const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
+    bf16_t* ycol = y + n0 + wn * (32 * NTW) + (lane & 3) * 8;
+    const float slope_v = ACT ? *slope_p : 0.f;
+    auto write_out = [&](auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+      for (int p = 0; p < TD; ++p) {
+        const int dd = d0 + p;
+        if (FULL || dd < D) {
+          bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            const float bv = bias_s[wn * (32 * NTW) + j * 32 + r];
+            char* tile_ = stg + ((p * NTW + j) & 1) * 2048;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+              const int m = (i & 3) + 8 * (i >> 2) + rh;
+              f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
+              if (ACT) { o[0] = o[0] > 0.f ? o[0] : o[0] * slope_v; o[1] = o[1] > 0.f ? o[1] : o[1] * slope_v; }
+              *reinterpret_cast<bf16_t*>(tile_ + m * 64 + r * 2) = (bf16_t)o[0];
+              *reinterpret_cast<bf16_t*>(tile_ + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
+              if (STATS) {
+                if (!FULL) {
+                  if (!((vmask >> i) & 1u)) o[0] = 0.f;
+                  if (!((vmask >> (i + 1)) & 1u)) o[1] = 0.f;
+                }
+                s1v[j] += o;
+                s2v[j] = __builtin_elementwise_fma(o, o, s2v[j]);
+              }
+            }
+            const uint4 pk0 = *reinterpret_cast<const uint4*>(tile_ + mrow * 64 + (lane & 3) * 16);
+            const uint4 pk1 = *reinterpret_cast<const uint4*>(tile_ + (mrow + 16) * 64 + (lane & 3) * 16);
+            if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
+            if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
+      }
+    };
+    auto write_partial = [&]() {
+      float* pz = partial + (int64_t)bz * ((int64_t)N * D * H * W) * Cout + n0 + wn * (32 * NTW) + (lane & 7) * 4;
+      float* stf = reinterpret_cast<float*>(stg);
+#pragma unroll
+      for (int p = 0; p < TD; ++p) {
+        const int dd = d0 + p;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            stf[((i & 3) + 8 * (i >> 2) + rh) * 32 + r] = acc[p][j][i];
+            acc[p][j][i] = 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int m = (lane >> 3) + 8 * q;
+            const int hh = h0 + hhalf * 4 + bk_row(m), ww = w0 + bk_col(m);
+            const float4 pk = *reinterpret_cast<const float4*>(stf + m * 32 + (lane & 7) * 4);
+            if (dd < D && hh < H && ww < W)
+              *reinterpret_cast<float4*>(pz + ((((int64_t)n * D + dd) * H + hh) * W + ww) * Cout + j * 32) = pk;
+          }
+        }
+      }
+    };
+    if (partial) write_partial();
+    else if (full) write_out(std::true_type{});
+    else write_out(std::false_type{});
+    if (STATS && stats) {
+      float* red = reinterpret_cast<float*>(dead + 16384);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const float a_ = s1v[j][0] + s1v[j][1], q_ = s2v[j][0] + s2v[j][1];
+        const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
+        if (lane < 32) {
+          red[(hhalf * 2 + 0) * G::NT + wn * (32 * NTW) + j * 32 + r] = a;
+          red[(hhalf * 2 + 1) * G::NT + wn * (32 * NTW) + j * 32 + r] = q2;
+        }
+      }
+      block_sync();
+      if (tid < 2 * G::NT) {
+        const int which = tid / G::NT, c = tid % G::NT;
+        float t_ = red[(0 * 2 + which) * G::NT + c];
+        if (WH == 2) t_ += red[(1 * 2 + which) * G::NT + c];
+        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = t_;
+      }
+    }
+#ifdef FPLX_STAMP
+    st_wo += __builtin_amdgcn_s_memtime() - st_wo0;
+#endif
+    if (!has_next) break;
+    block_sync();                       // the loaders may now fetch into the staging slot (their barrier in a brick's first stage)
+    tile = tile_nx;
+    cur = nxt;
+  }
+#ifdef FPLX_STAMP
+  if (lane == 0 && fplx_brick_stamp_buf) {
+    long long* o_ = fplx_brick_stamp_buf + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave8) * 10;
+    o_[0] = st_h1; o_[1] = 0; o_[2] = st_bar; o_[3] = 0; o_[4] = st_h2; o_[5] = st_wo; o_[6] = st_n;
+    o_[7] = __builtin_amdgcn_s_memtime() - st_begin; o_[8] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o_[9] = 1;
+  }
+#endif
+#undef STAMP
+}
+
 inline int brick_enabled() {
   return (int)fplx_knob(FPLX_K_BRICK);              // A/B knob (benchmarks only)
 }
@@ -621,6 +1086,9 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
   }
   dim3 grid((unsigned)gx, gy, ksplit);
   float* part = ksplit > 1 ? partial : nullptr;
+  // loader-wave form (conv_fwd_brick_lw, 512 threads): knob brick_lw, bit 0: <4,2,1>, bit 1: <4,2,2>, bit 2: <5,1,1>
+  const int lw_mask = (int)fplx_knob(FPLX_K_BRICK_LW);
+  const bool lw = (geo == 1 ? (lw_mask & 4) : nt == 128 ? (lw_mask & 2) : (lw_mask & 1)) != 0;
 #define LAUNCH_BRICK_K(KERNEL_, STATS_, NTW_, TD_, WH_)                                                              \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
@@ -630,25 +1098,51 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
         (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
         bW, xcd_on);                                                                                                 \
   } while (0)
-#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_) LAUNCH_BRICK_K(conv_fwd_brick, STATS_, NTW_, TD_, WH_)
+#define LAUNCH_BRICK_LW(STATS_, NTW_, TD_, WH_)                                                                      \
+  do {                                                                                                               \
+    using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<STATS_, NTW_, TD_, WH_>,                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick_lw<STATS_, NTW_, TD_, WH_><<<grid, 512, G_::LDS, st>>>(                                            \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
+        bW, xcd_on);                                                                                                 \
+  } while (0)
+#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_)                                                                         \
+  do { if (lw) LAUNCH_BRICK_LW(STATS_, NTW_, TD_, WH_); else LAUNCH_BRICK_K(conv_fwd_brick, STATS_, NTW_, TD_, WH_); } while (0)
   const bool st_ = stats && !part;
 #define LAUNCH_BRICK_ACT(NTW_, TD_, WH_)                                                                              \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true>,                              \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
-    conv_fwd_brick<false, NTW_, TD_, WH_, true><<<grid, BK::THREADS, G_::LDS, st>>>(                                  \
-        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-        bH, bW, xcd_on, slope);                                                                                      \
+    if (lw) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true>,                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
+      conv_fwd_brick_lw<false, NTW_, TD_, WH_, true><<<grid, 512, G_::LDS, st>>>(                                     \
+          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+          bH, bW, xcd_on, slope);                                                                                    \
+    } else {                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
+      conv_fwd_brick<false, NTW_, TD_, WH_, true><<<grid, BK::THREADS, G_::LDS, st>>>(                                \
+          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+          bH, bW, xcd_on, slope);                                                                                    \
+    }                                                                                                                \
   } while (0)
 #define LAUNCH_BRICK_ACT2(NTW_, TD_, WH_)                                                                             \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true, true>,                        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
-    conv_fwd_brick<false, NTW_, TD_, WH_, true, true><<<grid, BK::THREADS, G_::LDS, st>>>(                            \
-        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-        bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                            \
+    if (lw) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true>,                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
+      conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true><<<grid, 512, G_::LDS, st>>>(                               \
+          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+          bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                          \
+    } else {                                                                                                         \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true, true>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
+      conv_fwd_brick<false, NTW_, TD_, WH_, true, true><<<grid, BK::THREADS, G_::LDS, st>>>(                          \
+          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
+          bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                          \
+    }                                                                                                                \
   } while (0)
   if (x1) {
     if (geo == 1) LAUNCH_BRICK_ACT2(1, 5, 1);
@@ -666,6 +1160,7 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
 #undef LAUNCH_BRICK_ACT2
 #undef LAUNCH_BRICK_ACT
 #undef LAUNCH_BRICK
+#undef LAUNCH_BRICK_LW
 #undef LAUNCH_BRICK_K
   const int rc = fplx_check_launch("brick_conv3d_fwd");
   return rc < 0 ? rc : 1;

@@ -18,6 +18,7 @@ int64_t fplx_knob_values[FPLX_K_COUNT] = {
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
 int main(int argc, char** argv) {
+  if (getenv("BRICK_LW")) fplx_knob_values[FPLX_K_BRICK_LW] = atoi(getenv("BRICK_LW"));
   const int cin = atoi(argv[1]), cout = atoi(argv[2]), n = atoi(argv[3]), d = atoi(argv[4]), h = atoi(argv[5]), w = atoi(argv[6]);
   const int want_stats = argc > 7 ? atoi(argv[7]) : 0;
   const int64_t V = (int64_t)n * d * h * w;
@@ -61,8 +62,13 @@ int main(int argc, char** argv) {
 #ifdef FPLX_STAMP
   std::vector<long long> hs(nst);
   hipMemcpy(hs.data(), sb, nst * 8, hipMemcpyDeviceToHost);
-  double s[10] = {0}; size_t cnt = 0;
-  for (size_t i = 0; i < nst; i += 10) { if (hs[i + 9] == 0) continue; for (int k = 0; k < 10; ++k) s[k] += hs[i + k]; ++cnt; }
+  double s[10] = {0}, l[10] = {0}; size_t cnt = 0, lcnt = 0;
+  for (size_t i = 0; i < nst; i += 10) {
+    if (hs[i + 9] == 1) { for (int k = 0; k < 10; ++k) s[k] += hs[i + k]; ++cnt; }
+    if (hs[i + 9] == 2) { for (int k = 0; k < 10; ++k) l[k] += hs[i + k]; ++lcnt; }      // loader waves of conv_fwd_brick_lw
+  }
+  if (lcnt) printf("loader waves (avg over %zu): stages %.1f | cycles per stage: issue %.0f  vmcnt wait %.0f  barrier %.0f | total %.0f cycles\n",
+                   lcnt, l[6] / lcnt, l[0] / l[6], l[1] / l[6], l[2] / l[6], l[7] / lcnt);
   const double ns = s[6];
   printf("per wave (avg over %zu waves): stages %.1f | cycles per stage: first half %.0f  vmcnt wait %.0f  barrier %.0f  DMA issue %.0f  second half %.0f | "
          "write-out per wave %.0f | kernel total %.0f cycles, in-kernel clock %.3f GHz\n",
