@@ -819,15 +819,46 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         const int s1 = ws + 1 == G::NWS ? 0 : ws + 1;
         const char* wslot = wring + ws * G::WST_BYTES;
         const char* wslot_nx = wring + s1 * G::WST_BYTES;
-        auto half = [&](int hf) {
+        // a half-stage: M1 MFMAs on fragment set hf, and the OTHER set's SD + 3 NTW fragment reads spread between them, one
+        // read in front of an MFMA (knob-free A/B: -DFPLX_BRICK_LW_BURST restores the bursts of conv_fwd_brick - all A reads
+        // in front of the half, the B reads in its middle; the stamps showed the half behind the barrier, where four waves
+        // burst 6-7 reads each while the loaders' DMA writes land, 90 cycles longer than the other one)
+        auto half = [&](int hf, const char* abrick, int akh, int akw, int aks, const char* bslot, int bks) {
+          constexpr int NL = G::SD + 3 * NTW, M1 = G::M1;
+          int a0 = L0 + akh * G::SWP + akw;
+          asm volatile("" : "+v"(a0));
+          const char* pa = abrick + a0 * G::ROWB + (((2 * aks + khalf) ^ ((a0 >> 2) & 3)) << 4);
+          int b0 = bb;
+          asm volatile("" : "+v"(b0));
+          const char* pb = bslot + (b0 ^ (bks << 5));
+          auto load = [&](int li) {
+            if (li < G::SD) fa[hf ^ 1][li] = *reinterpret_cast<const bf16x8*>(pa + li * G::PL * G::ROWB);
+            else {
+              const int t = li - G::SD, kd = t / NTW, j = t % NTW;
+              fb[hf ^ 1][t] = *reinterpret_cast<const bf16x8*>(pb + (kd * G::NT + j * 32) * G::ROWB);
+            }
+          };
+#ifdef FPLX_BRICK_LW_BURST
+#pragma unroll
+          for (int li = 0; li < NL; ++li) load(li);
+#endif
+          int mi = 0, li = 0;
 #pragma unroll
           for (int kd = 0; kd < 3; ++kd) {
-            if (kd == 1) { if (hf == 0) load_b(wslot, 1, 1); else load_b(wslot_nx, 0, 0); }
 #pragma unroll
             for (int p = 0; p < TD; ++p)
 #pragma unroll
-              for (int j = 0; j < NTW; ++j)
+              for (int j = 0; j < NTW; ++j) {
+#ifndef FPLX_BRICK_LW_BURST
+                // reads li with li * M1 / NL <= mi go in front of MFMA mi (all of them by the last quarter of the half)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                  if (li < NL && (li * (M1 - M1 / 4)) / NL <= mi) { load(li); ++li; }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
+                ++mi;
+              }
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -835,13 +866,12 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         long long st_t = __builtin_amdgcn_s_memtime();
         ++st_n;
 #endif
-        load_a(brick, kh, kw, 1, 1);
-        half(0);
+        half(0, brick, kh, kw, 1, wslot, 1);
         STAMP(st_h1);
         block_sync();                                          // the stage's barrier (see the header)
         STAMP(st_bar);
-        if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
-        half(1);
+        if (t9 < 8) half(1, brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, wslot_nx, 0);
+        else half(1, brick_nx, 0, 0, 0, wslot_nx, 0);
         STAMP(st_h2);
         ws = s1;
       }
