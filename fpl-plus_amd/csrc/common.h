@@ -80,6 +80,18 @@ static inline int fplx_rows_for(int64_t voxels) {
 }
 
 #ifdef __HIPCC__
+// one element of torch.optim.Adam (get_optimizer.py:17) - shared by adam_k (elementwise.hip) and the fused Adam + weight-pack
+// kernel (conv_generic.hip) so that both form the same expression tree (same contractions): bit-identical parameters
+struct FplxAdamConst { float step_size, b1, b2, eps, wd, inv_sqrt_bc2, gscale, omb1, omb2; };      // omb: 1 - beta
+__device__ __forceinline__ void fplx_adam_elem(float& pi, float g, float& mi, float& vi, const FplxAdamConst& c) {
+  // every addition is written as an explicit fma and every product that feeds one stands alone: nothing is left for
+  // -ffp-contract to decide differently in a scalar and in a float4 context (it did: the two kernels differed in the last bit)
+  const float gi = fmaf(c.wd, pi, g * c.gscale);
+  mi = fmaf(c.b1, mi, c.omb1 * gi);
+  vi = fmaf(c.b2, vi, (c.omb2 * gi) * gi);
+  const float denom = fmaf(sqrtf(vi), c.inv_sqrt_bc2, c.eps);
+  pi = fmaf(-c.step_size, mi / denom, pi);
+}
 // XCD-aware block order.  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own
 // 4-MB L2, so blocks that share data (the cout blocks / tap splits of one voxel footprint, neighbouring footprints and
 // their halos) land on eight different L2s and the shared bytes are fetched eight times.  fplx_xcd_block re-labels the

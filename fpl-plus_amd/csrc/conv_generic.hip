@@ -344,6 +344,88 @@ pack_conv_w27_tiled_multi(const PackTable t) {
   pack27_tile(t.w[e], t.wf[e], t.wb[e], t.cout[e], t.cin[e], (int)blockIdx.x - t.first[e]);
 }
 
+// Adam + weight pack in ONE launch (round 5): the weights change only in the optimiser step, and every forward opened with
+// pack_conv_w27_tiled_multi re-reading all 22 M master weights (48 us at the head of the step, where nothing overlaps it).
+// Blocks [0, tiles): a pack tile (16 co x 32 ci x 27 taps) of one 3x3x3 layer - the block applies Adam to ITS 13 824
+// elements (p, g, m, v as float4 runs, the arithmetic of adam_k: fplx_adam_elem) and packs the updated values from LDS;
+// blocks [tiles, ...): the rest of the flat segment (biases, PReLU slopes, transposed convolutions, out_conv, the stem),
+// `gap` ranges of the table, 1024 elements per block.  Every element of the segment is updated exactly once.
+constexpr int AP_MAXGAP = PK_MAX + 1, AP_GAPBLK = 1024;
+struct AdamPackTable {
+  float *p, *m, *v;
+  const float* g;
+  FplxAdamConst c;
+  int64_t off[PK_MAX];                 // element offset of layer e's weight inside the segment
+  bf16_t* wf[PK_MAX];
+  bf16_t* wb[PK_MAX];
+  int cout[PK_MAX], cin[PK_MAX], first[PK_MAX + 1], n;
+  int64_t gstart[AP_MAXGAP], glen[AP_MAXGAP];
+  int gfirst[AP_MAXGAP + 1], ng;
+};
+__global__ void __launch_bounds__(256)
+adam_pack27_multi(const AdamPackTable t) {
+  const int b = (int)blockIdx.x;
+  if (b >= t.first[t.n]) {             // ---- a gap block: plain Adam on up to 1024 elements
+    const int gb = b - t.first[t.n];
+    int e = 0;
+    while (e + 1 < t.ng && gb >= t.gfirst[e + 1]) ++e;
+    const int64_t lo = (int64_t)(gb - t.gfirst[e]) * AP_GAPBLK, len = t.glen[e];
+#pragma unroll
+    for (int k = 0; k < AP_GAPBLK / 256; ++k) {
+      const int64_t i = lo + threadIdx.x + 256 * k;
+      if (i < len) {
+        const int64_t x = t.gstart[e] + i;
+        float pi = t.p[x], mi = t.m[x], vi = t.v[x];
+        fplx_adam_elem(pi, t.g[x], mi, vi, t.c);
+        t.m[x] = mi; t.v[x] = vi; t.p[x] = pi;
+      }
+    }
+    return;
+  }
+  int e = 0;
+  while (e + 1 < t.n && b >= t.first[e + 1]) ++e;
+  const int Cout = t.cout[e], Cin = t.cin[e], blk = b - t.first[e];
+  __shared__ bf16_t lds[PK_CO * PK_ROW];
+  const int ci_tiles = Cin / PK_CI;
+  const int co0 = (blk / ci_tiles) * PK_CO, ci0 = (blk % ci_tiles) * PK_CI;
+  constexpr int SEG4 = PK_CI * 27 / 4;
+  for (int i = threadIdx.x; i < PK_CO * SEG4; i += 256) {
+    const int co_l = i / SEG4, q = i % SEG4;
+    const int64_t x = t.off[e] + ((int64_t)(co0 + co_l) * Cin + ci0) * 27 + 4 * q;
+    float4 pv = *reinterpret_cast<const float4*>(t.p + x), mv = *reinterpret_cast<const float4*>(t.m + x);
+    float4 vv = *reinterpret_cast<const float4*>(t.v + x);
+    const float4 gv = *reinterpret_cast<const float4*>(t.g + x);
+    fplx_adam_elem(pv.x, gv.x, mv.x, vv.x, t.c);
+    fplx_adam_elem(pv.y, gv.y, mv.y, vv.y, t.c);
+    fplx_adam_elem(pv.z, gv.z, mv.z, vv.z, t.c);
+    fplx_adam_elem(pv.w, gv.w, mv.w, vv.w, t.c);
+    *reinterpret_cast<float4*>(t.m + x) = mv;
+    *reinterpret_cast<float4*>(t.v + x) = vv;
+    *reinterpret_cast<float4*>(t.p + x) = pv;
+    bf16_t* d = lds + co_l * PK_ROW + 4 * q;
+    Act<bf16_t>::st(d, pv.x); Act<bf16_t>::st(d + 1, pv.y); Act<bf16_t>::st(d + 2, pv.z); Act<bf16_t>::st(d + 3, pv.w);
+  }
+  __syncthreads();
+  bf16_t* wf = t.wf[e];
+  bf16_t* wb = t.wb[e];
+  union Pack8 { bf16_t h[8]; uint4 u; };
+  for (int i = threadIdx.x; i < 27 * PK_CO * (PK_CI / 8); i += 256) {          // wf: (tap, co, ci octet)
+    const int oct = i % (PK_CI / 8), co_l = (i / (PK_CI / 8)) % PK_CO, tap = i / ((PK_CI / 8) * PK_CO);
+    Pack8 pk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pk.h[j] = lds[co_l * PK_ROW + (8 * oct + j) * 27 + tap];
+    *reinterpret_cast<uint4*>(wf + ((int64_t)tap * Cout + co0 + co_l) * Cin + ci0 + 8 * oct) = pk.u;
+  }
+  if (wb)
+    for (int i = threadIdx.x; i < 27 * PK_CI * (PK_CO / 8); i += 256) {        // wb: (tap, ci, co octet), taps flipped
+      const int half = i % (PK_CO / 8), ci_l = (i / (PK_CO / 8)) % PK_CI, tap = i / ((PK_CO / 8) * PK_CI);
+      Pack8 pk;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pk.h[j] = lds[(8 * half + j) * PK_ROW + ci_l * 27 + tap];
+      *reinterpret_cast<uint4*>(wb + ((int64_t)(26 - tap) * Cin + ci0 + ci_l) * Cout + co0 + 8 * half) = pk.u;
+    }
+}
+
 template <typename T>
 __global__ void pack_deconv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin, int Cout,
                               int taps) {
@@ -574,6 +656,48 @@ int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf
   if (t.n == 0) return FPLX_OK;
   pack_conv_w27_tiled_multi<<<t.first[t.n], 256, 0, (hipStream_t)stream>>>(t);
   return fplx_check_launch("pack_conv_weights_batched");
+}
+
+int fplx_adam_pack_ok(int cout, int cin) {
+  return fplx_knob(FPLX_K_PACK_TILED) != 0 && fplx_knob(FPLX_K_PACK_MULTI) != 0 && cin % PK_CI == 0 && cout % PK_CO == 0;
+}
+
+int fplx_adam_pack_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int nl, const int64_t* off, const int* cout,
+                        const int* cin, void* const* wf, void* const* wb, fplx_stream_t stream) {
+  FPLX_REQUIRE(p && g && m && v && off && cout && cin && wf && wb, FPLX_E_NULL, "adam_pack_step: null pointer");
+  FPLX_REQUIRE(n > 0 && step >= 1 && nl > 0 && nl <= PK_MAX, FPLX_E_BADSHAPE, "adam_pack_step: n=%lld step=%d layers=%d (1..%d)",
+               (long long)n, step, nl, PK_MAX);
+  FPLX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+               FPLX_E_BADSHAPE, "adam_pack_step: the flat buffers must be 16-byte aligned");
+  AdamPackTable t;
+  t.p = p; t.g = g; t.m = m; t.v = v;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  t.c = {(float)((double)lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale, 1.f - beta1, 1.f - beta2};
+  t.n = nl;
+  t.first[0] = 0;
+  t.ng = 0;
+  t.gfirst[0] = 0;
+  int64_t pos = 0;
+  auto gap = [&](int64_t a, int64_t b_) {
+    if (b_ <= a) return;
+    t.gstart[t.ng] = a; t.glen[t.ng] = b_ - a;
+    t.gfirst[t.ng + 1] = t.gfirst[t.ng] + (int)((b_ - a + AP_GAPBLK - 1) / AP_GAPBLK);
+    ++t.ng;
+  };
+  for (int i = 0; i < nl; ++i) {
+    const int64_t len = (int64_t)cout[i] * cin[i] * 27;
+    FPLX_REQUIRE(fplx_adam_pack_ok(cout[i], cin[i]) && wf[i], FPLX_E_BADSHAPE, "adam_pack_step: layer %d (%d x %d) not packable here (fplx_adam_pack_ok)", i, cout[i], cin[i]);
+    FPLX_REQUIRE(off[i] >= pos && off[i] % 4 == 0 && off[i] + len <= n, FPLX_E_BADSHAPE, "adam_pack_step: layer %d: offsets must ascend, be multiples of 4 and lie inside the segment", i);
+    FPLX_REQUIRE(((uintptr_t)wf[i] % 16) == 0 && ((uintptr_t)wb[i] % 16) == 0, FPLX_E_BADSHAPE, "adam_pack_step: packs must be 16-byte aligned");
+    gap(pos, off[i]);
+    t.off[i] = off[i]; t.cout[i] = cout[i]; t.cin[i] = cin[i]; t.wf[i] = (bf16_t*)wf[i]; t.wb[i] = (bf16_t*)wb[i];
+    t.first[i + 1] = t.first[i] + (cout[i] / PK_CO) * (cin[i] / PK_CI);
+    pos = off[i] + len;
+  }
+  gap(pos, n);
+  adam_pack27_multi<<<t.first[t.n] + t.gfirst[t.ng], 256, 0, (hipStream_t)stream>>>(t);
+  return fplx_check_launch("adam_pack_step");
 }
 
 int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt, fplx_stream_t stream) {

@@ -914,15 +914,13 @@ pool_bwd_bn_reduce_col_k(const T* __restrict__ y, int64_t ldy, const T* __restri
 __global__ void __launch_bounds__(EW_THREADS)
 adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
        float step_size, float b1, float b2, float eps, float wd, float inv_sqrt_bc2, float gscale) {
+  const FplxAdamConst c = {step_size, b1, b2, eps, wd, inv_sqrt_bc2, gscale, 1.f - b1, 1.f - b2};
   for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
-    const float pi = p[i];
-    const float gi = fmaf(wd, pi, g[i] * gscale);
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float pi = p[i], mi = m[i], vi = v[i];
+    fplx_adam_elem(pi, g[i], mi, vi, c);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-    p[i] = pi - step_size * (mi / denom);
+    p[i] = pi;
   }
 }
 

@@ -35,6 +35,12 @@ class Engine(object):
         self.ws_side = None
         self._pack_cache = None
         self._train_packs = None                         # packs of the last train-mode forward (reuse_packs)
+        # persistent bf16 packs of the 3x3x3 layers the fused Adam + pack launch takes (fplx_adam_pack_step, round 5):
+        # (act dtype, device, {site: (wf, wb)}); _adam_packs = the _pack_key for which their CONTENT is current (the optimiser
+        # step wrote it) - any other parameter write drops it (invalidate(), a version-counter change)
+        self._pack_bufs = None
+        self._adam_packs = None
+        self.use_adam_pack = _lib.host_knob("adam_pack") != 0
         self.allow_pack_reuse = _lib.host_knob("pack_reuse") != 0      # A/B switches: fplx/_lib.py:_HOST_KNOBS
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
         # side_stream = 0 serialises all kernels on one stream (clean per-kernel profiles)
@@ -66,22 +72,65 @@ class Engine(object):
             self.ws_side = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         return self.ws
 
+    def _persistent_packs(self, act_dtype):
+        """-> {site: (wf, wb)}: the pack buffers the optimiser step writes in place (bf16, the layers fplx_adam_pack_ok takes);
+        empty when the fused step is off"""
+        net = self.net
+        if not self.use_adam_pack or act_dtype != torch.bfloat16:
+            return {}
+        dev = net.flat_params.device
+        if self._pack_bufs is None or self._pack_bufs[0] != act_dtype or self._pack_bufs[1] != dev:
+            first = next(iter(net.conv_sites()))[0]
+            bufs = {}
+            for name, conv in net.conv_sites():
+                w = conv.weight
+                if w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and name != first and ops.adam_pack_ok(w.shape[0], w.shape[1]):
+                    bufs[name] = (torch.empty((27, w.shape[0], w.shape[1]), dtype=act_dtype, device=dev),
+                                  torch.empty((27, w.shape[1], w.shape[0]), dtype=act_dtype, device=dev))
+            self._pack_bufs = (act_dtype, dev, bufs)
+            self._adam_packs = None
+        return self._pack_bufs[2]
+
+    def adam_pack_plan(self):
+        """for FusedAdam.step_flat: [(element offset in the flat buffer, cout, cin, wf, wb)] of the layers whose packs the
+        optimiser launch writes (ascending offsets, all inside the shared segment), or None"""
+        net = self.net
+        bufs = self._persistent_packs(net.act_dtype)
+        if not bufs:
+            return None
+        plan = []
+        for name, (wf, wb) in bufs.items():
+            o, n, shp = net._layout[name + ".weight"]
+            plan.append((o, shp[0], shp[1], wf, wb))
+        plan.sort(key=lambda t: t[0])
+        return plan
+
+    def packs_written_by_optimizer(self):
+        """the optimiser step has just written the persistent packs from the updated weights (after its invalidate())"""
+        self._adam_packs = self._pack_key(self.net.act_dtype)
+
     def _pack(self, act_dtype):
         net = self.net
         packs = {}
         first = next(iter(net.conv_sites()))[0]
         batch = []                                       # the 3x3x3 layers: one launch for all of them
+        bufs = self._persistent_packs(act_dtype)
+        fresh = bool(bufs) and self._adam_packs is not None and self._adam_packs == self._pack_key(act_dtype)
         for name, conv in net.conv_sites():
             want_wb = name != first                      # no data gradient w.r.t. the network input
             if conv.weight.dim() == 4:                   # Conv2d of a 2.5D level
                 packs[name] = ops.pack_conv2d_weight(conv.weight, act_dtype, want_wb)
+            elif fresh and name in bufs:                 # written by the optimiser step itself: nothing to do
+                packs[name] = bufs[name]
             else:
-                batch.append((name, conv.weight, want_wb))
+                batch.append((name, conv.weight, want_wb, bufs.get(name)))
         for i in range(0, len(batch), 32):
             part = batch[i:i + 32]
-            res = ops.pack_conv_weights_batched([b[1] for b in part], act_dtype, [b[2] for b in part])
+            res = ops.pack_conv_weights_batched([b[1] for b in part], act_dtype, [b[2] for b in part], [b[3] for b in part])
             for b, r in zip(part, res):
                 packs[b[0]] = r
+        if bufs and not fresh:
+            self._adam_packs = self._pack_key(act_dtype)     # the persistent buffers now hold the current weights' packs
         for name, tr in net.deconv_sites():
             if net.bilinear:                             # kernel-1 convolution in front of the (tri / bi)linear upsampling
                 w5 = tr.weight.reshape(tr.weight.shape[0], tr.weight.shape[1], 1, 1, 1)
@@ -110,6 +159,7 @@ class Engine(object):
         self._pack_cache = None
         self._train_packs = None
         self._fold_cache = {}
+        self._adam_packs = None
 
     def _folded(self, adt, domain, key, conv, bn):
         """forward pack and bias of a convolution with its eval-mode BatchNorm folded in (dsbn.py:54-57 on running statistics:

@@ -53,14 +53,18 @@ def pack_conv_weight(w, act_dtype, want_wb=True):
     return wf, wb
 
 
-def pack_conv_weights_batched(ws, act_dtype, want_wb):
-    """pack_conv_weight for a list of 3x3x3 weights in one launch -> list of (wf, wb)"""
+def pack_conv_weights_batched(ws, act_dtype, want_wb, into=None):
+    """pack_conv_weight for a list of 3x3x3 weights in one launch -> list of (wf, wb).
+    into: optional list of existing (wf, wb) destinations (None entries: allocate) - the engine's persistent pack buffers"""
     import ctypes
     n = len(ws)
     outs = []
-    for w, wantb in zip(ws, want_wb):
+    for i, (w, wantb) in enumerate(zip(ws, want_wb)):
         co, ci = w.shape[0], w.shape[1]
         assert tuple(w.shape[2:]) == (3, 3, 3) and w.dtype == torch.float32 and w.is_contiguous()
+        if into is not None and into[i] is not None:
+            outs.append(into[i])
+            continue
         wf = torch.empty((27, co, ci), dtype=act_dtype, device=w.device)
         wb = torch.empty((27, ci, co), dtype=act_dtype, device=w.device) if wantb else None
         outs.append((wf, wb))
@@ -397,6 +401,21 @@ def seg_loss_bwd(logits, label, pw, coef, gscale, weights, softmax, dlogits):
 def adam_step(p, g, m, v, lr, step, weight_decay, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
     call("fplx_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
          int(step), grad_scale, stream())
+
+
+def adam_pack_ok(cout, cin):
+    return _lib.lib().fplx_adam_pack_ok(int(cout), int(cin)) == 1
+
+
+def adam_pack_step(p, g, m, v, lr, step, weight_decay, grad_scale, betas, eps, layers):
+    """fplx_adam_step over the flat segment p AND the bf16 packs of the 3x3x3 weights inside it, one launch.
+    layers: [(element offset in p, cout, cin, wf, wb)] ascending by offset"""
+    import ctypes
+    n = len(layers)
+    vp, ip, lp = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+    call("fplx_adam_pack_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, int(step),
+         grad_scale, n, lp(*[int(l[0]) for l in layers]), ip(*[int(l[1]) for l in layers]), ip(*[int(l[2]) for l in layers]),
+         vp(*[ptr(l[3]) for l in layers]), vp(*[ptr(l[4]) or None for l in layers]), stream())
 
 
 def mc_filter(logits_tcv, thr=0.01, want_hards=True, want_maps=False):

@@ -116,12 +116,24 @@ class FusedAdam(Optimizer):
         self._opt_called = True                 # torch's lr schedulers check that an optimiser step preceded theirs
         group = self.param_groups[0]
         lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
+        fused = False
         for si, (start, end) in enumerate(self.seg_ranges):
             if si > 0 and (si - 1) not in active_domains:
                 continue
             self.seg_steps[si] += 1
+            plan = net.engine.adam_pack_plan() if si == 0 else None
+            if plan:
+                # the shared segment: Adam AND the bf16 packs of its 3x3x3 weights in one launch - the next forward finds
+                # them in place instead of re-reading every master weight (get_optimizer.py:17 + unet2d5_dsbn.py:54-55)
+                assert start == 0 and all(o + co * ci * 27 <= end for o, co, ci, _, _ in plan)
+                ops.adam_pack_step(net.flat_params[start:end], gflat[start:end], self.exp_avg[start:end],
+                                   self.exp_avg_sq[start:end], lr, self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps, plan)
+                fused = True
+                continue
             ops.adam_step(net.flat_params[start:end], gflat[start:end], self.exp_avg[start:end],
                           self.exp_avg_sq[start:end], lr, self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps)
+        if fused:
+            net.engine.packs_written_by_optimizer()
 
     def state_dict(self):
         """torch.optim.Adam's layout over the reference's parameter list (fplx/checkpoint.py): what the reference's

@@ -357,6 +357,15 @@ int fplx_seg_loss_bwd(const float* logits, const float* label, const float* pixe
  * grad_scale multiplies g first (1/world_size after an all-reduce sum). */
 int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, fplx_stream_t stream);
+/* fplx_adam_step over the flat segment [0, n) AND, in the same launch, the bf16 packs fplx_pack_conv_weights_batched makes
+ * of the `nl` (<= 32) 3x3x3 convolution weights that live inside it - from the UPDATED values (the weights change only here;
+ * what the train step otherwise re-reads at the head of every forward, unet2d5_dsbn.py:54-55 + get_optimizer.py:17).
+ * off[i]: element offset of layer i's [cout][cin][3][3][3] weight in the segment (ascending, multiples of 4); layers must
+ * satisfy fplx_adam_pack_ok; wb[i] may be NULL.  Same parameters, moments and packs as the two separate calls, bit for bit. */
+int fplx_adam_pack_ok(int cout, int cin);
+int fplx_adam_pack_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, int nl, const int64_t* off, const int* cout,
+                        const int* cin, void* const* wf, void* const* wb, fplx_stream_t stream);
 
 /* ------------------------------------------------------------------ pseudo-label filter
  * FPL branch of SegmentationAgent.infer (net_run_dsbn/agent_seg.py:911-931) for one volume:

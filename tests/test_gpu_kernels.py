@@ -349,6 +349,94 @@ def test_fused_adam_matches_torch():
         ops.adam_step(p, g.cuda(), m, v, 1e-3, 0, 1e-5)
 
 
+def test_fused_adam_pack_step_kernel():
+    """fplx_adam_pack_step (Adam over a flat segment + the bf16 packs of the 3x3x3 weights inside it, one launch) against
+    fplx_adam_step followed by fplx_pack_conv_weights_batched: parameters, both moments and both packs bit for bit, over three
+    steps; gaps in front of, between and behind the layers (odd lengths), a layer without a data-gradient pack."""
+    from fplx import ops
+    g = torch.Generator().manual_seed(21)
+    shapes = [(32, 32), (16, 64), (64, 96)]
+    gaps = [8, 1028, 36, 4097]
+    offs, pos = [], 0
+    for (co, ci), gp in zip(shapes, gaps):
+        pos += (gp + 3) // 4 * 4
+        offs.append(pos)
+        pos += co * ci * 27
+    n = pos + gaps[-1]
+    p0 = torch.randn(n, generator=g) * 0.1
+    res = {}
+    for fused in (True, False):
+        p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        packs = [(torch.empty((27, co, ci), dtype=torch.bfloat16, device="cuda"),
+                  None if k == 1 else torch.empty((27, ci, co), dtype=torch.bfloat16, device="cuda")) for k, (co, ci) in enumerate(shapes)]
+        gg = torch.Generator().manual_seed(5)
+        for step in range(1, 4):
+            grad = (torch.randn(n, generator=gg) * 0.01).cuda()
+            if fused:
+                ops.adam_pack_step(p, grad, m, v, 1e-3, step, 1e-5, 0.5, (0.9, 0.999), 1e-8,
+                                   [(o, co, ci, wf, wb) for o, (co, ci), (wf, wb) in zip(offs, shapes, packs)])
+            else:
+                ops.adam_step(p, grad, m, v, 1e-3, step, 1e-5, 0.5)
+                ws = [p[o:o + co * ci * 27].view(co, ci, 3, 3, 3) for o, (co, ci) in zip(offs, shapes)]
+                ops.pack_conv_weights_batched(ws, torch.bfloat16, [True, False, True], packs)
+        torch.cuda.synchronize()
+        res[fused] = (p.clone(), m.clone(), v.clone(), packs)
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert torch.equal(a, b)
+    assert float((res[True][0].cpu() - p0).abs().max()) > 1e-4
+    for (wf_a, wb_a), (wf_b, wb_b) in zip(res[True][3], res[False][3]):
+        assert torch.equal(wf_a, wf_b) and (wb_a is None or torch.equal(wb_a, wb_b))
+    with pytest.raises(ValueError):          # a layer the tiled pack does not take
+        ops.adam_pack_step(res[True][0], res[True][1], res[True][1], res[True][2], 1e-3, 1, 0.0, 1.0, (0.9, 0.999), 1e-8,
+                           [(0, 8, 32, res[True][3][0][0], None)])
+
+
+def test_train_step_with_the_fused_adam_pack_launch():
+    """TrainStep with the optimiser launch writing the 3x3x3 packs (Engine.use_adam_pack, the default) against the step that
+    repacks at the head of every forward: parameters bit-identical after four steps (both domains), no 3x3x3 layer is repacked by
+    a forward after the first one, and a torch-side in-place edit of a weight between two steps IS seen (version counters)."""
+    import fplx
+    from fplx import ops
+    p = dict(in_chns=1, feature_chns=[32, 64, 64, 128, 128], dropout=[0, 0, 0.3, 0, 0], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
+    lab = torch.zeros(2, 2, 16, 32, 64)
+    lab[:, 0] = 1.0
+    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
+    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
+    lab = lab.cuda()
+    res = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        net.engine.use_adam_pack = fuse
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+        packed = []
+        inner = ops.pack_conv_weights_batched
+
+        def counting(ws, *a, _inner=inner, _packed=packed, **kw):
+            _packed.append(len(ws))
+            return _inner(ws, *a, **kw)
+        ops.pack_conv_weights_batched = counting
+        try:
+            for it in range(4):
+                ts.step(x, lab, it % 2)
+                if it == 1:
+                    with torch.no_grad():
+                        net.block1.conv.conv3d_2.weight.mul_(0.5)       # a torch-side edit: the next forward must repack
+        finally:
+            ops.pack_conv_weights_batched = inner
+        torch.cuda.synchronize()
+        res.append((net.flat_params.detach().clone(), list(packed)))
+    assert torch.equal(res[0][0], res[1][0])
+    n3 = res[1][1][0]
+    assert res[1][1] == [n3] * 4                         # unfused: every forward packs every 3x3x3 layer
+    # fused: the first forward packs everything (nothing written yet), the forward behind the in-place edit again; the others
+    # only the stem (1 input channel: not a layer of the tiled pack)
+    assert res[0][1] == [n3, 1, n3, 1], res[0][1]
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32),
                                    # in_chns = 1 runs the LDS-free row kernel (stem_fwd_rows): a volume of one row, a width
                                    # one past a segment, a single voxel, several samples
