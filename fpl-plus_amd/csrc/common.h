@@ -149,6 +149,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(MARCH64_FW, "march64_fw", 0)           /* 16 / 32: force the footprint of the Cin = 64 march */                     \
   X(MARCH_DS, "march_ds", 0)               /* > 0: force the depth split of the march kernels */                        \
   X(MARCH128, "march128", 1)                                                                                           \
+  X(MARCH64_LW, "march64_lw", 1)           /* loader-wave form of conv_fwd_march64: bit 0 the 2.5D (Conv2d) forms, bit 1 the 3D forms; 0: off */ \
   X(MARCH32_V2, "march32_v2", 4)           /* 0: 8-wave kernel; 1: v2 everywhere; 4: v2 forward + v3 data gradient */   \
   X(WG_COT_MINVOX, "wg_cot_minvox", 0)                                                                                 \
   X(WG_TW, "wg_tw", 0)                                                                                                 \

@@ -1341,6 +1341,260 @@ conv_fwd_march64(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_fwd_march64_lw (round 5): conv_fwd_march64 with DEDICATED LOADER WAVES, the form that took 8-20 % off the brick kernels
+// (conv_brick.hip: conv_fwd_brick_lw).  conv_fwd_march64 issues every slab / weight piece from its four computing waves, in
+// the MFMA gaps: a 64-bit source address and a zero-page select per piece (about 2300 vector instructions and 200 branches per
+// depth step, DESIGN 7 (b) of round 4) and an issue stall of about 120 cycles per piece with the matrix pipe of that SIMD idle.
+// Here a block is 8 waves, two per SIMD:
+//   waves 0-3 (compute): fragment reads, MFMAs and the write-out of conv_fwd_march64, unchanged - no DMA, no source addresses;
+//   waves 4-7 (loaders): the next part-slab (and weight quarter, NQ = 4) through a BUFFER DESCRIPTOR on the depth slice (a
+//   lane's offset inside a slice is constant over the march; halo lanes carry an out-of-range offset and the hardware writes
+//   zeros: no zero page, no select), s_waitcnt vmcnt(0), the part-step's barrier.
+// The barrier count and order are conv_fwd_march64's: one per part-step; what it publishes (the part-slab fetched during the
+// part-step) and what it frees (the slot just read) are unchanged.  Same MFMAs in the same order: bit-identical output.
+template <class G, bool TWOD, int NQ, bool ACT = false>
+__global__ void __launch_bounds__(512)
+conv_fwd_march64_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp,
+                    const float* __restrict__ bias, bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W,
+                    int Cout, float* __restrict__ stats, int tilesH, int tilesW, int dsegs, int dlen,
+                    const bf16_t* __restrict__ x1, int xcd, const float* __restrict__ slope_p = nullptr, int nmod0 = 0) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* slabs = smem;                                        // [2 channel halves][SLAB][32]
+  char* wbuf = smem + 2 * G::SLAB_BYTES;                     // [2 channel halves][27][32 co][32 ci]
+  float* bias_s = reinterpret_cast<float*>(wbuf + 2 * G::WH_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave8 >= 4;                            // uniform per wave
+  const int wave = wave8 & 3;
+  const int r = lane & 31, khalf = lane >> 5;
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  int b = bid.x;
+  const int seg = b % dsegs; b /= dsegs;
+  const int tw = b % tilesW; b /= tilesW;
+  const int th = b % tilesH; b /= tilesH;
+  const int n = __builtin_amdgcn_readfirstlane(b);
+  const int h0 = __builtin_amdgcn_readfirstlane(th * G::FH), w0 = __builtin_amdgcn_readfirstlane(tw * G::FW);
+  const int d0 = __builtin_amdgcn_readfirstlane(seg * dlen);
+  const int d1 = (d0 + dlen < D) ? d0 + dlen : D;
+  const int n0 = bid.y * 32;
+  auto lds_dma = [&](const void* g, const char* l) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((const __attribute__((address_space(3))) char*)l));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+  };
+  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int CIN = NQ * 32;
+  const int sbase = TWOD ? d0 : d0 - 1;
+  const int nd = d1 - d0;                         // >= 2 (march_cfg)
+  const int nsteps = TWOD ? nd + 1 : nd + 2;
+  // ---- prologue, all 8 waves: the resident weights (NQ = 2: both halves; NQ = 4: quarter 0), bias
+  if constexpr (NQ == 2) {
+    for (int j = wave8; j < 2 * 27 * 32 * G::CH / 64; j += 8) {
+      const int i = j * 64 + lane;                           // chunk index over [half][tap][co][4 chunks]
+      const int hf = i / (27 * 32 * G::CH), ii = i % (27 * 32 * G::CH);
+      const int row = ii >> 2, c = (ii & 3) ^ G::swz(row);
+      lds_dma(wp + ((int64_t)(row >> 5) * Cout + n0 + (row & 31)) * 64 + hf * 32 + c * 8, wbuf + j * 1024);
+    }
+  }
+  const char* wlane = reinterpret_cast<const char*>(wp) + ((int64_t)(n0 + (lane >> 2)) * CIN) * 2 +
+                      (((lane & 3) ^ ((lane >> 4) & 3)) << 4);
+  auto w_piece = [&](int qt, int j) {
+    const int64_t row0 = (int64_t)(j >> 1) * Cout + (j & 1) * 16;      // uniform
+    lds_dma(wlane + row0 * (CIN * 2) + qt * 64, wbuf + (qt & 1) * G::WH_BYTES + j * 1024);
+  };
+  if constexpr (NQ != 2) {
+    for (int j = wave8; j < 54; j += 8) w_piece(0, j);
+  }
+  if (tid < 32) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
+
+  if (loader) {
+    // ================================================================ loader waves
+    constexpr int NPIECE = G::NPIECE;
+    // per lane and piece: byte offset of the source chunk (channel part 0) inside ONE depth slice, 0x40000000 = outside the
+    // volume (the descriptor's range check writes zeros), 0xFFFFFFFF = lane past the end of the slab (the last piece is 16 lanes)
+    unsigned soff[NPIECE];
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) {
+      const int i = (wave + 4 * k) * 64 + lane;
+      const int vox = i >> 2, c = (i & 3) ^ G::swz(vox);
+      const int hh = vox / G::SW + h0 - 1, ww = vox % G::SW + w0 - 1;
+      const bool in = hh >= 0 && hh < H && ww >= 0 && ww < W;
+      soff[k] = i >= G::SLAB_CHUNKS ? 0xFFFFFFFFu : (in ? (unsigned)((((int64_t)hh * W + ww) * ldx + c * 8) * 2) : 0x40000000u);
+    }
+    const int64_t xslice = (int64_t)H * W * ldx * 2;
+    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)(nmod0 > 0 ? n % nmod0 : n) * D * xslice;
+    const char* xn1 = reinterpret_cast<const char*>(x1 ? x1 : x + 32) + (int64_t)n * D * xslice;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+    auto slab_part = [&](int s_, int hf) {                   // all of this wave's pieces of channel part hf of slab s_ -> slot hf & 1
+      const char* xs = (NQ == 2 ? (hf ? xn1 : xn) : xn + hf * 64) + s_ * xslice;        // uniform
+      u32x4 rx;
+      rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xs);
+      rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xs >> 32) & 0xFFFFu);
+      rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xslice);
+      rx[3] = 0x00020000u;
+#pragma unroll
+      for (int k = 0; k < NPIECE; ++k)
+        if (wave + 4 * k < G::SLAB_DMA && soff[k] != 0xFFFFFFFFu) {
+          const unsigned dst = lds0 + (unsigned)((hf & 1) * G::SLAB_BYTES + (wave + 4 * k) * 1024);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(soff[k]), "s"(rx), "s"(0u), "s"(dst) : "memory");
+        }
+    };
+    if (sbase >= 0) slab_part(sbase, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    block_sync();                                            // P0
+    for (int t = 0; t < nsteps; ++t) {
+      const int s = sbase + t;
+      const bool live = TWOD ? t < nd : (s >= 0 && s < D);
+#pragma unroll
+      for (int hf = 0; hf < NQ; ++hf) {
+        const int ns = hf < NQ - 1 ? s : s + 1, nh = (hf + 1) % NQ;
+        const bool fetch = hf < NQ - 1 ? live : (TWOD ? ns < d1 : (ns >= 0 && ns < D && ns <= d1));
+        const bool wfetch = NQ > 2 && !(t == nsteps - 1 && hf == NQ - 1);
+        if (fetch) slab_part(ns, nh);
+        if constexpr (NQ > 2) {
+          if (wfetch)
+            for (int j = (TWOD ? 18 : 0) + wave; j < (TWOD ? 36 : 54); j += 4) w_piece(nh, j);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        block_sync();
+      }
+    }
+    if (stats) { block_sync(); block_sync(); }               // the compute waves' statistics tail
+    return;
+  }
+
+  // ================================================================ compute waves (conv_fwd_march64 without its DMA)
+  f32x16 K0a, K0b, K1a, K1b, K2a, K2b, Ra, Rb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = K1a[i] = K1b[i] = K2a[i] = K2b[i] = Ra[i] = Rb[i] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's share of the weights
+  block_sync();                                              // P0
+
+  const float bv = bias_s[r];
+  float ssum = 0.f, qsum = 0.f;
+  char* stg = reinterpret_cast<char*>(bias_s + 32) + wave * G::STAGE_BYTES;
+  char* stg_w = stg + (4 * khalf) * 64 + r * 2;
+  const char* stg_r = stg + lane * 16;
+  const int hb = h0 + wave * 2 * G::HPM;                     // first row of this wave's M-tile 0
+  unsigned wmask0 = 0, wmask1 = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int mr = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+    if (w0 + mr % G::FW < W) {
+      if (hb + mr / G::FW < H) wmask0 |= 1u << i;
+      if (hb + G::HPM + mr / G::FW < H) wmask1 |= 1u << i;
+    }
+  }
+  const unsigned ldy2 = (unsigned)ldy * 2u;
+  char* yn = reinterpret_cast<char*>(y) + ((((int64_t)n * D * H + hb) * W + w0) * ldy + n0) * 2;
+  const int64_t yslice = (int64_t)H * W * ldy * 2;
+  const unsigned soffb = (unsigned)(lane >> 2) * ldy2 + (unsigned)(lane & 3) * 16u;
+  const unsigned step1 = G::FW == 32 ? 16u : (unsigned)W;    // voxels between the two staged halves
+  const bool wok = w0 + (lane >> 2) < W;
+  bool sok[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    sok[m][0] = wok && hb + m * G::HPM < H;
+    sok[m][1] = G::FW == 32 ? (sok[m][0] && w0 + (lane >> 2) + 16 < W) : (wok && hb + m * G::HPM + 1 < H);
+  }
+  const float slope_v = ACT ? *slope_p : 0.f;
+  auto retire_elem = [&](f32x16& A, int m, int i) {
+    const int wu = (i & 3) + 8 * (i >> 2);
+    float ov = A[i] + bv;
+    if (ACT) ov = ov > 0.f ? ov : ov * slope_v;
+    *reinterpret_cast<bf16_t*>(stg_w + wu * 64) = (bf16_t)ov;
+    if (!ACT && (((m ? wmask1 : wmask0) >> i) & 1u)) {
+      ssum += ov;
+      qsum = fmaf(ov, ov, qsum);
+    }
+  };
+  auto retire_flush = [&](int m, int o) {
+    if (sok[m][0] || sok[m][1]) {
+      unsigned l2 = ldy2;
+      asm volatile("" : "+s"(l2));
+      char* rowp = yn + o * yslice + (unsigned)(m * G::HPM * W) * l2;
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(stg_r);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(stg_r + 1024);
+      if (sok[m][0]) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + soffb), "v"(v0) : "memory");
+      if (sok[m][1]) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(rowp + step1 * l2 + soffb), "v"(v1) : "memory");
+    }
+  };
+  for (int t = 0; t < nsteps; ++t) {
+    const int s = sbase + t;
+    const bool live = TWOD ? t < nd : (s >= 0 && s < D);   // a padding slab contributes nothing
+    const bool wout = t >= (TWOD ? 2 : 3);
+    const int o = s - 2;
+#pragma unroll
+    for (int hf = 0; hf < NQ; ++hf) {
+      auto side = [&](int q, int g) {
+        if (hf == 0 && wout && q < 8) {
+          if (g < 4) {
+            if (q < 4) retire_elem(Ra, 0, 4 * q + g);
+            else retire_elem(Rb, 1, 4 * (q - 4) + g);
+          }
+          if (g == 4 && q == 3) retire_flush(0, o);
+          if (g == 4 && q == 7) retire_flush(1, o);
+        }
+      };
+      const char* sl = slabs + (hf & 1) * G::SLAB_BYTES;
+      const char* wh = wbuf + (hf & 1) * G::WH_BYTES;
+#define M64_STEP(MASK)                                                                                              \
+  do {                                                                                                              \
+    if (hf == 0) march64_half<MASK, true, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);           \
+    else march64_half<MASK, false, G>(sl, wh, wave, r, khalf, K0a, K0b, K1a, K1b, K2a, K2b, side);                  \
+  } while (0)
+      if (live) {
+        if constexpr (TWOD) {
+          M64_STEP(2);
+        } else {
+          if (t == 0) M64_STEP(1);
+          else if (t == 1) M64_STEP(3);
+          else if (t < nd) M64_STEP(7);
+          else if (t == nd) M64_STEP(6);
+          else M64_STEP(4);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int g = 0; g < 6; ++g) side(q, g);
+        if (hf == 0) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) K0a[i] = K0b[i] = 0.f;
+        }
+      }
+#undef M64_STEP
+      block_sync();
+    }
+    Ra = K2a; Rb = K2b; K2a = K1a; K2b = K1b; K1a = K0a; K1b = K0b;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) retire_elem(Ra, 0, i);
+  retire_flush(0, d1 - 1);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) retire_elem(Rb, 1, i);
+  retire_flush(1, d1 - 1);
+
+  if (stats) {
+    FPLX_LDS_BARRIER();
+    float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][32]; the slabs are dead
+    const float a = ssum + __shfl_xor(ssum, 32, 64), q2 = qsum + __shfl_xor(qsum, 32, 64);
+    if (lane < 32) { red[(wave * 2 + 0) * 32 + r] = a; red[(wave * 2 + 1) * 32 + r] = q2; }
+    FPLX_LDS_BARRIER();
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float tt = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) tt += red[(wv * 2 + which) * 32 + c];
+      stats[((int64_t)bid.x * 2 + which) * Cout + n0 + c] = tt;
+    }
+  }
+}
+
 struct MarchCfg { int tilesH, tilesW, dsegs, dlen, nblk, fw; };
 
 inline int march_enabled() {
@@ -1437,11 +1691,36 @@ extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void*
                                                                          c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
     }                                                                                                               \
   } while (0)
-#define LAUNCH_M64(G_, TWOD_) do { if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2); } while (0)
+    // loader-wave form (knob march64_lw): needs a depth slice below 1 GiB (32-bit buffer offsets, the out-of-range marker)
+    // march64_lw bit 0: the Conv2d-per-slice forms (TWOD: one live accumulator role, 135-200 registers: -21..-28 % per launch,
+    // profiles/r05_kernel_ab.txt); bit 1: the 3D forms too - their eight accumulator tiles + the rotation's copies do not fit
+    // 256 registers (57-78 spilled registers inside the MFMA loop: +23 %), off by default
+    const int lwk = (int)fplx_knob(FPLX_K_MARCH64_LW);
+    const bool lw64 = (twod ? (lwk & 1) : (lwk & 2)) != 0 && (int64_t)h * w * ldx * 2 < ((int64_t)1 << 30);
+#define LAUNCH_M64LW(G_, TWOD_, NQ_)                                                                                \
+  do {                                                                                                              \
+    if (slope) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, TWOD_, NQ_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+      conv_fwd_march64_lw<G_, TWOD_, NQ_, true><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+                                                                         (bf16_t*)y, ldy, n, d, h, w, cout, nullptr, c.tilesH, \
+                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on(), slope, nmod0); \
+    } else {                                                                                                        \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, TWOD_, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_fwd_march64_lw<G_, TWOD_, NQ_><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+                                                                         (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
+                                                                         c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
+    }                                                                                                               \
+  } while (0)
+#define LAUNCH_M64(G_, TWOD_)                                                                                       \
+  do {                                                                                                              \
+    if (lw64) { if (cin == 128) LAUNCH_M64LW(G_, TWOD_, 4); else LAUNCH_M64LW(G_, TWOD_, 2); }                      \
+    else if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2);                                 \
+  } while (0)
     using G16 = MG64T<16>;
     if (c.fw == 16) { if (twod) LAUNCH_M64(G16, true); else LAUNCH_M64(G16, false); }
     else { if (twod) LAUNCH_M64(MG64, true); else LAUNCH_M64(MG64, false); }
 #undef LAUNCH_M64
+#undef LAUNCH_M64LW
 #undef LAUNCH_M64Q
     const int rc64 = fplx_check_launch("march64_conv3d_fwd");
     return rc64 < 0 ? rc64 : 1;

@@ -939,6 +939,7 @@ def test_fused_out_conv_backward_on_a_narrow_network_with_many_level0_tiles():
         net = fplx.UNet2D5_dsbn(dict(p)).cuda()
         net.engine.use_outconv_fusion = fuse
         net.train()
+        net._ensure_flat()
         before = net.flat_params.detach().clone()
         ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
         out = ts.step(x, lab, 0)

@@ -27,6 +27,16 @@ LAYERS = [  # (name, cin, cout, dims, stats)
 ]
 
 
+# layers of the depth-march kernels for Cin = 64 / 128 (conv_fwd_march64 / _lw): the benchmark's level-0 decoder forward, and the
+# shipped 2.5D configuration's Conv2d levels (mid = 1: the 9 taps in the middle depth plane), batch 4 x 28 x 128 x 128
+MARCH64 = [
+    ("L0 64->32 fwd", 64, 32, (2, 80, 160, 160), 1, 0), ("L0 64->32 nostats", 64, 32, (2, 80, 160, 160), 0, 0),
+    ("2.5D L0 64->32 fwd", 64, 32, (4, 28, 128, 128), 1, 1), ("2.5D L1 64->64 fwd", 64, 64, (4, 28, 64, 64), 1, 1),
+    ("2.5D L1 128->64 fwd", 128, 64, (4, 28, 64, 64), 1, 1), ("2.5D L1 64->128 dgrad", 64, 128, (4, 28, 64, 64), 0, 1),
+    ("cfg4 L0 64->32 fwd", 64, 32, (4, 28, 128, 128), 1, 0),
+]
+
+
 def parse(arg):
     kn = {}
     for item in arg.split(","):
@@ -49,36 +59,43 @@ def main():
     dt = ops._DT[torch.bfloat16]
     print("%-20s" % "layer" + "".join("%24s" % s[0] for s in settings) + "   (us per launch, median of %d rounds x %d; '=' bit-identical to the first)" % (rounds, iters))
     tot = np.zeros(len(settings))
-    for name, cin, cout, dims, want_stats in LAYERS:
+    layers = [l + (0,) for l in LAYERS] if opts.get("set", "brick") == "brick" else MARCH64
+    for name, cin, cout, dims, want_stats, mid in layers:
+        mid = bool(mid)
         if only and only not in name:
             continue
         n, d, h, w = dims
         v = n * d * h * w
         g = torch.Generator(device=dev).manual_seed(0)
         x = torch.randn(v, cin, device=dev, generator=g).bfloat16()
-        wt = torch.randn(cout, cin, 3, 3, 3, device=dev, generator=g) * 0.05
-        wf, _ = ops.pack_conv_weight(wt, torch.bfloat16)
+        if mid:
+            wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) * 0.05
+            wf, _ = ops.pack_conv2d_weight(wt, torch.bfloat16, False)
+        else:
+            wt = torch.randn(cout, cin, 3, 3, 3, device=dev, generator=g) * 0.05
+            wf, _ = ops.pack_conv_weight(wt, torch.bfloat16)
         b = torch.randn(cout, device=dev, generator=g)
         res, times = [], [[] for _ in settings]
         outs = []
         for si, (_, kn) in enumerate(settings):
             for k in keys:
                 _lib.set_tuning(k, kn.get(k, defaults[k]))
-            rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+            rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt, mid)
             stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device=dev) if want_stats else None
             y = torch.full((v, cout), 7.0, device=dev, dtype=torch.bfloat16)
-            ops.conv3d_fwd(x, ops.cl_strides(d, h, w, cin), dt, wf, b, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout, (3, 3, 3), stats)
+            ops.conv3d_fwd(x, ops.cl_strides(d, h, w, cin), dt, wf, b, y, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout, (3, 3, 3), stats,
+                           mid=mid)
             torch.cuda.synchronize()
             outs.append((y.clone(), None if stats is None else stats.sum(0).clone()))
         for rd in range(rounds):
             for si, (_, kn) in enumerate(settings):
                 for k in keys:
                     _lib.set_tuning(k, kn.get(k, defaults[k]))
-                rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
+                rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt, mid)
                 stats = torch.zeros((rows, 2, cout), dtype=torch.float32, device=dev) if want_stats else None
                 y = torch.empty(v, cout, device=dev, dtype=torch.bfloat16)
                 run = lambda: ops.conv3d_fwd(x, ops.cl_strides(d, h, w, cin), dt, wf, b, y, ops.cl_strides(d, h, w, cout), dt, dims, cin,
-                                             cout, (3, 3, 3), stats)
+                                             cout, (3, 3, 3), stats, mid=mid)
                 for _ in range(3):
                     run()
                 torch.cuda.synchronize()
