@@ -492,6 +492,46 @@ wgrad_stream_reduce(const float* __restrict__ part, int nblk, int npairs, int Ci
   }
 }
 
+// The same sum for FEW partial blocks and a large gradient (the deep levels: 7-28 MB of dw, 1-8 partial blocks): above, a
+// thread ends with four ci of ONE (co, tap) - four 4-byte stores 108 bytes apart, 7 M scattered stores for a 512 x 512 layer
+// (55 us, a third of that layer's weight-gradient time).  Here a block owns one output row (pair, co): its 27 x 32 values are
+// 27 runs of 128 bytes in every partial block (coalesced float4 loads, summed over the blocks in index order), transposed
+// through LDS into the row's 864 CONTIGUOUS floats of dw[co][ci0 .. ci0 + 31][27] and written as 16-byte stores.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_rows(const float* __restrict__ part, int nblk, int npairs, int Cin, int Cout, float* __restrict__ dw) {
+  __shared__ __attribute__((aligned(16))) float tile[32 * 27 + 4];
+  const int pair = blockIdx.x >> 5, co_l = blockIdx.x & 31;
+  const int64_t total = (int64_t)npairs * 27 * 1024;
+  const int t = threadIdx.x;
+  if (t < 216) {
+    const int tap = t >> 3, c4 = t & 7;
+    const float* p = part + ((int64_t)pair * 27 + tap) * 1024 + co_l * 32 + c4 * 4;
+    float4 a = *reinterpret_cast<const float4*>(p);
+    for (int b = 1; b < nblk; ++b) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)b * total);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    tile[(4 * c4 + 0) * 27 + tap] = a.x;
+    tile[(4 * c4 + 1) * 27 + tap] = a.y;
+    tile[(4 * c4 + 2) * 27 + tap] = a.z;
+    tile[(4 * c4 + 3) * 27 + tap] = a.w;
+  }
+  __syncthreads();
+  if (t < 216) {
+    const int ncit = Cin / 32;
+    const int co = (pair / ncit) * 32 + co_l, ci0 = (pair % ncit) * 32;
+    *reinterpret_cast<float4*>(dw + ((int64_t)co * Cin + ci0) * 27 + 4 * t) = *reinterpret_cast<const float4*>(tile + 4 * t);
+  }
+}
+// partial blocks -> dw: the row kernel for few blocks and many outputs (3x3x3 form, dw 16-byte aligned), else the lane kernel
+static inline void wgrad_finish(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid, hipStream_t st) {
+  const int64_t total = (int64_t)npairs * 27 * 1024;
+  if (!mid && nblk <= (int)fplx_knob(FPLX_K_WG_REDUCE_ROWS) && npairs >= 16 && ((uintptr_t)dw % 16) == 0)
+    wgrad_reduce_rows<<<(unsigned)(npairs * 32), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw);
+  else
+    wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw, mid);
+}
+
 struct WgCfg { int tw, cit, cot, tilesH, tilesW, dsegs, dlen, nblk, npairs; size_t ws; };
 
 static inline int64_t cot_env_min_vox() {
@@ -2193,7 +2233,7 @@ extern "C" int fplx_wgroll_conv3d_wgrad(const void* x, int64_t ldx, const void* 
 extern "C" int fplx_wgrad_reduce_launch(const float* part, int nblk, int npairs, int cin, int cout, float* dw, int mid,
                                         hipStream_t st) {
   const int64_t total = (int64_t)npairs * 27 * 1024;
-  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>(part, nblk, npairs, cin, cout, dw, mid);
+  wgrad_finish(part, nblk, npairs, cin, cout, dw, mid, st);
   return fplx_check_launch("wgrad_stream_reduce");
 }
 
@@ -2230,8 +2270,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
         (void)hipFuncSetAttribute((const void*)conv_wgrad_vox<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
         conv_wgrad_vox<1><<<grid, 256, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
       }
-      const int64_t total = (int64_t)v.npairs * 27 * 1024;
-      wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, v.g.S, v.npairs, cin, cout, dw, 0);
+      wgrad_finish((const float*)ws, v.g.S, v.npairs, cin, cout, dw, 0, st);
       int rcv = fplx_check_launch("mfma_conv3d_wgrad_vox");
       return rcv < 0 ? rcv : 1;
     }
@@ -2257,7 +2296,7 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
 #undef LAUNCH_WG
 #undef LAUNCH_WG2
   const int64_t total = (int64_t)c.npairs * 27 * 1024;
-  wgrad_stream_reduce<<<(unsigned)((total + 63) / 64), 256, 0, st>>>((const float*)ws, c.nblk, c.npairs, cin, cout, dw, mid);
+  wgrad_finish((const float*)ws, c.nblk, c.npairs, cin, cout, dw, mid, st);
   int rc = fplx_check_launch("mfma_conv3d_wgrad");
   return rc < 0 ? rc : 1;
 }
