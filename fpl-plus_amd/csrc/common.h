@@ -167,6 +167,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(WG_ROLL2D, "wg_roll2d", 1)             /* 0: the 2.5D levels' weight gradients on conv_wgrad_stream<.., TWOD> instead of conv_wgrad_roll2d */ \
   X(WG_ROLL2D_OVH, "wg_roll2d_ovh", 3)     /* per-block overhead of conv_wgrad_roll2d in depth steps (depth-split cost model) */ \
   X(WG_REDUCE_ROWS, "wg_reduce_rows", 8)   /* largest number of partial blocks the row-wise finish of the weight gradients takes (0: the lane kernel everywhere) */ \
+  X(WG_VOX_LW, "wg_vox_lw", 1)             /* loader-wave voxel-GEMM weight gradient: 1 volumes <= 2048 voxels, 2 everywhere, 0 never */ \
   X(WG_VOX_CUS, "wg_vox_cus", 128)         /* blocks the voxel-GEMM weight gradient aims at: HALF the CUs - the main stream's deep-level kernels are small latency-bound grids that need free CUs at once (step -0.9 % against 256) */ \
   X(WG_VOX_MAXV, "wg_vox_maxv", 10000)     /* largest voxel count (whole batch) the voxel-GEMM weight gradient takes */    \
   X(STREAM_MIN_W, "stream_min_w", 64)                                                                                  \

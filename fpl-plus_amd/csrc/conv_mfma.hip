@@ -868,6 +868,212 @@ conv_wgrad_vox(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv_wgrad_vox_lw (round 5): the voxel-GEMM weight gradient with DEDICATED LOADER WAVES (the form of conv_fwd_brick_lw).
+// conv_wgrad_vox stages the next chunk global -> registers -> LDS from its four computing waves, two batches of seven 16-byte
+// loads per lane issued and committed at fixed items of a 112-MFMA chunk: 600 cycles between a load and its commit against an
+// L2 latency of 1-2 K cycles under load - the level-4 512 -> 512 layer ran 42 us for 14 us of MFMA issue (0.05-0.12 of peak:
+// the lowest row of the round-5 kernel table).  Here a block is 8 waves:
+//   waves 0-3 (compute): the item stream of wgrad_vox_chunk - transposed fragment reads, border masks, MFMAs - and nothing
+//   else; one co tile per block (7 accumulator tiles per wave: two waves per SIMD have 256 registers), so a layer has twice
+//   the blocks of conv_wgrad_vox<2>;
+//   waves 4-7 (loaders): the next chunk's three x planes and its dy rows by LDS-DMA through buffer descriptors (a row that
+//   must read as zeros - outside the tensor, a depth that cannot pair - gets an out-of-range offset), the chunk's masks
+//   (waves 4, 5), s_waitcnt, the chunk's barrier.
+// Same partial-tile format and finish (wgrad_finish) as conv_wgrad_vox; sums in the same order per tile (chunks ascending).
+template <int WV, int SL>
+__device__ __forceinline__ void wgrad_vox_lw_chunk(f32x16 (&acc)[7], const char* const (&xb)[7], const char* dyb, const char* mkb) {
+  using L = VXL<1>;
+  constexpr int NT = (27 - WV + 3) / 4, NKS = VX_KC / 16, NI = NKS * NT;
+  constexpr int XOFF = SL * L::X_SLOT, DOFF = SL * L::DY_SLOT, MOFF = SL * L::MK_SLOT;
+  constexpr int PD = 3, RING = PD + 1;
+  bf16x8 fbw[2], far[RING];
+  u32x4v mkr[RING];
+  auto masked = [](int j) { const int tap = WV + 4 * j; return ((tap / 3) % 3) != 1 || (tap % 3) != 1; };
+  auto load_item = [&](int t) {
+    const int ks = t / NT, j = t % NT, tap = WV + 4 * j;
+    far[t % RING] = tr_frag(xb[j] + XOFF + ks * 1024);
+    if (masked(j)) mkr[t % RING] = *reinterpret_cast<const u32x4v*>(mkb + MOFF + ((tap % 9) * 16 + 2 * ks) * 16);
+  };
+  fbw[0] = tr_frag(dyb + DOFF);
+#pragma unroll
+  for (int t = 0; t < PD; ++t) load_item(t);
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    const int ks = t / NT, j = t % NT;
+    if (t + PD < NI) load_item(t + PD);
+    if (j == 0 && ks + 1 < NKS) fbw[(ks + 1) & 1] = tr_frag(dyb + DOFF + (ks + 1) * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 a = far[t % RING];
+    if (masked(j)) a = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4v, a) & mkr[t % RING]);
+    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fbw[ks & 1], acc[j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int WV>
+__device__ __forceinline__ void wgrad_vox_lw_compute(float* __restrict__ part, int Cin, int Cout, const VoxGeo& g, const FplxBlock& bid,
+                                                     char* smem, int lane, int k0, int k1) {
+  using L = VXL<1>;
+  const int W = g.W, XR = VX_KC + 2 * W + 2, xplane = XR * 64;
+  const int gq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int lane_off = (8 * (gq >> 1) + q) * 64 + (16 * (gq & 1) + 4 * pp) * 2;
+  constexpr int NT = (27 - WV + 3) / 4;
+  const char* xb[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int tap = j < NT ? WV + 4 * j : WV;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    xb[j] = smem + L::X0 + kd * xplane + (kh * W + kw) * 64 + lane_off;
+  }
+  const char* dyb = smem + L::DY0 + lane_off;
+  const char* mkb = smem + L::MK0 + (gq >> 1) * 16;
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // P0: chunk k0 sits in slot 0
+  for (int kc = k0;;) {
+    wgrad_vox_lw_chunk<WV, 0>(acc, xb, dyb, mkb);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kc += VX_KC;
+    if (kc >= k1) break;
+    wgrad_vox_lw_chunk<WV, 1>(acc, xb, dyb, mkb);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kc += VX_KC;
+    if (kc >= k1) break;
+  }
+  // partial tiles, the format of conv_wgrad_stream: part[split][pair][tap][co][ci]
+  const int ncit = Cin / 32;
+  const int cot = bid.y / ncit, cit = bid.y % ncit;
+  const int co = lane & 31, rbase = (lane >> 5) * 4;
+  const int pair = cot * ncit + cit;
+  float* out = part + ((int64_t)bid.x * (ncit * (Cout / 32)) + pair) * (27 * 1024);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int tap = WV + 4 * i;
+    if (tap < 27) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(out + (tap * 32 + co) * 32 + 8 * g4 + rbase) =
+            make_float4(acc[i][4 * g4 + 0], acc[i][4 * g4 + 1], acc[i][4 * g4 + 2], acc[i][4 * g4 + 3]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512)
+conv_wgrad_vox_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ dy, int64_t ldy,
+                  float* __restrict__ part, int Cin, int Cout, const VoxGeo g, int xcd) {
+  using L = VXL<1>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const FplxBlock bid = fplx_xcd_block(xcd);
+  const int W = g.W, HW = g.HW, V = g.V;
+  const int XR = VX_KC + 2 * W + 2;
+  unsigned char* vc = reinterpret_cast<unsigned char*>(smem + L::VC0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncit = Cin / 32;
+  const int cot = bid.y / ncit, cit = bid.y % ncit;
+  const int k0 = bid.x * g.kper;
+  const int k1 = (k0 + g.kper < V) ? k0 + g.kper : V;
+  // border codes of the voxels this block can touch (as conv_wgrad_vox), by all 8 waves
+  const int halo = HW + W + 1;
+  const int tb0 = k0 - halo, tbn = (k1 - k0 + VX_KC - 1) / VX_KC * VX_KC + 2 * halo;
+  for (int t = tid; t < tbn; t += 512) {
+    const int u = tb0 + t;
+    unsigned char c = 0xFF;
+    if (u >= 0 && u < V) {
+      const unsigned q1 = __umulhi((unsigned)u, g.mW), w_ = (unsigned)u - q1 * (unsigned)W;
+      const unsigned q2 = __umulhi(q1, g.mH), h_ = q1 - q2 * (unsigned)g.H;
+      const unsigned q3 = __umulhi(q2, g.mD), d_ = q2 - q3 * (unsigned)g.D;
+      c = (unsigned char)((d_ == 0 ? 1 : 0) | (d_ == (unsigned)g.D - 1 ? 2 : 0) | (h_ == 0 ? 4 : 0) |
+                          (h_ == (unsigned)g.H - 1 ? 8 : 0) | (w_ == 0 ? 16 : 0) | (w_ == (unsigned)W - 1 ? 32 : 0));
+    }
+    vc[t] = c;
+  }
+  __syncthreads();                                         // the code table is complete
+  if (wave8 < 4) {
+    switch (wave8) {
+      case 0: wgrad_vox_lw_compute<0>(part, Cin, Cout, g, bid, smem, lane, k0, k1); break;
+      case 1: wgrad_vox_lw_compute<1>(part, Cin, Cout, g, bid, smem, lane, k0, k1); break;
+      case 2: wgrad_vox_lw_compute<2>(part, Cin, Cout, g, bid, smem, lane, k0, k1); break;
+      default: wgrad_vox_lw_compute<3>(part, Cin, Cout, g, bid, smem, lane, k0, k1); break;
+    }
+    return;
+  }
+  // ================================================================ loader waves
+  const int lw = wave8 - 4;
+  const bf16_t* xg = x + cit * 32;
+  const bf16_t* dyg = dy + cot * 32;
+  u32x4v rx, ry;
+  rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xg);
+  rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xg >> 32) & 0xFFFFu);
+  rx[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)V * ldx * 2));
+  rx[3] = 0x00020000u;
+  ry[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dyg);
+  ry[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)dyg >> 32) & 0xFFFFu);
+  ry[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)V * ldy * 2));
+  ry[3] = 0x00020000u;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
+  auto buf_dma = [&](const u32x4v& rsrc, unsigned vo, unsigned dst_off) {
+    const unsigned dst = lds0 + dst_off;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(0u), "s"(dst) : "memory");
+  };
+  const int nxp = (3 * XR + 15) / 16;                      // x pieces of a chunk (16 rows of 64 bytes each), then 8 dy pieces
+  auto stage = [&](int kn, int slot) {
+    for (int p = lw; p < nxp + VX_KC / 16; p += 4) {
+      if (p < nxp) {
+        const int rr = p * 16 + (lane >> 2);
+        const int pl = (rr >= XR ? 1 : 0) + (rr >= 2 * XR ? 1 : 0), row = rr - pl * XR;
+        const int u = kn + row - (W + 1) + (pl - 1) * HW;
+        const int t = u - tb0;
+        const bool in = t >= 0 && t < tbn;
+        const unsigned c = vc[in ? t : 0];
+        const bool ok = in && c != 0xFFu && !((pl == 0 && (c & 2u)) || (pl == 2 && (c & 1u)));
+        const unsigned vo = ok ? (unsigned)(((int64_t)u * ldx + (lane & 3) * 8) * 2) : 0x80000000u;
+        if (rr < 3 * XR) buf_dma(rx, vo, (unsigned)(L::X0 + slot * L::X_SLOT + p * 1024));      // (rows past the planes: not written)
+      } else {
+        const int v_ = kn + (p - nxp) * 16 + (lane >> 2);
+        const unsigned vo = v_ < k1 ? (unsigned)(((int64_t)v_ * ldy + (lane & 3) * 8) * 2) : 0x80000000u;
+        buf_dma(ry, vo, (unsigned)(L::DY0 + slot * L::DY_SLOT + (p - nxp) * 1024));
+      }
+    }
+    if (lw < 2) {                                          // the chunk's masks (VXS::masks): wave lw takes 64 voxels
+      const unsigned c = vc[kn - tb0 + lw * 64 + lane];
+      const uint64_t h0 = __ballot(c & 4), h2 = __ballot(c & 8), w0 = __ballot(c & 16), w2 = __ballot(c & 32);
+      char* mk_n = smem + L::MK0 + slot * L::MK_SLOT;
+#pragma unroll
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        const int e = rnd * 64 + lane;
+        if (e < 72) {
+          const int combo = e >> 3, jj = e & 7, kh = combo / 3, kw = combo - 3 * kh;
+          const uint64_t inv = (kh == 0 ? h0 : (kh == 2 ? h2 : 0)) | (kw == 0 ? w0 : (kw == 2 ? w2 : 0));
+          const unsigned by = (unsigned)(inv >> (8 * jj)) & 0xFFu;
+          u32x4v m_;
+#pragma unroll
+          for (int q_ = 0; q_ < 4; ++q_)
+            m_[q_] = ((by >> (2 * q_)) & 1u ? 0u : 0xFFFFu) | ((by >> (2 * q_ + 1)) & 1u ? 0u : 0xFFFF0000u);
+          *reinterpret_cast<u32x4v*>(mk_n + (combo * 16 + lw * 8 + jj) * 16) = m_;
+        }
+      }
+    }
+  };
+  stage(k0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // P0
+  for (int kc = k0, slot = 0;; slot ^= 1) {
+    const int kn = kc + VX_KC;
+    if (kn < k1) stage(kn, slot ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    kc = kn;
+    if (kc >= k1) break;
+  }
+}
+
 struct VoxCfg { int ok, cot, npairs; VoxGeo g; size_t ws, lds; };
 // deep levels only: small volumes (the footprint march wins where its tiles fit and the voxel count amortises its
 // partial tiles), W <= 40 (LDS windows), 3 x 3 x 3 in all three dimensions (not the 2.5D middle-plane form)
@@ -877,7 +1083,13 @@ inline VoxCfg vox_cfg(int n, int d, int h, int w, int cin, int cout) {
   const int mode = (int)fplx_knob(FPLX_K_WG_VOX);           // 0: never, 1: the rule below, 2: wherever the kernel can run (tests)
   if (!mode || cin % 32 != 0 || cout % 32 != 0 || w > VX_MAXW || w < 2 || h < 2 || d < 2 || V >= ((int64_t)1 << 24)) return c;
   if (mode == 1 && V > (int64_t)fplx_knob(FPLX_K_WG_VOX_MAXV)) return c;
-  c.cot = cout % 64 == 0 ? 2 : 1;
+  // the loader-wave form (conv_wgrad_vox_lw) has one co tile per block: every x fragment and mask then feeds ONE MFMA and
+  // the LDS (2 transposed reads + 1 mask read per MFMA and wave) is as busy as the matrix pipe - it wins only where the
+  // register-staged kernel is latency-bound outright, the tiny level-4 volumes (512 -> 512: 57 -> 43 us; level 3 512 -> 256:
+  // 150 -> 175).  Knob wg_vox_lw: 1 = volumes of at most 2048 voxels, 2 = everywhere (tests), 0 = never
+  const int lwk = (int)fplx_knob(FPLX_K_WG_VOX_LW);
+  const bool lw = lwk == 2 || (lwk == 1 && V <= 2048);
+  c.cot = (cout % 64 == 0 && !lw) ? 2 : 1;
   c.npairs = (cin / 32) * (cout / 32);
   const int groups = c.npairs / c.cot;
   const int chunks = (int)((V + VX_KC - 1) / VX_KC);
@@ -2263,7 +2475,12 @@ extern "C" int fplx_mfma_conv3d_wgrad(const void* x, int64_t ldx, const void* dy
     if (v.ok) {
       if (ws_bytes < v.ws) return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_wgrad: workspace %zu < %zu", ws_bytes, v.ws);
       dim3 grid(v.g.S, v.npairs / v.cot);
-      if (v.cot == 2) {
+      const int lwk = (int)fplx_knob(FPLX_K_WG_VOX_LW);
+      if ((lwk == 2 || (lwk == 1 && v.g.V <= 2048)) && v.cot == 1 && (int64_t)v.g.V * ldx * 2 < ((int64_t)1 << 31) &&
+          (int64_t)v.g.V * ldy * 2 < ((int64_t)1 << 31)) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_vox_lw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
+        conv_wgrad_vox_lw<<<grid, 512, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
+      } else if (v.cot == 2) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_vox<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
         conv_wgrad_vox<2><<<grid, 256, v.lds, st>>>((const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, (float*)ws, cin, cout, v.g, fplx_xcd_on());
       } else {

@@ -679,10 +679,11 @@ def test_pool_bwd_bn_reduce_bf16_against_torch_autograd(shape, pd):
     (3, 32, 96, 3, 7, 9),            # odd everything, n = 3, Cout % 64 != 0 (one co tile per block), tiny volume (567 voxels)
     (1, 96, 64, 2, 2, 2),            # 8 voxels: every pair crosses a border
     (1, 64, 64, 9, 33, 17)])         # K split whose ranges cut through rows and slices
-def test_conv3d_wgrad_vox_kernel(shape):
-    """conv_wgrad_vox (voxel-GEMM weight gradient of the deep levels, conv_mfma.hip): against torch autograd, bf16 operands,
-    forced on every shape by the tuning knob wg_vox = 2; and the same numbers as the footprint march (wg_vox = 0) up to the
-    order of the fp32 additions."""
+@pytest.mark.parametrize("lw", [2, 0])
+def test_conv3d_wgrad_vox_kernel(shape, lw):
+    """conv_wgrad_vox / conv_wgrad_vox_lw (voxel-GEMM weight gradient of the deep levels, conv_mfma.hip; lw = 2: the loader-wave
+    form of round 5 on every shape - by default it takes the volumes of at most 2048 voxels): against torch autograd, bf16 operands, forced on every shape by the tuning knob
+    wg_vox = 2; and the same numbers as the footprint march (wg_vox = 0) up to the order of the fp32 additions."""
     from fplx import ops
     _lib = ops._lib
     n, cin, cout, d, h, w = shape
@@ -701,6 +702,7 @@ def test_conv3d_wgrad_vox_kernel(shape):
     got = {}
     for mode in (2, 0):
         _lib.set_tuning("wg_vox", mode)
+        _lib.set_tuning("wg_vox_lw", lw)
         try:
             ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
             dw = torch.full((cout, cin, 3, 3, 3), 7.0, dtype=torch.float32, device="cuda")
@@ -709,6 +711,7 @@ def test_conv3d_wgrad_vox_kernel(shape):
             got[mode] = dw.cpu()
         finally:
             _lib.set_tuning("wg_vox", 1)
+            _lib.set_tuning("wg_vox_lw", 1)
     scale = float(wr.grad.abs().max())
     assert float((got[2] - wr.grad).abs().max()) < 1e-4 * scale + 1e-6, float((got[2] - wr.grad).abs().max()) / scale
     assert float((got[2] - got[0]).abs().max()) < 1e-4 * scale + 1e-6
