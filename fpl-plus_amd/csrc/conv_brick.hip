@@ -30,6 +30,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct BK {
   static constexpr int TW = 8, KC = 32, ROWB = 64, SWP = 12, THREADS = 256;
@@ -856,7 +857,11 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
                   if (li < NL && (li * (M1 - M1 / 4)) / NL <= mi) { load(li); ++li; }
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
+                // statistics-free forms (data gradients, split-K partials, inference): the product TRANSPOSED, D^T[cout][voxel]
+                // (operands swapped: same fragments, same products in the same k order) - a lane then holds 16 output
+                // channels of ONE voxel and the write-out needs no LDS transpose
+                if constexpr (STATS) acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
+                else acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[hf][kd * NTW + j], fa[hf][p + kd], acc[p][j], 0, 0, 0);
                 ++mi;
               }
             __builtin_amdgcn_sched_barrier(0);
@@ -966,7 +971,71 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         }
       }
     };
-    if (partial) write_partial();
+    // transposed accumulators (STATS = false): lane (r, khalf) holds, for the voxel of patch row r, the channels
+    // c(i) = 8 (i >> 2) + (i & 3) + 4 khalf of N-tile j in register i
+    auto write_transposed = [&]() {
+      const int vh = h0 + hhalf * 4 + bk_row(r), vw = w0 + bk_col(r);
+      const bool vok = vh < H && vw < W;
+      if (partial) {
+        // split-K: four 16-byte fp32 stores per tile straight from the registers into partial[z][voxel][Cout]
+        float* pz = partial + (int64_t)bz * ((int64_t)N * D * H * W) * Cout + n0 + wn * (32 * NTW) + 4 * khalf;
+#pragma unroll
+        for (int p = 0; p < TD; ++p) {
+          const int dd = d0 + p;
+          float* dst = pz + ((((int64_t)n * D + dd) * H + vh) * W + vw) * Cout;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            if (dd < D && vok) {
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<float4*>(dst + j * 32 + 8 * g4) =
+                    make_float4(acc[p][j][4 * g4], acc[p][j][4 * g4 + 1], acc[p][j][4 * g4 + 2], acc[p][j][4 * g4 + 3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
+          }
+        }
+        return;
+      }
+      const bool has_bias = bias != nullptr;                   // uniform
+#pragma unroll
+      for (int p = 0; p < TD; ++p) {
+        const int dd = d0 + p;
+        bf16_t* dst = y + ((((int64_t)n * D + dd) * H + vh) * W + vw) * ldy + n0 + wn * (32 * NTW) + 8 * khalf;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+          unsigned pk[8];
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            float o0 = acc[p][j][i], o1 = acc[p][j][i + 1];
+            if (has_bias) {
+              const int c = wn * (32 * NTW) + j * 32 + 8 * (i >> 2) + (i & 3) + 4 * khalf;
+              o0 += bias_s[c]; o1 += bias_s[c + 1];
+            }
+            if (ACT) { o0 = o0 > 0.f ? o0 : o0 * slope_v; o1 = o1 > 0.f ? o1 : o1 * slope_v; }
+            const bf16_t b0 = (bf16_t)o0, b1 = (bf16_t)o1;
+            pk[i >> 1] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+            acc[p][j][i] = 0.f; acc[p][j][i + 1] = 0.f;
+          }
+          // channels 8 g + 4 khalf + (0..3) sit in pk[2 g], pk[2 g + 1]: two v_permlane32_swap per pair of groups give the low
+          // lane of a voxel channels 0-7 and 16-23, the high lane 8-15 and 24-31 - two 16-byte stores each
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const u32x2 sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+              pk[4 * g2 + e] = sw[0];
+              pk[4 * g2 + 2 + e] = sw[1];
+            }
+          if (dd < D && vok) {
+            *reinterpret_cast<u32x4*>(dst + j * 32) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *reinterpret_cast<u32x4*>(dst + j * 32 + 16) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+          }
+        }
+      }
+    };
+    if constexpr (!STATS) write_transposed();
+    else if (partial) write_partial();
     else if (full) write_out(std::true_type{});
     else write_out(std::false_type{});
     if (STATS && stats) {
