@@ -13,9 +13,14 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), name[:44]))
 rows.sort()
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-# steady state: the last nsteps train steps, delimited by the optimiser launches (two adam_k per step: shared + domain segment)
+# steady state: the last nsteps train steps, delimited by the optimiser launches: since round 5 the shared segment's launch is
+# adam_pack27_multi (Adam + weight packs, one per step); before, two adam_k per step (shared + domain segment)
+fused = [e for s, e, q, n in rows if n.startswith("adam_pack27_multi")]
 adam = [e for s, e, q, n in rows if n.startswith("adam_k")]
-t0, t1 = adam[-2 * nsteps - 1], adam[-1]
+if len(fused) > nsteps:
+    t0, t1 = fused[-nsteps - 1], fused[-1]
+else:
+    t0, t1 = adam[-2 * nsteps - 1], adam[-1]
 rows = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 span = rows[-1][1] - rows[0][0]
 per_q = defaultdict(int)
