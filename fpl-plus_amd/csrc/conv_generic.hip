@@ -426,6 +426,49 @@ adam_pack27_multi(const AdamPackTable t) {
     }
 }
 
+// the small packs of a step in ONE launch (round 5): stem, transposed convolutions, out_conv - seven launches of 3-6 us each with
+// 10-us gaps between them at the head of every step, where nothing overlaps them
+constexpr int PS_MAX = 16, PS_BLK = 1024;
+struct PackSmallTable {
+  const float* w[PS_MAX];
+  void* wf[PS_MAX];
+  void* wb[PS_MAX];
+  int a[PS_MAX], b[PS_MAX], taps[PS_MAX], kind[PS_MAX], dt[PS_MAX], first[PS_MAX + 1], n;
+};
+template <typename T>
+__device__ __forceinline__ void pack_small_elem(const PackSmallTable& t, int e, int64_t i) {
+  const int taps = t.taps[e];
+  const float v = t.w[e][i];
+  T* wf = (T*)t.wf[e];
+  T* wb = (T*)t.wb[e];
+  if (t.kind[e] == 0) {                 // Conv: w[Cout = a][Cin = b][taps] -> wf[tap][Cout][Cin], wb[taps-1-tap][Cin][Cout]
+    const int Cout = t.a[e], Cin = t.b[e];
+    const int tap = (int)(i % taps), ci = (int)((i / taps) % Cin), co = (int)(i / ((int64_t)taps * Cin));
+    if (wf) Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
+    if (wb) Act<T>::st(wb + ((int64_t)(taps - 1 - tap) * Cin + ci) * Cout + co, v);
+  } else {                              // ConvTranspose: w[Cin = a][Cout = b][taps] -> wf[tap][Cout][Cin], wb[tap][Cin][Cout]
+    const int Cin = t.a[e], Cout = t.b[e];
+    const int tap = (int)(i % taps), co = (int)((i / taps) % Cout), ci = (int)(i / ((int64_t)taps * Cout));
+    if (wf) Act<T>::st(wf + ((int64_t)tap * Cout + co) * Cin + ci, v);
+    if (wb) Act<T>::st(wb + ((int64_t)tap * Cin + ci) * Cout + co, v);
+  }
+}
+__global__ void __launch_bounds__(256)
+pack_small_multi(const PackSmallTable t) {
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
+  const int64_t total = (int64_t)t.a[e] * t.b[e] * t.taps[e];
+  const int64_t lo = (int64_t)((int)blockIdx.x - t.first[e]) * PS_BLK;
+#pragma unroll
+  for (int k = 0; k < PS_BLK / 256; ++k) {
+    const int64_t i = lo + threadIdx.x + 256 * k;
+    if (i < total) {
+      if (t.dt[e] == FPLX_F32) pack_small_elem<float>(t, e, i);
+      else pack_small_elem<bf16_t>(t, e, i);
+    }
+  }
+}
+
 template <typename T>
 __global__ void pack_deconv_w(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin, int Cout,
                               int taps) {
@@ -656,6 +699,26 @@ int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf
   if (t.n == 0) return FPLX_OK;
   pack_conv_w27_tiled_multi<<<t.first[t.n], 256, 0, (hipStream_t)stream>>>(t);
   return fplx_check_launch("pack_conv_weights_batched");
+}
+
+int fplx_pack_weights_multi(int n, const int* kind, const float* const* w, void* const* wf, void* const* wb, const int* a,
+                            const int* b, const int* taps, const int* dt, fplx_stream_t stream) {
+  FPLX_REQUIRE(kind && w && wf && wb && a && b && taps && dt, FPLX_E_NULL, "pack_weights_multi: null pointer");
+  FPLX_REQUIRE(n > 0 && n <= PS_MAX, FPLX_E_BADSHAPE, "pack_weights_multi: %d jobs (1..%d)", n, PS_MAX);
+  PackSmallTable t;
+  t.n = n;
+  t.first[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    FPLX_REQUIRE(w[i] && (wf[i] || wb[i]) && a[i] > 0 && b[i] > 0 && taps[i] > 0 && (kind[i] == 0 || kind[i] == 1), FPLX_E_BADSHAPE,
+                 "pack_weights_multi: job %d", i);
+    FPLX_REQUIRE(dt[i] == FPLX_F32 || dt[i] == FPLX_BF16, FPLX_E_BADDTYPE, "pack_weights_multi: dtype %d", dt[i]);
+    t.w[i] = w[i]; t.wf[i] = wf[i]; t.wb[i] = wb[i]; t.a[i] = a[i]; t.b[i] = b[i]; t.taps[i] = taps[i]; t.kind[i] = kind[i]; t.dt[i] = dt[i];
+    const int64_t total = (int64_t)a[i] * b[i] * taps[i];
+    FPLX_REQUIRE(total < ((int64_t)1 << 30), FPLX_E_BADSHAPE, "pack_weights_multi: job %d too large for this entry point", i);
+    t.first[i + 1] = t.first[i] + (int)((total + PS_BLK - 1) / PS_BLK);
+  }
+  pack_small_multi<<<t.first[n], 256, 0, (hipStream_t)stream>>>(t);
+  return fplx_check_launch("pack_weights_multi");
 }
 
 int fplx_adam_pack_ok(int cout, int cin) {

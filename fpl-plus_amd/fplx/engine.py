@@ -41,6 +41,7 @@ class Engine(object):
         self._pack_bufs = None
         self._adam_packs = None
         self.use_adam_pack = _lib.host_knob("adam_pack") != 0
+        self.use_pack_multi = _lib.host_knob("pack_small_multi") != 0       # transposed-convolution + out_conv packs in one launch
         self.allow_pack_reuse = _lib.host_knob("pack_reuse") != 0      # A/B switches: fplx/_lib.py:_HOST_KNOBS
         self._side = None                  # second HIP stream: weight gradients run beside the data-gradient chain
         # side_stream = 0 serialises all kernels on one stream (clean per-kernel profiles)
@@ -131,13 +132,32 @@ class Engine(object):
                 packs[b[0]] = r
         if bufs and not fresh:
             self._adam_packs = self._pack_key(act_dtype)     # the persistent buffers now hold the current weights' packs
+        oc = net.out_conv
+        if self.use_pack_multi and not net.bilinear:
+            # the remaining small packs (transposed convolutions, out_conv) in ONE launch instead of six
+            dev = net.flat_params.device
+            jobs = []
+            for name, tr in net.deconv_sites():
+                w = tr.weight
+                ci, co, taps = w.shape[0], w.shape[1], (8 if w.dim() == 5 else 4)
+                wf = torch.empty((taps, co, ci), dtype=act_dtype, device=dev)
+                wb = torch.empty((taps, ci, co), dtype=act_dtype, device=dev)
+                packs[name] = (wf, wb)
+                jobs.append((1, w, wf, wb, ci, co, taps))
+            ncls, c0 = oc.weight.shape[0], oc.weight.shape[1]
+            owf = torch.empty((9, ncls, c0), dtype=torch.float32, device=dev)      # fp32 planar logits
+            owb = torch.empty((9, c0, ncls), dtype=act_dtype, device=dev)
+            jobs.append((0, oc.weight, owf, None, ncls, c0, 9))
+            jobs.append((0, oc.weight, None, owb, ncls, c0, 9))
+            ops.pack_weights_multi(jobs)
+            packs["out_conv"] = (owf, owb)
+            return packs
         for name, tr in net.deconv_sites():
             if net.bilinear:                             # kernel-1 convolution in front of the (tri / bi)linear upsampling
                 w5 = tr.weight.reshape(tr.weight.shape[0], tr.weight.shape[1], 1, 1, 1)
                 packs[name] = ops.pack_conv_weight(w5, act_dtype, True)
             else:
                 packs[name] = ops.pack_deconv_weight(tr.weight, act_dtype)
-        oc = net.out_conv
         wf, _ = ops.pack_conv_weight(oc.weight, torch.float32, False)       # fp32 planar logits
         _, wb = ops.pack_conv_weight(oc.weight, act_dtype, True)
         packs["out_conv"] = (wf, wb)

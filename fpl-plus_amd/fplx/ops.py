@@ -76,6 +76,18 @@ def pack_conv_weights_batched(ws, act_dtype, want_wb, into=None):
     return outs
 
 
+def pack_weights_multi(jobs):
+    """jobs: [(kind, w fp32 contiguous, wf or None, wb or None, a, b, taps)] (kind 0: conv weight [a = Cout][b = Cin][taps];
+    1: transposed conv [a = Cin][b = Cout][taps]) - all of them in ONE launch (fplx_pack_weights_multi)"""
+    import ctypes
+    n = len(jobs)
+    vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+    dts = [_DT[(j[2] if j[2] is not None else j[3]).dtype] for j in jobs]
+    call("fplx_pack_weights_multi", n, ip(*[j[0] for j in jobs]), vp(*[ptr(j[1]) for j in jobs]), vp(*[ptr(j[2]) or None for j in jobs]),
+         vp(*[ptr(j[3]) or None for j in jobs]), ip(*[j[4] for j in jobs]), ip(*[j[5] for j in jobs]), ip(*[j[6] for j in jobs]),
+         ip(*dts), stream())
+
+
 def pack_deconv_weight(w, act_dtype):
     """ConvTranspose3d weight [Cin,Cout,2,2,2] (8 taps) or ConvTranspose2d weight [Cin,Cout,2,2] (4 taps)"""
     ci, co = w.shape[0], w.shape[1]

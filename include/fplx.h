@@ -87,6 +87,12 @@ int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin,
  * step does after every optimizer step for all ConvBlockND convolutions, unet2d5_dsbn.py:54-55).  wb[i] may be NULL. */
 int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf, void* const* wb, const int* cout,
                                    const int* cin, int dt, fplx_stream_t stream);
+/* n (<= 16) small packs in one launch: job i is a convolution weight [a][b][taps] fp32 (kind 0: a = Cout, b = Cin, layouts of
+ * fplx_pack_conv_weight) or a transposed-convolution weight (kind 1: a = Cin, b = Cout, layouts of fplx_pack_deconv_weight /
+ * _deconv122_weight) packed into wf[i] / wb[i] (either may be NULL) in dtype dt[i] - the stem, the four transposed convolutions
+ * and out_conv of the network (unet2d5_dsbn.py:54, 152, 293): what a train step otherwise launches one by one after Adam */
+int fplx_pack_weights_multi(int n, const int* kind, const float* const* w, void* const* wf, void* const* wb, const int* a,
+                            const int* b, const int* taps, const int* dt, fplx_stream_t stream);
 /* nn.ConvTranspose3d weight [Cin][Cout][2][2][2] fp32 (unet2d5_dsbn.py:152)
  *   -> wf[tap][Cout][Cin] and wb[tap][Cin][Cout] (dtype dt), tap = (i*2+j)*2+k */
 int fplx_pack_deconv_weight(const float* w, void* wf, void* wb, int cin, int cout, int dt,

@@ -349,6 +349,32 @@ def test_fused_adam_matches_torch():
         ops.adam_step(p, g.cuda(), m, v, 1e-3, 0, 1e-5)
 
 
+def test_pack_weights_multi_equals_the_single_packs():
+    """fplx_pack_weights_multi (the transposed-convolution and out_conv packs of a step in one launch) against
+    fplx_pack_deconv_weight / fplx_pack_deconv122_weight / fplx_pack_conv_weight: bit for bit, incl. the fp32 out_conv pack, a
+    job with only the data-gradient layout, a ConvTranspose2d weight (4 taps) and odd channel counts."""
+    from fplx import ops
+    g = torch.Generator().manual_seed(4)
+    bf = torch.bfloat16
+    wd3 = torch.randn(24, 40, 2, 2, 2, generator=g).cuda()
+    wd2 = torch.randn(16, 8, 2, 2, generator=g).cuda()
+    wo = torch.randn(3, 32, 1, 3, 3, generator=g).cuda()
+    ws = torch.randn(32, 1, 3, 3, 3, generator=g).cuda()
+    ref3, ref2 = ops.pack_deconv_weight(wd3, bf), ops.pack_deconv_weight(wd2, bf)
+    ref_of, _ = ops.pack_conv_weight(wo, torch.float32, False)
+    _, ref_ob = ops.pack_conv_weight(wo, bf, True)
+    ref_s, _ = ops.pack_conv_weight(ws, bf, False)
+    e = lambda *shape, dt=bf: torch.full(shape, 7.0, dtype=dt, device="cuda")
+    o3, o2 = (e(8, 40, 24), e(8, 24, 40)), (e(4, 8, 16), e(4, 16, 8))
+    of, ob, os_ = e(9, 3, 32, dt=torch.float32), e(9, 32, 3), e(27, 32, 1)
+    ops.pack_weights_multi([(1, wd3, o3[0], o3[1], 24, 40, 8), (1, wd2, o2[0], o2[1], 16, 8, 4), (0, wo, of, None, 3, 32, 9),
+                            (0, wo, None, ob, 3, 32, 9), (0, ws, os_, None, 32, 1, 27)])
+    assert torch.equal(o3[0], ref3[0]) and torch.equal(o3[1], ref3[1]) and torch.equal(o2[0], ref2[0]) and torch.equal(o2[1], ref2[1])
+    assert torch.equal(of, ref_of) and torch.equal(ob, ref_ob) and torch.equal(os_, ref_s)
+    with pytest.raises(ValueError):
+        ops.pack_weights_multi([(2, wo, of, None, 3, 32, 9)])
+
+
 def test_fused_adam_pack_step_kernel():
     """fplx_adam_pack_step (Adam over a flat segment + the bf16 packs of the 3x3x3 weights inside it, one launch) against
     fplx_adam_step followed by fplx_pack_conv_weights_batched: parameters, both moments and both packs bit for bit, over three
