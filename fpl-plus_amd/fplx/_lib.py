@@ -155,6 +155,12 @@ _HOST_KNOBS = {
     "bucket_elems": 1 << 21,    # TrainStep: gradient all-reduce bucket size (elements)
     "pack_small_multi": 1,  # Engine._pack: the transposed-convolution and out_conv packs of a step in one launch (fplx_pack_weights_multi)
     "adam_pack": 1,         # FusedAdam.step_flat: the shared segment's Adam and the 3x3x3 weight packs in one launch (fplx_adam_pack_step)
+    # Engine.use_deep_fused: sites of at most 8192 voxels run split-K finish + BatchNorm chain in one launch each way.  OFF: measured
+    # slower (step +1.5 %, profiles/r05_kernel_ab.txt section 12: a block per channel group uses 16-32 bytes of every 128-byte line)
+    "deep_fused": 0,
+    # TrainStep.step on a single rank: the shared segment's Adam bucket by bucket during backward (AdamBehindBackward).  OFF: measured
+    # neutral (8.03 vs 8.04 ms, section 13: the update's 0.7 GB of traffic competes with the BatchNorm passes it runs beside)
+    "adam_overlap": 0,
     "ddp_overlap_all": 1,   # TrainStep.step_all under data parallelism: buckets folded + all-reduced during the last domain's backward
 }
 _host_vals = {}

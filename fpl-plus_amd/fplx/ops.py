@@ -358,6 +358,62 @@ def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta,
          dt_of(y), stream())
 
 
+# ---- one-launch sites of the small deep levels (fplx.h: fplx_conv3d_site_fwd / _bwd, fplx_bn_act_bwd_site)
+def deep_site_ok(voxels, c):
+    return _lib.lib().fplx_deep_site_ok(int(voxels), int(c)) == 1
+
+
+def conv3d_site_fwd_ok(dims, cin, cout, mid=False):
+    n, d, h, w = dims
+    return _lib.lib().fplx_conv3d_site_fwd_ok(n, d, h, w, int(cin), int(cout), 1 if mid else 0) == 1
+
+
+_site_scratch = {}
+
+
+def _fwd_workspace(dev, need):
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _fwd_ws or _fwd_ws[key].numel() < need:
+        _fwd_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    return _fwd_ws[key]
+
+
+def site_scratch(dev):
+    """the counter + per-block slots of the deep-site backward kernels: zero-filled once, per (device, stream)"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _site_scratch:
+        _site_scratch[key] = torch.zeros(int(_lib.lib().fplx_deep_site_scratch_bytes()), dtype=torch.uint8, device=dev)
+    return _site_scratch[key]
+
+
+def conv3d_site_fwd(x, wp, bias, dims, cin, cout, mid, bnm, bnbuf, slope, p, seed, sid, y, out):
+    """conv (split-K) -> batch statistics -> BN apply + PReLU + dropout in two launches (bnm: the domain's BatchNorm module)"""
+    n, d, h, w = dims
+    ws = _fwd_workspace(y.device, conv3d_fwd_ws_bytes(dims, cin, cout, (3, 3, 3), BF16, BF16, mid))
+    call("fplx_conv3d_site_fwd", ptr(x), ld_of(x), ptr(wp), ptr(bias), n, d, h, w, int(cin), int(cout), 1 if mid else 0, ptr(ws),
+         ws.numel(), ptr(bnm.weight), ptr(bnm.bias), ptr(bnm.running_mean), ptr(bnm.running_var), ptr(bnm.num_batches_tracked),
+         float(bnm.momentum), float(bnm.eps), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p),
+         int(seed), int(sid), ptr(y), ld_of(y), ptr(out), ld_of(out), stream())
+
+
+def conv3d_site_bwd(dyin, wb, dims, cin, cout, mid, y, bnbuf, slope, p, seed, sid, train, dgamma, dbeta, dslope, dy):
+    """data gradient of the NEXT convolution (split-K) + the whole backward of this site on it, in two launches"""
+    n, d, h, w = dims
+    ws = _fwd_workspace(y.device, conv3d_fwd_ws_bytes(dims, cin, cout, (3, 3, 3), BF16, BF16, mid))
+    sc = site_scratch(y.device)
+    call("fplx_conv3d_site_bwd", ptr(dyin), ld_of(dyin), ptr(wb), n, d, h, w, int(cin), int(cout), 1 if mid else 0, ptr(ws), ws.numel(),
+         ptr(y), ld_of(y), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid),
+         1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(dy), ld_of(dy), ptr(sc), sc.numel(), stream())
+
+
+def bn_act_bwd_site(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope):
+    """bn_act_bwd's three stages in one launch (sites of at most 8192 voxels, deep_site_ok); dy may alias dout"""
+    sc = site_scratch(y.device)
+    call("fplx_bn_act_bwd_site", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]), ptr(bnbuf[1]),
+         ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), y.shape[0], int(c), 1 if train else 0, ptr(dgamma),
+         ptr(dbeta), ptr(dslope), ptr(sc), sc.numel(), stream())
+
+
 def maxpool2_fwd(x, y, dims, c, pd=2):
     """pd = 2: MaxPool3d(2); pd = 1: MaxPool2d(2) on every depth slice"""
     n, d, h, w = dims

@@ -264,6 +264,43 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
                           const float* slope, const float* coef, float p, uint64_t seed, uint32_t stream_id,
                           int64_t voxels, int c, int dt, fplx_stream_t stream);
 
+/* ---- one-launch sites of the small deep levels (round 5).  Where a site has at most 8192 voxels (levels 3 - 4 of the benchmark:
+ * 8000 x 256, 1000 x 512) its passes are launch latency, not bandwidth; BatchNorm is independent per channel, so a block that
+ * owns a group of channels for ALL voxels runs the whole chain without leaving the CU.  Replaces, per site of ConvBlockND
+ * (unet2d5_dsbn.py:66-81: Conv3d -> DomainSpecificBatchNorm3d -> PReLU -> Dropout) in train mode:
+ *   forward   the split-K finish of fplx_conv3d_fwd + fplx_bn_train_finalize + fplx_bn_act_fwd
+ *   backward  the split-K finish of the data-gradient convolution that produces dout + fplx_bn_act_bwd_reduce / _finalize /
+ *             _apply (fplx_conv3d_site_bwd), or the three BatchNorm stages alone (fplx_bn_act_bwd_site)
+ * Same arithmetic per element (y and dout are rounded to bf16 exactly where the stored tensors were), sums in another fixed
+ * order.  bf16 only.  scratch: fplx_deep_site_scratch_bytes() bytes, zero-filled ONCE by the caller and then owned by these
+ * calls on one stream (a counter that the last block of every launch resets + one double per block). */
+int fplx_deep_site_ok(int64_t voxels, int c);
+size_t fplx_deep_site_scratch_bytes(void);
+/* 1 if the 3x3x3 layer (mid: a Conv2d per depth slice as a 27-tap pack) has a split-K plan AND fplx_deep_site_ok holds */
+int fplx_conv3d_site_fwd_ok(int n, int d, int h, int w, int cin, int cout, int mid);
+/* x [V, cin] bf16 ld ldx, wp: fplx_pack_conv_weight's forward pack, ws: fplx_conv3d_fwd_ws_bytes bytes.  Writes y (the
+ * convolution output, kept for backward), mean / rstd / scale / shift, updates the running statistics and nbt like
+ * fplx_bn_train_finalize, and out = dropout(PReLU(scale y + shift)) like fplx_bn_act_fwd. */
+int fplx_conv3d_site_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, int n, int d, int h, int w, int cin,
+                         int cout, int mid, void* ws, size_t ws_bytes, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* mean,
+                         float* rstd, float* scale, float* shift, const float* slope, float p, uint64_t seed,
+                         uint32_t stream_id, void* y, int64_t ldy, void* out, int64_t ldo, fplx_stream_t stream);
+/* dyin [V, cin] bf16: the gradient w.r.t. the output of the NEXT convolution (cin -> ... its data gradient has cout channels),
+ * wb: that convolution's backward pack.  dout = bf16(data gradient) is never stored: the site's backward runs on it -> dy
+ * [V, cout]; dgamma / dbeta / dslope are ACCUMULATED like fplx_bn_act_bwd_finalize.  y, mean .. shift, slope, p, seed,
+ * stream_id: the site's own (cout channels). */
+int fplx_conv3d_site_bwd(const void* dyin, int64_t ldx, const void* wb, int n, int d, int h, int w, int cin, int cout, int mid,
+                         void* ws, size_t ws_bytes, const void* y, int64_t ldy, const float* mean, const float* rstd,
+                         const float* scale, const float* shift, const float* slope, float p, uint64_t seed, uint32_t stream_id,
+                         int train, float* dgamma, float* dbeta, float* dslope, void* dy, int64_t ldo, void* scratch,
+                         size_t scratch_bytes, fplx_stream_t stream);
+/* fplx_bn_act_bwd_reduce + _finalize + _apply in one launch (dy may alias dout) */
+int fplx_bn_act_bwd_site(const void* y, int64_t ldy, const void* dout, int64_t ldd, void* dy, int64_t ldo, const float* mean,
+                         const float* rstd, const float* scale, const float* shift, const float* slope, float p, uint64_t seed,
+                         uint32_t stream_id, int64_t voxels, int c, int train, float* dgamma, float* dbeta, float* dslope,
+                         void* scratch, size_t scratch_bytes, fplx_stream_t stream);
+
 /* ------------------------------------------------------------------ pooling
  * nn.MaxPool3d(2,2) (unet2d5_dsbn.py:106,117).  x [N,D,H,W,C] ld ldx -> y [N,D/2,H/2,W/2,C] ld ldy */
 int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,

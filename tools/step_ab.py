@@ -4,7 +4,7 @@ interleaved rounds (workspaces grow on first use: two untimed steps follow every
 per setting with min / max.
 
     python tools/step_ab.py "wg_roll=0" "wg_roll=1" ["wg_roll=1,wg_roll_geo=1" ...] [--steps 20] [--rounds 5]
-    engine attributes are set with a leading '@':  "@use_side_stream=0"
+    engine attributes are set with a leading '@':  "@use_side_stream=0";  TrainStep attributes with '%':  "%adam_overlap=0"
 """
 import os
 import sys
@@ -29,8 +29,8 @@ def parse(arg):
         if not item or item == "default":
             continue
         k, v = item.split("=")
-        if k.startswith("@"):
-            attrs[k[1:]] = int(v)
+        if k.startswith("@") or k.startswith("%"):
+            attrs[k] = int(v)
         else:
             knobs[k] = int(v)
     return knobs, attrs
@@ -59,7 +59,8 @@ def main():
     net._ensure_flat()
     ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-4, weight_decay=1e-5, milestones=[10000, 20000], gamma=0.5)
     attr_keys = sorted({k for _, _, at in settings for k in at})
-    attr_def = {k: getattr(net.engine, k) for k in attr_keys}
+    owner = lambda k: net.engine if k[0] == "@" else ts
+    attr_def = {k: getattr(owner(k), k[1:]) for k in attr_keys}
     runs = [(name, kn, at, []) for name, kn, at in settings]
     import contextlib
     ctx = torch.cuda.stream(hi) if hi is not None else contextlib.nullcontext()
@@ -69,7 +70,7 @@ def main():
               apply(kn)
               net.engine.invalidate()                     # packs / plans cached under the previous knobs
               for k in attr_keys:
-                  setattr(net.engine, k, type(attr_def[k])(at[k]) if k in at else attr_def[k])
+                  setattr(owner(k), k[1:], type(attr_def[k])(at[k]) if k in at else attr_def[k])
               for i in range(3 if r else 6):
                   ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
               torch.cuda.synchronize()

@@ -13,13 +13,14 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "0"), name[:44]))
 rows.sort()
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-# steady state: the last nsteps train steps, delimited by the optimiser launches: since round 5 the shared segment's launch is
-# adam_pack27_multi (Adam + weight packs, one per step); before, two adam_k per step (shared + domain segment)
-fused = [e for s, e, q, n in rows if n.startswith("adam_pack27_multi")]
-adam = [e for s, e, q, n in rows if n.startswith("adam_k")]
-if len(fused) > nsteps:
-    t0, t1 = fused[-nsteps - 1], fused[-1]
+# steady state: the last nsteps train steps, delimited by the first kernel of a forward pass (the stem convolution: one per
+# step).  (The optimiser launches no longer mark a step's end: since round 5 the shared segment's Adam runs in pieces during
+# backward - train.py AdamBehindBackward.)
+stem = [s for s, e, q, n in rows if n.startswith("stem_fwd")]
+if len(stem) > nsteps:
+    t0, t1 = stem[-nsteps - 1], stem[-1] - 1
 else:
+    adam = [e for s, e, q, n in rows if n.startswith("adam_k")]
     t0, t1 = adam[-2 * nsteps - 1], adam[-1]
 rows = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 span = rows[-1][1] - rows[0][0]
