@@ -65,20 +65,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// number of partial rows (= blocks) used by the streaming reductions: a fixed function of the voxel count
-// so that producer and consumer agree without extra plumbing.  One row per 64 voxels, at most 512: the deep levels
-// (8000 / 1000 voxels x 256 / 512 channels) still spread over the chip - with one row per 2048 voxels they ran on 1-32
-// CUs and cost as much as level 0 - and the finalize kernels read at most 512 rows (measured: +4% on the train step).
-// (Part of the ABI's contract - callers size their buffers from fplx_num_partials / fplx_*_stats_rows - so a constant,
-// not an environment knob.)
-static inline int fplx_rows_for(int64_t voxels) {
-  constexpr int div = 64, cap = 512;
-  int64_t r = (voxels + div - 1) / div;
-  if (r > cap) r = cap;
-  if (r < 1) r = 1;
-  return (int)r;
-}
-
 #ifdef __HIPCC__
 // one element of torch.optim.Adam (get_optimizer.py:17) - shared by adam_k (elementwise.hip) and the fused Adam + weight-pack
 // kernel (conv_generic.hip) so that both form the same expression tree (same contractions): bit-identical parameters
@@ -177,6 +163,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(MID_TILE, "mid_tile", 1)                                                                                           \
   X(DECONV_ROWS, "deconv_rows", 1)                                                                                     \
   X(DECONV_DGRAD_ROWS, "deconv_dgrad_rows", 1)  /* 0: conv_fwd_direct for the shallow transposed-convolution data gradients */ \
+  X(ROWS_SMALL_DIV, "rows_small_div", 16)  /* voxels per partial row of the streaming reductions for volumes <= 32768 voxels (64: as for the large ones) */ \
   X(EW_GROUP, "ew_group", 1)                                                                                           \
   X(POOL_COL, "pool_col", 1)               /* 0: the fused DownBlock-tail passes with a thread per pooled voxel */          \
   X(EW_INFLIGHT, "ew_inflight", 2)         /* voxels (pairs of 16-byte loads) in flight per lane of bn_act_bwd_apply: 4, 2, 1 (131 / 99 / 72 registers) */ \
@@ -190,3 +177,21 @@ enum FplxKnobId {
 extern "C" __attribute__((visibility("hidden"))) int64_t fplx_knob_values[FPLX_K_COUNT];     // conv_generic.hip
 static inline int64_t fplx_knob(int id) { return __atomic_load_n(&fplx_knob_values[id], __ATOMIC_RELAXED); }
 static inline int fplx_xcd_on() { return (int)fplx_knob(FPLX_K_XCD); }
+
+// number of partial rows (= blocks) used by the streaming reductions: a fixed function of the voxel count
+// so that producer and consumer agree without extra plumbing.  One row per 64 voxels, at most 512: the deep levels
+// (8000 / 1000 voxels x 256 / 512 channels) still spread over the chip - with one row per 2048 voxels they ran on 1-32
+// CUs and cost as much as level 0 - and the finalize kernels read at most 512 rows (measured: +4% on the train step).
+// Round 5: one row per 16 voxels for volumes of at most 32768 voxels - with 64 the reduction of a 1000-voxel site ran on 16
+// blocks, 16 voxels one after the other per lane (14 us; 63 blocks: see profiles/r05_kernel_ab.txt section 14).
+// (Part of the ABI's contract - callers size their buffers from fplx_num_partials / fplx_*_stats_rows.  The knob "rows_small_div"
+// exists for A/B only: it must not change between a producer and its consumer, i.e. inside a step.)
+static inline int fplx_rows_for(int64_t voxels) {
+  constexpr int cap = 512;
+  const int div = voxels <= 32768 ? (int)fplx_knob(FPLX_K_ROWS_SMALL_DIV) : 64;
+  int64_t r = (voxels + div - 1) / div;
+  if (r > cap) r = cap;
+  if (r < 1) r = 1;
+  return (int)r;
+}
+
