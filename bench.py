@@ -22,6 +22,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # see fplx/_lib.py: keeps the two backward streams on queues of their own
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (fplx/_lib.py)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "fpl-plus_amd"), os.path.join(ROOT, "tests", "golden")):

@@ -16,6 +16,11 @@ import re
 # (profiles/r02_rccl_single_rank.txt).  Must be in the environment before the HIP runtime initialises, i.e. before the
 # first GPU call of the process; an explicit setting of the user wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in DEVICE memory: by default the runtime leaves the kernarg segment in host memory and every dispatch reads it
+# across the host link before its first wave starts - about 1.1 us per launch.  The train step is 211 dependent launches, a
+# quarter of them shorter than 10 us: 8.62 -> 8.38 ms (-2.8 %, three alternating pairs of processes on one box,
+# profiles/r05_kernel_ab.txt section 19).  Same rule: read when the HIP runtime initialises, an explicit setting of the user wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 # torch first: libfplx.so must bind to the SAME HIP runtime (libamdhip64.so.7) the process uses
 # for its device memory and streams.  PyTorch-ROCm ships its own copy; whichever copy is loaded

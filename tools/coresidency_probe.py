@@ -9,6 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fpl-plus_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (fplx/_lib.py)
 import torch  # noqa: E402
 
 from fplx import ops, _lib  # noqa: E402

@@ -24,6 +24,7 @@ def run():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29577")
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     sys.path.insert(0, os.path.join(ROOT, "fpl-plus_amd"))
     sys.path.insert(0, ROOT)
     import torch

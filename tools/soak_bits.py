@@ -8,6 +8,7 @@ import sys
 
 sys.path.insert(0, os.path.join(os.getcwd(), "fpl-plus_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # kernel arguments in device memory (fplx/_lib.py)
 import torch  # noqa: E402
 import fplx  # noqa: E402
 
