@@ -124,7 +124,6 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(BRICK_FILL, "brick_fill", 192)         /* the Cin split of the brick kernel grows until the launch has this many blocks */  \
   X(BRICK_GEO, "brick_geo", -1)            /* >= 0: force this brick geometry on every eligible layer (tests) */        \
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
-  X(BRICK_LW, "brick_lw", 7)               /* loader-wave bricks (conv_fwd_brick_lw): bit 0 <4,2,1>, bit 1 <4,2,2>, bit 2 <5,1,1>; 0: conv_fwd_brick */ \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \
   X(STEM_ROWS, "stem_rows", 1)             /* 0: the tile kernel for in_chns = 1 too */                                 \
   X(OUTCONV_T, "outconv_t", 1)             /* 0: the 32 x 32 out_conv forward (classes as columns) */                    \
@@ -135,7 +134,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(MARCH64_FW, "march64_fw", 0)           /* 16 / 32: force the footprint of the Cin = 64 march */                     \
   X(MARCH_DS, "march_ds", 0)               /* > 0: force the depth split of the march kernels */                        \
   X(MARCH128, "march128", 1)                                                                                           \
-  X(MARCH64_LW, "march64_lw", 1)           /* loader-wave form of conv_fwd_march64: bit 0 the 2.5D (Conv2d) forms, bit 1 the 3D forms; 0: off */ \
+  X(MARCH64_LW, "march64_lw", 1)           /* loader-wave form of conv_fwd_march64 for the 2.5D (Conv2d) forms; 0: conv_fwd_march64 (A/B, tested both ways) */ \
   X(MARCH32_V2, "march32_v2", 4)           /* 0: 8-wave kernel; 1: v2 everywhere; 4: v2 forward + v3 data gradient */   \
   X(WG_COT_MINVOX, "wg_cot_minvox", 0)                                                                                 \
   X(WG_TW, "wg_tw", 0)                                                                                                 \

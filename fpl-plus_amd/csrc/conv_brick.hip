@@ -1,4 +1,4 @@
-// conv_fwd_brick: 3x3x3 convolution (forward and, with the mirrored pack, data gradient) for the levels whose planes are too
+// conv_fwd_brick_lw: 3x3x3 convolution (forward and, with the mirrored pack, data gradient) for the levels whose planes are too
 // small for the depth march (W < 64) and whose channel counts are too large for resident weights: Cin % 32 == 0,
 // Cout % 128 == 0 - levels 2.. of the 32-base network (128 / 256 channels on 20 x 40 x 40 at the benchmark shape).
 // (reference op: PyMIC/pymic/net/net3d/unet2d5_dsbn.py:66-81 ConvBlockND's nn.Conv3d(k=3, padding=1))
@@ -62,457 +62,6 @@ struct BKG : BK {
 __device__ __forceinline__ int bk_row(int m) { return 2 * (m >> 4) + (((m >> 4) ^ (m >> 3) ^ (m >> 2)) & 1); }
 __device__ __forceinline__ int bk_col(int m) { return ((m >> 3) & 1) * 4 + (m & 3); }
 
-// ACT (inference, eval-mode BatchNorm folded into the pack): PReLU(slope) in the write-out (STATS must be false)
-// CAT2 (inference forms only): the input is the channel concatenation of TWO tensors of Cin / 2 channels and one leading
-// dimension - chunks below Cin / 2 come from x, sample n % nmod0 (nmod0 > 0: the skip tensor that the Monte-Carlo passes
-// share, one copy for all of them), the rest from x1
-template <bool STATS, int NTW, int TD, int WH, bool ACT = false, bool CAT2 = false>
-__global__ void __launch_bounds__(BK::THREADS)
-conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
-               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int Cin, int Cout,
-               float* __restrict__ stats, float* __restrict__ partial, int bD, int bH, int bW, int xcd, const float* __restrict__ slope_p = nullptr,
-               const bf16_t* __restrict__ x1 = nullptr, int nmod0 = 0) {
-  using G = BKG<TD, WH, NTW>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* bricks = smem;
-  char* wring = smem + 2 * G::BRICK_BYTES;
-  float* bias_s = reinterpret_cast<float*>(wring + G::NWS * G::WST_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, khalf = lane >> 5;
-  const int hhalf = wave / G::WN, wn = wave % G::WN;
-  // Which (output-channel tile, Cin split) = weight slice and which part of the brick list this block takes.  The dispatcher
-  // deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own 4-MB L2 (common.h):
-  //   xcd == 1: XCD j sweeps its contiguous eighth of the brick list for every slice (fplx_xcd_tiles) - neighbouring bricks,
-  //             shared halos, one L2: the levels whose weights fit an L2 beside the activations (levels 1-2);
-  //   xcd == 2: (the launcher made grid.x * U a multiple of 8, U = grid.y * grid.z slices) every XCD works on ONE slice (U
-  //             divides 8) or on U / 8 of them: the slice - 27 x NT x Cin / grid.z weights, streamed once per brick - stays
-  //             in that XCD's L2.  The deep levels' packs are 3.5-14 MB: dealt the other way every L2 streams all of it for
-  //             every brick (level 3, 256 -> 512: 122 -> 75 us).
-  int by = blockIdx.y, bz = blockIdx.z;
-  FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd == 1);
-  if (xcd == 2) {
-    const unsigned gx = gridDim.x, U = gridDim.y * gridDim.z;
-    const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x, xc = L & 7u, idx = L >> 3;
-    unsigned u, stripe;
-    if (8 % U == 0) { u = xc % U; stripe = idx * (8 / U) + xc / U; }
-    else { u = xc + 8 * (idx % (U / 8)); stripe = idx / (U / 8); }
-    by = __builtin_amdgcn_readfirstlane((int)(u % gridDim.y));
-    bz = __builtin_amdgcn_readfirstlane((int)(u / gridDim.y));
-    tr.first = __builtin_amdgcn_readfirstlane((int)stripe);
-    tr.step = gx;
-  }
-  const int n0 = by * G::NT;
-  // persistent: the next brick's first chunk is fetched during the current brick's last one, the weight ring never stops
-  if (tr.first >= tr.end) return;
-
-  // blockIdx.z deals the 32-channel chunks of Cin (split-K for the small deep volumes): fp32 partial tiles, summed by
-  // splitk_finish_k (conv_mfma.hip)
-  const int c_lo = (int)((int64_t)(Cin / G::KC) * bz / gridDim.z);
-  const int nch = (int)((int64_t)(Cin / G::KC) * (bz + 1) / gridDim.z) - c_lo;
-
-  // ---- DMA plumbing (see conv_fwd_march32v2): out-of-range lanes of a buffer load to LDS write zeros
-  const int64_t xsample = (int64_t)D * H * W * ldx * 2;
-  u32x4 rw;
-  rw[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wp);
-  rw[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)wp >> 32) & 0xFFFFu);
-  rw[2] = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)27 * Cout * Cin * 2));
-  rw[3] = 0x00020000u;
-  // (LDS destinations as plain integers: a pointer cast per piece costs a null check and a branch)
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((__attribute__((address_space(3))) char*)smem));
-  auto buf_dma = [&](const u32x4& rsrc, unsigned vo, unsigned so, unsigned dst_off) {        // dst_off: byte offset inside smem
-    const unsigned dst = lds0 + dst_off;
-    const unsigned so_ = __builtin_amdgcn_readfirstlane(so);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so_), "s"(dst) : "memory");
-  };
-  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  auto block_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  // a brick's coordinates, its descriptor (the sample's volume) and its DMA lane offsets: piece p = wave + 4 k covers LDS
-  // bytes [p * 1024, +1024) of the slot, lane -> 16-byte chunk
-  struct Brick { int n, n0, d0, h0, w0; unsigned vo[G::NPB]; };
-  auto setup = [&](int64_t tile, Brick& B) {
-    int b = (int)tile;
-    const int bw = b % bW; b /= bW;
-    const int bh = b % bH; b /= bH;
-    const int bd = b % bD; b /= bD;
-    B.n = __builtin_amdgcn_readfirstlane(b);
-    B.n0 = (CAT2 && nmod0 > 0) ? __builtin_amdgcn_readfirstlane(b % nmod0) : B.n;
-    B.d0 = __builtin_amdgcn_readfirstlane(bd * G::TD);
-    B.h0 = __builtin_amdgcn_readfirstlane(bh * G::TH);
-    B.w0 = __builtin_amdgcn_readfirstlane(bw * G::TW);
-#pragma unroll
-    for (int k = 0; k < G::NPB; ++k) {
-      // (a piece index past the slot's end repeats the slot's last piece - same bytes, same place: every wave issues NPB pieces)
-      const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
-      const int ci = pidx * 64 + lane;
-      const int L = ci >> 2, cc = (ci & 3) ^ ((L >> 2) & 3);
-      const int q = L / G::PL, rem = L % G::PL, hh = rem / G::SWP, ww = rem % G::SWP;
-      const int gd = B.d0 - 1 + q, gh = B.h0 - 1 + hh, gw = B.w0 - 1 + ww;
-      const bool in = q < G::SD && rem < G::SH * G::SWP && ww < 10 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-      B.vo[k] = in ? (unsigned)(((((int64_t)gd * H + gh) * W + gw) * ldx + cc * 8) * 2) : 0x40000000u;
-    }
-  };
-  // weight pieces: piece j = wave + 4 k of a stage: rows j * 16 + (lane >> 2) of [kd][NT couts], swizzle (lane >> 4) & 3
-  const unsigned wvo = (unsigned)((((int64_t)(n0 + (lane >> 2))) * Cin + ((lane & 3) ^ ((lane >> 4) & 3)) * 8) * 2);
-  const unsigned tapstride = (unsigned)((int64_t)Cout * Cin * 2);       // bytes per tap of the pack
-  auto brick_pieces = [&](const Brick& B, int ch, int slot, int k0, int cnt) {     // pieces k0 .. k0 + cnt - 1 of chunk ch
-    int c = c_lo + ch;                                                            // uniform
-    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
-    if (CAT2) {
-      const int half = Cin / (2 * G::KC);
-      if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
-      else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
-    }
-    u32x4 rx;
-    rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
-    rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
-    rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
-    rx[3] = 0x00020000u;
-#pragma unroll
-    for (int k = k0; k < k0 + cnt; ++k)
-      if (k < G::NPB && wave + 4 * k < G::NP_TOT)            // uniform
-        buf_dma(rx, B.vo[k], (unsigned)(c * G::KC * 2), (unsigned)(slot * G::BRICK_BYTES + (wave + 4 * k) * 1024));
-  };
-  // the stage loop's form: every wave issues the SAME number of pieces per stage (the stage's closing wait counts them; see
-  // setup for the piece past the slot's end); on = false (nothing follows): the scalar offset is out of the descriptor's range,
-  // the free slot gets zeros.  brick_rsrc: the descriptor and channel offset of (brick, chunk), made once per stage.
-  struct BrickSrc { u32x4 rx; unsigned so; };
-  auto brick_rsrc = [&](const Brick& B, int ch, bool on) {
-    int c = c_lo + ch;
-    const char* xn = reinterpret_cast<const char*>(x) + (int64_t)B.n * xsample;
-    if (CAT2) {
-      const int half = Cin / (2 * G::KC);
-      if (c >= half) { xn = reinterpret_cast<const char*>(x1) + (int64_t)B.n * xsample; c -= half; }
-      else xn = reinterpret_cast<const char*>(x) + (int64_t)B.n0 * xsample;
-    }
-    BrickSrc r;
-    r.rx[0] = __builtin_amdgcn_readfirstlane((unsigned)(size_t)xn);
-    r.rx[1] = __builtin_amdgcn_readfirstlane((unsigned)((size_t)xn >> 32) & 0xFFFFu);
-    r.rx[2] = __builtin_amdgcn_readfirstlane((unsigned)xsample);
-    r.rx[3] = 0x00020000u;
-    r.so = __builtin_amdgcn_readfirstlane(on ? (unsigned)(c * G::KC * 2) : 0x40000000u);
-    return r;
-  };
-  auto brick_piece = [&](const BrickSrc& src, const Brick& B, int slot, int k) {
-    const int pidx = wave + 4 * k < G::NP_TOT ? wave + 4 * k : G::NP_TOT - 1;
-    buf_dma(src.rx, B.vo[k], src.so, (unsigned)(slot * G::BRICK_BYTES + pidx * 1024));
-  };
-  auto weight_stage = [&](int ch, int t9, int slot) {       // all pieces of stage (chunk ch, taps (., t9 / 3, t9 % 3))
-#pragma unroll
-    for (int k = 0; k < G::NPW; ++k) {
-      const int j = wave + 4 * k, kd = j / (G::NT / 16);
-      const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
-      buf_dma(rw, wvo, so, (unsigned)(2 * G::BRICK_BYTES + slot * G::WST_BYTES + j * 1024));
-    }
-  };
-
-  // one DMA piece at a time, for the second half of a stage where the pieces ride between the MFMAs.  Cycle stamps (tools/micro/
-  // brick_bench.hip, -DFPLX_STAMP), level 1 64 -> 64: a half without DMA runs its 12 MFMAs in 435-450 cycles (384 of issue); the 5
-  // pieces of a wave issued as a block behind the barrier cost 520 cycles with the matrix pipe idle (790 for 8 pieces at level 2).
-  // Between the MFMAs the half takes 1090 cycles instead of 483 + 523: a piece still holds the issuing wave for about 120 cycles
-  // wherever it sits (2 pieces 6 MFMAs apart: +235 cycles; without the M0 save / restore: the same) - only the surrounding scalar
-  // work is hidden.  Alone -5..-10 % per launch, the train step -0.9 %.
-  auto weight_piece = [&](int ch, int t9, int slot, int k, bool on) {
-    const int j = wave + 4 * k, kd = j / (G::NT / 16);
-    const unsigned so = (unsigned)(kd * 9 + t9) * tapstride + (unsigned)(((j % (G::NT / 16)) * 16 * Cin + (c_lo + ch) * G::KC) * 2);
-    buf_dma(rw, wvo, on ? so : 0x40000000u, (unsigned)(2 * G::BRICK_BYTES + slot * G::WST_BYTES + j * 1024));
-  };
-
-  f32x16 acc[TD][NTW];
-#pragma unroll
-  for (int p = 0; p < TD; ++p)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
-
-  Brick cur, nxt;
-  int64_t tile = tr.first;
-  setup(tile, cur);
-  // prologue: brick chunk 0 -> brick slot 0, weight stages 0 and 1
-  brick_pieces(cur, 0, 0, 0, G::NPB);
-  weight_stage(0, 0, 0);
-  weight_stage(0, 1, 1);
-  if (tid < G::NT) bias_s[tid] = bias ? bias[n0 + tid] : 0.f;
-  dma_wait();
-  block_sync();
-
-  // fragment addresses: A lane base (voxel index of the patch's tap (0, 0, 0) corner voxel), B lane base
-  const int L0 = (hhalf * 4 + bk_row(r)) * G::SWP + bk_col(r);
-  const int bb = (wn * (32 * NTW) + r) * G::ROWB + ((khalf ^ ((r >> 2) & 3)) << 4);
-  bf16x8 fa[2][G::SD], fb[2][3 * NTW];
-  auto load_a = [&](const char* brick, int kh, int kw, int ks, int buf) {
-    int a0 = L0 + kh * G::SWP + kw;
-    asm volatile("" : "+v"(a0));
-    const char* p = brick + a0 * G::ROWB + (((2 * ks + khalf) ^ ((a0 >> 2) & 3)) << 4);
-#pragma unroll
-    for (int q = 0; q < G::SD; ++q) fa[buf][q] = *reinterpret_cast<const bf16x8*>(p + q * G::PL * G::ROWB);
-  };
-  auto load_b = [&](const char* wslot, int ks, int buf) {
-    int b0 = bb;
-    asm volatile("" : "+v"(b0));
-    const char* p = wslot + (b0 ^ (ks << 5));
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        fb[buf][kd * NTW + j] = *reinterpret_cast<const bf16x8*>(p + (kd * G::NT + j * 32) * G::ROWB);
-  };
-  auto mfmas = [&](int buf, int kd) {
-#pragma unroll
-    for (int p = 0; p < TD; ++p)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j)
-        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][p + kd], fb[buf][kd * NTW + j], acc[p][j], 0, 0, 0);
-  };
-  const int rh = khalf * 4;
-
-  load_a(bricks, 0, 0, 0, 0);
-  load_b(wring, 0, 0);
-  int cc = 0;                                               // chunks done so far (all bricks): brick slot = cc & 1
-  int gs = 0;                                               // stages done so far
-  int ws = 0;                                               // ... modulo the ring: this stage's weight slot
-#ifdef FPLX_STAMP
-  long long st_h1 = 0, st_wait = 0, st_bar = 0, st_dma = 0, st_h2 = 0, st_wo = 0, st_n = 0;
-  const long long st_begin = __builtin_amdgcn_s_memtime();
-  const long long st_rbegin = __builtin_amdgcn_s_memrealtime();
-#define STAMP(var_) do { const long long t__ = __builtin_amdgcn_s_memtime(); var_ += t__ - st_t; st_t = t__; } while (0)
-#else
-#define STAMP(var_) do { } while (0)
-#endif
-  for (;;) {
-    const int64_t tile_nx = tile + tr.step;
-    const bool has_next = tile_nx < tr.end;                  // uniform
-    if (has_next) setup(tile_nx, nxt);
-    for (int ch = 0; ch < nch; ++ch, ++cc) {
-      const char* brick = bricks + (cc & 1) * G::BRICK_BYTES;
-      const char* brick_nx = bricks + ((cc + 1) & 1) * G::BRICK_BYTES;
-      const bool last_ch = ch + 1 == nch;
-#pragma unroll
-      for (int t9 = 0; t9 < 9; ++t9, ++gs) {
-        const int kh = t9 / 3, kw = t9 % 3;
-        const int s1 = ws + 1 == G::NWS ? 0 : ws + 1, s2 = s1 + 1 == G::NWS ? 0 : s1 + 1;      // slots of stages gs + 1, gs + 2
-        const char* wslot = wring + ws * G::WST_BYTES;
-        const char* wslot_nx = wring + s1 * G::WST_BYTES;
-        // ---- this stage's DMA work: the NPW pieces of stage gs + 2's weights and up to two pieces of the next chunk of the
-        // brick (the next brick's first chunk behind the last one).  Every wave issues ALL of them in every stage - nothing
-        // follows: out of range, zeros into a free slot - so that the stage's closing wait can count.
-        int ch2 = ch, t92 = t9 + 2;
-        if (t92 >= 9) { t92 -= 9; ++ch2; }
-        const bool w_on = ch2 < nch || has_next;             // uniform
-        if (ch2 >= nch) ch2 = 0;
-        const bool b_on = !last_ch || has_next;
-        const int nbp = 2 * t9 + 1 < G::NPB ? 2 : (2 * t9 < G::NPB ? 1 : 0);      // brick pieces of this stage (compile-time)
-        const int nps = G::NPW + nbp;
-        BrickSrc bsrc;
-        if (nbp > 0) bsrc = last_ch ? brick_rsrc(nxt, 0, b_on) : brick_rsrc(cur, ch + 1, true);
-        auto piece = [&](int i) {
-          if (i < G::NPW) weight_piece(ch2, t92, s2, i, w_on);
-          else brick_piece(bsrc, last_ch ? nxt : cur, (cc + 1) & 1, 2 * t9 + (i - G::NPW));
-        };
-        // Where the pieces sit (cycle stamps, tools/micro/brick_bench.hip and lds_dma_issue.hip: a piece of 16 separate 64-byte
-        // rows takes the issuing wave's memory path about 130-160 cycles; closer together they queue and the wave cannot issue
-        // its MFMAs): three weight slots - the slot of stage gs + 2 is free all stage long, one piece every 2 M1 / nps MFMAs
-        // over BOTH halves; two slots - that slot is this stage's own until the barrier: the pieces share the second half.
-        const int gap = G::NWS == 3 ? 2 * G::M1 / nps : G::M1 / nps;
-        const int first = G::NWS == 3 ? 0 : G::M1;            // MFMA index behind which piece 0 goes
-        auto half = [&](int hf) {                             // hf: 0 = input channels 0-15 of the chunk, 1 = 16-31
-          int mi = hf * G::M1;
-#pragma unroll
-          for (int kd = 0; kd < 3; ++kd) {
-            if (kd == 1) { if (hf == 0) load_b(wslot, 1, 1); else load_b(wslot_nx, 0, 0); }
-#pragma unroll
-            for (int p = 0; p < TD; ++p)
-#pragma unroll
-              for (int j = 0; j < NTW; ++j) {
-                acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hf][p + kd], fb[hf][kd * NTW + j], acc[p][j], 0, 0, 0);
-                const int rel = mi - first;
-                if (rel >= 0 && rel % gap == 0 && rel / gap < nps) {
-                  __builtin_amdgcn_sched_barrier(0);
-                  piece(rel / gap);
-                  __builtin_amdgcn_sched_barrier(0);
-                }
-                ++mi;
-              }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        };
-        // ---- first half: prefetch the second half's fragments
-#ifdef FPLX_STAMP
-        long long st_t = __builtin_amdgcn_s_memtime();
-        ++st_n;
-#endif
-        load_a(brick, kh, kw, 1, 1);
-        half(0);
-        STAMP(st_h1);
-        // the next stage's weights and, at t9 == 8, the next chunk of the brick / the next brick's first chunk have landed -
-        // everything but what THIS stage's first half requested; nobody reads the stage before's weight slot / (at t9 == 8)
-        // this chunk's brick slot any more once past this barrier
-        {
-          int nfirst = 0;                                     // pieces issued in the first half (compile-time)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) if (i < nps && first + i * gap < G::M1) ++nfirst;
-          if (nfirst == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else if (nfirst == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          else if (nfirst == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-          else if (nfirst == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-          else if (nfirst == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if (nfirst == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        STAMP(st_wait);
-        block_sync();
-        STAMP(st_bar);
-        // ---- second half: next stage's fragments
-        STAMP(st_dma);
-        if (t9 < 8) load_a(brick, (t9 + 1) / 3, (t9 + 1) % 3, 0, 0); else load_a(brick_nx, 0, 0, 0, 0);
-        half(1);
-        STAMP(st_h2);
-        ws = s1;
-      }
-    }
-#ifdef FPLX_STAMP
-    const long long st_wo0 = __builtin_amdgcn_s_memtime();
-#endif
-
-    // ---- write-out of this brick: bias, statistics, bf16 through 2-KiB per-wave LDS tiles, 16-byte stores.  The tiles
-    // live in the brick slot of the chunk just finished: nobody has read it since the last stage's barrier, and the next
-    // DMA into it is issued behind the next stage's barrier, i.e. after every wave has left this write-out
-    char* dead = bricks + ((cc - 1) & 1) * G::BRICK_BYTES;
-    char* stg = dead + wave * 4096;
-    const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
-    // ragged bricks at the volume's far faces: validity of the 16 accumulator rows of this lane / of the rows it stores
-    const bool full = d0 + G::TD <= D && h0 + G::TH <= H && w0 + G::TW <= W;          // uniform
-    unsigned vmask = 0xFFFFu;
-    if (!full) {
-      vmask = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = (i & 3) + 8 * (i >> 2) + rh;
-        if (h0 + hhalf * 4 + bk_row(m) < H && w0 + bk_col(m) < W) vmask |= 1u << i;
-      }
-    }
-    // statistics in packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32: accumulator elements i, i + 1 sit in consecutive registers)
-    f32x2 s1[NTW], s2[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
-    const int mrow = lane >> 2;                                // this lane stores tile rows mrow and mrow + 16
-    const int64_t yrow0 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow)) * W + w0 + bk_col(mrow)) * ldy;
-    const int64_t yrow1 = ((int64_t)(h0 + hhalf * 4 + bk_row(mrow + 16)) * W + w0 + bk_col(mrow + 16)) * ldy;
-    const bool ok0 = h0 + hhalf * 4 + bk_row(mrow) < H && w0 + bk_col(mrow) < W;
-    const bool ok1 = h0 + hhalf * 4 + bk_row(mrow + 16) < H && w0 + bk_col(mrow + 16) < W;
-    bf16_t* ycol = y + n0 + wn * (32 * NTW) + (lane & 3) * 8;
-    const float slope_v = ACT ? *slope_p : 0.f;
-    auto write_out = [&](auto full_c) {
-      constexpr bool FULL = decltype(full_c)::value;
-#pragma unroll
-      for (int p = 0; p < TD; ++p) {
-        const int dd = d0 + p;
-        if (FULL || dd < D) {                                  // uniform
-          bf16_t* yp = ycol + ((int64_t)n * D + dd) * H * W * ldy;
-#pragma unroll
-          for (int j = 0; j < NTW; ++j) {
-            const float bv = bias_s[wn * (32 * NTW) + j * 32 + r];
-            char* tile_ = stg + ((p * NTW + j) & 1) * 2048;    // two tiles per wave, used alternately
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-              const int m = (i & 3) + 8 * (i >> 2) + rh;       // rows m, m + 1
-              f32x2 o = f32x2{acc[p][j][i], acc[p][j][i + 1]} + f32x2{bv, bv};
-              if (ACT) { o[0] = o[0] > 0.f ? o[0] : o[0] * slope_v; o[1] = o[1] > 0.f ? o[1] : o[1] * slope_v; }
-              *reinterpret_cast<bf16_t*>(tile_ + m * 64 + r * 2) = (bf16_t)o[0];
-              *reinterpret_cast<bf16_t*>(tile_ + (m + 1) * 64 + r * 2) = (bf16_t)o[1];
-              if (STATS) {
-                if (!FULL) {
-                  if (!((vmask >> i) & 1u)) o[0] = 0.f;
-                  if (!((vmask >> (i + 1)) & 1u)) o[1] = 0.f;
-                }
-                s1[j] += o;
-                s2[j] = __builtin_elementwise_fma(o, o, s2[j]);
-              }
-            }
-            const uint4 pk0 = *reinterpret_cast<const uint4*>(tile_ + mrow * 64 + (lane & 3) * 16);
-            const uint4 pk1 = *reinterpret_cast<const uint4*>(tile_ + (mrow + 16) * 64 + (lane & 3) * 16);
-            if (FULL || ok0) *reinterpret_cast<uint4*>(yp + yrow0 + j * 32) = pk0;
-            if (FULL || ok1) *reinterpret_cast<uint4*>(yp + yrow1 + j * 32) = pk1;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[p][j][i] = 0.f;
-      }
-    };
-    // split-K: the fp32 tile of (plane p, N-tile j) goes through the wave's 4 KiB as [voxel row m][32 channels] and leaves as
-    // 16-byte stores into partial[z][voxel][Cout]; bias, bf16 and statistics are splitk_finish_k's
-    auto write_partial = [&]() {
-      float* pz = partial + (int64_t)bz * ((int64_t)N * D * H * W) * Cout + n0 + wn * (32 * NTW) + (lane & 7) * 4;
-      float* stf = reinterpret_cast<float*>(stg);
-#pragma unroll
-      for (int p = 0; p < TD; ++p) {
-        const int dd = d0 + p;
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            stf[((i & 3) + 8 * (i >> 2) + rh) * 32 + r] = acc[p][j][i];
-            acc[p][j][i] = 0.f;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int m = (lane >> 3) + 8 * q;
-            const int hh = h0 + hhalf * 4 + bk_row(m), ww = w0 + bk_col(m);
-            const float4 pk = *reinterpret_cast<const float4*>(stf + m * 32 + (lane & 7) * 4);
-            if (dd < D && hh < H && ww < W)
-              *reinterpret_cast<float4*>(pz + ((((int64_t)n * D + dd) * H + hh) * W + ww) * Cout + j * 32) = pk;
-          }
-        }
-      }
-    };
-    if (partial) write_partial();
-    else if (full) write_out(std::true_type{});
-    else write_out(std::false_type{});
-    if (STATS && stats) {
-      float* red = reinterpret_cast<float*>(dead + 16384);     // [WH (hhalf)][2][NT]
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const float a_ = s1[j][0] + s1[j][1], q_ = s2[j][0] + s2[j][1];
-        const float a = a_ + __shfl_xor(a_, 32, 64), q2 = q_ + __shfl_xor(q_, 32, 64);
-        if (lane < 32) {
-          red[(hhalf * 2 + 0) * G::NT + wn * (32 * NTW) + j * 32 + r] = a;
-          red[(hhalf * 2 + 1) * G::NT + wn * (32 * NTW) + j * 32 + r] = q2;
-        }
-      }
-      block_sync();                                            // not __syncthreads(): that would wait for the stores' acknowledgement
-      if (tid < 2 * G::NT) {
-        const int which = tid / G::NT, c = tid % G::NT;
-        float t_ = red[(0 * 2 + which) * G::NT + c];
-        if (WH == 2) t_ += red[(1 * 2 + which) * G::NT + c];
-        stats[((int64_t)tile * 2 + which) * Cout + n0 + c] = t_;
-      }
-    }
-#ifdef FPLX_STAMP
-    st_wo += __builtin_amdgcn_s_memtime() - st_wo0;
-#endif
-    if (!has_next) break;
-    // three weight slots: the next stage's FIRST half already requests brick pieces - into the slot the write-out tiles live in
-    if (G::NWS == 3) block_sync();
-    tile = tile_nx;
-    cur = nxt;
-  }
-#ifdef FPLX_STAMP
-  if (lane == 0 && fplx_brick_stamp_buf) {
-    long long* o_ = fplx_brick_stamp_buf + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 10;
-    o_[0] = st_h1; o_[1] = st_wait; o_[2] = st_bar; o_[3] = st_dma; o_[4] = st_h2; o_[5] = st_wo; o_[6] = st_n;
-    o_[7] = __builtin_amdgcn_s_memtime() - st_begin; o_[8] = __builtin_amdgcn_s_memrealtime() - st_rbegin; o_[9] = 1;
-  }
-#endif
-#undef STAMP
-}
-
-
 // ------------------------------------------------------------------------------------------
 // conv_fwd_brick_lw (round 5): the same bricks, rings and LDS images with DEDICATED LOADER WAVES.  Cycle stamps of round 4
 // (profiles/r04_brick_stamps_after.txt): a stage's MFMAs are 768-960 cycles of issue, the stage takes 1135-1798 - every LDS-DMA
@@ -531,6 +80,11 @@ conv_fwd_brick(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restri
 //   * the write-out's staging tiles live in the dead brick slot, which is also where the NEXT brick's second chunk goes: the
 //     loaders pass one more barrier (behind the compute waves' write-out) before they issue brick pieces in a brick's first stage.
 // Registers: 2 waves per SIMD = 256 per lane; the accumulators (64-128) and the two fragment sets fit.
+// ACT (inference, eval-mode BatchNorm folded into the pack): PReLU(slope) in the write-out (STATS must be false)
+// CAT2 (inference forms only): the input is the channel concatenation of TWO tensors of Cin / 2 channels and one leading
+// dimension - chunks below Cin / 2 come from x, sample n % nmod0 (nmod0 > 0: the skip tensor that the Monte-Carlo passes
+// share, one copy for all of them), the rest from x1
+// (The round-2 kernel without loader waves, conv_fwd_brick, computed the same bits; it was removed in round 6 - git history.)
 template <bool STATS, int NTW, int TD, int WH, bool ACT = false, bool CAT2 = false>
 __global__ void __launch_bounds__(512)
 conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ wp, const float* __restrict__ bias,
@@ -548,9 +102,17 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
   const int wave = wave8 & 3;                                  // index inside the role
   const int r = lane & 31, khalf = lane >> 5;
   const int hhalf = wave / G::WN, wn = wave % G::WN;
+  // Which (output-channel tile, Cin split) = weight slice and which part of the brick list this block takes.  The dispatcher
+  // deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own 4-MB L2 (common.h):
+  //   xcd == 1: XCD j sweeps its contiguous eighth of the brick list for every slice (fplx_xcd_tiles) - neighbouring bricks,
+  //             shared halos, one L2: the levels whose weights fit an L2 beside the activations (levels 1-2);
+  //   xcd == 2: (the launcher made grid.x * U a multiple of 8, U = grid.y * grid.z slices) every XCD works on ONE slice (U
+  //             divides 8) or on U / 8 of them: the slice - 27 x NT x Cin / grid.z weights, streamed once per brick - stays
+  //             in that XCD's L2.  The deep levels' packs are 3.5-14 MB: dealt the other way every L2 streams all of it for
+  //             every brick (level 3, 256 -> 512: 122 -> 75 us).
   int by = blockIdx.y, bz = blockIdx.z;
   FplxTileRange tr = fplx_xcd_tiles((int64_t)N * bD * bH * bW, xcd == 1);
-  if (xcd == 2) {                                              // weight slice per XCD (see conv_fwd_brick)
+  if (xcd == 2) {
     const unsigned gx = gridDim.x, U = gridDim.y * gridDim.z;
     const unsigned L = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x, xc = L & 7u, idx = L >> 3;
     unsigned u, stripe;
@@ -595,7 +157,7 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(vo), "s"(rsrc), "s"(so_), "s"(dst) : "memory");
     };
-    // A brick's DMA lane offsets are NOT tabulated per brick (conv_fwd_brick's setup(): 12 pieces x 64-bit address arithmetic,
+    // A brick's DMA lane offsets are NOT tabulated per brick (the round-2 kernel's setup(): 12 pieces x 64-bit address arithmetic,
     // about 5 K cycles per brick in front of its first stage - 18 % of a level-1 launch by the stamps): a lane's offset is
     // brick base + a brick-independent delta, only its validity depends on the brick - the loaders have idle vector slots and
     // form it when they issue the piece.  dlt[k]: byte offset of the lane's 16 bytes of piece k relative to the voxel
@@ -821,7 +383,7 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
         const char* wslot = wring + ws * G::WST_BYTES;
         const char* wslot_nx = wring + s1 * G::WST_BYTES;
         // a half-stage: M1 MFMAs on fragment set hf, and the OTHER set's SD + 3 NTW fragment reads spread between them, one
-        // read in front of an MFMA (knob-free A/B: -DFPLX_BRICK_LW_BURST restores the bursts of conv_fwd_brick - all A reads
+        // read in front of an MFMA (knob-free A/B: -DFPLX_BRICK_LW_BURST restores the bursts of the round-2 kernel - all A reads
         // in front of the half, the B reads in its middle; the stamps showed the half behind the barrier, where four waves
         // burst 6-7 reads each while the loaders' DMA writes land, 90 cycles longer than the other one)
         auto half = [&](int hf, const char* abrick, int akh, int akw, int aks, const char* bslot, int bks) {
@@ -884,7 +446,7 @@ conv_fwd_brick_lw(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __res
 #ifdef FPLX_STAMP
     const long long st_wo0 = __builtin_amdgcn_s_memtime();
 #endif
-    // ---- write-out (as conv_fwd_brick): per-wave LDS tiles in the dead brick slot, 16-byte stores
+    // ---- write-out: per-wave LDS tiles in the dead brick slot, 16-byte stores
     char* dead = bricks + ((cc - 1) & 1) * G::BRICK_BYTES;
     char* stg = dead + wave * 4096;
     const int d0 = cur.d0, h0 = cur.h0, w0 = cur.w0, n = cur.n;
@@ -1185,19 +747,7 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
   }
   dim3 grid((unsigned)gx, gy, ksplit);
   float* part = ksplit > 1 ? partial : nullptr;
-  // loader-wave form (conv_fwd_brick_lw, 512 threads): knob brick_lw, bit 0: <4,2,1>, bit 1: <4,2,2>, bit 2: <5,1,1>
-  const int lw_mask = (int)fplx_knob(FPLX_K_BRICK_LW);
-  const bool lw = (geo == 1 ? (lw_mask & 4) : nt == 128 ? (lw_mask & 2) : (lw_mask & 1)) != 0;
-#define LAUNCH_BRICK_K(KERNEL_, STATS_, NTW_, TD_, WH_)                                                              \
-  do {                                                                                                               \
-    using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
-    (void)hipFuncSetAttribute((const void*)KERNEL_<STATS_, NTW_, TD_, WH_>,                                          \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
-    KERNEL_<STATS_, NTW_, TD_, WH_><<<grid, BK::THREADS, G_::LDS, st>>>(                                              \
-        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
-        bW, xcd_on);                                                                                                 \
-  } while (0)
-#define LAUNCH_BRICK_LW(STATS_, NTW_, TD_, WH_)                                                                      \
+#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_)                                                                         \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
     (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<STATS_, NTW_, TD_, WH_>,                                \
@@ -1206,42 +756,24 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
         (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, stats, part, bD, bH,  \
         bW, xcd_on);                                                                                                 \
   } while (0)
-#define LAUNCH_BRICK(STATS_, NTW_, TD_, WH_)                                                                         \
-  do { if (lw) LAUNCH_BRICK_LW(STATS_, NTW_, TD_, WH_); else LAUNCH_BRICK_K(conv_fwd_brick, STATS_, NTW_, TD_, WH_); } while (0)
   const bool st_ = stats && !part;
 #define LAUNCH_BRICK_ACT(NTW_, TD_, WH_)                                                                              \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
-    if (lw) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true>,                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
-      conv_fwd_brick_lw<false, NTW_, TD_, WH_, true><<<grid, 512, G_::LDS, st>>>(                                     \
-          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-          bH, bW, xcd_on, slope);                                                                                    \
-    } else {                                                                                                         \
-      (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true>,                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
-      conv_fwd_brick<false, NTW_, TD_, WH_, true><<<grid, BK::THREADS, G_::LDS, st>>>(                                \
-          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-          bH, bW, xcd_on, slope);                                                                                    \
-    }                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true>,                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick_lw<false, NTW_, TD_, WH_, true><<<grid, 512, G_::LDS, st>>>(                                       \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD,  \
+        bH, bW, xcd_on, slope);                                                                                      \
   } while (0)
 #define LAUNCH_BRICK_ACT2(NTW_, TD_, WH_)                                                                             \
   do {                                                                                                               \
     using G_ = BKG<TD_, WH_, NTW_>;                                                                                  \
-    if (lw) {                                                                                                        \
-      (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true>,                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
-      conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true><<<grid, 512, G_::LDS, st>>>(                               \
-          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-          bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                          \
-    } else {                                                                                                         \
-      (void)hipFuncSetAttribute((const void*)conv_fwd_brick<false, NTW_, TD_, WH_, true, true>,                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                \
-      conv_fwd_brick<false, NTW_, TD_, WH_, true, true><<<grid, BK::THREADS, G_::LDS, st>>>(                          \
-          (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD, \
-          bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                          \
-    }                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true>,                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS);                                  \
+    conv_fwd_brick_lw<false, NTW_, TD_, WH_, true, true><<<grid, 512, G_::LDS, st>>>(                                 \
+        (const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y, ldy, n, d, h, w, cin, cout, nullptr, nullptr, bD,  \
+        bH, bW, xcd_on, slope, (const bf16_t*)x1, nmod0);                                                            \
   } while (0)
   if (x1) {
     if (geo == 1) LAUNCH_BRICK_ACT2(1, 5, 1);
@@ -1259,8 +791,6 @@ extern "C" int fplx_brick_conv3d_fwd_act(const void* x, int64_t ldx, const void*
 #undef LAUNCH_BRICK_ACT2
 #undef LAUNCH_BRICK_ACT
 #undef LAUNCH_BRICK
-#undef LAUNCH_BRICK_LW
-#undef LAUNCH_BRICK_K
   const int rc = fplx_check_launch("brick_conv3d_fwd");
   return rc < 0 ? rc : 1;
 }

@@ -805,7 +805,7 @@ int fplx_pack_conv2d_weight(const float* w, void* wf, void* wb, int cout, int ci
   return fplx_check_launch("pack_conv2d_weight");
 }
 
-int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream) {
+static int conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream) {
   FPLX_REQUIRE(dw27 && dw9, FPLX_E_NULL, "conv2d_wgrad_extract: null pointer");
   FPLX_REQUIRE(cout > 0 && cin > 0, FPLX_E_BADSHAPE, "conv2d_wgrad_extract: bad shape");
   const int64_t pairs = (int64_t)cout * cin;
@@ -1062,15 +1062,17 @@ int fplx_conv2d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const vo
 }
 
 /* ---- out_conv (C0 -> classes, 1x3x3) fused with the BatchNorm + PReLU passes of the convolution site in front of it ---- */
-int fplx_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls) {
+static bool outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls) {
   return n > 0 && d > 0 && h > 0 && w > 0 && fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls);
 }
-int fplx_outconv_bn_rows(int n, int d, int h, int w) { return fplx_edge_outconv_bn_rows(n, d, h, w); }
+int fplx_outconv_bn_rows(int n, int d, int h, int w, int c0, int ncls) {
+  return outconv_bn_ok(n, d, h, w, c0, ncls) ? fplx_edge_outconv_bn_rows(n, d, h, w) : 0;
+}
 int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
                         int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,
                         int ncls, fplx_stream_t stream) {
   FPLX_REQUIRE(y && scale && shift && prelu_slope && a && wf && logits, FPLX_E_NULL, "outconv_fwd_bn: null pointer");
-  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_fwd_bn: c0 = %d, classes = %d not supported (fplx_outconv_bn_ok)", c0, ncls);
+  FPLX_REQUIRE(outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_fwd_bn: c0 = %d, classes = %d not supported (fplx_outconv_bn_rows == 0)", c0, ncls);
   const int r = fplx_edge_outconv_fwd_bn(y, ldy, scale, shift, prelu_slope, a, lda, wf, bias, logits, n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_fwd_bn: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
@@ -1079,7 +1081,7 @@ int fplx_outconv_dgrad_bn_reduce(const float* dlogits, const void* wb, const voi
                                  const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
                                  float* part, int n, int d, int h, int w, int c0, int ncls, fplx_stream_t stream) {
   FPLX_REQUIRE(dlogits && wb && y && mean && rstd && scale && shift && prelu_slope && part, FPLX_E_NULL, "outconv_dgrad_bn_reduce: null pointer");
-  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_reduce: shape not supported (fplx_outconv_bn_ok)");
+  FPLX_REQUIRE(outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_reduce: shape not supported (fplx_outconv_bn_rows == 0)");
   const int r = fplx_edge_outconv_dgrad_bn(1, dlogits, wb, y, ldy, mean, rstd, scale, shift, prelu_slope, nullptr, part, nullptr, 0,
                                            n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_reduce: pointers / leading dimensions not 16-byte aligned");
@@ -1090,7 +1092,7 @@ int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void
                                 const float* coef, void* dy, int64_t lddy, int n, int d, int h, int w, int c0, int ncls,
                                 fplx_stream_t stream) {
   FPLX_REQUIRE(dlogits && wb && y && mean && rstd && scale && shift && prelu_slope && coef && dy, FPLX_E_NULL, "outconv_dgrad_bn_apply: null pointer");
-  FPLX_REQUIRE(fplx_outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: shape not supported (fplx_outconv_bn_ok)");
+  FPLX_REQUIRE(outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: shape not supported (fplx_outconv_bn_rows == 0)");
   const int r = fplx_edge_outconv_dgrad_bn(2, dlogits, wb, y, ldy, mean, rstd, scale, shift, prelu_slope, coef, nullptr, dy, lddy,
                                            n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: pointers / leading dimensions not 16-byte aligned");
@@ -1196,7 +1198,7 @@ int fplx_conv2d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
   int rc = fplx_conv3d_wgrad(x, x_dt, sn, sd, sh, sw, sc, dy, dy_dt, yn, yd, yh, yw, yc, dw27, db, n, d, h, w, cin, cout, 3,
                              3, 3, ws, w3, stream);
   if (rc != FPLX_OK) return rc;
-  return fplx_conv2d_wgrad_extract(dw27, dw, cout, cin, stream);
+  return conv2d_wgrad_extract(dw27, dw, cout, cin, stream);
 }
 
 // sd = 2: ConvTranspose3d(k=2,s=2); sd = 1: ConvTranspose2d(k=2,s=2) on every depth slice (2.5D levels)

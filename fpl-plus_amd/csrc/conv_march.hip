@@ -1691,34 +1691,37 @@ extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void*
                                                                          c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
     }                                                                                                               \
   } while (0)
-    // loader-wave form (knob march64_lw): needs a depth slice below 1 GiB (32-bit buffer offsets, the out-of-range marker)
-    // march64_lw bit 0: the Conv2d-per-slice forms (TWOD: one live accumulator role, 135-200 registers: -21..-28 % per launch,
-    // profiles/r05_kernel_ab.txt); bit 1: the 3D forms too - their eight accumulator tiles + the rotation's copies do not fit
-    // 256 registers (57-78 spilled registers inside the MFMA loop: +23 %), off by default
-    const int lwk = (int)fplx_knob(FPLX_K_MARCH64_LW);
-    const bool lw64 = (twod ? (lwk & 1) : (lwk & 2)) != 0 && (int64_t)h * w * ldx * 2 < ((int64_t)1 << 30);
-#define LAUNCH_M64LW(G_, TWOD_, NQ_)                                                                                \
+    // loader-wave form (knob march64_lw, default on): the Conv2d-per-slice forms only (TWOD: one live accumulator role, 135-200
+    // registers: -21..-28 % per launch, profiles/r05_kernel_ab.txt).  Needs a depth slice below 1 GiB (32-bit buffer offsets, the
+    // out-of-range marker).  The 3D forms stay on conv_fwd_march64: their eight accumulator tiles + the rotation's copies do not
+    // fit 256 registers (57-78 spilled registers inside the MFMA loop: +23 %, profiles/r05_kernel_ab.txt section 4) - that
+    // instantiation was removed in round 6
+    const bool lw64 = twod && fplx_knob(FPLX_K_MARCH64_LW) != 0 && (int64_t)h * w * ldx * 2 < ((int64_t)1 << 30);
+#define LAUNCH_M64LW(G_, NQ_)                                                                                       \
   do {                                                                                                              \
     if (slope) {                                                                                                    \
-      (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, TWOD_, NQ_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
-      conv_fwd_march64_lw<G_, TWOD_, NQ_, true><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+      (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, true, NQ_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+      conv_fwd_march64_lw<G_, true, NQ_, true><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
                                                                          (bf16_t*)y, ldy, n, d, h, w, cout, nullptr, c.tilesH, \
                                                                          c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on(), slope, nmod0); \
     } else {                                                                                                        \
-    (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, TWOD_, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
-    conv_fwd_march64_lw<G_, TWOD_, NQ_><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
+    (void)hipFuncSetAttribute((const void*)conv_fwd_march64_lw<G_, true, NQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS); \
+    conv_fwd_march64_lw<G_, true, NQ_><<<grid, 512, G_::LDS, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, \
                                                                          (bf16_t*)y, ldy, n, d, h, w, cout, stats, c.tilesH, \
                                                                          c.tilesW, c.dsegs, c.dlen, (const bf16_t*)x1, fplx_xcd_on()); \
     }                                                                                                               \
   } while (0)
 #define LAUNCH_M64(G_, TWOD_)                                                                                       \
+  do { if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2); } while (0)
+#define LAUNCH_M64_2D(G_)                                                                                           \
   do {                                                                                                              \
-    if (lw64) { if (cin == 128) LAUNCH_M64LW(G_, TWOD_, 4); else LAUNCH_M64LW(G_, TWOD_, 2); }                      \
-    else if (cin == 128) LAUNCH_M64Q(G_, TWOD_, 4); else LAUNCH_M64Q(G_, TWOD_, 2);                                 \
+    if (lw64) { if (cin == 128) LAUNCH_M64LW(G_, 4); else LAUNCH_M64LW(G_, 2); }                                    \
+    else LAUNCH_M64(G_, true);                                                                                      \
   } while (0)
     using G16 = MG64T<16>;
-    if (c.fw == 16) { if (twod) LAUNCH_M64(G16, true); else LAUNCH_M64(G16, false); }
-    else { if (twod) LAUNCH_M64(MG64, true); else LAUNCH_M64(MG64, false); }
+    if (c.fw == 16) { if (twod) LAUNCH_M64_2D(G16); else LAUNCH_M64(G16, false); }
+    else { if (twod) LAUNCH_M64_2D(MG64); else LAUNCH_M64(MG64, false); }
+#undef LAUNCH_M64_2D
 #undef LAUNCH_M64
 #undef LAUNCH_M64LW
 #undef LAUNCH_M64Q

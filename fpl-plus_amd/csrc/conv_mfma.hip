@@ -2306,14 +2306,8 @@ extern "C" size_t fplx_mfma_conv3d_mid_fwd_ws_bytes(int n, int d, int h, int w, 
 // finish; the caller has checked fplx_mfma_conv3d_act_ok (the stream / unsplit tile / direct kernels have no such form)
 static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float* bias, void* y, int64_t ldy, int n, int d,
                          int h, int w, int cin, int cout, float* stats, void* ws, size_t ws_bytes, int mid,
-                         hipStream_t st, const float* slope = nullptr, bool no_finish = false) {
-  // no_finish (fplx_mfma_conv3d_fwd_partial): the layer's split-K kernel only - partial[ks][V][cout] fp32 stays in ws for a
-  // fused finish (elementwise.hip: deep_site_fwd_k / deep_site_bwd_k); y is not written
-  if (!mfma_applicable(ldx, no_finish ? cout : ldy, cin, cout, x, no_finish ? x : y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
-  if (no_finish) {
-    int kernel, geo, ksp;
-    if (!fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ksp) || ksp <= 1) return 0;
-  }
+                         hipStream_t st, const float* slope = nullptr) {
+  if (!mfma_applicable(ldx, ldy, cin, cout, x, y, wp) || (int64_t)n * d * h * w >= ((int64_t)1 << 31)) return 0;
   const bool midt = mid_tile(mid, n, d, h, w, cin, cout);
   const int tap_lo = midt ? 9 : 0, tap_cnt = midt ? 9 : 27;
   auto brick_launch = [&]() -> int {
@@ -2323,9 +2317,9 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     if (ks > 1 && (!ws || ws_bytes < (size_t)ks * Vb * cout * sizeof(float)))
       return fplx_fail(FPLX_E_WORKSPACE, "mfma_conv3d_fwd: split-K needs %zu workspace bytes (fplx_conv3d_fwd_ws_bytes)",
                        (size_t)ks * Vb * cout * sizeof(float));
-    const int rb = fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, no_finish ? (void*)x : y, no_finish ? cout : ldy, n, d, h, w, cin, cout, stats,
+    const int rb = fplx_brick_conv3d_fwd_act(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats,
                                              (float*)ws, geo, ks, st, slope, nullptr, 0);
-    if (rb == 1 && ks > 1 && !no_finish) {
+    if (rb == 1 && ks > 1) {
       splitk_finish_k<<<splitk_fin_blocks(Vb), 256, 0, st>>>((const float*)ws, ks, Vb, cout, bias, (bf16_t*)y, ldy, stats, slope);
       const int rf = fplx_check_launch("brick_splitk_finish");
       if (rf < 0) return rf;
@@ -2380,7 +2374,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
     else if (c.tile_nt == 128) { if (k64) LAUNCH_TILE(128, 64, 128); else LAUNCH_TILE(128, 32, 128); }
     else { if (k64) LAUNCH_TILE(64, 64, 128); else LAUNCH_TILE(64, 32, 128); }
 #undef LAUNCH_TILE
-    if (ks > 1 && !no_finish) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats, slope);
+    if (ks > 1) splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats, slope);
     int rct = fplx_check_launch("mfma_conv3d_fwd_tile");
     return rct < 0 ? rct : 1;
   }
@@ -2391,7 +2385,7 @@ static int mfma_fwd_impl(const void* x, int64_t ldx, const void* wp, const float
   else
     conv_fwd_direct<4, 1, 0><<<grid, DIRECT_THREADS, 0, st>>>((const bf16_t*)x, ldx, (const bf16_t*)wp, bias, (bf16_t*)y,
                                                            ldy, n, d, h, w, cin, cout, stats, partial);
-  if (ks > 1 && !no_finish)
+  if (ks > 1)
     splitk_finish_k<<<c.fin_blocks, 256, 0, st>>>(partial, ks, V, cout, bias, (bf16_t*)y, ldy, stats, slope);
   int rc = fplx_check_launch("mfma_conv3d_fwd");
   return rc < 0 ? rc : 1;
@@ -2402,12 +2396,6 @@ extern "C" int fplx_mfma_conv3d_fwd(const void* x, int64_t ldx, const void* wp, 
                                     int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,
                                     size_t ws_bytes, hipStream_t st) {
   return mfma_fwd_impl(x, ldx, wp, bias, y, ldy, n, d, h, w, cin, cout, stats, ws, ws_bytes, 0, st);
-}
-// the split-K kernel of a layer whose plan has ksplit > 1, WITHOUT the finish: 1 = partial[ksplit][V][cout] (fp32, no bias) is in
-// ws, 0 = the layer has no split (nothing launched), < 0 error
-extern "C" int fplx_mfma_conv3d_fwd_partial(const void* x, int64_t ldx, const void* wp, int n, int d, int h, int w, int cin, int cout,
-                                            void* ws, size_t ws_bytes, int mid, hipStream_t st) {
-  return mfma_fwd_impl(x, ldx, wp, nullptr, nullptr, 0, n, d, h, w, cin, cout, nullptr, ws, ws_bytes, mid, st, nullptr, true);
 }
 extern "C" int fplx_mfma_conv3d_mid_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, void* y,
                                         int64_t ldy, int n, int d, int h, int w, int cin, int cout, float* stats, void* ws,

@@ -949,283 +949,6 @@ channel_stats_k(const T* __restrict__ x, int64_t ld, int64_t V, int C, float* __
   }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// Small-volume sites (levels 3 - 4 of the benchmark: 8000 and 1000 voxels x 256 / 512 channels).  There every pass above is a
-// few microseconds of latency, not bandwidth, and a conv -> DSBN -> PReLU site is a chain of them: split-K finish, statistics
-// finalize, apply forward; finish, reduction, finalize, apply backward - 21-25 us per site for 4-8 MB of traffic.  BatchNorm
-// is independent per channel, so ONE block can own a group of VEC channels for ALL voxels and run the whole chain without
-// ever leaving the CU: its <= 8 voxels per thread stay in registers (packed bf16) between the statistics and the apply step,
-// the per-channel constants are block-uniform (scalar registers), the only cross-block value - the PReLU slope gradient, one
-// number per layer - is summed by the last block to arrive, in block order (bitwise reproducible).
-//   deep_site_fwd_k   partial[ks][V][C] (+ bias) -> y (bf16), batch statistics -> mean / rstd / scale / shift / running
-//                     statistics, out = dropout(PReLU(scale y + shift))         (splitk_finish_k + bn_train_finalize_k + bn_act_fwd)
-//   deep_site_bwd_k   d = bf16(sum of partial) (PART) or d = dout; the three-stage backward of the site -> dy, dgamma, dbeta,
-//                     dslope                                            (splitk_finish_k + bn_act_bwd_reduce / _finalize / _apply)
-// Same arithmetic per element as those kernels (y and d are rounded to bf16 exactly where the stored tensors were); the sums
-// are taken in a different (fixed) order.  XCD j (blocks j, j + 8, ..) owns a contiguous eighth of the channel groups, so
-// each 128-byte line of a voxel row is fetched into one L2.
-constexpr int DS_THREADS = 1024, DS_MAXV = 8, DS_MAXBLOCKS = 256;
-
-__device__ __forceinline__ int ds_group(int G) {
-  const int b = blockIdx.x;
-  return (G % 8 == 0) ? (b & 7) * (G / 8) + (b >> 3) : b;
-}
-__device__ __forceinline__ uint32_t ds_pack2(float a, float b) {
-  const bf16_t x = (bf16_t)a, y = (bf16_t)b;
-  return (uint32_t)__builtin_bit_cast(unsigned short, x) | ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
-}
-__device__ __forceinline__ float ds_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float ds_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
-template <int VEC>
-__device__ __forceinline__ void ds_store(bf16_t* p, const uint32_t (&w)[VEC / 2]) {
-  if constexpr (VEC == 8) *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-  else *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
-}
-template <int VEC>
-__device__ __forceinline__ void ds_load(const bf16_t* p, uint32_t (&w)[VEC / 2]) {
-  if constexpr (VEC == 8) { const uint4 r = *reinterpret_cast<const uint4*>(p); w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w; }
-  else { const uint2 r = *reinterpret_cast<const uint2*>(p); w[0] = r.x; w[1] = r.y; }
-}
-// o[VEC] = init + sum over z of partial[z][v][c0 ..], in z order (splitk_finish_k's order)
-template <int VEC>
-__device__ __forceinline__ void ds_sum_partial(const float* __restrict__ partial, int ks, int V, int C, int v, int c0, float (&o)[VEC]) {
-  for (int z = 0; z < ks; ++z) {
-    const float* p = partial + ((int64_t)z * V + v) * C + c0;
-#pragma unroll
-    for (int j4 = 0; j4 < VEC / 4; ++j4) {
-      const float4 a = *reinterpret_cast<const float4*>(p + 4 * j4);
-      o[4 * j4] += a.x; o[4 * j4 + 1] += a.y; o[4 * j4 + 2] += a.z; o[4 * j4 + 3] += a.w;
-    }
-  }
-}
-// block totals of NV doubles per thread: wave butterflies, then the 16 wave totals in wave order (every thread gets them)
-template <int NV>
-__device__ __forceinline__ void ds_block_sum(double (&v)[NV], double (*wred)[NV]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = wave_sum_d(v[k]);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) wred[wave][k] = v[k];
-  }
-  __syncthreads();
-}
-
-template <int VEC, int MAXV>
-__global__ void __launch_bounds__(DS_THREADS)
-deep_site_fwd_k(const float* __restrict__ partial, int ks, int V, int C, const float* __restrict__ bias,
-                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
-                int64_t* __restrict__ nbt, float momentum, float eps, float* __restrict__ mean, float* __restrict__ rstd,
-                float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ slope_p, DropCfg dc,
-                bf16_t* __restrict__ y, int64_t ldy, bf16_t* __restrict__ out, int64_t ldo) {
-  const int c0 = __builtin_amdgcn_readfirstlane(ds_group(C / VEC) * VEC);
-  __shared__ double wred[DS_THREADS / 64][2 * VEC];
-  __shared__ float bc[2][VEC];
-  uint32_t yp[MAXV][VEC / 2];
-  float s[VEC], q[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = threadIdx.x + i * DS_THREADS;
-    if (v < V) {
-      float o[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] = bias ? bias[c0 + j] : 0.f;
-      ds_sum_partial<VEC>(partial, ks, V, C, v, c0, o);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) { s[j] += o[j]; q[j] = fmaf(o[j], o[j], q[j]); }
-#pragma unroll
-      for (int j = 0; j < VEC / 2; ++j) yp[i][j] = ds_pack2(o[2 * j], o[2 * j + 1]);
-      ds_store<VEC>(y + (int64_t)v * ldy + c0, yp[i]);
-    }
-  }
-  double dv[2 * VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { dv[j] = (double)s[j]; dv[VEC + j] = (double)q[j]; }
-  ds_block_sum<2 * VEC>(dv, wred);
-  if (threadIdx.x < VEC) {                               // bn_train_finalize_k's arithmetic for channel c0 + threadIdx.x
-    const int j = threadIdx.x, c = c0 + j;
-    double s1 = 0.0, s2 = 0.0;
-    for (int wv = 0; wv < DS_THREADS / 64; ++wv) { s1 += wred[wv][j]; s2 += wred[wv][VEC + j]; }
-    const double count = (double)V;
-    if (c == 0 && nbt) *nbt += 1;
-    const double m = s1 / count;
-    double var = s2 / count - m * m;
-    if (var < 0.0) var = 0.0;
-    const float rs = (float)(1.0 / sqrt(var + (double)eps));
-    const float mf = (float)m;
-    mean[c] = mf;
-    rstd[c] = rs;
-    const float sc = gamma[c] * rs;
-    const float sh = beta[c] - mf * sc;
-    scale[c] = sc;
-    shift[c] = sh;
-    bc[0][j] = sc;
-    bc[1][j] = sh;
-    if (rm) rm[c] = (1.f - momentum) * rm[c] + momentum * mf;
-    if (rv) {
-      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
-    }
-  }
-  __syncthreads();
-  const float slope = *slope_p;
-  float sc[VEC], sh[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { sc[j] = bc[0][j]; sh[j] = bc[1][j]; }
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = threadIdx.x + i * DS_THREADS;
-    if (v < V) {
-      bool keep[VEC];
-      if (dc.on) keep_flags<VEC>((int64_t)v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
-      float a[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC / 2; ++j) { a[2 * j] = ds_lo(yp[i][j]); a[2 * j + 1] = ds_hi(yp[i][j]); }
-      uint32_t op[VEC / 2];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float z = fmaf(a[j], sc[j], sh[j]);
-        z = z > 0.f ? z : z * slope;
-        if (dc.on) z = keep[j] ? z * dc.inv_keep : 0.f;
-        a[j] = z;
-      }
-#pragma unroll
-      for (int j = 0; j < VEC / 2; ++j) op[j] = ds_pack2(a[2 * j], a[2 * j + 1]);
-      ds_store<VEC>(out + (int64_t)v * ldo + c0, op);
-    }
-  }
-}
-
-template <int VEC, bool PART, int MAXV>
-__global__ void __launch_bounds__(DS_THREADS)
-deep_site_bwd_k(const float* __restrict__ partial, int ks, const bf16_t* __restrict__ dout, int64_t ldd, int V, int C,
-                const bf16_t* __restrict__ y, int64_t ldy, const float* __restrict__ mean, const float* __restrict__ rstd,
-                const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ slope_p, DropCfg dc,
-                int train, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dslope,
-                bf16_t* __restrict__ dy, int64_t ldo, double* __restrict__ bsum, unsigned* __restrict__ counter) {
-  const int c0 = __builtin_amdgcn_readfirstlane(ds_group(C / VEC) * VEC);
-  __shared__ double wred[DS_THREADS / 64][2 * VEC + 1];
-  __shared__ float bc[2][VEC];
-  const float slope = *slope_p;
-  float sc[VEC], sh[VEC], m[VEC], rs[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { sc[j] = scale[c0 + j]; sh[j] = shift[c0 + j]; m[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; }
-  uint32_t ap[MAXV][VEC / 2], dp[MAXV][VEC / 2];
-  uint32_t km[MAXV * VEC / 32 > 0 ? MAXV * VEC / 32 : 1];
-#pragma unroll
-  for (int k = 0; k < (int)(sizeof(km) / 4); ++k) km[k] = 0xFFFFFFFFu;
-  float sdz[VEC], sdx[VEC], sds = 0.f;
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) sdz[j] = sdx[j] = 0.f;
-  const bool on = dc.on;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = threadIdx.x + i * DS_THREADS;
-    if (v < V) {
-      ds_load<VEC>(y + (int64_t)v * ldy + c0, ap[i]);
-      if constexpr (PART) {
-        float o[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = 0.f;
-        ds_sum_partial<VEC>(partial, ks, V, C, v, c0, o);
-#pragma unroll
-        for (int j = 0; j < VEC / 2; ++j) dp[i][j] = ds_pack2(o[2 * j], o[2 * j + 1]);
-      } else {
-        ds_load<VEC>(dout + (int64_t)v * ldd + c0, dp[i]);
-      }
-      bool keep[VEC];
-      if (on) {
-        keep_flags<VEC>((int64_t)v * C + c0, dc.thr, dc.k0, dc.k1, dc.sid, keep);
-        uint32_t bits = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) bits |= (keep[j] ? 1u : 0u) << j;
-        km[(i * VEC) / 32] = (km[(i * VEC) / 32] & ~(((1u << VEC) - 1u) << ((i * VEC) % 32))) | (bits << ((i * VEC) % 32));
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float a = (j & 1) ? ds_hi(ap[i][j / 2]) : ds_lo(ap[i][j / 2]);
-        const float d = (j & 1) ? ds_hi(dp[i][j / 2]) : ds_lo(dp[i][j / 2]);
-        const bool kp = on ? keep[j] : true;
-        float z;
-        const float dz = dz_of(a, d, sc[j], sh[j], slope, on, kp, dc.inv_keep, z);
-        float da = d;
-        if (on) da = kp ? d * dc.inv_keep : 0.f;
-        sds += z > 0.f ? 0.f : da * z;
-        sdz[j] += dz;
-        sdx[j] = fmaf(dz, (a - m[j]) * rs[j], sdx[j]);
-      }
-    }
-  }
-  double dv[2 * VEC + 1];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { dv[j] = (double)sdz[j]; dv[VEC + j] = (double)sdx[j]; }
-  dv[2 * VEC] = (double)sds;
-  ds_block_sum<2 * VEC + 1>(dv, wred);
-  if (threadIdx.x < VEC) {                               // bn_act_bwd_finalize_k's arithmetic for channel c0 + threadIdx.x
-    const int j = threadIdx.x, c = c0 + j;
-    double s0 = 0.0, s1 = 0.0;
-    for (int wv = 0; wv < DS_THREADS / 64; ++wv) { s0 += wred[wv][j]; s1 += wred[wv][VEC + j]; }
-    if (dbeta) dbeta[c] += (float)s0;
-    if (dgamma) dgamma[c] += (float)s1;
-    bc[0][j] = train ? (float)(s0 / (double)V) : 0.f;
-    bc[1][j] = train ? (float)(s1 / (double)V) : 0.f;
-  } else if (threadIdx.x == 64) {
-    // the slope gradient: this block's share, then - in the last block to arrive - all shares in block order
-    double t = 0.0;
-    for (int wv = 0; wv < DS_THREADS / 64; ++wv) t += wred[wv][2 * VEC];
-    __hip_atomic_store(&bsum[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence();
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == gridDim.x - 1) {
-      __threadfence();
-      double tot = 0.0;
-      for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&bsum[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dslope) dslope[0] += (float)tot;
-      __hip_atomic_store(counter, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch
-    }
-  }
-  __syncthreads();
-  float k0[VEC], k1[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) { k0[j] = bc[0][j]; k1[j] = bc[1][j]; }
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = threadIdx.x + i * DS_THREADS;
-    if (v < V) {
-      const uint32_t bits = km[(i * VEC) / 32] >> ((i * VEC) % 32);
-      float o[VEC];
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float a = (j & 1) ? ds_hi(ap[i][j / 2]) : ds_lo(ap[i][j / 2]);
-        const float d = (j & 1) ? ds_hi(dp[i][j / 2]) : ds_lo(dp[i][j / 2]);
-        float z;
-        const float dz = dz_of(a, d, sc[j], sh[j], slope, on, on ? ((bits >> j) & 1u) != 0 : true, dc.inv_keep, z);
-        const float xh = (a - m[j]) * rs[j];
-        o[j] = sc[j] * (dz - k0[j] - xh * k1[j]);
-      }
-      uint32_t op[VEC / 2];
-#pragma unroll
-      for (int j = 0; j < VEC / 2; ++j) op[j] = ds_pack2(o[2 * j], o[2 * j + 1]);
-      ds_store<VEC>(dy + (int64_t)v * ldo + c0, op);
-    }
-  }
-}
-
-// the channel-group width for a site of C channels: 8 where that still makes 64 blocks, else 4
-inline int ds_vec(int c) { return c / 8 >= 64 ? 8 : 4; }
-inline int ds_maxv(int64_t voxels) {                     // voxels per thread: the smallest of 1, 2, 4, 8 that covers the volume
-  const int64_t per = (voxels + DS_THREADS - 1) / DS_THREADS;
-  return per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : 8;
-}
-inline bool ds_ok(int64_t voxels, int c) {
-  if (voxels <= 0 || voxels > (int64_t)DS_THREADS * DS_MAXV || c % 8 != 0) return false;
-  const int g = c / ds_vec(c);
-  return g >= 32 && g <= DS_MAXBLOCKS;
-}
-
 inline int ew_grid(int64_t total) {
   int64_t g = (total + EW_THREADS - 1) / EW_THREADS;
   if (g > 4096) g = 4096;
@@ -1241,11 +964,6 @@ bool vec_ok(const void* a, int64_t lda, const void* b, int64_t ldb, const void* 
 }
 
 }  // namespace
-
-// conv_mfma.hip
-extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int cout, int mid, int* kernel, int* geo, int* ksplit);
-extern "C" int fplx_mfma_conv3d_fwd_partial(const void* x, int64_t ldx, const void* wp, int n, int d, int h, int w, int cin, int cout,
-                                            void* ws, size_t ws_bytes, int mid, hipStream_t st);
 
 static inline bool ew_group_form() {     // A/B knob (benchmarks only): FPLX_EW_GROUP=0 selects the flat-index kernels
   return fplx_knob(FPLX_K_EW_GROUP) != 0;
@@ -1399,105 +1117,6 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
 }
 
 
-/* ---- one-launch sites of the small deep levels (deep_site_fwd_k / deep_site_bwd_k above) ---- */
-int fplx_deep_site_ok(int64_t voxels, int c) { return ds_ok(voxels, c) ? 1 : 0; }
-
-size_t fplx_deep_site_scratch_bytes(void) { return 16 + sizeof(double) * DS_MAXBLOCKS; }
-
-int fplx_conv3d_site_fwd_ok(int n, int d, int h, int w, int cin, int cout, int mid) {
-  int kernel, geo, ks;
-  if (!ds_ok((int64_t)n * d * h * w, cout)) return 0;
-  if (!fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks)) return 0;
-  return ks > 1 ? 1 : 0;
-}
-
-int fplx_conv3d_site_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, int n, int d, int h, int w, int cin,
-                         int cout, int mid, void* ws, size_t ws_bytes, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* mean,
-                         float* rstd, float* scale, float* shift, const float* slope, float p, uint64_t seed,
-                         uint32_t stream_id, void* y, int64_t ldy, void* out, int64_t ldo, fplx_stream_t stream) {
-  FPLX_REQUIRE(x && wp && ws && gamma && beta && mean && rstd && scale && shift && slope && y && out, FPLX_E_NULL,
-               "conv3d_site_fwd: null pointer");
-  FPLX_REQUIRE(fplx_conv3d_site_fwd_ok(n, d, h, w, cin, cout, mid), FPLX_E_BADSHAPE,
-               "conv3d_site_fwd: %dx%dx%dx%d %d -> %d is not a split-K site of at most %d voxels (fplx_conv3d_site_fwd_ok)", n, d, h,
-               w, cin, cout, DS_THREADS * DS_MAXV);
-  FPLX_REQUIRE(p >= 0.f && p < 1.f && ldy >= cout && ldo >= cout && ldy % 8 == 0 && ldo % 8 == 0 && (uintptr_t)y % 16 == 0 &&
-                   (uintptr_t)out % 16 == 0, FPLX_E_BADSHAPE, "conv3d_site_fwd: bad p / leading dimension / alignment");
-  hipStream_t st = (hipStream_t)stream;
-  const int V = n * d * h * w;
-  const int rc = fplx_mfma_conv3d_fwd_partial(x, ldx, wp, n, d, h, w, cin, cout, ws, ws_bytes, mid, st);
-  if (rc < 0) return rc;
-  FPLX_REQUIRE(rc == 1, FPLX_E_BADSHAPE, "conv3d_site_fwd: the operands do not allow the split-K kernel (alignment)");
-  int kernel, geo, ks;
-  fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks);
-  const DropCfg dc = make_drop(p, seed, stream_id);
-#define DS_FWD(VEC_, MAXV_)                                                                                                     \
-  deep_site_fwd_k<VEC_, MAXV_><<<cout / VEC_, DS_THREADS, 0, st>>>((const float*)ws, ks, V, cout, bias, gamma, beta, running_mean, \
-                                                                  running_var, nbt, momentum, eps, mean, rstd, scale, shift, slope, \
-                                                                  dc, (bf16_t*)y, ldy, (bf16_t*)out, ldo)
-  const int mv = ds_maxv(V);
-  if (ds_vec(cout) == 8) { if (mv == 1) DS_FWD(8, 1); else if (mv == 2) DS_FWD(8, 2); else if (mv == 4) DS_FWD(8, 4); else DS_FWD(8, 8); }
-  else { if (mv == 1) DS_FWD(4, 1); else if (mv == 2) DS_FWD(4, 2); else if (mv == 4) DS_FWD(4, 4); else DS_FWD(4, 8); }
-#undef DS_FWD
-  return fplx_check_launch("conv3d_site_fwd");
-}
-
-static int deep_site_bwd_launch(const float* partial, int ks, const void* dout, int64_t ldd, int V, int c, const void* y, int64_t ldy,
-                                const float* mean, const float* rstd, const float* scale, const float* shift, const float* slope,
-                                float p, uint64_t seed, uint32_t stream_id, int train, float* dgamma, float* dbeta, float* dslope,
-                                void* dy, int64_t ldo, void* scratch, size_t scratch_bytes, hipStream_t st, const char* what) {
-  FPLX_REQUIRE(y && mean && rstd && scale && shift && slope && dy && scratch, FPLX_E_NULL, "%s: null pointer", what);
-  FPLX_REQUIRE(scratch_bytes >= fplx_deep_site_scratch_bytes() && (uintptr_t)scratch % 8 == 0, FPLX_E_WORKSPACE,
-               "%s: scratch of %zu bytes (fplx_deep_site_scratch_bytes, zero-filled once) needed", what, fplx_deep_site_scratch_bytes());
-  FPLX_REQUIRE(p >= 0.f && p < 1.f && ldy >= c && ldo >= c && ldy % 8 == 0 && ldo % 8 == 0 && (uintptr_t)y % 16 == 0 &&
-                   (uintptr_t)dy % 16 == 0 && (!dout || (ldd >= c && ldd % 8 == 0 && (uintptr_t)dout % 16 == 0)),
-               FPLX_E_BADSHAPE, "%s: bad p / leading dimension / alignment", what);
-  const DropCfg dc = make_drop(p, seed, stream_id);
-  unsigned* counter = (unsigned*)scratch;
-  double* bsum = (double*)((char*)scratch + 16);
-#define DS_BWD_(VEC_, PART_, MAXV_)                                                                                            \
-  deep_site_bwd_k<VEC_, PART_, MAXV_><<<c / VEC_, DS_THREADS, 0, st>>>(partial, ks, (const bf16_t*)dout, ldd, V, c, (const bf16_t*)y, \
-                                                                      ldy, mean, rstd, scale, shift, slope, dc, train, dgamma,  \
-                                                                      dbeta, dslope, (bf16_t*)dy, ldo, bsum, counter)
-#define DS_BWD(VEC_, PART_)                                                                                              \
-  do { if (mv == 1) DS_BWD_(VEC_, PART_, 1); else if (mv == 2) DS_BWD_(VEC_, PART_, 2); else if (mv == 4) DS_BWD_(VEC_, PART_, 4); \
-       else DS_BWD_(VEC_, PART_, 8); } while (0)
-  const int mv = ds_maxv(V);
-  if (ds_vec(c) == 8) { if (partial) DS_BWD(8, true); else DS_BWD(8, false); }
-  else { if (partial) DS_BWD(4, true); else DS_BWD(4, false); }
-#undef DS_BWD
-#undef DS_BWD_
-  return fplx_check_launch(what);
-}
-
-int fplx_conv3d_site_bwd(const void* dyin, int64_t ldx, const void* wb, int n, int d, int h, int w, int cin, int cout, int mid,
-                         void* ws, size_t ws_bytes, const void* y, int64_t ldy, const float* mean, const float* rstd,
-                         const float* scale, const float* shift, const float* slope, float p, uint64_t seed, uint32_t stream_id,
-                         int train, float* dgamma, float* dbeta, float* dslope, void* dy, int64_t ldo, void* scratch,
-                         size_t scratch_bytes, fplx_stream_t stream) {
-  FPLX_REQUIRE(dyin && wb && ws, FPLX_E_NULL, "conv3d_site_bwd: null pointer");
-  FPLX_REQUIRE(fplx_conv3d_site_fwd_ok(n, d, h, w, cin, cout, mid), FPLX_E_BADSHAPE,
-               "conv3d_site_bwd: %dx%dx%dx%d %d -> %d is not a split-K site of at most %d voxels (fplx_conv3d_site_fwd_ok)", n, d, h,
-               w, cin, cout, DS_THREADS * DS_MAXV);
-  hipStream_t st = (hipStream_t)stream;
-  const int rc = fplx_mfma_conv3d_fwd_partial(dyin, ldx, wb, n, d, h, w, cin, cout, ws, ws_bytes, mid, st);
-  if (rc < 0) return rc;
-  FPLX_REQUIRE(rc == 1, FPLX_E_BADSHAPE, "conv3d_site_bwd: the operands do not allow the split-K kernel (alignment)");
-  int kernel, geo, ks;
-  fplx_mfma_conv3d_plan(n, d, h, w, cin, cout, mid, &kernel, &geo, &ks);
-  return deep_site_bwd_launch((const float*)ws, ks, nullptr, 0, n * d * h * w, cout, y, ldy, mean, rstd, scale, shift, slope, p, seed,
-                              stream_id, train, dgamma, dbeta, dslope, dy, ldo, scratch, scratch_bytes, st, "conv3d_site_bwd");
-}
-
-int fplx_bn_act_bwd_site(const void* y, int64_t ldy, const void* dout, int64_t ldd, void* dy, int64_t ldo, const float* mean,
-                         const float* rstd, const float* scale, const float* shift, const float* slope, float p, uint64_t seed,
-                         uint32_t stream_id, int64_t voxels, int c, int train, float* dgamma, float* dbeta, float* dslope,
-                         void* scratch, size_t scratch_bytes, fplx_stream_t stream) {
-  FPLX_REQUIRE(dout, FPLX_E_NULL, "bn_act_bwd_site: null pointer");
-  FPLX_REQUIRE(ds_ok(voxels, c), FPLX_E_BADSHAPE, "bn_act_bwd_site: %lld voxels x %d channels (fplx_deep_site_ok)", (long long)voxels, c);
-  return deep_site_bwd_launch(nullptr, 0, dout, ldd, (int)voxels, c, y, ldy, mean, rstd, scale, shift, slope, p, seed, stream_id, train,
-                              dgamma, dbeta, dslope, dy, ldo, scratch, scratch_bytes, (hipStream_t)stream, "bn_act_bwd_site");
-}
 
 static int maxpool_fwd_impl(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c, int dt,
                             int pd, fplx_stream_t stream) {

@@ -10,22 +10,50 @@ import ctypes
 import os
 import re
 
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) round-robin.  fplx runs backward on two streams (data
-# gradients | weight gradients); once a process group exists RCCL adds streams of its own, and with 4 queues the two fplx
-# streams end up sharing one - serialised, the whole overlap (about 1 ms of the 10 ms train step) is lost
-# (profiles/r02_rccl_single_rank.txt).  Must be in the environment before the HIP runtime initialises, i.e. before the
-# first GPU call of the process; an explicit setting of the user wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# Kernel arguments in DEVICE memory: by default the runtime leaves the kernarg segment in host memory and every dispatch reads it
-# across the host link before its first wave starts - about 1.1 us per launch.  The train step is 211 dependent launches, a
-# quarter of them shorter than 10 us: 8.62 -> 8.38 ms (-2.8 %, three alternating pairs of processes on one box,
-# profiles/r05_kernel_ab.txt section 19).  Same rule: read when the HIP runtime initialises, an explicit setting of the user wins.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Two switches of the HIP runtime, both read ONCE when the runtime initialises (the first GPU call of the process); an explicit
+# setting of the user always wins:
+#  GPU_MAX_HW_QUEUES=8      HIP maps streams onto hardware queues (default 4) round-robin.  fplx runs backward on two streams
+#                           (data gradients | weight gradients); once a process group exists RCCL adds streams of its own, and
+#                           with 4 queues the two fplx streams end up sharing one - serialised, the whole overlap (about 1 ms of
+#                           the train step) is lost (profiles/r02_rccl_single_rank.txt).
+#  HIP_FORCE_DEV_KERNARG=1  kernel arguments in DEVICE memory: by default the kernarg segment lives in host memory and every
+#                           dispatch reads it across the host link before its first wave starts - about 1.1 us per launch.  The
+#                           train step is 211 dependent launches, a quarter of them shorter than 10 us: 8.62 -> 8.38 ms (-2.8 %,
+#                           three alternating pairs of processes on one box, profiles/r05_kernel_ab.txt section 19).
+# Set here they only help if fplx is imported BEFORE the first GPU call.  A host program that initialised the GPU first (PyMIC
+# imports torch, builds its device, and reaches fplx through the registry later - INTEGRATION.md section 1) would lose them
+# SILENTLY: that case raises a RuntimeWarning below.
+_RUNTIME_ENV = (("GPU_MAX_HW_QUEUES", "8"), ("HIP_FORCE_DEV_KERNARG", "1"))
+_env_preset = {k: os.environ.get(k) for k, _ in _RUNTIME_ENV}      # what the user / launcher had set before this import
+for _k, _v in _RUNTIME_ENV:
+    os.environ.setdefault(_k, _v)
 
 # torch first: libfplx.so must bind to the SAME HIP runtime (libamdhip64.so.7) the process uses
 # for its device memory and streams.  PyTorch-ROCm ships its own copy; whichever copy is loaded
 # first serves both, and the ROCm-7.2 system copy does not see the devices torch opened.
-import torch  # noqa: F401
+import torch  # noqa: F401,E402
+
+
+def runtime_env_report():
+    """-> {variable: (value now in os.environ, 'preset' | 'fplx' | 'too late')}: 'too late' = the GPU was already initialised
+    when fplx was imported and the variable was not in the environment, so the HIP runtime never saw it"""
+    return dict(_env_report)
+
+
+_gpu_was_up = bool(torch.cuda.is_initialized())
+_env_report = {}
+for _k, _v in _RUNTIME_ENV:
+    _env_report[_k] = (os.environ.get(_k), "preset" if _env_preset[_k] is not None else ("too late" if _gpu_was_up else "fplx"))
+_late = [k for k, (_, how) in _env_report.items() if how == "too late"]
+if _late:
+    import warnings
+    warnings.warn(
+        "fplx was imported after the GPU had been initialised and %s %s not in the environment: the HIP runtime reads %s only "
+        "at its start, so this process runs without %s (about 3-4 %% of the train step: launch latency and stream overlap; "
+        "results are unaffected).  Import fplx before the first GPU call, or export %s." % (
+            " / ".join(_late), "was" if len(_late) == 1 else "were", "it" if len(_late) == 1 else "them",
+            "it" if len(_late) == 1 else "them", " ".join("%s=%s" % (k, dict(_RUNTIME_ENV)[k]) for k in _late)),
+        RuntimeWarning, stacklevel=2)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
@@ -160,12 +188,6 @@ _HOST_KNOBS = {
     "bucket_elems": 1 << 21,    # TrainStep: gradient all-reduce bucket size (elements)
     "pack_small_multi": 1,  # Engine._pack: the transposed-convolution and out_conv packs of a step in one launch (fplx_pack_weights_multi)
     "adam_pack": 1,         # FusedAdam.step_flat: the shared segment's Adam and the 3x3x3 weight packs in one launch (fplx_adam_pack_step)
-    # Engine.use_deep_fused: sites of at most 8192 voxels run split-K finish + BatchNorm chain in one launch each way.  OFF: measured
-    # slower (step +1.5 %, profiles/r05_kernel_ab.txt section 12: a block per channel group uses 16-32 bytes of every 128-byte line)
-    "deep_fused": 0,
-    # TrainStep.step on a single rank: the shared segment's Adam bucket by bucket during backward (AdamBehindBackward).  OFF: measured
-    # neutral (8.03 vs 8.04 ms, section 13: the update's 0.7 GB of traffic competes with the BatchNorm passes it runs beside)
-    "adam_overlap": 0,
     "ddp_overlap_all": 1,   # TrainStep.step_all under data parallelism: buckets folded + all-reduced during the last domain's backward
 }
 _host_vals = {}

@@ -55,9 +55,6 @@ class Engine(object):
         # out_conv fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn / _dgrad_bn_*):
         # one pass over that site's tensor forward, two instead of three (+ the data gradient's write) backward
         self.use_outconv_fusion = _lib.host_knob("outconv_fuse") != 0
-        # the small deep levels (a site of <= 8192 voxels: levels 3 - 4 of the benchmark): split-K finish + statistics + apply in
-        # ONE launch forward, finish + reduction + finalize + apply in one backward (fplx_conv3d_site_fwd / _bwd, fplx_bn_act_bwd_site)
-        self.use_deep_fused = _lib.host_knob("deep_fused") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
         # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
@@ -376,12 +373,6 @@ class Engine(object):
             y = empty(vox[l], cout)
             bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
             bnm = bn.bns[domain]
-            if (train and self.use_deep_fused and pool is None and not defer_act and not cat2 and x_dt == a_dt and
-                    adt == torch.bfloat16 and ops.conv3d_site_fwd_ok(dims[l], cin, cout, mid)):
-                # a small deep site: the split-K convolution, then ONE launch for finish + statistics + apply
-                ops.conv3d_site_fwd(xin, packs[key][0], conv.bias, dims[l], cin, cout, mid, bnm, bnbuf, prelu.weight, pp, seed, sid,
-                                    y, out_view)
-                return y, bnbuf, pp
             if train:
                 rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt, mid)
                 stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
@@ -603,26 +594,16 @@ class Engine(object):
         outconv_wgrad()
         ready("out_conv.bias")
 
-        deep = self.use_deep_fused and tap is None and adt == torch.bfloat16
-
         def site_bwd(key, bnkey, relukey, y, bnbuf, p, sid, d_out, xin, xs, x_dt, cin, l, want_dx, dx_view, reduced=False,
-                     wgrad_here=False, from_logits=False, bn_done=False, next_site=None):
+                     wgrad_here=False, from_logits=False):
             """backward of conv -> DSBN -> PReLU -> dropout.  d_out is overwritten with dy.
-            reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)
-            bn_done: d_out already IS dy (the site above ran this site's BatchNorm backward with its data gradient)
-            next_site: (bnkey, relukey, y, bnbuf, p, sid) of the site BELOW, whose BatchNorm backward is to run on this site's
-            data gradient in the same launch as its split-K finish (small deep levels) - dx_view then receives that site's dy"""
+            reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)"""
             c = ft[l]
             gkey = "%s.bns.%d" % (bnkey, domain)
-            if bn_done:
-                pass
-            elif from_logits:     # d_out is not given: it is out_conv's data gradient, recomputed inside the two BatchNorm passes
+            if from_logits:     # d_out is not given: it is out_conv's data gradient, recomputed inside the two BatchNorm passes
                 ops.outconv_dgrad_bn_bwd(dlogits, packs["out_conv"][1], y, bnbuf, net.get_param(relukey + ".weight"), sv.train,
                                          gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, d_out,
                                          dims[l], c, ncls)
-            elif deep and not reduced and ops.deep_site_ok(vox[l], c):
-                ops.bn_act_bwd_site(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
-                                    gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"])
             else:
                 ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
                                gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced)
@@ -655,12 +636,7 @@ class Engine(object):
                 else:
                     on_side(lambda: ops.conv3d_wgrad(xin, xs, x_dt, d_out, ops.cl_strides(*dims[l][1:], c), a_dt, gw, db,
                                                      dims[l], cin, c, (3, 3, 3), ws_w), d_out, xin)
-            if want_dx and next_site is not None:
-                nbn, nrelu, ny, nbuf, npp, nsid = next_site
-                ngk = "%s.bns.%d" % (nbn, domain)
-                ops.conv3d_site_bwd(d_out, packs[key][1], dims[l], c, cin, two_d, ny, nbuf, net.get_param(nrelu + ".weight"), npp,
-                                    sv.seed, nsid, sv.train, gv[ngk + ".weight"], gv[ngk + ".bias"], gv[nrelu + ".weight"], dx_view)
-            elif want_dx:
+            if want_dx:
                 ops.conv3d_fwd(d_out, ops.cl_strides(*dims[l][1:], c), a_dt, packs[key][1], None, dx_view,
                                ops.cl_strides(*dims[l][1:], ops.ld_of(dx_view)), a_dt, dims[l], c, cin, (3, 3, 3), None,
                                mid=two_d)
@@ -678,21 +654,16 @@ class Engine(object):
             mod = net.block_modules[b]
             l, c, cin = blk["l"], ft[blk["l"]], blk["cin"]
             d_a1 = empty(vox[l], c)
-            # small deep levels: site 1's BatchNorm backward runs inside the finish of site 2's (split-K) data gradient
-            two_d2 = gv[key + "." + mod.cname(2) + ".weight"].dim() == 4
-            chain = (deep and ops.ld_of(d_out) % 8 == 0 and d_out.data_ptr() % 16 == 0 and
-                     ops.conv3d_site_fwd_ok(dims[l], c, c, two_d2))
-            nxt = (key + "." + mod.bname(1), key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"], blk["sid"]) if chain else None
             site_bwd(key + "." + mod.cname(2), key + "." + mod.bname(2), key + ".relu_2", blk["y2"], blk["bn2"], 0.0, 0,
                      d_out, blk["a1"], ops.cl_strides(*dims[l][1:], c), a_dt, c, l, True, d_a1, reduced,
-                     from_logits=(b == 8 and oc_fused), next_site=nxt)
+                     from_logits=(b == 8 and oc_fused))
             if isinstance(blk["xin"], tuple):
                 d_in = (empty(vox[l], cin // 2), empty(vox[l], cin // 2)) if want_dx else None
             else:
                 d_in = empty(vox[l], cin) if want_dx else None
             site_bwd(key + "." + mod.cname(1), key + "." + mod.bname(1), key + ".relu_1", blk["y1"], blk["bn1"], blk["p1"],
                      blk["sid"], d_a1, blk["xin"], blk["xs"], blk["x_dt"], cin, l, want_dx, d_in,
-                     wgrad_here=(b == 0 and side_on and self.stem_wgrad_on_main), bn_done=chain)
+                     wgrad_here=(b == 0 and side_on and self.stem_wgrad_on_main))
             return d_in
 
         # ---- decoder, up4 .. up1
@@ -736,9 +707,7 @@ class Engine(object):
         ready("block4.conv.relu_1.weight")
         for i in range(3, -1, -1):
             d_a2 = empty(vox[i], ft[i])
-            # (a small deep level: the plain pooling gradient, then the site's whole BatchNorm backward in one launch - two
-            # launches instead of three)
-            fused = self.use_fused_pool and ops.bn_pool_fused_ok(ft[i], adt) and not (deep and ops.deep_site_ok(vox[i], ft[i]))
+            fused = self.use_fused_pool and ops.bn_pool_fused_ok(ft[i], adt)
             if fused:      # pooling gradient + skip gradient AND the BatchNorm reduction over the result, in one pass
                 blk = sv.blocks[i]
                 ops.pool_bwd_bn_reduce(blk["y2"], d_pool, d_skips[i], d_a2, blk["bn2"],

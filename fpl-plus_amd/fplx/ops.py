@@ -108,11 +108,6 @@ def pack_conv2d_weight(w, act_dtype, want_wb=True):
     return wf, wb
 
 
-def conv2d_wgrad_extract(dw27, dw9):
-    co, ci = dw9.shape[0], dw9.shape[1]
-    call("fplx_conv2d_wgrad_extract", ptr(dw27), ptr(dw9), co, ci, stream())
-
-
 def conv3d_stats_rows(dims, cin, cout, k, x_dt, y_dt, mid=False):
     """mid: the pack is a Conv2d in the middle depth plane (pack_conv2d_weight) - the fplx_conv2d_* form"""
     n, d, h, w = dims
@@ -289,16 +284,16 @@ def num_partials(voxels):
     return _lib.lib().fplx_num_partials(voxels)
 
 
+def outconv_bn_rows(dims, c0=32, ncls=2):
+    """partial rows of the fused out_conv backward (fplx_outconv_bn_rows); 0 where the fused forms do not apply"""
+    n, d, h, w = dims
+    return _lib.lib().fplx_outconv_bn_rows(n, d, h, w, int(c0), int(ncls))
+
+
 def outconv_bn_ok(dims, c0, ncls):
     """True if out_conv can be fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn,
     fplx_outconv_dgrad_bn_reduce / _apply: bf16, C0 = 32, classes <= 4)"""
-    n, d, h, w = dims
-    return _lib.lib().fplx_outconv_bn_ok(n, d, h, w, int(c0), int(ncls)) == 1
-
-
-def outconv_bn_rows(dims):
-    n, d, h, w = dims
-    return _lib.lib().fplx_outconv_bn_rows(n, d, h, w)
+    return outconv_bn_rows(dims, c0, ncls) > 0
 
 
 def outconv_fwd_bn(y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls):
@@ -356,62 +351,6 @@ def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta,
     call("fplx_bn_act_bwd_apply", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]),
          ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(coef), float(p), int(seed), int(sid), v, c,
          dt_of(y), stream())
-
-
-# ---- one-launch sites of the small deep levels (fplx.h: fplx_conv3d_site_fwd / _bwd, fplx_bn_act_bwd_site)
-def deep_site_ok(voxels, c):
-    return _lib.lib().fplx_deep_site_ok(int(voxels), int(c)) == 1
-
-
-def conv3d_site_fwd_ok(dims, cin, cout, mid=False):
-    n, d, h, w = dims
-    return _lib.lib().fplx_conv3d_site_fwd_ok(n, d, h, w, int(cin), int(cout), 1 if mid else 0) == 1
-
-
-_site_scratch = {}
-
-
-def _fwd_workspace(dev, need):
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    if key not in _fwd_ws or _fwd_ws[key].numel() < need:
-        _fwd_ws[key] = torch.empty(int(need), dtype=torch.uint8, device=dev)
-    return _fwd_ws[key]
-
-
-def site_scratch(dev):
-    """the counter + per-block slots of the deep-site backward kernels: zero-filled once, per (device, stream)"""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    if key not in _site_scratch:
-        _site_scratch[key] = torch.zeros(int(_lib.lib().fplx_deep_site_scratch_bytes()), dtype=torch.uint8, device=dev)
-    return _site_scratch[key]
-
-
-def conv3d_site_fwd(x, wp, bias, dims, cin, cout, mid, bnm, bnbuf, slope, p, seed, sid, y, out):
-    """conv (split-K) -> batch statistics -> BN apply + PReLU + dropout in two launches (bnm: the domain's BatchNorm module)"""
-    n, d, h, w = dims
-    ws = _fwd_workspace(y.device, conv3d_fwd_ws_bytes(dims, cin, cout, (3, 3, 3), BF16, BF16, mid))
-    call("fplx_conv3d_site_fwd", ptr(x), ld_of(x), ptr(wp), ptr(bias), n, d, h, w, int(cin), int(cout), 1 if mid else 0, ptr(ws),
-         ws.numel(), ptr(bnm.weight), ptr(bnm.bias), ptr(bnm.running_mean), ptr(bnm.running_var), ptr(bnm.num_batches_tracked),
-         float(bnm.momentum), float(bnm.eps), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p),
-         int(seed), int(sid), ptr(y), ld_of(y), ptr(out), ld_of(out), stream())
-
-
-def conv3d_site_bwd(dyin, wb, dims, cin, cout, mid, y, bnbuf, slope, p, seed, sid, train, dgamma, dbeta, dslope, dy):
-    """data gradient of the NEXT convolution (split-K) + the whole backward of this site on it, in two launches"""
-    n, d, h, w = dims
-    ws = _fwd_workspace(y.device, conv3d_fwd_ws_bytes(dims, cin, cout, (3, 3, 3), BF16, BF16, mid))
-    sc = site_scratch(y.device)
-    call("fplx_conv3d_site_bwd", ptr(dyin), ld_of(dyin), ptr(wb), n, d, h, w, int(cin), int(cout), 1 if mid else 0, ptr(ws), ws.numel(),
-         ptr(y), ld_of(y), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid),
-         1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope), ptr(dy), ld_of(dy), ptr(sc), sc.numel(), stream())
-
-
-def bn_act_bwd_site(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope):
-    """bn_act_bwd's three stages in one launch (sites of at most 8192 voxels, deep_site_ok); dy may alias dout"""
-    sc = site_scratch(y.device)
-    call("fplx_bn_act_bwd_site", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]), ptr(bnbuf[1]),
-         ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), y.shape[0], int(c), 1 if train else 0, ptr(dgamma),
-         ptr(dbeta), ptr(dslope), ptr(sc), sc.numel(), stream())
 
 
 def maxpool2_fwd(x, y, dims, c, pd=2):

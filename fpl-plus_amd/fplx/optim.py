@@ -135,63 +135,6 @@ class FusedAdam(Optimizer):
         if fused:
             net.engine.packs_written_by_optimizer()
 
-    # ---- step_flat in pieces (TrainStep on a single rank, round 5): the update of a range of the shared segment is enqueued
-    # as soon as backward has finished that range's gradients - from the weight-gradient stream, beside the rest of backward -
-    # instead of one 0.13-ms launch behind the last kernel.  Adam is elementwise and the pack jobs are per layer: the pieces
-    # leave exactly the bits of the one-launch update.
-    @torch.no_grad()
-    def step_flat_begin(self):
-        net = self.net
-        net.engine.invalidate()
-        self._opt_called = True
-        self.seg_steps[0] += 1
-        self._piece_plan = net.engine.adam_pack_plan() or []
-        self._piece_fused = False
-        self._piece_done = self.seg_ranges[0][0]
-
-    @torch.no_grad()
-    def step_flat_range(self, gflat, start, end):
-        """Adam (+ the bf16 packs of the 3x3x3 weights inside) over flat elements [start, end) of the shared segment; the ranges
-        of a step must be contiguous, ascending and cut at parameter boundaries"""
-        if end <= start:
-            return
-        s0, e0 = self.seg_ranges[0]
-        assert start == self._piece_done and s0 <= start and end <= e0, (start, end, self._piece_done)
-        group = self.param_groups[0]
-        lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
-        net = self.net
-        sub = []
-        for o, co, ci, wf, wb in self._piece_plan:
-            if o + co * ci * 27 <= start or o >= end:
-                continue
-            assert start <= o and o + co * ci * 27 <= end, "a range of step_flat_range cuts a weight tensor"
-            sub.append((o - start, co, ci, wf, wb))
-        args = (net.flat_params[start:end], gflat[start:end], self.exp_avg[start:end], self.exp_avg_sq[start:end], lr,
-                self.seg_steps[0], wd, self.grad_scale, (b1, b2), eps)
-        if sub:
-            ops.adam_pack_step(*(args + (sub,)))
-            self._piece_fused = True
-        else:
-            ops.adam_step(*args)
-        self._piece_done = end
-
-    @torch.no_grad()
-    def step_flat_end(self, gflat, active_domains):
-        """the rest of the shared segment and the listed domains' BatchNorm segments"""
-        net = self.net
-        self.step_flat_range(gflat, self._piece_done, self.seg_ranges[0][1])
-        group = self.param_groups[0]
-        lr, (b1, b2), eps, wd = group['lr'], group['betas'], group['eps'], group['weight_decay']
-        for si, (start, end) in enumerate(self.seg_ranges):
-            if si == 0 or (si - 1) not in active_domains:
-                continue
-            self.seg_steps[si] += 1
-            ops.adam_step(net.flat_params[start:end], gflat[start:end], self.exp_avg[start:end], self.exp_avg_sq[start:end], lr,
-                          self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps)
-        if self._piece_fused:                  # the ranges covered the whole shared segment: every layer of the plan was packed
-            net.engine.packs_written_by_optimizer()
-        self._piece_plan = []
-
     def state_dict(self):
         """torch.optim.Adam's layout over the reference's parameter list (fplx/checkpoint.py): what the reference's
         agent saves as 'optimizer_state_dict' and what its create_optimizer loads back (agent_abstract.py:327-330)"""

@@ -14,44 +14,6 @@ from .ddp import GradAllReducer
 from .optim import FusedAdam
 
 
-class AdamBehindBackward(object):
-    """Single rank: the optimiser update of the shared segment, bucket by bucket, WHILE backward runs.  Same hook protocol as
-    GradAllReducer (`pending` / `ready(end)`, called by Engine.backward at block boundaries from its weight-gradient stream once
-    that stream has caught up with the main one): when the gradients of a bucket are final, its Adam (+ weight packs) launch is
-    enqueued right there - behind the bucket's own weight gradients, beside the data-gradient chain of the shallower blocks -
-    so only the last bucket and the BatchNorm segments are left behind the last backward kernel (0.13 ms of the step before).
-    What the update overwrites has no reader left in this step: master weights are read by the pack kernels only, a block's
-    bf16 packs by its own data-gradient kernels, which precede the hook on the main stream."""
-
-    def __init__(self, opt, bucket_ranges):
-        self.opt, self.buckets = opt, list(bucket_ranges)
-        self._next, self._g, self._begun = 0, None, False
-        self.launched = []                       # (start, end) enqueued from the hook in the current step (tests)
-
-    def begin(self, gflat):
-        self._next, self._g, self._begun = 0, gflat, False
-        self.launched = []
-
-    def pending(self, end):
-        # the last bucket stays for finish(): it completes with the last kernel of backward anyway
-        return self._next < len(self.buckets) - 1 and self.buckets[self._next][1] <= end
-
-    def ready(self, end):
-        while self.pending(end):
-            if not self._begun:
-                self.opt.step_flat_begin()
-                self._begun = True
-            s, e = self.buckets[self._next]
-            self.opt.step_flat_range(self._g, s, e)
-            self.launched.append((s, e))
-            self._next += 1
-
-    def finish(self, active_domains):
-        if not self._begun:
-            self.opt.step_flat_begin()
-        self.opt.step_flat_end(self._g, active_domains)
-
-
 class TrainStep(object):
     def __init__(self, net, loss_terms=(1.0, 0.0, 0.0, 0.0), softmax=True, lr=1e-4, weight_decay=1e-5,
                  milestones=(), gamma=0.5, group=None, bucket_elems=1 << 21, optimizer=None):
@@ -79,9 +41,6 @@ class TrainStep(object):
         self.opt.grad_scale = 1.0
         self.dist_loss = self.reducer.enabled
         self.overlap_all = _lib.host_knob("ddp_overlap_all") != 0      # A/B switch: step_all's collectives behind the last backward
-        # single rank: Adam bucket by bucket during backward (AdamBehindBackward); with a process group the reducer owns the hook
-        self.adam_overlap = _lib.host_knob("adam_overlap") != 0
-        self.adam_pipe = AdamBehindBackward(self.opt, net.bucket_ranges(bucket_elems))
         self._one = torch.ones(1, dtype=torch.float32, device=net.flat_params.device)
         self._half = torch.full((1,), 0.5, dtype=torch.float32, device=net.flat_params.device)
         self._loss_bufs = {}
@@ -134,13 +93,6 @@ class TrainStep(object):
         """one batch of one domain; returns the device tensor [total, dice, ce, entropy, class dice...]"""
         if not self.external_lr:
             self.opt.param_groups[0]['lr'] = self._lr()
-        if self.adam_overlap and not self.reducer.enabled:
-            pipe = self.adam_pipe
-            pipe.begin(self.gflat)
-            out = self._fwd_bwd(x, label, domain, pixel_weight, image_weight, self._one, self.gflat, pipe.ready)
-            pipe.finish([domain])
-            self.iteration += 1
-            return out
         self.reducer.begin(self.gflat)
         out = self._fwd_bwd(x, label, domain, pixel_weight, image_weight, self._one, self.gflat, self.reducer.ready)
         self.reducer.finish([domain])

@@ -182,7 +182,7 @@ int fplx_deconv2_wgrad(const void* x, int64_t ldx, const void* dy, int64_t ldy, 
  * runs 2D modules (unet2d5_dsbn.py:110-127, 160-188); on [N,D,H,W,C] volumes that is
  *  - Conv2d(3x3, pad 1)  = the 3x3x3 kernels with the 9 taps packed into the middle depth plane (pack_conv2d_weight:
  *    w fp32 [Cout][Cin][3][3] -> the same wf / wb layouts as fplx_pack_conv_weight); weight gradient = middle plane of
- *    the 27-tap gradient (conv2d_wgrad_extract: dw27 [Cout][Cin][27] -> dw9 [Cout][Cin][9])
+ *    the 27-tap gradient (dw27 [Cout][Cin][27] -> dw9 [Cout][Cin][9], taps 9..17)
  *  - MaxPool2d(2)        = maxpool122: x [N,D,H,W,C] -> y [N,D,H/2,W/2,C]
  *  - ConvTranspose2d(2,2) = deconv122: x [N,D,H,W,Cin] -> y [N,D,2H,2W,Cout]; weights fp32 [Cin][Cout][2][2] packed to
  *    wf [4][Cout][Cin], wb [4][Cin][Cout]; dw fp32 [Cin][Cout][2][2]
@@ -209,7 +209,6 @@ int fplx_conv2d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
                       void* ws, size_t ws_bytes, fplx_stream_t stream);
 int fplx_conv2d_wgrad_cat2(const void* x0, const void* x1, int64_t ldx, const void* dy, int64_t ldy, float* dw, int n,
                            int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream);
-int fplx_conv2d_wgrad_extract(const float* dw27, float* dw9, int cout, int cin, fplx_stream_t stream);
 int fplx_maxpool122_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
                         int dt, fplx_stream_t stream);
 int fplx_maxpool122_bwd(const void* x, int64_t ldx, const void* dy, int64_t ldy, const void* dskip, int64_t lds,
@@ -264,43 +263,6 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
                           const float* slope, const float* coef, float p, uint64_t seed, uint32_t stream_id,
                           int64_t voxels, int c, int dt, fplx_stream_t stream);
 
-/* ---- one-launch sites of the small deep levels (round 5).  Where a site has at most 8192 voxels (levels 3 - 4 of the benchmark:
- * 8000 x 256, 1000 x 512) its passes are launch latency, not bandwidth; BatchNorm is independent per channel, so a block that
- * owns a group of channels for ALL voxels runs the whole chain without leaving the CU.  Replaces, per site of ConvBlockND
- * (unet2d5_dsbn.py:66-81: Conv3d -> DomainSpecificBatchNorm3d -> PReLU -> Dropout) in train mode:
- *   forward   the split-K finish of fplx_conv3d_fwd + fplx_bn_train_finalize + fplx_bn_act_fwd
- *   backward  the split-K finish of the data-gradient convolution that produces dout + fplx_bn_act_bwd_reduce / _finalize /
- *             _apply (fplx_conv3d_site_bwd), or the three BatchNorm stages alone (fplx_bn_act_bwd_site)
- * Same arithmetic per element (y and dout are rounded to bf16 exactly where the stored tensors were), sums in another fixed
- * order.  bf16 only.  scratch: fplx_deep_site_scratch_bytes() bytes, zero-filled ONCE by the caller and then owned by these
- * calls on one stream (a counter that the last block of every launch resets + one double per block). */
-int fplx_deep_site_ok(int64_t voxels, int c);
-size_t fplx_deep_site_scratch_bytes(void);
-/* 1 if the 3x3x3 layer (mid: a Conv2d per depth slice as a 27-tap pack) has a split-K plan AND fplx_deep_site_ok holds */
-int fplx_conv3d_site_fwd_ok(int n, int d, int h, int w, int cin, int cout, int mid);
-/* x [V, cin] bf16 ld ldx, wp: fplx_pack_conv_weight's forward pack, ws: fplx_conv3d_fwd_ws_bytes bytes.  Writes y (the
- * convolution output, kept for backward), mean / rstd / scale / shift, updates the running statistics and nbt like
- * fplx_bn_train_finalize, and out = dropout(PReLU(scale y + shift)) like fplx_bn_act_fwd. */
-int fplx_conv3d_site_fwd(const void* x, int64_t ldx, const void* wp, const float* bias, int n, int d, int h, int w, int cin,
-                         int cout, int mid, void* ws, size_t ws_bytes, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps, float* mean,
-                         float* rstd, float* scale, float* shift, const float* slope, float p, uint64_t seed,
-                         uint32_t stream_id, void* y, int64_t ldy, void* out, int64_t ldo, fplx_stream_t stream);
-/* dyin [V, cin] bf16: the gradient w.r.t. the output of the NEXT convolution (cin -> ... its data gradient has cout channels),
- * wb: that convolution's backward pack.  dout = bf16(data gradient) is never stored: the site's backward runs on it -> dy
- * [V, cout]; dgamma / dbeta / dslope are ACCUMULATED like fplx_bn_act_bwd_finalize.  y, mean .. shift, slope, p, seed,
- * stream_id: the site's own (cout channels). */
-int fplx_conv3d_site_bwd(const void* dyin, int64_t ldx, const void* wb, int n, int d, int h, int w, int cin, int cout, int mid,
-                         void* ws, size_t ws_bytes, const void* y, int64_t ldy, const float* mean, const float* rstd,
-                         const float* scale, const float* shift, const float* slope, float p, uint64_t seed, uint32_t stream_id,
-                         int train, float* dgamma, float* dbeta, float* dslope, void* dy, int64_t ldo, void* scratch,
-                         size_t scratch_bytes, fplx_stream_t stream);
-/* fplx_bn_act_bwd_reduce + _finalize + _apply in one launch (dy may alias dout) */
-int fplx_bn_act_bwd_site(const void* y, int64_t ldy, const void* dout, int64_t ldd, void* dy, int64_t ldo, const float* mean,
-                         const float* rstd, const float* scale, const float* shift, const float* slope, float p, uint64_t seed,
-                         uint32_t stream_id, int64_t voxels, int c, int train, float* dgamma, float* dbeta, float* dslope,
-                         void* scratch, size_t scratch_bytes, fplx_stream_t stream);
-
 /* ------------------------------------------------------------------ pooling
  * nn.MaxPool3d(2,2) (unet2d5_dsbn.py:106,117).  x [N,D,H,W,C] ld ldx -> y [N,D/2,H/2,W/2,C] ld ldy */
 int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,
@@ -326,17 +288,17 @@ int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t 
 
 /* out_conv (Conv3d C0 -> classes, kernel (1,3,3), unet2d5_dsbn.py:293-294, 307) fused with the BatchNorm + PReLU passes of the
  * convolution site in front of it (ConvBlockND's second site of the last UpBlock, unet2d5_dsbn.py:79-81; dropout-free, bf16
- * NDHWC, C0 = 32, classes <= 4: fplx_outconv_bn_ok).  The out_conv operands are 1 / 8 the size of that site's tensors, so
+ * NDHWC, C0 = 32, classes <= 4: fplx_outconv_bn_rows > 0).  The out_conv operands are 1 / 8 the size of that site's tensors, so
  *   fplx_outconv_fwd_bn          reads the site's PRE-BatchNorm output y, applies a = PReLU(scale y + shift) on the way into its
  *                                tiles, writes a (what backward keeps) and the fp32 planar logits: fplx_bn_act_fwd + fplx_conv3d_fwd
  *                                in one pass over y; a and the logits are the bits of the two-call path;
  *   fplx_outconv_dgrad_bn_reduce / _apply   never store out_conv's data gradient: both RECOMPUTE it from dlogits (fp32 planar)
  *                                and the mirrored pack wb and run fplx_bn_act_bwd_reduce / _apply on it - _reduce writes
- *                                fplx_outconv_bn_rows(n, d, h, w) partial rows of 2 C0 + 1 floats for fplx_bn_act_bwd_finalize,
+ *                                fplx_outconv_bn_rows(...) partial rows of 2 C0 + 1 floats for fplx_bn_act_bwd_finalize,
  *                                _apply takes the finalize's coef and writes dy (gradient w.r.t. y).
  * mean / rstd / scale / shift: the site's BatchNorm constants (fplx_bn_train_finalize / fplx_bn_eval_prepare). */
-int fplx_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls);
-int fplx_outconv_bn_rows(int n, int d, int h, int w);
+/* partial rows the fused backward writes, or 0 where the fused forms do not apply (the caller then runs the separate passes) */
+int fplx_outconv_bn_rows(int n, int d, int h, int w, int c0, int ncls);
 int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
                         int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,
                         int ncls, fplx_stream_t stream);

@@ -129,7 +129,7 @@ def test_conv2d_through_the_3d_kernels(dtype, shape):
     dw9 = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device="cuda")
     ops.conv3d_wgrad(xg, ops.cl_strides(d, h, w, cin), dt, dyg, ops.cl_strides(d, h, w, cout), dt, dw27, None, dims, cin,
                      cout, (3, 3, 3), ws)
-    ops.conv2d_wgrad_extract(dw27, dw9)
+    dw9.copy_(dw27[:, :, 9:18].reshape(cout, cin, 3, 3))          # the middle depth plane of the 27-tap gradient
     assert float((dw9.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
     # the fplx_conv2d_wgrad form: 9-tap gradient directly (+ bias gradient); MFMA stream kernel in middle-plane mode
     ws2 = torch.empty(ops.conv2d_wgrad_ws_bytes(dims, cin, cout), dtype=torch.uint8, device="cuda")
@@ -139,6 +139,27 @@ def test_conv2d_through_the_3d_kernels(dtype, shape):
                      ws2)
     assert float((dw9b.cpu() - wr.grad).abs().max()) < max(tol, 1e-4) * float(wr.grad.abs().max())
     assert float((db.cpu() - cl(dy).sum(0)).abs().max()) < max(tol, 1e-4) * float(cl(dy).sum(0).abs().max())
+    if dtype == torch.bfloat16 and cin in (64, 128) and w >= 64:
+        # the Cin = 64 / 128 depth march in Conv2d mode has two forms: conv_fwd_march64_lw (loader waves, the default) and
+        # conv_fwd_march64 (knob march64_lw = 0) - same products in the same order: the same bits, statistics included
+        from fplx import _lib
+        assert _lib.get_tuning("march64_lw") == 1
+        _lib.set_tuning("march64_lw", 0)
+        try:
+            y3, stats3 = torch.empty_like(y), torch.zeros_like(stats)
+            ops.conv3d_fwd(xg, ops.cl_strides(d, h, w, cin), dt, wf, b.cuda(), y3, ops.cl_strides(d, h, w, cout), dt, dims, cin,
+                           cout, (3, 3, 3), stats3, mid=True)
+            dx3 = torch.empty_like(dx)
+            ops.conv3d_fwd(dyg, ops.cl_strides(d, h, w, cout), dt, wb, None, dx3, ops.cl_strides(d, h, w, cin), dt, dims, cout, cin,
+                           (3, 3, 3), None, mid=True)
+        finally:
+            _lib.set_tuning("march64_lw", 1)
+        assert torch.equal(y3, y2) and torch.equal(stats3, stats)
+        dx2 = torch.empty_like(dx)
+        ops.conv3d_fwd(dyg, ops.cl_strides(d, h, w, cout), dt, wb, None, dx2, ops.cl_strides(d, h, w, cin), dt, dims, cout, cin,
+                       (3, 3, 3), None, mid=True)
+        assert torch.equal(dx3, dx2)
+        assert float((uncl(dx2.float().cpu(), n, d, h, w) - xr.grad).abs().max()) < tol * float(xr.grad.abs().max())
 
 
 # (fplx_conv3d_cat2_ok: 32 + 32 -> 32 channels, W >= 64, at least 32000 voxels per sample)

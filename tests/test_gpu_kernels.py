@@ -1011,230 +1011,3 @@ def test_network_step_with_and_without_the_out_conv_fusion():
     assert abs(res[0][2] - res[1][2]) < 1e-6
     rel = float((res[0][1] - res[1][1]).abs().max()) / float(res[1][1].abs().max())
     assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr
-
-
-
-# ---- one-launch sites of the small deep levels (round 5: fplx_conv3d_site_fwd / _bwd, fplx_bn_act_bwd_site)
-def _close_bf16(a, b, frac=2e-3):
-    """two bf16 tensors computed with per-channel constants that may differ in the last fp32 bit: equal almost everywhere,
-    never more than a bf16 step apart"""
-    a, b = a.float(), b.float()
-    d = (a - b).abs()
-    assert float(d.max()) <= 2.0 ** -6 * float(b.abs().max()) + 1e-30, float(d.max())
-    assert float((d > 0).float().mean()) <= frac, float((d > 0).float().mean())
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("shape,p", [((2, 10, 20, 20, 256), 0.4),    # level 3 of the benchmark: 8 voxels per thread, groups of 4 channels
-                                     ((2, 5, 10, 10, 512), 0.5),     # level 4: one voxel per thread, groups of 8
-                                     ((1, 5, 10, 10, 512), 0.0),
-                                     ((1, 4, 9, 11, 256), 0.3),      # ragged: 396 voxels
-                                     ((1, 7, 16, 19, 128), 0.0)])    # 2128 voxels: 4 per thread, 32 groups
-def test_deep_site_backward_kernel_against_autograd_and_the_three_stage_path(shape, p):
-    """deep_site_bwd_k (no split-K input): one launch instead of reduce + finalize + apply.  Against float64 autograd with the
-    tolerances of the three-stage test, against the three-stage kernels element by element, and twice in a row - the counter
-    that elects the block summing the slope gradient must be back at zero, the second result the bits of the first."""
-    from fplx import ops
-    from oracle import np_ref as N
-    n, d, h, w, c = shape
-    v, y, yg, gamma, beta, slope, bnbuf = _bn_site_setup(n, d, h, w, c, "ds")
-    assert ops.deep_site_ok(v, c)
-    seed, sid = 4321, 5
-    keep = torch.from_numpy(N.philox_keep_mask(seed, sid, v * c, p).reshape(v, c)) if p > 0 else None
-    yd, gd, bd, sd, a_ref = _bn_site_torch(y, gamma, beta, slope, keep, p)
-    g = torch.Generator().manual_seed(6)
-    dout = (torch.randn(v, c, generator=g) * 0.01).bfloat16()
-    a_ref.backward(dout.double())
-    doutg, sl = dout.cuda(), slope.cuda()
-    runs = []
-    for rep in range(2):
-        dgamma, dbeta, dslope = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -0.25, device="cuda"), torch.full((1,), 2.0, device="cuda")
-        dy = torch.empty_like(yg)
-        ops.bn_act_bwd_site(yg, doutg, dy, bnbuf, sl, p, seed, sid, c, True, dgamma, dbeta, dslope)
-        runs.append((dy.clone(), dgamma - 0.5, dbeta + 0.25, dslope - 2.0))        # the sums are ACCUMULATED into the gradients
-    for a, b in zip(runs[0], runs[1]):
-        assert torch.equal(a, b)
-    dy, dgamma, dbeta, dslope = runs[0]
-    dx_ref = yd.grad
-    assert float((dy.float().cpu().double() - dx_ref).abs().max()) < 2e-2 * float(dx_ref.abs().max())
-    for got, ref in ((dgamma, gd.grad), (dbeta, bd.grad), (dslope, sd.grad)):
-        assert float((got.cpu().double() - ref).abs().max()) < 1e-2 * float(ref.abs().max()) + 1e-6, (got, ref)
-    # the three-stage path on the same operands
-    g3, b3, s3 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
-    part = torch.empty((ops.num_partials(v), 2 * c + 1), dtype=torch.float32, device="cuda")
-    coef = torch.empty((2, c), dtype=torch.float32, device="cuda")
-    dy3 = torch.empty_like(yg)
-    ops.bn_act_bwd(yg, doutg, dy3, bnbuf, sl, p, seed, sid, c, True, g3, b3, s3, part, coef)
-    _close_bf16(dy, dy3, frac=2e-2)
-    for got, ref in ((dgamma, g3), (dbeta, b3), (dslope, s3)):
-        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
-    # in place (dy aliases dout), as the engine calls it
-    d2 = doutg.clone()
-    ops.bn_act_bwd_site(yg, d2, d2, bnbuf, sl, p, seed, sid, c, True, torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"),
-                        torch.zeros(1, device="cuda"))
-    assert torch.equal(d2, dy)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("shape,p", [((2, 128, 256, 10, 20, 20), 0.4),      # level 3, first site of the block
-                                     ((2, 512, 512, 5, 10, 10), 0.5),       # level 4, second site
-                                     ((1, 256, 256, 6, 11, 13), 0.0)])      # ragged
-def test_deep_site_forward_and_conv_backward_equal_the_separate_launches(shape, p):
-    """fplx_conv3d_site_fwd against fplx_conv3d_fwd (split-K finish) + fplx_bn_train_finalize + fplx_bn_act_fwd: the convolution
-    output y bit for bit, statistics to fp32 rounding, the activation to a bf16 step on < 0.2 % of the elements; and
-    fplx_conv3d_site_bwd against the data-gradient convolution + the three BatchNorm stages."""
-    from fplx import ops
-    n, cin, cout, d, h, w = shape
-    dims, bf, dt = (n, d, h, w), torch.bfloat16, ops._DT[torch.bfloat16]
-    assert ops.conv3d_site_fwd_ok(dims, cin, cout) and plan_kernel(n, d, h, w, cin, cout, full=True)[2] > 1
-    q = lambda t: t.bfloat16().float()
-    x = cl(q(torch.from_numpy(detdata.normal("ds.x%s" % (shape,), (n, cin, d, h, w))))).to(bf).cuda()
-    wt = q(torch.from_numpy(detdata.normal("ds.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.05))).cuda()
-    bias = torch.from_numpy(detdata.normal("ds.b%s" % (shape,), (cout,))).cuda()
-    wf, _ = ops.pack_conv_weight(wt, bf, want_wb=False)
-    v = x.shape[0]
-    bn_f, bn_r = torch.nn.BatchNorm3d(cout).cuda(), torch.nn.BatchNorm3d(cout).cuda()
-    with torch.no_grad():
-        for bn in (bn_f, bn_r):
-            bn.weight.copy_(torch.linspace(0.5, 1.5, cout))
-            bn.bias.copy_(torch.linspace(-0.3, 0.3, cout))
-    slope = torch.full((1,), 0.25, device="cuda")
-    seed, sid = 77, 3
-    # separate launches
-    y_r = torch.empty((v, cout), dtype=bf, device="cuda")
-    rows = ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), dt, dt)
-    stats = torch.empty((rows, 2, cout), dtype=torch.float32, device="cuda")
-    ops.conv3d_fwd(x, ops.cl_strides(d, h, w, cin), dt, wf, bias, y_r, ops.cl_strides(d, h, w, cout), dt, dims, cin, cout, (3, 3, 3), stats)
-    buf_r = torch.empty((4, cout), dtype=torch.float32, device="cuda")
-    ops.bn_train_finalize(stats, rows, cout, v, bn_r.weight, bn_r.bias, bn_r.running_mean, bn_r.running_var, bn_r.num_batches_tracked,
-                          buf_r, bn_r.momentum, bn_r.eps)
-    a_r = torch.empty_like(y_r)
-    ops.bn_act_fwd(y_r, a_r, buf_r, slope, p, seed, sid, cout)
-    # one launch behind the split-K kernel, into channel slices of wider buffers
-    yw = torch.full((v, cout + 16), 7.0, dtype=bf, device="cuda")
-    aw = torch.full((v, cout + 8), 7.0, dtype=bf, device="cuda")
-    y_f, a_f = yw[:, 8:8 + cout], aw[:, :cout]
-    buf_f = torch.empty((4, cout), dtype=torch.float32, device="cuda")
-    ops.conv3d_site_fwd(x, wf, bias, dims, cin, cout, False, bn_f, buf_f, slope, p, seed, sid, y_f, a_f)
-    assert torch.equal(y_f, y_r)
-    assert float(yw[:, :8].float().min()) == 7.0 and float(yw[:, 8 + cout:].float().min()) == 7.0 and float(aw[:, cout:].float().min()) == 7.0
-    assert float((buf_f - buf_r).abs().max()) <= 2e-6 * float(buf_r.abs().max())
-    assert float((bn_f.running_mean - bn_r.running_mean).abs().max()) <= 1e-6 * float(bn_r.running_mean.abs().max()) + 1e-8
-    assert float((bn_f.running_var - bn_r.running_var).abs().max()) <= 1e-6 * float(bn_r.running_var.abs().max())
-    assert int(bn_f.num_batches_tracked) == 1 and int(bn_r.num_batches_tracked) == 1
-    _close_bf16(a_f, a_r)
-    if p > 0:
-        assert torch.equal(a_f == 0, a_r == 0)                                    # the same Philox mask
-    # ---- backward: the NEXT convolution (cout -> cout) hands its data gradient to this site
-    if not ops.conv3d_site_fwd_ok(dims, cout, cout):
-        return
-    w2 = q(torch.from_numpy(detdata.normal("ds.w2%s" % (shape,), (cout, cout, 3, 3, 3), 0.05))).cuda()
-    _, wb2 = ops.pack_conv_weight(w2, bf, want_wb=True)
-    dy2 = (cl(torch.from_numpy(detdata.normal("ds.dy%s" % (shape,), (n, cout, d, h, w)))) * 0.01).to(bf).cuda()
-    d_a = torch.empty((v, cout), dtype=bf, device="cuda")
-    ops.conv3d_fwd(dy2, ops.cl_strides(d, h, w, cout), dt, wb2, None, d_a, ops.cl_strides(d, h, w, cout), dt, dims, cout, cout, (3, 3, 3), None)
-    g3, b3, s3 = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
-    part = torch.empty((ops.num_partials(v), 2 * cout + 1), dtype=torch.float32, device="cuda")
-    coef = torch.empty((2, cout), dtype=torch.float32, device="cuda")
-    dy_r = torch.empty_like(d_a)
-    ops.bn_act_bwd(y_r, d_a, dy_r, buf_r, slope, p, seed, sid, cout, True, g3, b3, s3, part, coef)
-    gf, bfz, sf = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
-    dy_f = torch.empty_like(d_a)
-    ops.conv3d_site_bwd(dy2, wb2, dims, cout, cout, False, y_r, buf_r, slope, p, seed, sid, True, gf, bfz, sf, dy_f)
-    _close_bf16(dy_f, dy_r, frac=2e-2)
-    for got, ref in ((gf, g3), (bfz, b3), (sf, s3)):
-        assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-7
-
-
-@pytest.mark.gpu
-def test_network_step_with_and_without_the_deep_site_fusion():
-    """the engine with the one-launch sites on the small deep levels (Engine.use_deep_fused, the default) against the separate
-    launches: logits within a bf16 step (the batch statistics are summed in another order), the parameters after one Adam step
-    within the noise of that; two fused runs are bit-identical (the slope gradient's cross-block sum has a fixed order)."""
-    import fplx
-    from fplx import ops
-    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
-             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
-    g = torch.Generator().manual_seed(5)
-    shp = (2, 1, 32, 64, 96)                       # level 3: 2 x 4 x 8 x 12 = 768 voxels, level 4: 96
-    x = torch.randn(*shp, generator=g).cuda()
-    lab = torch.zeros(2, 2, *shp[2:])
-    lab[:, 0] = 1.0
-    lab[:, 0, 8:20, 16:40, 30:70] = 0.0
-    lab[:, 1, 8:20, 16:40, 30:70] = 1.0
-    lab = lab.cuda()
-    calls = {"fwd": 0, "bwd": 0, "bn": 0}
-    orig = (ops.conv3d_site_fwd, ops.conv3d_site_bwd, ops.bn_act_bwd_site)
-
-    def counted(name, fn):
-        def f(*a, **k):
-            calls[name] += 1
-            return fn(*a, **k)
-        return f
-    ops.conv3d_site_fwd, ops.conv3d_site_bwd, ops.bn_act_bwd_site = (counted("fwd", orig[0]), counted("bwd", orig[1]),
-                                                                      counted("bn", orig[2]))
-    try:
-        res = []
-        for fuse in (True, True, False):
-            torch.manual_seed(3)
-            net = fplx.UNet2D5_dsbn(dict(p)).cuda()
-            net.engine.use_deep_fused = fuse
-            net.train()
-            with torch.no_grad():
-                net.dropout_seed, net._fwd_counter = 9, 0
-            ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
-            before = dict(calls)
-            logits, sv = net.engine.forward(x, 1, True, net.dropout_active(), 9, 0, keep=True)
-            out = ts.step(x, lab, 1)
-            used = {k: calls[k] - before[k] for k in calls}
-            res.append((logits.clone(), net.flat_params.detach().clone(), float(out[0]), used))
-    finally:
-        ops.conv3d_site_fwd, ops.conv3d_site_bwd, ops.bn_act_bwd_site = orig
-    assert res[0][3]["fwd"] >= 4 and res[0][3]["bwd"] >= 2 and res[0][3]["bn"] >= 2, res[0][3]
-    assert res[2][3] == {"fwd": 0, "bwd": 0, "bn": 0}
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])          # run to run: the same bits
-    scale = float(res[2][0].abs().max())
-    assert float((res[0][0] - res[2][0]).abs().max()) < 2e-2 * scale
-    assert abs(res[0][2] - res[2][2]) < 1e-4
-    rel = float((res[0][1] - res[2][1]).abs().max()) / float(res[2][1].abs().max())
-    assert rel < 2e-3, rel
-
-
-def test_train_step_with_adam_behind_backward_equals_the_single_launch():
-    """TrainStep.step on one rank: the shared segment's Adam (+ weight packs) enqueued bucket by bucket from Engine.backward's
-    block-boundary hook (AdamBehindBackward, the default) against the one launch behind backward: the parameters, both Adam
-    moments and the loss are the same bits after five steps over both domains, with and without the second stream; the hook
-    did launch ranges (all but the last bucket), contiguous from 0."""
-    import fplx
-    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
-             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
-    lab = torch.zeros(2, 2, 16, 32, 64)
-    lab[:, 0] = 1.0
-    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
-    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
-    lab = lab.cuda()
-    res = []
-    for overlap, side in ((True, True), (False, True), (True, False)):
-        torch.manual_seed(3)
-        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
-        net.engine.use_side_stream = side
-        with torch.no_grad():
-            net.dropout_seed, net._fwd_counter = 9, 0
-        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
-        ts.adam_overlap = overlap
-        assert len(ts.adam_pipe.buckets) >= 3
-        losses, launched = [], []
-        for it in range(5):
-            losses.append(ts.step(x, lab, it % 2).clone())
-            launched.append(list(ts.adam_pipe.launched))
-        torch.cuda.synchronize()
-        res.append((net.flat_params.detach().clone(), ts.opt.exp_avg.clone(), ts.opt.exp_avg_sq.clone(), torch.stack(losses), launched,
-                    list(ts.opt.seg_steps)))
-    for other in (1, 2):
-        for k in range(4):
-            assert torch.equal(res[0][k], res[other][k]), (other, k)
-        assert res[0][5] == res[other][5]
-    b = net.bucket_ranges(1 << 21)
-    assert res[0][4][0] == b[:-1] and res[0][4][4] == b[:-1] and res[1][4][0] == []

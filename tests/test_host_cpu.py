@@ -267,9 +267,9 @@ def test_bench_refuses_a_world_size_that_is_not_its_gpus_argument():
         assert r.returncode != 0 and '"metric"' not in r.stdout and "2-rank child" in r.stderr
 
 
-def test_partial_rows_contract_and_deep_site_predicates():
+def test_partial_rows_contract():
     """fplx_num_partials (what callers size the reductions' partial-row buffers from, round 5: one row per 16 voxels up to 32768
-    voxels, one per 64 above, at most 512, monotonic) and the host-side predicates of the one-launch deep-level sites - no launch"""
+    voxels, one per 64 above, at most 512, monotonic) - no launch"""
     from fplx import _lib
     lib = _lib.lib()
     rows = [lib.fplx_num_partials(v) for v in (1, 16, 17, 1000, 8000, 8192, 32768, 32769, 64000, 4096000)]
@@ -280,52 +280,37 @@ def test_partial_rows_contract_and_deep_site_predicates():
         assert [lib.fplx_num_partials(v) for v in (1000, 8000, 64000)] == [16, 125, 512]
     finally:
         _lib.set_tuning("rows_small_div", 16)
-    # one-launch sites: <= 8192 voxels, 32..256 channel groups of 4 (or 8 where that still makes 64 blocks)
-    assert lib.fplx_deep_site_ok(8000, 256) == 1 and lib.fplx_deep_site_ok(1000, 512) == 1 and lib.fplx_deep_site_ok(8192, 128) == 1
-    assert lib.fplx_deep_site_ok(8193, 256) == 0 and lib.fplx_deep_site_ok(64000, 128) == 0 and lib.fplx_deep_site_ok(1000, 64) == 0
-    assert lib.fplx_deep_site_ok(1000, 260) == 0 and lib.fplx_deep_site_ok(0, 256) == 0
-    assert lib.fplx_deep_site_scratch_bytes() >= 16 + 8 * 256
-    # ... and behind a convolution only where its plan splits the reduction (levels 3 - 4 of the benchmark, not level 2)
-    assert lib.fplx_conv3d_site_fwd_ok(2, 10, 20, 20, 256, 256, 0) == 1 and lib.fplx_conv3d_site_fwd_ok(2, 5, 10, 10, 512, 512, 0) == 1
-    assert lib.fplx_conv3d_site_fwd_ok(2, 20, 40, 40, 128, 128, 0) == 0 and lib.fplx_conv3d_site_fwd_ok(2, 10, 20, 20, 256, 512, 0) == 0
-    # bad arguments are refused before any launch
-    assert lib.fplx_bn_act_bwd_site(None, 0, None, 0, None, 0, None, None, None, None, None, 0.0, 0, 0, 1000, 512, 1, None, None, None,
-                                    None, 0, None) == -5
 
 
-def test_adam_behind_backward_orders_its_ranges():
-    """train.py AdamBehindBackward (host logic only, a recording stand-in for FusedAdam): the hook launches every bucket but the
-    last as soon as `end` covers it, in order, begins the optimiser step exactly once, and finish() hands the rest over"""
-    from fplx.train import AdamBehindBackward
 
-    class Rec(object):
-        def __init__(self):
-            self.calls = []
+def test_late_import_warns_about_the_runtime_environment():
+    """fplx/_lib.py: GPU_MAX_HW_QUEUES / HIP_FORCE_DEV_KERNARG only reach the HIP runtime if fplx is imported before the first GPU
+    call.  A host program that initialised the GPU first (PyMIC imports torch, builds its device, reaches
+    fplx through the registry) gets a RuntimeWarning naming what it lost; a preset variable or an early import stays silent."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    prog = ("import sys, warnings, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "late = sys.argv[1] == '1'\n"
+            "torch.cuda.is_initialized = lambda: late\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    from fplx import _lib\n"
+            "msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]\n"
+            "print(len(msgs), sorted(_lib.runtime_env_report().items()))\n"
+            "print('|'.join(msgs))\n") % os.path.join(root, "fpl-plus_amd")
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG")}
 
-        def step_flat_begin(self):
-            self.calls.append(("begin",))
-
-        def step_flat_range(self, g, s, e):
-            self.calls.append(("range", s, e))
-
-        def step_flat_end(self, g, doms):
-            self.calls.append(("end", tuple(doms)))
-    opt = Rec()
-    pipe = AdamBehindBackward(opt, [(0, 100), (100, 250), (250, 400), (400, 420)])
-    pipe.begin("g")
-    assert not pipe.pending(99) and pipe.pending(100)
-    pipe.ready(99)
-    assert opt.calls == []
-    pipe.ready(260)                                     # two buckets complete at once
-    assert opt.calls == [("begin",), ("range", 0, 100), ("range", 100, 250)]
-    pipe.ready(420)                                     # the third; the last bucket is finish()'s
-    assert opt.calls[3:] == [("range", 250, 400)] and not pipe.pending(420)
-    pipe.finish([1])
-    assert opt.calls[4:] == [("end", (1,))] and pipe.launched == [(0, 100), (100, 250), (250, 400)]
-    # a step whose hook never fired (one bucket, or the second stream off and no boundary reached): begin + end only
-    opt2 = Rec()
-    p2 = AdamBehindBackward(opt2, [(0, 50)])
-    p2.begin("g")
-    p2.ready(50)
-    p2.finish([0])
-    assert opt2.calls == [("begin",), ("end", (0,))]
+    def run(late, extra):
+        r = subprocess.run([sys.executable, "-c", prog, "1" if late else "0"], env=dict(base, **extra), capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+    out = run(True, {})
+    assert out.startswith("1 ") and "GPU_MAX_HW_QUEUES / HIP_FORCE_DEV_KERNARG" in out and "'too late'" in out
+    out = run(True, {"GPU_MAX_HW_QUEUES": "8"})                      # one preset: only the other is named
+    assert out.startswith("1 ") and "HIP_FORCE_DEV_KERNARG was not" in out and "('8', 'preset')" in out
+    out = run(True, {"GPU_MAX_HW_QUEUES": "4", "HIP_FORCE_DEV_KERNARG": "0"})     # the user's own settings win, silently
+    assert out.startswith("0 ") and "('4', 'preset')" in out and "('0', 'preset')" in out
+    out = run(False, {})                                             # imported in time: set by fplx, no warning
+    assert out.startswith("0 ") and "('8', 'fplx')" in out and "('1', 'fplx')" in out
