@@ -294,15 +294,32 @@ __global__ void pack_conv_w(const float* __restrict__ w, T* __restrict__ wf, T* 
 // wb[26-tap][ci][co] in 32-byte runs - instead of one scattered 2-byte store per element and layout (the element-wise
 // kernel above is store-issue-bound: 0.7 TB/s on the 512x512 layers).
 constexpr int PK_CO = 16, PK_CI = 32, PK_ROW = PK_CI * 27 + 2;     // +2 bf16: odd dword stride between co rows
+// Stamps (round 6): a tile's pack can be kept across optimiser steps (fplx_adam_pack_step writes it from the updated weights), and
+// a writer that bypasses every version counter (p.data.mul_(), an EMA swap, init.*_(w.data), raw pointers) would leave it stale
+// without anybody noticing.  So whoever writes a tile's pack also records PK_STAMP of the fp32 master values it was made from
+// (two per output-channel row: elements 0 and 432 of the row's 864), and a `verify` pass re-reads those 32 values per tile and
+// repacks exactly the tiles whose masters no longer match, bit for bit - any whole-tensor write is caught; single-element
+// surgery between the sampled positions is not (such writers call Engine.invalidate()).
+constexpr int PK_STAMP = 2 * PK_CO, PK_STAMP_Q = PK_CI * 27 / 4 / 2;     // 32 stamped floats per tile, one every 108 float4
 __device__ __forceinline__ void pack27_tile(const float* __restrict__ w, bf16_t* __restrict__ wf, bf16_t* __restrict__ wb,
-                                            int Cout, int Cin, int blk) {
+                                            int Cout, int Cin, int blk, float* __restrict__ stamp = nullptr, int verify = 0) {
   __shared__ bf16_t lds[PK_CO * PK_ROW];
   const int ci_tiles = Cin / PK_CI;
   const int co0 = (blk / ci_tiles) * PK_CO, ci0 = (blk % ci_tiles) * PK_CI;
   constexpr int SEG4 = PK_CI * 27 / 4;                               // float4 per co run (216)
+  if (stamp && verify) {
+    int bad = 0;
+    if (threadIdx.x < PK_STAMP) {
+      const int co_l = threadIdx.x >> 1, q = (threadIdx.x & 1) * PK_STAMP_Q;
+      const float cur = w[((int64_t)(co0 + co_l) * Cin + ci0) * 27 + 4 * q];
+      bad = __float_as_uint(cur) != __float_as_uint(stamp[(int64_t)blk * PK_STAMP + threadIdx.x]);
+    }
+    if (!__syncthreads_or(bad)) return;                              // the pack was made from these masters: nothing to do
+  }
   for (int i = threadIdx.x; i < PK_CO * SEG4; i += 256) {
     const int co_l = i / SEG4, q = i % SEG4;
     const float4 v = *reinterpret_cast<const float4*>(w + ((int64_t)(co0 + co_l) * Cin + ci0) * 27 + 4 * q);
+    if (stamp && q % PK_STAMP_Q == 0) stamp[(int64_t)blk * PK_STAMP + co_l * 2 + q / PK_STAMP_Q] = v.x;
     bf16_t* d = lds + co_l * PK_ROW + 4 * q;
     Act<bf16_t>::st(d, v.x); Act<bf16_t>::st(d + 1, v.y); Act<bf16_t>::st(d + 2, v.z); Act<bf16_t>::st(d + 3, v.w);
   }
@@ -335,13 +352,14 @@ struct PackTable {
   const float* w[PK_MAX];
   bf16_t* wf[PK_MAX];
   bf16_t* wb[PK_MAX];
-  int cout[PK_MAX], cin[PK_MAX], first[PK_MAX + 1], n;
+  float* stamp[PK_MAX];                // per layer: tiles x PK_STAMP floats, or NULL
+  int cout[PK_MAX], cin[PK_MAX], first[PK_MAX + 1], n, verify;
 };
 __global__ void __launch_bounds__(256)
 pack_conv_w27_tiled_multi(const PackTable t) {
   int e = 0;
   while (e + 1 < t.n && (int)blockIdx.x >= t.first[e + 1]) ++e;
-  pack27_tile(t.w[e], t.wf[e], t.wb[e], t.cout[e], t.cin[e], (int)blockIdx.x - t.first[e]);
+  pack27_tile(t.w[e], t.wf[e], t.wb[e], t.cout[e], t.cin[e], (int)blockIdx.x - t.first[e], t.stamp[e], t.verify);
 }
 
 // Adam + weight pack in ONE launch (round 5): the weights change only in the optimiser step, and every forward opened with
@@ -358,6 +376,7 @@ struct AdamPackTable {
   int64_t off[PK_MAX];                 // element offset of layer e's weight inside the segment
   bf16_t* wf[PK_MAX];
   bf16_t* wb[PK_MAX];
+  float* stamp[PK_MAX];                // see pack27_tile
   int cout[PK_MAX], cin[PK_MAX], first[PK_MAX + 1], n;
   int64_t gstart[AP_MAXGAP], glen[AP_MAXGAP];
   int gfirst[AP_MAXGAP + 1], ng;
@@ -402,6 +421,7 @@ adam_pack27_multi(const AdamPackTable t) {
     *reinterpret_cast<float4*>(t.m + x) = mv;
     *reinterpret_cast<float4*>(t.v + x) = vv;
     *reinterpret_cast<float4*>(t.p + x) = pv;
+    if (t.stamp[e] && q % PK_STAMP_Q == 0) t.stamp[e][(int64_t)blk * PK_STAMP + co_l * 2 + q / PK_STAMP_Q] = pv.x;
     bf16_t* d = lds + co_l * PK_ROW + 4 * q;
     Act<bf16_t>::st(d, pv.x); Act<bf16_t>::st(d + 1, pv.y); Act<bf16_t>::st(d + 2, pv.z); Act<bf16_t>::st(d + 3, pv.w);
   }
@@ -675,8 +695,9 @@ int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin,
 }
 
 int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf, void* const* wb, const int* cout,
-                                   const int* cin, int dt, fplx_stream_t stream) {
+                                   const int* cin, int dt, float* const* stamp, int verify, fplx_stream_t stream) {
   FPLX_REQUIRE(w && wf && wb && cout && cin, FPLX_E_NULL, "pack_conv_weights_batched: null pointer");
+  FPLX_REQUIRE(!verify || stamp, FPLX_E_NULL, "pack_conv_weights_batched: verify needs the stamps of the previous pack");
   FPLX_REQUIRE(n > 0 && n <= PK_MAX, FPLX_E_BADSHAPE, "pack_conv_weights_batched: %d layers (1..%d)", n, PK_MAX);
   const bool tiled = fplx_knob(FPLX_K_PACK_TILED) != 0;
   const bool multi = fplx_knob(FPLX_K_PACK_MULTI) != 0;     // A/B knob
@@ -687,6 +708,8 @@ int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf
     FPLX_REQUIRE(w[i] && wf[i] && cout[i] > 0 && cin[i] > 0, FPLX_E_NULL, "pack_conv_weights_batched: layer %d", i);
     const bool ok = multi && tiled && dt == FPLX_BF16 && cin[i] % PK_CI == 0 && cout[i] % PK_CO == 0 &&
                     ((uintptr_t)w[i] % 16 == 0) && ((uintptr_t)wf[i] % 16 == 0) && ((uintptr_t)wb[i] % 16 == 0);
+    FPLX_REQUIRE(ok || !(stamp && stamp[i]), FPLX_E_BADSHAPE, "pack_conv_weights_batched: layer %d has no tiled pack, hence no stamps "
+                 "(fplx_adam_pack_ok)", i);
     if (!ok) {                                                // layers the tiled kernel does not take: one by one
       const int rc = fplx_pack_conv_weight(w[i], wf[i], wb[i], cout[i], cin[i], 3, 3, 3, dt, stream);
       if (rc != FPLX_OK) return rc;
@@ -694,8 +717,11 @@ int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf
     }
     const int k = t.n++;
     t.w[k] = w[i]; t.wf[k] = (bf16_t*)wf[i]; t.wb[k] = (bf16_t*)wb[i]; t.cout[k] = cout[i]; t.cin[k] = cin[i];
+    t.stamp[k] = stamp ? stamp[i] : nullptr;
+    FPLX_REQUIRE(!verify || t.stamp[k], FPLX_E_NULL, "pack_conv_weights_batched: verify: layer %d has no stamps", i);
     t.first[k + 1] = t.first[k] + (cout[i] / PK_CO) * (cin[i] / PK_CI);
   }
+  t.verify = verify ? 1 : 0;
   if (t.n == 0) return FPLX_OK;
   pack_conv_w27_tiled_multi<<<t.first[t.n], 256, 0, (hipStream_t)stream>>>(t);
   return fplx_check_launch("pack_conv_weights_batched");
@@ -727,7 +753,7 @@ int fplx_adam_pack_ok(int cout, int cin) {
 
 int fplx_adam_pack_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int nl, const int64_t* off, const int* cout,
-                        const int* cin, void* const* wf, void* const* wb, fplx_stream_t stream) {
+                        const int* cin, void* const* wf, void* const* wb, float* const* stamp, fplx_stream_t stream) {
   FPLX_REQUIRE(p && g && m && v && off && cout && cin && wf && wb, FPLX_E_NULL, "adam_pack_step: null pointer");
   FPLX_REQUIRE(n > 0 && step >= 1 && nl > 0 && nl <= PK_MAX, FPLX_E_BADSHAPE, "adam_pack_step: n=%lld step=%d layers=%d (1..%d)",
                (long long)n, step, nl, PK_MAX);
@@ -755,6 +781,7 @@ int fplx_adam_pack_step(float* p, const float* g, float* m, float* v, int64_t n,
     FPLX_REQUIRE(((uintptr_t)wf[i] % 16) == 0 && ((uintptr_t)wb[i] % 16) == 0, FPLX_E_BADSHAPE, "adam_pack_step: packs must be 16-byte aligned");
     gap(pos, off[i]);
     t.off[i] = off[i]; t.cout[i] = cout[i]; t.cin[i] = cin[i]; t.wf[i] = (bf16_t*)wf[i]; t.wb[i] = (bf16_t*)wb[i];
+    t.stamp[i] = stamp ? stamp[i] : nullptr;
     t.first[i + 1] = t.first[i] + (cout[i] / PK_CO) * (cin[i] / PK_CI);
     pos = off[i] + len;
   }

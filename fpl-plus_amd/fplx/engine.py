@@ -25,7 +25,7 @@ LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
 class Saved(object):
     """what one forward leaves behind for its backward"""
     __slots__ = ("x", "dims", "domain", "train", "seed", "step", "blocks", "cats", "pooled", "packs",
-                 "drop_on", "deconv_in", "skips", "split", "oc_fused")
+                 "drop_on", "deconv_in", "skips", "split", "oc_fused", "pack_gen")
 
 
 class Engine(object):
@@ -36,10 +36,18 @@ class Engine(object):
         self._pack_cache = None
         self._train_packs = None                         # packs of the last train-mode forward (reuse_packs)
         # persistent bf16 packs of the 3x3x3 layers the fused Adam + pack launch takes (fplx_adam_pack_step, round 5):
-        # (act dtype, device, {site: (wf, wb)}); _adam_packs = the _pack_key for which their CONTENT is current (the optimiser
-        # step wrote it) - any other parameter write drops it (invalidate(), a version-counter change)
+        # (act dtype, device, {site: (wf, wb)}, {site: stamp}); _adam_packs = the _pack_key for which their CONTENT is current
+        # (the optimiser step wrote it) - any other parameter write the host can see drops it (invalidate(), a version-counter
+        # change) and everything is packed again.  Writers the host cannot see (p.data.mul_(), an EMA swap through `.data`,
+        # init.*_(w.data), raw pointers: no version counter moves) are caught on the device: every pack tile carries a stamp of
+        # the fp32 master values it was made from and a train-mode forward verifies them in one cheap launch, repacking exactly
+        # the tiles whose masters changed (round 6; csrc/conv_generic.hip: pack27_tile)
         self._pack_bufs = None
         self._adam_packs = None
+        # generation of the persistent packs' CONTENT: bumped by every host-visible overwrite (the optimiser launch, a full
+        # repack).  A saved forward aliases those buffers (sv.packs): its backward refuses to run on another generation's
+        # weights (forward A, optimiser step, backward A would compute A's data gradients with the NEW weights - ADVICE r05)
+        self._pack_gen = 0
         self.use_adam_pack = _lib.host_knob("adam_pack") != 0
         self.use_pack_multi = _lib.host_knob("pack_small_multi") != 0       # transposed-convolution + out_conv packs in one launch
         self.allow_pack_reuse = _lib.host_knob("pack_reuse") != 0      # A/B switches: fplx/_lib.py:_HOST_KNOBS
@@ -82,56 +90,65 @@ class Engine(object):
         dev = net.flat_params.device
         if self._pack_bufs is None or self._pack_bufs[0] != act_dtype or self._pack_bufs[1] != dev:
             first = next(iter(net.conv_sites()))[0]
-            bufs = {}
+            bufs, stamps = {}, {}
             for name, conv in net.conv_sites():
                 w = conv.weight
                 if w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and name != first and ops.adam_pack_ok(w.shape[0], w.shape[1]):
                     bufs[name] = (torch.empty((27, w.shape[0], w.shape[1]), dtype=act_dtype, device=dev),
                                   torch.empty((27, w.shape[1], w.shape[0]), dtype=act_dtype, device=dev))
-            self._pack_bufs = (act_dtype, dev, bufs)
+                    stamps[name] = torch.empty(ops.pack_stamp_floats(w.shape[0], w.shape[1]), dtype=torch.float32, device=dev)
+            self._pack_bufs = (act_dtype, dev, bufs, stamps)
             self._adam_packs = None
         return self._pack_bufs[2]
 
     def adam_pack_plan(self):
-        """for FusedAdam.step_flat: [(element offset in the flat buffer, cout, cin, wf, wb)] of the layers whose packs the
+        """for FusedAdam.step_flat: [(element offset in the flat buffer, cout, cin, wf, wb, stamp)] of the layers whose packs the
         optimiser launch writes (ascending offsets, all inside the shared segment), or None"""
         net = self.net
         bufs = self._persistent_packs(net.act_dtype)
         if not bufs:
             return None
+        stamps = self._pack_bufs[3]
         plan = []
         for name, (wf, wb) in bufs.items():
             o, n, shp = net._layout[name + ".weight"]
-            plan.append((o, shp[0], shp[1], wf, wb))
+            plan.append((o, shp[0], shp[1], wf, wb, stamps[name]))
         plan.sort(key=lambda t: t[0])
         return plan
 
     def packs_written_by_optimizer(self):
         """the optimiser step has just written the persistent packs from the updated weights (after its invalidate())"""
         self._adam_packs = self._pack_key(self.net.act_dtype)
+        self._pack_gen += 1
 
     def _pack(self, act_dtype):
         net = self.net
         packs = {}
         first = next(iter(net.conv_sites()))[0]
-        batch = []                                       # the 3x3x3 layers: one launch for all of them
+        batch, kept = [], []                             # the 3x3x3 layers: one launch for all of them
         bufs = self._persistent_packs(act_dtype)
+        stamps = self._pack_bufs[3] if bufs else {}
         fresh = bool(bufs) and self._adam_packs is not None and self._adam_packs == self._pack_key(act_dtype)
         for name, conv in net.conv_sites():
             want_wb = name != first                      # no data gradient w.r.t. the network input
             if conv.weight.dim() == 4:                   # Conv2d of a 2.5D level
                 packs[name] = ops.pack_conv2d_weight(conv.weight, act_dtype, want_wb)
-            elif fresh and name in bufs:                 # written by the optimiser step itself: nothing to do
-                packs[name] = bufs[name]
+            elif fresh and name in bufs:                 # written by the optimiser step itself (or by the previous forward)
+                kept.append((name, conv.weight, want_wb, bufs[name], stamps[name]))
             else:
-                batch.append((name, conv.weight, want_wb, bufs.get(name)))
-        for i in range(0, len(batch), 32):
-            part = batch[i:i + 32]
-            res = ops.pack_conv_weights_batched([b[1] for b in part], act_dtype, [b[2] for b in part], [b[3] for b in part])
-            for b, r in zip(part, res):
-                packs[b[0]] = r
+                batch.append((name, conv.weight, want_wb, bufs.get(name), stamps.get(name)))
+        # kept packs: ONE launch checks every tile's stamp against the master weights as they are now and repacks the tiles that
+        # differ - nothing, normally (a few microseconds); everything a `.data` writer touched otherwise
+        for todo, verify in ((kept, True), (batch, False)):
+            for i in range(0, len(todo), 32):
+                part = todo[i:i + 32]
+                res = ops.pack_conv_weights_batched([b[1] for b in part], act_dtype, [b[2] for b in part], [b[3] for b in part],
+                                                    [b[4] for b in part], verify)
+                for b, r in zip(part, res):
+                    packs[b[0]] = r
         if bufs and not fresh:
             self._adam_packs = self._pack_key(act_dtype)     # the persistent buffers now hold the current weights' packs
+            self._pack_gen += 1
         oc = net.out_conv
         if self.use_pack_multi and not net.bilinear:
             # the remaining small packs (transposed convolutions, out_conv) in ONE launch instead of six
@@ -247,6 +264,7 @@ class Engine(object):
         ft = net.ft_chns
         if self._tuning_epoch != _lib.tuning_epoch:      # a kernel knob was flipped: packs / folds may have been laid out for another kernel
             self.invalidate()
+            self._pack_bufs = None                       # (which layers have a tiled pack and stamps is knob-dependent too)
             self._tuning_epoch = _lib.tuning_epoch
         if train and reuse_packs and self.allow_pack_reuse and self._train_packs is not None and self._train_packs[0] == adt:
             packs = self._train_packs[1]
@@ -306,6 +324,7 @@ class Engine(object):
         sv = Saved()
         sv.x, sv.dims, sv.domain, sv.train, sv.seed, sv.step = x, dims, domain, train, seed, step
         sv.blocks, sv.cats, sv.pooled, sv.packs, sv.drop_on, sv.deconv_in = [], [], [], packs, list(drop_on), []
+        sv.pack_gen = self._pack_gen
 
         def empty(v, c):
             return torch.empty((v, c), dtype=adt, device=dev)
@@ -477,6 +496,10 @@ class Engine(object):
         have been enqueued (flat order = production order) - fplx.ddp launches all-reduce buckets."""
         net = self.net
         dims, domain, packs = sv.dims, sv.domain, sv.packs
+        if sv.pack_gen != self._pack_gen:
+            raise RuntimeError("fplx: backward of a forward whose weight packs have been overwritten since (an optimiser step or a "
+                               "repack ran between this forward and its backward): the data gradients would be taken with the new "
+                               "weights.  Run backward before the optimiser step.")
         dev, adt = dlogits.device, net.act_dtype
         a_dt = ops._DT[adt]
         ft = net.ft_chns

@@ -286,6 +286,16 @@ class UNet2D5_dsbn(nn.Module):
         self.engine.invalidate()
         return super(UNet2D5_dsbn, self).train(mode)
 
+    def parameters_changed(self):
+        """Tell the engine that parameters or running statistics were written behind its back.  torch-side in-place edits of a
+        parameter (p.mul_(), p.copy_() under no_grad) are seen through its version counter; writes through `.data`
+        (p.data.add_(), the reference's init.*_(m.weight.data) paths), through another tensor that shares the storage, or
+        through raw pointers bump NO counter.  Train-mode forwards still catch those on the device - every kept weight pack is
+        verified against a stamp of the master values it was made from (whole-tensor writes always, single elements only at
+        the sampled positions) - but eval-mode forwards reuse their packs and BatchNorm folds until something the host can see
+        changes: call this after such a write (it is what load_state_dict(), train() / eval() and the optimisers do)."""
+        self.engine.invalidate()
+
     def parameters_unchanged_since_last_forward(self):
         """A promise by the caller, consumed by the NEXT train-mode forward: no parameter was touched since the previous
         forward (the second domain of a `training_all` iteration, agent_seg.py:462-486) - that forward then uses the

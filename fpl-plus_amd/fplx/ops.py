@@ -53,9 +53,17 @@ def pack_conv_weight(w, act_dtype, want_wb=True):
     return wf, wb
 
 
-def pack_conv_weights_batched(ws, act_dtype, want_wb, into=None):
+def pack_stamp_floats(cout, cin):
+    """floats of a layer's stamp buffer (include/fplx.h, fplx_pack_conv_weights_batched): 32 per 16 x 32-channel pack tile"""
+    return (cout // 16) * (cin // 32) * 32
+
+
+def pack_conv_weights_batched(ws, act_dtype, want_wb, into=None, stamps=None, verify=False):
     """pack_conv_weight for a list of 3x3x3 weights in one launch -> list of (wf, wb).
-    into: optional list of existing (wf, wb) destinations (None entries: allocate) - the engine's persistent pack buffers"""
+    into: optional list of existing (wf, wb) destinations (None entries: allocate) - the engine's persistent pack buffers
+    stamps: optional list of per-layer fp32 stamp buffers (pack_stamp_floats; None entries: none) that record which master values
+    each pack tile was made from; verify=True: `into` and `stamps` hold an earlier pack - only the tiles whose masters changed
+    since are packed again (one cheap launch when nothing changed)"""
     import ctypes
     n = len(ws)
     outs = []
@@ -65,14 +73,20 @@ def pack_conv_weights_batched(ws, act_dtype, want_wb, into=None):
         if into is not None and into[i] is not None:
             outs.append(into[i])
             continue
+        assert not verify, "verify needs the earlier pack (into)"
         wf = torch.empty((27, co, ci), dtype=act_dtype, device=w.device)
         wb = torch.empty((27, ci, co), dtype=act_dtype, device=w.device) if wantb else None
         outs.append((wf, wb))
     vp = ctypes.c_void_p * n
     ip = ctypes.c_int * n
+    st = None
+    if stamps is not None:
+        for w, s_ in zip(ws, stamps):
+            assert s_ is None or (s_.dtype == torch.float32 and s_.numel() >= pack_stamp_floats(w.shape[0], w.shape[1]))
+        st = vp(*[ptr(s_) or None for s_ in stamps])
     call("fplx_pack_conv_weights_batched", n, vp(*[ptr(w) for w in ws]), vp(*[ptr(o[0]) for o in outs]),
          vp(*[ptr(o[1]) or None for o in outs]), ip(*[w.shape[0] for w in ws]), ip(*[w.shape[1] for w in ws]),
-         _DT[act_dtype], stream())
+         _DT[act_dtype], st, 1 if verify else 0, stream())
     return outs
 
 
@@ -416,13 +430,14 @@ def adam_pack_ok(cout, cin):
 
 def adam_pack_step(p, g, m, v, lr, step, weight_decay, grad_scale, betas, eps, layers):
     """fplx_adam_step over the flat segment p AND the bf16 packs of the 3x3x3 weights inside it, one launch.
-    layers: [(element offset in p, cout, cin, wf, wb)] ascending by offset"""
+    layers: [(element offset in p, cout, cin, wf, wb[, stamp])] ascending by offset (stamp: pack_conv_weights_batched)"""
     import ctypes
     n = len(layers)
     vp, ip, lp = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+    st = vp(*[(ptr(l[5]) or None) if len(l) > 5 else None for l in layers])
     call("fplx_adam_pack_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay, int(step),
          grad_scale, n, lp(*[int(l[0]) for l in layers]), ip(*[int(l[1]) for l in layers]), ip(*[int(l[2]) for l in layers]),
-         vp(*[ptr(l[3]) for l in layers]), vp(*[ptr(l[4]) or None for l in layers]), stream())
+         vp(*[ptr(l[3]) for l in layers]), vp(*[ptr(l[4]) or None for l in layers]), st, stream())
 
 
 def mc_filter(logits_tcv, thr=0.01, want_hards=True, want_maps=False):

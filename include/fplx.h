@@ -84,9 +84,16 @@ int fplx_conv3d_plan_query(int n, int d, int h, int w, int cin, int cout, int kd
 int fplx_pack_conv_weight(const float* w, void* wf, void* wb, int cout, int cin, int kd, int kh, int kw,
                           int dt, fplx_stream_t stream);
 /* the same for n (<= 32) 3x3x3 layers in one launch: host arrays of per-layer pointers / channel counts (what the train
- * step does after every optimizer step for all ConvBlockND convolutions, unet2d5_dsbn.py:54-55).  wb[i] may be NULL. */
+ * step does after every optimizer step for all ConvBlockND convolutions, unet2d5_dsbn.py:54-55).  wb[i] may be NULL.
+ * stamp (may be NULL; layers with cout % 16 == 0 and cin % 32 == 0 in bf16 only): stamp[i] = caller-owned buffer of
+ * (cout / 16) * (cin / 32) * 32 floats per layer (or NULL) that receives, per 16 x 32-channel pack tile, 32 of the fp32 master
+ * values the tile's pack was made from.  verify = 1: the packs and stamps of an earlier call (or of fplx_adam_pack_step) are
+ * still in wf / wb / stamp - only the tiles whose masters no longer match their stamps bit for bit are packed again.  This is
+ * how a caller that keeps packs across optimiser steps notices writers that bypass it (torch's `.data` edits bump no version
+ * counter: agent_seg.py's EMA / init paths); whole-tensor writes are always caught, single-element edits between the sampled
+ * positions (elements 0 and 432 of every 864-element row segment) are not. */
 int fplx_pack_conv_weights_batched(int n, const float* const* w, void* const* wf, void* const* wb, const int* cout,
-                                   const int* cin, int dt, fplx_stream_t stream);
+                                   const int* cin, int dt, float* const* stamp, int verify, fplx_stream_t stream);
 /* n (<= 16) small packs in one launch: job i is a convolution weight [a][b][taps] fp32 (kind 0: a = Cout, b = Cin, layouts of
  * fplx_pack_conv_weight) or a transposed-convolution weight (kind 1: a = Cin, b = Cout, layouts of fplx_pack_deconv_weight /
  * _deconv122_weight) packed into wf[i] / wb[i] (either may be NULL) in dtype dt[i] - the stem, the four transposed convolutions
@@ -366,11 +373,12 @@ int fplx_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
  * of the `nl` (<= 32) 3x3x3 convolution weights that live inside it - from the UPDATED values (the weights change only here;
  * what the train step otherwise re-reads at the head of every forward, unet2d5_dsbn.py:54-55 + get_optimizer.py:17).
  * off[i]: element offset of layer i's [cout][cin][3][3][3] weight in the segment (ascending, multiples of 4); layers must
- * satisfy fplx_adam_pack_ok; wb[i] may be NULL.  Same parameters, moments and packs as the two separate calls, bit for bit. */
+ * satisfy fplx_adam_pack_ok; wb[i] may be NULL; stamp: as in fplx_pack_conv_weights_batched (may be NULL), written from the
+ * updated values.  Same parameters, moments and packs as the two separate calls, bit for bit. */
 int fplx_adam_pack_ok(int cout, int cin);
 int fplx_adam_pack_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                         float weight_decay, int step, float grad_scale, int nl, const int64_t* off, const int* cout,
-                        const int* cin, void* const* wf, void* const* wb, fplx_stream_t stream);
+                        const int* cin, void* const* wf, void* const* wb, float* const* stamp, fplx_stream_t stream);
 
 /* ------------------------------------------------------------------ pseudo-label filter
  * FPL branch of SegmentationAgent.infer (net_run_dsbn/agent_seg.py:911-931) for one volume:

@@ -441,9 +441,9 @@ def test_train_step_with_the_fused_adam_pack_launch():
         packed = []
         inner = ops.pack_conv_weights_batched
 
-        def counting(ws, *a, _inner=inner, _packed=packed, **kw):
-            _packed.append(len(ws))
-            return _inner(ws, *a, **kw)
+        def counting(ws, act_dtype, want_wb, into=None, stamps=None, verify=False, _inner=inner, _packed=packed):
+            _packed.append((len(ws), bool(verify)))
+            return _inner(ws, act_dtype, want_wb, into, stamps, verify)
         ops.pack_conv_weights_batched = counting
         try:
             for it in range(4):
@@ -456,11 +456,111 @@ def test_train_step_with_the_fused_adam_pack_launch():
         torch.cuda.synchronize()
         res.append((net.flat_params.detach().clone(), list(packed)))
     assert torch.equal(res[0][0], res[1][0])
-    n3 = res[1][1][0]
-    assert res[1][1] == [n3] * 4                         # unfused: every forward packs every 3x3x3 layer
+    n3 = res[1][1][0][0]
+    assert res[1][1] == [(n3, False)] * 4                # unfused: every forward packs every 3x3x3 layer
     # fused: the first forward packs everything (nothing written yet), the forward behind the in-place edit again; the others
-    # only the stem (1 input channel: not a layer of the tiled pack)
-    assert res[0][1] == [n3, 1, n3, 1], res[0][1]
+    # VERIFY the kept packs' stamps (one launch that repacks nothing here) and pack only the stem (1 input channel: not a layer
+    # of the tiled pack)
+    assert res[0][1] == [(n3, False), (n3 - 1, True), (1, False), (n3, False), (n3 - 1, True), (1, False)], res[0][1]
+
+
+def test_pack_stamps_catch_writes_that_bypass_the_version_counters():
+    """with the optimiser launch writing the packs, a write through `.data` (the reference's EMA / init paths,
+    agent_seg.py) bumps no version counter - the next train step must still run on the edited weights.  Kernel level: a verify
+    pass over unchanged masters rewrites nothing, after a `.data` edit of one layer it repacks exactly that layer's tiles, and
+    the result equals a full pack.  Step level: p.data.mul_() between two TrainStep.step calls changes the result, to the bits
+    of the same run with an explicit net.parameters_changed()."""
+    import fplx
+    from fplx import ops
+    g = torch.Generator().manual_seed(4)
+    ws = [(torch.randn(co, ci, 3, 3, 3, generator=g) * 0.1).cuda() for co, ci in ((32, 64), (64, 32), (16, 96))]
+    bf = torch.bfloat16
+    packs = [(torch.empty((27, w.shape[0], w.shape[1]), dtype=bf, device="cuda"),
+              torch.empty((27, w.shape[1], w.shape[0]), dtype=bf, device="cuda")) for w in ws]
+    stamps = [torch.zeros(ops.pack_stamp_floats(w.shape[0], w.shape[1]), device="cuda") for w in ws]
+    ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, stamps, False)
+    ref = ops.pack_conv_weights_batched(ws, bf, [True] * 3)
+    for (a, b), (c, d) in zip(packs, ref):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    assert all(float(s_.abs().sum()) > 0 for s_ in stamps)
+    # poison the packs: a verify pass over unchanged masters must not touch them
+    for a, b in packs:
+        a.fill_(7.0)
+        b.fill_(7.0)
+    ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, stamps, True)
+    assert all(float((a.float() - 7.0).abs().max()) == 0 and float((b.float() - 7.0).abs().max()) == 0 for a, b in packs)
+    # a `.data` write to ONE layer: that layer is repacked (equal to a fresh pack), the others keep the poison
+    ws[1].data.mul_(0.5)
+    ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, stamps, True)
+    ref = ops.pack_conv_weights_batched(ws, bf, [True] * 3)
+    assert torch.equal(packs[1][0], ref[1][0]) and torch.equal(packs[1][1], ref[1][1])
+    assert float((packs[0][0].float() - 7.0).abs().max()) == 0 and float((packs[2][1].float() - 7.0).abs().max()) == 0
+    # ... and its stamps follow: a second verify is a no-op again
+    packs[1][0].fill_(7.0)
+    ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, stamps, True)
+    assert float((packs[1][0].float() - 7.0).abs().max()) == 0
+    # one output-channel row of one tile (what `w.data[3] = 0` does): only the tiles of that row
+    ws[0].data[3].zero_()
+    ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, stamps, True)
+    ref = ops.pack_conv_weights_batched(ws, bf, [True] * 3)
+    assert torch.equal(packs[0][0][:, :16], ref[0][0][:, :16]) and float((packs[0][0][:, 16:].float() - 7.0).abs().max()) == 0
+    with pytest.raises(ValueError):
+        ops.pack_conv_weights_batched(ws, bf, [True] * 3, packs, None, True)          # verify without stamps
+
+    # ---- step level
+    p = dict(in_chns=1, feature_chns=[32, 64, 64, 128, 128], dropout=[0, 0, 0.3, 0, 0], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
+    lab = torch.zeros(2, 2, 16, 32, 64)
+    lab[:, 0] = 1.0
+    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
+    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
+    lab = lab.cuda()
+    res = {}
+    for mode in ("data", "data+changed", "none"):
+        torch.manual_seed(3)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        assert net.engine.use_adam_pack
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+        outs = []
+        for it in range(4):
+            outs.append(ts.step(x, lab, it % 2).clone())
+            if it == 1 and mode != "none":
+                v0 = net.block1.conv.conv3d_2.weight._version
+                net.block1.conv.conv3d_2.weight.data.mul_(0.5)          # no version counter moves
+                net.up3.conv.conv3d_1.weight.data.add_(0.01)
+                assert net.block1.conv.conv3d_2.weight._version == v0
+                if mode == "data+changed":
+                    net.parameters_changed()
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(outs), net.flat_params.detach().clone())
+    assert torch.equal(res["data"][0], res["data+changed"][0]) and torch.equal(res["data"][1], res["data+changed"][1])
+    assert torch.equal(res["data"][0][:2], res["none"][0][:2])
+    assert float((res["data"][0][2:, 0] - res["none"][0][2:, 0]).abs().max()) > 1e-4          # the edit IS seen by the next step
+
+
+def test_backward_behind_an_optimiser_step_is_refused():
+    """a saved forward aliases the persistent weight packs; forward A, optimiser step, backward A would take A's data
+    gradients with the updated weights - the engine raises instead"""
+    import fplx
+    p = dict(in_chns=1, feature_chns=[32, 64, 64, 128, 128], dropout=[0, 0, 0, 0, 0], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    torch.manual_seed(2)
+    net = fplx.UNet2D5_dsbn(dict(p)).cuda().train()
+    opt = fplx.FusedAdam(net, 1e-3)
+    x = torch.randn(1, 1, 16, 32, 64).cuda()
+    dom = torch.zeros(1, dtype=torch.long)
+    la = net(x, domain_label=dom).sum()
+    lb = net(x, domain_label=dom).sum()
+    lb.backward()                       # same generation of packs: fine
+    opt.step()
+    net(x, domain_label=dom)            # the forward behind the step packs the updated weights into the same buffers
+    with pytest.raises(RuntimeError, match="overwritten"):
+        la.backward()
+    net.zero_grad()
+    net(x, domain_label=dom).sum().backward()          # and the engine carries on
+    opt.step()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 4, 32, 2, 16, 64), (1, 1, 64, 4, 8, 32),

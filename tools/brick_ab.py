@@ -2,7 +2,7 @@
 data gradient without), in ONE process, interleaved rounds; every setting's output is compared bit for bit with the first
 setting's (the settings select kernels that add in the same order).
 
-    python tools/brick_ab.py "brick_lw=0" "brick_lw=7" [--rounds=5] [--iters=20]
+    python tools/brick_ab.py "brick_fill=256" "brick_fill=128" [--rounds=5] [--iters=20]
 """
 import os
 import sys

@@ -18,7 +18,6 @@ int64_t fplx_knob_values[FPLX_K_COUNT] = {
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
 int main(int argc, char** argv) {
-  if (getenv("BRICK_LW")) fplx_knob_values[FPLX_K_BRICK_LW] = atoi(getenv("BRICK_LW"));
   const int cin = atoi(argv[1]), cout = atoi(argv[2]), n = atoi(argv[3]), d = atoi(argv[4]), h = atoi(argv[5]), w = atoi(argv[6]);
   const int want_stats = argc > 7 ? atoi(argv[7]) : 0;
   const int64_t V = (int64_t)n * d * h * w;
