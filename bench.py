@@ -66,7 +66,8 @@ class KernelTimer(object):
         self._orig = {}
         for name in ("conv3d_fwd", "conv3d_wgrad", "conv3d_fwd_cat2", "conv3d_dgrad_split2", "conv3d_wgrad_cat2",
                      "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad", "maxpool2_fwd",
-                     "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "outconv_fwd_bn", "outconv_dgrad_bn_bwd"):
+                     "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "adam_pack_step", "pack_weights_multi",
+                     "pack_conv_weights_batched", "outconv_fwd_bn", "outconv_dgrad_bn_bwd"):
             self._wrap(name)
 
     def _key(self, name, a, kw={}):
@@ -107,6 +108,16 @@ class KernelTimer(object):
             return (name, tuple(a[0].shape), a[2] is not None)
         if name == "adam_step":                 # (p, g, m, v, ...)
             return (name, int(a[0].numel()))
+        if name == "adam_pack_step":            # (p, g, m, v, lr, step, wd, gscale, betas, eps, layers): segment + packed elements
+            return (name, int(a[0].numel()), int(sum(l[1] * l[2] * 27 * (2 if l[4] is not None else 1) for l in a[10])))
+        if name == "pack_weights_multi":        # (jobs): [(kind, w, wf, wb, a, b, taps)]
+            return (name, int(sum(j[1].numel() for j in a[0])),
+                    int(sum(j[1].numel() * sum(t.element_size() for t in (j[2], j[3]) if t is not None) for j in a[0])))
+        if name == "pack_conv_weights_batched":     # (ws, dtype, want_wb, into, stamps, verify)
+            verify = bool(kw.get("verify", a[5] if len(a) > 5 else False))
+            nel = int(sum(w.numel() for w in a[0]))
+            nb = int(sum(w.numel() * (2 if wb else 1) for w, wb in zip(a[0], a[2])))
+            return (name + ("(verify)" if verify else ""), nel, nb)
         return (name,)
 
     def _wrap(self, name):
@@ -207,6 +218,14 @@ def row_model(key):
         nbytes = vox * (12.0 * shp[1] + (4.0 if has_pw else 0.0))
     elif name == "adam_step":
         nbytes = 28.0 * key[1]
+    elif name == "adam_pack_step":               # p, g, m, v read + p, m, v written (28 B / element) + the bf16 packs written
+        nbytes = 28.0 * key[1] + 2.0 * key[2]
+    elif name == "pack_weights_multi":           # fp32 masters read, packs written (key[2] already in bytes)
+        nbytes = 4.0 * key[1] + 1.0 * key[2]
+    elif name == "pack_conv_weights_batched":    # fp32 masters read, bf16 packs written
+        nbytes = 4.0 * key[1] + 2.0 * key[2]
+    elif name == "pack_conv_weights_batched(verify)":     # 32 of every tile's 13 824 masters + as many stamped floats
+        nbytes = 8.0 * key[1] * 32.0 / 13824.0
     else:
         return None
     ridge = MFMA_BF16_PEAK_TF * 1e3 / HBM_PEAK_GBS
@@ -328,6 +347,67 @@ def cpu_baseline():
         sample = "extrapolated from the " + note + " (a full step would take about %.0f s here)" % est_full
     return {"value": value, "unit": "volumes/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
             "sample": "32-base UNet-DSBN, DiceLoss + Adam, oracle/torch_ref.py, %d threads: %s" % (cores, sample)}
+
+
+def rccl_report(ts, dev, rank, world):
+    """The `rccl` object of a data-parallel bench line (BASELINE.md section 3 asks for the measured bus
+    bandwidth as the denominator of the scaling figure), measured BEFORE the timed region on the step's own buffers and bucket
+    ranges, HIP events on the stream the collectives are enqueued from:
+      world / backend / version      what torch.distributed reports (backend "nccl" = RCCL on ROCm)
+      devices                        per rank: device name, PCI bus id, uuid - gathered to rank 0, so the record shows that
+                                     RCCL really saw N different GPUs
+      allreduce_flat_ms              ONE all-reduce(sum) of the whole flat fp32 gradient buffer (90 MB for the 32-base network)
+      allreduce_buckets_ms           the step's own sequence: every bucket of TrainStep's reducer + one BatchNorm segment,
+                                     launched asynchronously back to back as backward does, then waited for
+      busbw_GBps                     ring bus bandwidth of the flat all-reduce: 2 (N - 1) / N x bytes / time (0 at N = 1:
+                                     nothing crosses a link; algbw_GBps = bytes / time is reported beside it)"""
+    g = ts.gflat
+    nbytes = g.numel() * 4
+
+    def timed(fn, warm=2, reps=5):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def buckets():
+        works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in ts.reducer.buckets]
+        s, e = ts.reducer.domain_ranges[0]
+        works.append(dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+
+    g.zero_()                                            # (sums of zeros: the measurement leaves the buffer as the step expects it)
+    t_flat = timed(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM))
+    t_b = timed(buckets)
+    props = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device": props.name,
+            "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                              getattr(props, "pci_device_id", 0)),
+            "uuid": str(getattr(props, "uuid", "")), "cuda_index": dev.index}
+    devs = [None] * world
+    dist.all_gather_object(devs, mine)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                               # noqa: BLE001
+        ver = "unknown (%s)" % type(e).__name__
+    return {"world": world, "backend": dist.get_backend(), "version": ver, "devices": devs,
+            "flat_gradient_MB": round(nbytes / 1e6, 2), "buckets": len(ts.reducer.buckets) + 1,
+            "bucket_MB": [round((e - s) * 4 / 1e6, 2) for s, e in ts.reducer.buckets],
+            "allreduce_flat_ms": round(t_flat, 4), "allreduce_90MB_ms": round(t_flat * 90e6 / nbytes, 4),
+            "allreduce_buckets_ms": round(t_b, 4),
+            "algbw_GBps": round(nbytes / (t_flat * 1e-3) / 1e9, 2),
+            "busbw_GBps": round(2.0 * (world - 1) / world * nbytes / (t_flat * 1e-3) / 1e9, 2),
+            "distinct_devices": len({d["pci_bus_id"] + d["uuid"] for d in devs})}
 
 
 SECONDARY_PARTS = ("plugin_path", "config4", "config5_one_gpu")
@@ -546,19 +626,26 @@ def main():
         return out
 
     run(0, args.warmup)
+    rccl = rccl_report(ts, dev, rank, world) if use_dist else None       # before (and outside) the timed region
+
+    def timed_region(k0_):
+        """EXACTLY --steps steps between barrier + synchronize pairs; -> (seconds on this rank, last step's output)"""
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        o_ = run(k0_, args.steps)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0_, o_
+
     regions, k0, out = [], args.warmup, None
     for _ in range(args.repeats):                    # each region: EXACTLY --steps steps between barrier + synchronize pairs
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        out = run(k0, args.steps)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        regions.append(time.perf_counter() - t0)
+        t_reg, out = timed_region(k0)
+        regions.append(t_reg)
         k0 += args.steps
     if use_dist:                                     # a region's time = the slowest rank's
         tt = torch.tensor(regions, dtype=torch.float64, device=dev)
@@ -566,6 +653,25 @@ def main():
         regions = [float(v) for v in tt.tolist()]
     dt = float(np.median(regions))
     loss = float(out[0].item())
+    # exposed communication: the same regions with every collective of the step switched off - no gradient
+    # buckets, no all-reduce of the loss sums (each rank then differentiates its LOCAL loss: a timing probe, its results are
+    # discarded) - AFTER the headline regions; exposed_comm_ms = headline step - this step
+    exposed = None
+    if use_dist:
+        red_on, loss_on = ts.reducer.enabled, ts.dist_loss
+        ts.reducer.enabled, ts.dist_loss = False, False
+        run(k0, 2)
+        quiet = []
+        for _ in range(min(args.repeats, 3)):
+            t_reg, _o = timed_region(k0)
+            quiet.append(t_reg)
+        ts.reducer.enabled, ts.dist_loss = red_on, loss_on
+        tq = torch.tensor(quiet, dtype=torch.float64, device=dev)
+        dist.all_reduce(tq, op=dist.ReduceOp.MAX)
+        dq = float(np.median(tq.tolist()))
+        exposed = {"ms_per_step_without_collectives": round(dq / args.steps * 1e3, 3),
+                   "exposed_comm_ms": round((dt - dq) / args.steps * 1e3, 3),
+                   "note": "same process, after the headline regions: gradient buckets and the loss sums' all-reduce off"}
 
     # per-kernel timing pass (separate, short, so the event records do not perturb the headline number)
     roof = None
@@ -642,6 +748,10 @@ def main():
                               "frac_mfma": round(2.793 * vols / dt / world / MFMA_BF16_PEAK_TF, 5),
                               "frac_hbm": round(10.1 * vols / dt / world / HBM_PEAK_GBS, 5)},
         }
+        if rccl is not None:
+            res["rccl"] = rccl
+            res["exposed_comm_ms"] = exposed["exposed_comm_ms"]
+            res["comm"] = exposed
         if roof is not None:
             res["roofline"] = roof
         if roof_hbm is not None:

@@ -204,12 +204,39 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
 
 // CIN = 4 (round 4, config 5): the same two MFMAs per input channel - the planar input makes a channel just another base
 // offset, the tap -> k-slot map and the padding selects are shared - 64 loads in flight per lane, two blocks per CU.
-template <int CIN>
-__global__ void __launch_bounds__(256, CIN == 1 ? 4 : 2)
+//
+// MODE (round 6): the stem site without its pre-BatchNorm tensor.  The stem convolution is 27 taps of ONE input channel: its
+// output y costs 64 bytes per voxel to store and to re-read, but only two MFMAs to recompute from 4 bytes of input that L1 / L2
+// serve.  So the site's four passes over y (write it; BN-apply reads it; the backward reduction reads it; the backward apply
+// reads it: 4 x 262 MB at the benchmark shape, unet2d5_dsbn.py:74-77 Conv3d -> DSBN -> PReLU) are replaced by recomputation
+// in this kernel's own register layout (a lane holds 16 output channels of one voxel):
+//   STEM_CONV        y = conv(x) + b -> bf16, statistics                     (the plain forward: eval mode, dropout, fp32 callers)
+//   STEM_STATS       statistics only, nothing is stored                       (train forward, pass 1)
+//   STEM_ACT         a = PReLU(scale * bf16(y) + shift) -> bf16               (train forward, pass 2: fplx_bn_act_fwd's arithmetic)
+//   STEM_BWD_REDUCE  partial sums of dz, dz * x-hat, the slope term           (fplx_bn_act_bwd_reduce's arithmetic on y, d(a))
+//   STEM_BWD_APPLY   dy = scale * (dz - k0 - x-hat * k1) -> bf16              (fplx_bn_act_bwd_apply's arithmetic)
+// y is rounded to bf16 exactly where the stored tensor was, so every mode sees the values the separate passes saw.
+// Stores and the d(a) loads (round 6): a lane's two 16-byte runs (channels 8 khalf .. + 7 and 16 + 8 khalf .. + 7 of voxel r)
+// made every store instruction write HALF of each 64-byte voxel row of the segment - two partial writes per row.  One more
+// exchange, v_permlane16_swap between the runs, gives lane L the run (L >> 5) + 2 ((L >> 4) & 1) of voxel L & 15 (+ 16 for
+// the second register set): each instruction then covers 16 complete rows = 1 KiB of contiguous, fully written lines.
+enum { STEM_CONV = 0, STEM_STATS = 1, STEM_ACT = 2, STEM_BWD_REDUCE = 3, STEM_BWD_APPLY = 4 };
+struct StemBn {
+  const float *mean, *rstd, *scale, *shift, *slope, *coef;      // the site's BatchNorm constants [Cout] (coef: [2][Cout], mode 4)
+  const bf16_t* dout;                                            // modes 3, 4: gradient w.r.t. the site's output a, [V][ldd]
+  int64_t ldd;
+  float* part;                                                   // mode 3: one partial row of 2 Cout + 1 floats per block
+};
+
+template <int CIN, int MODE>
+__global__ void __launch_bounds__(256, (CIN == 1 && MODE <= STEM_ACT) ? 4 : 2)
 stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
-              float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd) {
-  __shared__ float red[4][2][32];
+              float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd, const StemBn bn) {
+  constexpr bool WRITES = MODE == STEM_CONV || MODE == STEM_ACT || MODE == STEM_BWD_APPLY;
+  constexpr bool FSTATS = MODE == STEM_CONV || MODE == STEM_STATS;
+  constexpr bool BWD = MODE == STEM_BWD_REDUCE || MODE == STEM_BWD_APPLY;
+  __shared__ float red[4][3][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, khalf = lane >> 5;
   // k-slot p = 8 s + j of lane half khalf: combo = p / 3 + 5 khalf (kd = combo / 3, kh = combo % 3), kw = p % 3
@@ -228,6 +255,20 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   f32x16 cinit;                                      // D[row = channel (i & 3) + 8 (i >> 2) + 4 khalf][col = voxel r]
 #pragma unroll
   for (int i = 0; i < 16; ++i) cinit[i] = bias ? bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf] : 0.f;
+  // the site's BatchNorm constants for the lane's 16 channels (accumulator order)
+  constexpr int NBN = MODE >= STEM_ACT ? 16 : 1, NBW = BWD ? 16 : 1, NBA = MODE == STEM_BWD_APPLY ? 16 : 1;
+  float sc[NBN], sh[NBN], bm[NBW], brs[NBW], k0[NBA], k1[NBA];
+  float slope = 0.f;
+  if constexpr (MODE >= STEM_ACT) {
+    slope = *bn.slope;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ch = co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+      sc[i] = bn.scale[ch]; sh[i] = bn.shift[ch];
+      if constexpr (BWD) { bm[i] = bn.mean[ch]; brs[i] = bn.rstd[ch]; }
+      if constexpr (MODE == STEM_BWD_APPLY) { k0[i] = bn.coef[ch]; k1[i] = bn.coef[Cout + ch]; }
+    }
+  }
   // the lane's six (kd, kh) rows as element offsets relative to the voxel (combo c + 5 khalf)
   int roff[6];
 #pragma unroll
@@ -238,9 +279,10 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   const int64_t xbytes = (int64_t)N * CIN * D * H * W * 4;
   // (the launcher keeps the input below 2 GiB; raw buffer, no stride: out-of-range offsets read as zeros)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
-  float ssum[16], qsum[16];
+  constexpr int NS = (FSTATS || MODE == STEM_BWD_REDUCE) ? 16 : 1;
+  float ssum[NS], qsum[NS], sds = 0.f;               // forward: sum, sum of squares; backward reduction: sum dz, sum dz x-hat, slope term
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { ssum[i] = 0.f; qsum[i] = 0.f; }
+  for (int i = 0; i < NS; ++i) { ssum[i] = 0.f; qsum[i] = 0.f; }
 
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
   struct Seg { int n, d, h, w0; };
@@ -253,10 +295,13 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
     g.n = (int)(t / (unsigned)D);                    // >= N: a segment past the end of the list (the last tile may be ragged)
     return g;
   };
+  // row-contiguous register sets (see the header): set 0 = voxel lane & 15, set 1 = voxel 16 + (lane & 15), 16-byte run
+  // (lane >> 5) + 2 ((lane >> 4) & 1) of the voxel's 64-byte row
+  const int rv = lane & 15, rrun = (lane >> 5) + 2 * ((lane >> 4) & 1);
   // the segment's 16 loads per lane.  Byte offset of (row c, kw): a VECTOR offset that is negative (= huge, out of range -> 0)
   // exactly when the element lies before the tensor.  (A scalar offset must not carry the kw shift: the range check sees the
   // vector offset alone, and a row that starts one element before the tensor would lose its two valid taps.)
-  auto issue = [&](const Seg& g, float (&xv)[CIN][16]) {
+  auto issue = [&](const Seg& g, float (&xv)[CIN][16], u32x4e (&dv)[2]) {
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
       const int vidx = (((g.n * CIN + ci) * D + g.d) * H + g.h) * W + g.w0 + r;
@@ -269,8 +314,16 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
         xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
       }
     }
+    if constexpr (BWD) {
+      const bf16_t* drow = bn.dout + ((int64_t)((g.n * D + g.d) * H + g.h) * W + g.w0) * bn.ldd + co0 + 8 * rrun;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool ok = g.n < N && g.w0 + rv + 16 * q < W;
+        dv[q] = ok ? *reinterpret_cast<const u32x4e*>(drow + (int64_t)(rv + 16 * q) * bn.ldd) : u32x4e{0u, 0u, 0u, 0u};
+      }
+    }
   };
-  auto consume = [&](const Seg& g, const float (&xv)[CIN][16]) {
+  auto consume = [&](const Seg& g, const float (&xv)[CIN][16], const u32x4e (&dv)[2]) {
     if (g.n >= N) return;                            // wave-uniform
     const int n = g.n, d = g.d, h = g.h;
     // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
@@ -296,59 +349,133 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
     }
-    if (wc) {
+    if constexpr (FSTATS) {
+      if (wc) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
-    }
-    // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the swaps the low half holds 0-7 and 16-23, the high
-    // half 8-15 and 24-31 of its voxel
-    unsigned pk[8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const bf16_t e0 = (bf16_t)acc[4 * q], e1 = (bf16_t)acc[4 * q + 1], e2 = (bf16_t)acc[4 * q + 2], e3 = (bf16_t)acc[4 * q + 3];
-      pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
-      pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
-    }
-#pragma unroll
-    for (int g2 = 0; g2 < 2; ++g2)                    // (q0, q1) and (q2, q3): high half of the first <-> low half of the second
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
-        pk[4 * g2 + e] = sw[0];
-        pk[4 * g2 + 2 + e] = sw[1];
+        for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
       }
-    if (wc) {
-      bf16_t* dst = y + ((int64_t)(((n * D + d) * H + h)) * W + wv) * ldy + co0 + 8 * khalf;
-      *reinterpret_cast<u32x4e*>(dst) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
-      *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
+    }
+    if constexpr (MODE == STEM_STATS) return;
+    // d(a) of the lane's voxel in accumulator order: the two exchanges of the store path, backwards (both are involutions)
+    float dd_[BWD ? 16 : 1];
+    if constexpr (BWD) {
+      unsigned pk[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const u32x2e sw = __builtin_amdgcn_permlane16_swap(dv[0][e], dv[1][e], false, false);
+        pk[e] = sw[0];
+        pk[4 + e] = sw[1];
+      }
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+          pk[4 * g2 + e] = sw[0];
+          pk[4 * g2 + 2 + e] = sw[1];
+        }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        dd_[2 * q] = __builtin_bit_cast(float, pk[q] << 16);
+        dd_[2 * q + 1] = __builtin_bit_cast(float, pk[q] & 0xffff0000u);
+      }
+    }
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if constexpr (MODE == STEM_CONV) v[i] = acc[i];
+      else {
+        const float yq = (float)(bf16_t)acc[i];                      // y as the separate passes read it back
+        const float z = fmaf(yq, sc[i], sh[i]);
+        if constexpr (MODE == STEM_ACT) v[i] = z > 0.f ? z : z * slope;
+        else {
+          const float da = dd_[i];
+          const float dz = z > 0.f ? da : da * slope;
+          const float xh = (yq - bm[i]) * brs[i];
+          if constexpr (MODE == STEM_BWD_REDUCE) {
+            if (wc) {
+              sds += z > 0.f ? 0.f : da * z;
+              ssum[i] += dz;
+              qsum[i] = fmaf(dz, xh, qsum[i]);
+            }
+          } else v[i] = sc[i] * (dz - k0[i] - xh * k1[i]);
+        }
+      }
+    }
+    if constexpr (WRITES) {
+      // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the 32-lane swaps the low half holds 0-7 and 16-23, the
+      // high half 8-15 and 24-31 of its voxel; after the 16-lane swaps a register set holds whole 64-byte rows of 16 voxels
+      unsigned pk[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bf16_t e0 = (bf16_t)v[4 * q], e1 = (bf16_t)v[4 * q + 1], e2 = (bf16_t)v[4 * q + 2], e3 = (bf16_t)v[4 * q + 3];
+        pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+        pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+      }
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2)                    // (q0, q1) and (q2, q3): high half of the first <-> low half of the second
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+          pk[4 * g2 + e] = sw[0];
+          pk[4 * g2 + 2 + e] = sw[1];
+        }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                     // run 8 khalf (pk[0..3]) <-> run 16 + 8 khalf (pk[4..7]) across 16-lane rows
+        const u32x2e sw = __builtin_amdgcn_permlane16_swap(pk[e], pk[4 + e], false, false);
+        pk[e] = sw[0];
+        pk[4 + e] = sw[1];
+      }
+      bf16_t* drow = y + ((int64_t)((n * D + d) * H + h) * W + g.w0) * ldy + co0 + 8 * rrun;
+      if (g.w0 + rv < W) *reinterpret_cast<u32x4e*>(drow + (int64_t)rv * ldy) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
+      if (g.w0 + rv + 16 < W) *reinterpret_cast<u32x4e*>(drow + (int64_t)(rv + 16) * ldy) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
     }
   };
   // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured: 134 us
   // against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
   float xa[CIN][16];
+  u32x4e da[2];
   for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
     const Seg ga = seg_of(tt);
-    issue(ga, xa);
-    consume(ga, xa);
+    issue(ga, xa, da);
+    consume(ga, xa, da);
   }
-  if (stats) {
-    // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
+  if constexpr (FSTATS || MODE == STEM_BWD_REDUCE) {
+    if (!FSTATS || stats) {
+      // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+      for (int i = 0; i < 16; ++i)
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); qsum[i] += __shfl_xor(qsum[i], o, 64); }
-    if (r == 0) {
+        for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); qsum[i] += __shfl_xor(qsum[i], o, 64); }
+      if constexpr (MODE == STEM_BWD_REDUCE) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int ch = (i & 3) + 8 * (i >> 2) + 4 * khalf;
-        red[wave][0][ch] = ssum[i];
-        red[wave][1][ch] = qsum[i];
+        for (int o = 32; o > 0; o >>= 1) sds += __shfl_xor(sds, o, 64);
+        if (lane == 0) red[wave][2][0] = sds;
       }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-      stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ch = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+          red[wave][0][ch] = ssum[i];
+          red[wave][1][ch] = qsum[i];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+        const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+        if constexpr (FSTATS) stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = t;
+        else bn.part[(int64_t)blockIdx.x * (2 * Cout + 1) + which * Cout + co0 + c] = t;
+      }
+      if constexpr (MODE == STEM_BWD_REDUCE) {
+        // the slope term is ONE number per layer: the launch of channel block co0 ADDS its share (launches are stream-ordered,
+        // block co0 = 0 starts the row's sum)
+        if (threadIdx.x == 64) {
+          const float t = red[0][2][0] + red[1][2][0] + red[2][2][0] + red[3][2][0];
+          float* p = bn.part + (int64_t)blockIdx.x * (2 * Cout + 1) + 2 * Cout;
+          *p = co0 == 0 ? t : *p + t;
+        }
+      }
     }
   }
 }
@@ -1115,6 +1242,26 @@ extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout
   return edge_blocks(tiles_of(n, d, h, w, &th, &tw));
 }
 
+// the LDS-free row kernel's launch: the same number of blocks (= statistics rows) as the tile kernel
+template <int MODE>
+static int stem_rows_launch(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d, int h, int w,
+                            int cin, int cout, float* stats, const StemBn& bn, hipStream_t st, const char* what) {
+  int th, tw;
+  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+  const int tilesW = (w + 31) / 32;
+  const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
+  for (int co0 = 0; co0 < cout; co0 += 32) {
+    if (cin == 1) stem_fwd_rows<1, MODE><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on(), bn);
+    else stem_fwd_rows<4, MODE><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on(), bn);
+  }
+  const int rc = fplx_check_launch(what);
+  return rc < 0 ? rc : 1;
+}
+static bool stem_rows_shape_ok(int n, int d, int h, int w, int cin, int cout) {
+  return (cin == 1 || cin == 4) && cout % 32 == 0 && fplx_knob(FPLX_K_STEM_ROWS) && (cin == 1 || fplx_knob(FPLX_K_STEM_ROWS) != 2) &&
+         (int64_t)n * cin * d * h * w < ((int64_t)1 << 29) && (int64_t)n * d * h * w < ((int64_t)1 << 31);
+}
+
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                                   int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
@@ -1122,18 +1269,8 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
-  if (vec_ok && fplx_knob(FPLX_K_STEM_ROWS) && (cin == 1 || fplx_knob(FPLX_K_STEM_ROWS) != 2) &&
-      (int64_t)n * cin * d * h * w < ((int64_t)1 << 29)) {
-    // the LDS-free row kernel; the same number of blocks (= statistics rows) as the tile kernel  (knob 2: in_chns = 1 only)
-    const int tilesW = (w + 31) / 32;
-    const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
-    for (int co0 = 0; co0 < cout; co0 += 32) {
-      if (cin == 1) stem_fwd_rows<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
-      else stem_fwd_rows<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
-    }
-    int rc0 = fplx_check_launch("edge_stem_fwd_rows");
-    return rc0 < 0 ? rc0 : 1;
-  }
+  if (vec_ok && stem_rows_shape_ok(n, d, h, w, cin, cout))         // the LDS-free row kernel (knob stem_rows = 2: in_chns = 1 only)
+    return stem_rows_launch<STEM_CONV>(x, wf, bias, y, ldy, n, d, h, w, cin, cout, stats, StemBn{}, st, "edge_stem_fwd_rows");
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1)
       stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok, fplx_xcd_on());
@@ -1142,6 +1279,31 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   }
   int rc = fplx_check_launch("edge_stem_fwd");
   return rc < 0 ? rc : 1;
+}
+
+// ---- the stem site without its pre-BatchNorm tensor (round 6; see stem_fwd_rows): rows > 0 = the statistics rows of the forward
+// passes = the partial rows (2 cout + 1 floats each) of the backward reduction; 0 = not available for this shape
+extern "C" int fplx_edge_stem_site_rows(int n, int d, int h, int w, int cin, int cout) {
+  if (!fplx_knob(FPLX_K_STEM_SITE) || !stem_rows_shape_ok(n, d, h, w, cin, cout)) return 0;
+  int th, tw;
+  return edge_blocks(tiles_of(n, d, h, w, &th, &tw));
+}
+// mode: 1 statistics, 2 activation, 3 backward reduction, 4 backward apply (STEM_*); out: a (mode 2) or dy (mode 4: may alias dout)
+extern "C" int fplx_edge_stem_site(int mode, const float* x, const void* wf, const float* bias, void* out, int64_t ldo, int n, int d,
+                                   int h, int w, int cin, int cout, float* stats, const float* mean, const float* rstd,
+                                   const float* scale, const float* shift, const float* slope, const float* coef,
+                                   const void* dout, int64_t ldd, float* part, hipStream_t st) {
+  if (!fplx_edge_stem_site_rows(n, d, h, w, cin, cout)) return 0;
+  if ((mode == STEM_ACT || mode == STEM_BWD_APPLY) && (ldo % 8 != 0 || ((uintptr_t)out % 16) != 0)) return 0;
+  if ((mode == STEM_BWD_REDUCE || mode == STEM_BWD_APPLY) && (ldd % 8 != 0 || ((uintptr_t)dout % 16) != 0)) return 0;
+  const StemBn bn{mean, rstd, scale, shift, slope, coef, (const bf16_t*)dout, ldd, part};
+  switch (mode) {
+    case STEM_STATS: return stem_rows_launch<STEM_STATS>(x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, stats, bn, st, "edge_stem_site_stats");
+    case STEM_ACT: return stem_rows_launch<STEM_ACT>(x, wf, bias, out, ldo, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_act");
+    case STEM_BWD_REDUCE: return stem_rows_launch<STEM_BWD_REDUCE>(x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_bwd_reduce");
+    case STEM_BWD_APPLY: return stem_rows_launch<STEM_BWD_APPLY>(x, wf, bias, out, ldo, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_bwd_apply");
+  }
+  return 0;
 }
 
 extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {

@@ -125,7 +125,7 @@ class FusedAdam(Optimizer):
             if plan:
                 # the shared segment: Adam AND the bf16 packs of its 3x3x3 weights in one launch - the next forward finds
                 # them in place instead of re-reading every master weight (get_optimizer.py:17 + unet2d5_dsbn.py:54-55)
-                assert start == 0 and all(o + co * ci * 27 <= end for o, co, ci, _, _ in plan)
+                assert start == 0 and all(l[0] + l[1] * l[2] * 27 <= end for l in plan)
                 ops.adam_pack_step(net.flat_params[start:end], gflat[start:end], self.exp_avg[start:end],
                                    self.exp_avg_sq[start:end], lr, self.seg_steps[si], wd, self.grad_scale, (b1, b2), eps, plan)
                 fused = True

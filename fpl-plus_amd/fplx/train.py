@@ -113,6 +113,12 @@ class TrainStep(object):
         outs = []
         red = self.reducer
         overlap = red.enabled and self.overlap_all
+        if overlap and nd > 2:
+            # reduce_domain(k) all-reduces gflat's domain-k BatchNorm range asynchronously while the next non-last domain's
+            # `gflat.add_(gacc)` would read-modify-write the whole buffer on the main stream, and loss = (l0 + l1) / 2 fixes the
+            # 1 / 2 weights: this path is the reference's two-domain iteration (agent_seg.py:459-495), nothing more
+            raise ValueError("fplx: TrainStep.step_all overlaps the gradient exchange for at most two domains (got %d); set "
+                             "overlap_all = False for more" % nd)
         if self.gacc is None and nd > 1:
             self.gacc = torch.zeros_like(self.gflat)
         red.begin(self.gflat)

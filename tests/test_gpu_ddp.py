@@ -116,8 +116,44 @@ def test_two_rank_train_step_equals_dataparallel_emulation(tmp_path):
     torch.cuda.synchronize()
     np.testing.assert_allclose(r0["losses"], losses, rtol=0, atol=2e-6)
     ref = net.flat_params.cpu().numpy()
-    # Adam normalises the step: compare the update itself, scaled by lr (2 steps of at most lr each)
-    assert np.abs(r0["flat"] - ref).max() <= 0.05 * 2e-3
+    # the same kernels on the same chunks; what differs is where the two chunks' gradients are added (gloo's sum against
+    # `g += gi`) and the loss sums' all-reduce: Adam normalises the step, so the comparison is on the update, scaled by lr
+    # (2 steps of at most lr = 1e-3 each)
+    d_self = np.abs(r0["flat"] - ref)
+    print("two ranks vs fplx emulation: max %.3g, share above 1e-6: %.3g" % (d_self.max(), (d_self > 1e-6).mean()))
+    assert d_self.max() <= 1e-7, d_self.max()           # (measured: 0 - two ranks' sums commute; 1e-7 leaves room for a reordered all-reduce)
+    # ---- the ORACLE's DataParallel emulation of the same two steps (not only fplx against itself): replica
+    # forwards on the chunks with per-chunk BatchNorm statistics, gather, ONE loss over the full batch, backward, Adam
+    # (agent_seg.py:692-698 + 336-357; the numbers tests/test_ddp_equivalence_cpu.py pins for the gradient exchange on CPU)
+    from oracle import torch_ref as R
+    sd, prm = R.split_state(detdata.state_dict_3d(p))
+    opt_r = R.AdamRef(prm, 1e-3, 1e-5)
+    xs_c, ys_c = xs.cpu(), ys.cpu()
+    o_losses = []
+    for it in range(2):
+        dom = it % 2
+        opt_r.zero_grad()
+        lg = torch.cat([R.unet_forward(sd, p, xs_c[i:i + 2], dom, True) for i in (0, 2)], 0)
+        l = 1.0 * R.dice_loss(lg, ys_c) + 0.5 * R.ce_loss(lg, ys_c)
+        l.backward()
+        opt_r.step()
+        o_losses.append(float(l.item()))
+    np.testing.assert_allclose(r0["losses"], o_losses, rtol=0, atol=5e-5)
+    flat = r0["flat"]
+    checked = 0
+    for k in net._order:
+        o, n, shp = net._layout[k]
+        if k not in prm or (k.endswith("bias") and "conv3d" in k):
+            continue          # conv bias under train-mode BN: the oracle random-walks on fp noise (Adam), fplx decays it
+        diff = np.abs(flat[o:o + n].reshape(shp) - prm[k].detach().numpy())
+        refv = np.abs(prm[k].detach().numpy())
+        assert diff.max() <= 1e-3 * 2 + 1e-6, (k, diff.max())
+        # (Adam normalises the step: an element whose gradient is fp32 noise around zero moves by up to lr either way - one such
+        # element per small tensor is allowed, 1 % of a large one)
+        out = int((diff > 5e-5 * 2 + 1e-4 * refv).sum())
+        assert out <= max(1, diff.size // 100), (k, out, diff.size)
+        checked += 1
+    assert checked > 40
 
 
 _WORKER_ALL = r"""

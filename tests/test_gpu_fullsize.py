@@ -235,6 +235,15 @@ def test_bench_under_torchrun_exercises_the_rccl_path():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 10 and np.isfinite(d["final_loss"])
     assert d["repeats"] == 5 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
+    # the record describes what RCCL saw and what the exchange costs: world, version, one device entry per
+    # rank gathered to rank 0, the all-reduce of the flat gradient timed with the step's own buckets, the exposed share
+    rc = d["rccl"]
+    assert rc["world"] == 1 and rc["backend"] == "nccl" and rc["version"] and len(rc["devices"]) == 1
+    assert rc["devices"][0]["rank"] == 0 and rc["devices"][0]["device"] and rc["distinct_devices"] == 1
+    assert 80 < rc["flat_gradient_MB"] < 100 and rc["buckets"] == len(rc["bucket_MB"]) + 1 >= 3
+    assert rc["allreduce_flat_ms"] > 0 and rc["allreduce_90MB_ms"] > 0 and rc["allreduce_buckets_ms"] > 0
+    assert rc["busbw_GBps"] == 0.0 and rc["algbw_GBps"] > 10          # one rank: nothing crosses a link
+    assert abs(d["exposed_comm_ms"]) < 0.25 * d["ms_per_step"] and d["comm"]["ms_per_step_without_collectives"] > 0
     # the other way: no launcher - `bench.py --gpus 1` runs in-process, and with --launch it starts the rank itself as a child
     # torch.distributed.run (what `bench.py --gpus N`, N > 1, does when RANK is not set) and relays rank 0's line
     env_nolaunch = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -247,6 +256,7 @@ def test_bench_under_torchrun_exercises_the_rccl_path():
         assert len(lines) == 1
         d = json.loads(lines[0])
         assert d["n_gpus"] == 1 and d["steps"] == 2 and d["repeats"] == 2 and d["value"] > 10
+        assert ("rccl" in d) == bool(extra)               # in-process single rank: no process group, no rccl object
 
 
 def test_config5_full_size_weighted_dual_domain_step():

@@ -602,6 +602,121 @@ def test_stem_kernels_bf16(shape):
     assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
 
 
+# ---- the stem site without its pre-BatchNorm tensor (round 6: fplx_stem_site_rows / _fwd / _bwd)
+@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 1, 32, 5, 16, 64), (1, 4, 32, 2, 16, 64), (3, 1, 32, 5, 7, 161),
+                                   (1, 1, 32, 1, 1, 1), (1, 1, 32, 1, 1, 40), (2, 1, 64, 6, 20, 96), (2, 4, 32, 3, 10, 48)])
+def test_stem_site_passes_equal_the_separate_passes(shape):
+    """Conv3d(in_chns -> C0) -> DSBN -> PReLU of the first site with the convolution RECOMPUTED in every pass instead of stored:
+    pass 1 writes the statistics rows of the plain stem forward (bit for bit), pass 2 the activation fplx_bn_act_fwd forms from
+    the stored tensor (bit for bit); the backward reduction and apply against fplx_bn_act_bwd on the stored tensor (the sums in
+    another fixed order: gradients of the affine parameters to 1e-5, dy equal up to rare single bf16 steps) and against float64
+    autograd through the same chain.  Ragged widths, single rows, several samples, 4 input channels, 64 output channels."""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    dims, v = (n, d, h, w), n * d * h * w
+    rows = ops.stem_site_rows(dims, cin, cout)
+    assert rows > 0 and rows == ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), ops.F32, ops.BF16)
+    assert ops.stem_site_rows(dims, 2, cout) == 0 and ops.stem_site_rows(dims, cin, 48) == 0
+    x = torch.from_numpy(detdata.normal("ss.x%s" % (shape,), (n, cin, d, h, w))).cuda()
+    wt = torch.from_numpy(detdata.normal("ss.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.3)).bfloat16().float()
+    b = torch.from_numpy(detdata.normal("ss.b%s" % (shape,), (cout,))).cuda()
+    gamma = torch.from_numpy(detdata.normal("ss.g%s" % (shape,), (cout,)) * 0.3 + 1.0).float().cuda()
+    beta = torch.from_numpy(detdata.normal("ss.be%s" % (shape,), (cout,)) * 0.3).float().cuda()
+    slope = torch.full((1,), 0.25, device="cuda")
+    dout = torch.from_numpy(detdata.normal("ss.d%s" % (shape,), (v, cout))).bfloat16().cuda()
+    wf, _ = ops.pack_conv_weight(wt.cuda(), torch.bfloat16, False)
+    # ---- the separate passes (the path the engine takes with the knob off)
+    stats0 = torch.zeros((rows, 2, cout), device="cuda")
+    y = torch.zeros((v, cout), dtype=torch.bfloat16, device="cuda")
+    ops.conv3d_fwd(x, ops.planar_strides(cin, d, h, w), ops.F32, wf, b, y, ops.cl_strides(d, h, w, cout), ops.BF16, dims, cin, cout,
+                   (3, 3, 3), stats0)
+    rm, rv, nbt = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda")
+    bnbuf = torch.empty((4, cout), device="cuda")
+    ops.bn_train_finalize(stats0, rows, cout, v, gamma, beta, rm, rv, nbt, bnbuf)
+    a0 = torch.empty_like(y)
+    ops.bn_act_fwd(y, a0, bnbuf, slope, 0.0, 0, 0, cout)
+    part = torch.zeros(max(ops.num_partials(v), rows) * (2 * cout + 1), device="cuda")
+    coef = torch.empty((2, cout), device="cuda")
+    g0, b0, s0 = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
+    dy0 = torch.empty_like(y)
+    ops.bn_act_bwd(y, dout, dy0, bnbuf, slope, 0.0, 0, 0, cout, True, g0, b0, s0, part, coef)
+    # ---- the site passes
+    stats1 = torch.full((rows, 2, cout), 7.0, device="cuda")
+    ops.stem_site_fwd_stats(x, wf, b, dims, cin, cout, stats1)
+    assert torch.equal(stats1, stats0)
+    a1 = torch.full_like(y, 3.0)
+    ops.stem_site_fwd_act(x, wf, b, dims, cin, cout, bnbuf, slope, a1)
+    assert torch.equal(a1, a0)
+    g1, b1, s1 = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
+    part.fill_(float("nan"))
+    dy1 = torch.full_like(y, 3.0)
+    ops.stem_site_bwd(x, wf, b, dims, cin, cout, dout, dy1, bnbuf, slope, True, g1, b1, s1, part, coef)
+    for got, ref in ((g1, g0), (b1, b0), (s1, s0)):
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6 * v ** 0.5, (got, ref)
+    dd = (dy1.float() - dy0.float()).abs()
+    assert float(dd.max()) <= 2.0 ** -6 * float(dy0.float().abs().max()) + 1e-30 and float((dd > 0).float().mean()) <= 2e-3
+    # in place (dy aliases dout), as the engine calls it
+    d2 = dout.clone()
+    ops.stem_site_bwd(x, wf, b, dims, cin, cout, d2, d2, bnbuf, slope, True, torch.zeros_like(g1), torch.zeros_like(b1),
+                      torch.zeros_like(s1), part, coef)
+    assert torch.equal(d2, dy1)
+    # ---- float64 autograd through conv -> batch statistics -> affine -> PReLU on the bf16-rounded operands
+    if v > 1:
+        xq = x.cpu().bfloat16().double()
+        yq = y.cpu().double().requires_grad_(True)              # the stored convolution output IS the chain's input here
+        ga, be, sl = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True), slope.cpu().double().requires_grad_(True)
+        mu, var = yq.mean(0), yq.var(0, unbiased=False)
+        z = (yq - mu) / torch.sqrt(var + 1e-5) * ga + be
+        act = torch.where(z > 0, z, z * sl)
+        act.backward(dout.cpu().double())
+        sc = float(yq.grad.abs().max())
+        assert float((dy1.cpu().double() - yq.grad).abs().max()) <= 2e-2 * sc + 1e-6
+        assert float((g1.cpu().double() - ga.grad).abs().max()) <= 1e-2 * float(ga.grad.abs().max()) + 1e-4
+        assert float((b1.cpu().double() - be.grad).abs().max()) <= 1e-2 * float(be.grad.abs().max()) + 1e-4
+        assert abs(float(s1.cpu()) - float(sl.grad)) <= 1e-2 * abs(float(sl.grad)) + 1e-3
+
+
+def test_network_step_with_and_without_the_stem_site():
+    """the engine with the stem site recomputed in every pass (Engine.use_stem_site, the default: the first convolution's output
+    is never stored) against the separate passes: same logits bit for bit (the forward arithmetic is identical), the loss equal,
+    the parameters after one Adam step within the noise of another order of additions in three BatchNorm sums; the 2.5D stem
+    (a Conv2d) and a dropout at the stem site keep the separate passes"""
+    import fplx
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
+    lab = torch.zeros(2, 2, 16, 32, 64)
+    lab[:, 0] = 1.0
+    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
+    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
+    lab = lab.cuda()
+    res = []
+    for fuse in (True, False):
+        torch.manual_seed(3)
+        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
+        net.engine.use_stem_site = fuse
+        net.train()
+        with torch.no_grad():
+            net.dropout_seed, net._fwd_counter = 9, 0
+        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+        logits, sv = net.engine.forward(x, 1, True, net.dropout_active(), 9, 0, keep=True)
+        assert (sv.blocks[0]["y1"] is None) == fuse
+        out = ts.step(x, lab, 1)
+        res.append((logits.clone(), net.flat_params.detach().clone(), float(out[0])))
+    assert torch.equal(res[0][0], res[1][0])
+    assert abs(res[0][2] - res[1][2]) < 1e-6
+    rel = float((res[0][1] - res[1][1]).abs().max()) / float(res[1][1].abs().max())
+    assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr
+    for extra in (dict(conv_dims=[2, 2, 3, 3, 3]), dict(dropout=[0.2, 0, 0.3, 0.4, 0.5])):
+        net = fplx.UNet2D5_dsbn(dict(p, **extra)).cuda().train()
+        _, sv = net.engine.forward(x, 0, True, net.dropout_active(), 9, 0, keep=True)
+        assert sv.blocks[0]["y1"] is not None
+    net = fplx.UNet2D5_dsbn(dict(p)).cuda().eval()           # eval-mode BatchNorm with a backward: the stored tensor
+    _, sv = net.engine.forward(x, 0, False, net.dropout_active(), 9, 0, keep=True)
+    assert sv.blocks[0]["y1"] is not None
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 2, 3, 9, 35), (1, 32, 3, 2, 16, 64), (1, 64, 2, 2, 8, 40)])
 def test_outconv_kernels_bf16(shape):
     """bf16 NDHWC features <-> fp32 NCDHW logits, kernel (1,3,3): forward, data gradient, weight gradient"""

@@ -542,6 +542,7 @@ def test_bf16_eval_inference_against_oracle(case, fused):
         rep.close()
         assert e16 < 3e-2 * rng and e32 < 3e-2 * rng, (e16, e32, rng)
         # (with active dropout the deep levels' 1 / (1 - p) scaling widens the range to 50-120 and single bf16 roundings of a few
-        # huge activations decide the maximum: the small ragged 2.5D case sits 4 % above the oracles' own gap - a quarter is allowed)
-        assert min(e16, e32) <= 1.25 * gap + 1e-3 * rng, (e16, e32, gap)
+        # huge activations decide the maximum: the small ragged 2.5D case sits 4 % above the oracles' own gap - the ragged cases
+        # get a tenth of slack, every other case stays at the oracles' own gap)
+        assert min(e16, e32) <= (1.1 if case in RAGGED_EVAL_CASES else 1.0) * gap + 1e-3 * rng, (e16, e32, gap)
         assert float((mc[:n] - mc[n:]).abs().max()) > 1e-3 * rng          # the passes differ
