@@ -126,9 +126,9 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(BRICK_KSPLIT, "brick_ksplit", 0)       /* > 0: force this Cin split (tests) */                                      \
   X(EDGE_BLOCKS, "edge_blocks", 1024)      /* persistent blocks of the stem / out_conv kernels */                       \
   X(STEM_ROWS, "stem_rows", 1)             /* 0: the tile kernel for in_chns = 1 too */                                 \
-  X(STEM_SITE, "stem_site", 1)             /* 0: fplx_stem_site_rows answers 0 - the stem site keeps its pre-BatchNorm tensor and the separate passes (A/B, tests) */ \
   X(OUTCONV_T, "outconv_t", 1)             /* 0: the 32 x 32 out_conv forward (classes as columns) */                    \
   X(OUTCONV_DGRAD_MFMA, "outconv_dgrad_mfma", 1)                                                                       \
+  X(OUTCONV_DGRAD_ROWS, "outconv_dgrad_rows", 1) /* fused out_conv backward as a stream of row segments (outconv_dgrad_rows); 0: the tile kernel (A/B, tested both ways) */ \
   X(PACK_TILED, "pack_tiled", 1)                                                                                       \
   X(PACK_MULTI, "pack_multi", 1)                                                                                       \
   X(MARCH, "march", 1)                     /* 0: previous-generation stream kernels; 2: Cin = 32 march only */          \

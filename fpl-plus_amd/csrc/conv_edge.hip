@@ -204,40 +204,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4e;
 
 // CIN = 4 (round 4, config 5): the same two MFMAs per input channel - the planar input makes a channel just another base
 // offset, the tap -> k-slot map and the padding selects are shared - 64 loads in flight per lane, two blocks per CU.
-//
-// MODE (round 6): the stem site without its pre-BatchNorm tensor.  The stem convolution is 27 taps of ONE input channel: its
-// output y costs 64 bytes per voxel to store and to re-read, but only two MFMAs to recompute from 4 bytes of input that L1 / L2
-// serve.  So the site's four passes over y (write it; BN-apply reads it; the backward reduction reads it; the backward apply
-// reads it: 4 x 262 MB at the benchmark shape, unet2d5_dsbn.py:74-77 Conv3d -> DSBN -> PReLU) are replaced by recomputation
-// in this kernel's own register layout (a lane holds 16 output channels of one voxel):
-//   STEM_CONV        y = conv(x) + b -> bf16, statistics                     (the plain forward: eval mode, dropout, fp32 callers)
-//   STEM_STATS       statistics only, nothing is stored                       (train forward, pass 1)
-//   STEM_ACT         a = PReLU(scale * bf16(y) + shift) -> bf16               (train forward, pass 2: fplx_bn_act_fwd's arithmetic)
-//   STEM_BWD_REDUCE  partial sums of dz, dz * x-hat, the slope term           (fplx_bn_act_bwd_reduce's arithmetic on y, d(a))
-//   STEM_BWD_APPLY   dy = scale * (dz - k0 - x-hat * k1) -> bf16              (fplx_bn_act_bwd_apply's arithmetic)
-// y is rounded to bf16 exactly where the stored tensor was, so every mode sees the values the separate passes saw.
-// Stores and the d(a) loads (round 6): a lane's two 16-byte runs (channels 8 khalf .. + 7 and 16 + 8 khalf .. + 7 of voxel r)
-// made every store instruction write HALF of each 64-byte voxel row of the segment - two partial writes per row.  One more
-// exchange, v_permlane16_swap between the runs, gives lane L the run (L >> 5) + 2 ((L >> 4) & 1) of voxel L & 15 (+ 16 for
-// the second register set): each instruction then covers 16 complete rows = 1 KiB of contiguous, fully written lines.
-enum { STEM_CONV = 0, STEM_STATS = 1, STEM_ACT = 2, STEM_BWD_REDUCE = 3, STEM_BWD_APPLY = 4 };
-struct StemBn {
-  const float *mean, *rstd, *scale, *shift, *slope, *coef;      // the site's BatchNorm constants [Cout] (coef: [2][Cout], mode 4)
-  const bf16_t* dout;                                            // modes 3, 4: gradient w.r.t. the site's output a, [V][ldd]
-  int64_t ldd;
-  float* part;                                                   // mode 3: one partial row of 2 Cout + 1 floats per block
-};
-
-template <int CIN, int MODE>
-__global__ void __launch_bounds__(256, (CIN == 1 && MODE <= STEM_ACT) ? 4 : 2)
+template <int CIN>
+__global__ void __launch_bounds__(256, CIN == 1 ? 4 : 2)
 stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const float* __restrict__ bias,
               bf16_t* __restrict__ y, int64_t ldy, int N, int D, int H, int W, int co0, int Cout,
-              float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd, const StemBn bn) {
-  constexpr bool WRITES = MODE == STEM_CONV || MODE == STEM_ACT || MODE == STEM_BWD_APPLY;
-  constexpr bool FSTATS = MODE == STEM_CONV || MODE == STEM_STATS;
-  constexpr bool BWD = MODE == STEM_BWD_REDUCE || MODE == STEM_BWD_APPLY;
-  __shared__ float red[4][3][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+              float* __restrict__ stats, int tilesW, int64_t ntiles, int xcd) {
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the segment walk below is scalar work
   const int r = lane & 31, khalf = lane >> 5;
   // k-slot p = 8 s + j of lane half khalf: combo = p / 3 + 5 khalf (kd = combo / 3, kh = combo % 3), kw = p % 3
   // (low half: slots 0-14 = combos 0-4, slot 15 spare; high half: slots 0-11 = combos 5-8, slots 12-15 spare)
@@ -255,160 +229,111 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   f32x16 cinit;                                      // D[row = channel (i & 3) + 8 (i >> 2) + 4 khalf][col = voxel r]
 #pragma unroll
   for (int i = 0; i < 16; ++i) cinit[i] = bias ? bias[co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf] : 0.f;
-  // the site's BatchNorm constants for the lane's 16 channels (accumulator order)
-  constexpr int NBN = MODE >= STEM_ACT ? 16 : 1, NBW = BWD ? 16 : 1, NBA = MODE == STEM_BWD_APPLY ? 16 : 1;
-  float sc[NBN], sh[NBN], bm[NBW], brs[NBW], k0[NBA], k1[NBA];
-  float slope = 0.f;
-  if constexpr (MODE >= STEM_ACT) {
-    slope = *bn.slope;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int ch = co0 + (i & 3) + 8 * (i >> 2) + 4 * khalf;
-      sc[i] = bn.scale[ch]; sh[i] = bn.shift[ch];
-      if constexpr (BWD) { bm[i] = bn.mean[ch]; brs[i] = bn.rstd[ch]; }
-      if constexpr (MODE == STEM_BWD_APPLY) { k0[i] = bn.coef[ch]; k1[i] = bn.coef[Cout + ch]; }
-    }
-  }
-  // the lane's six (kd, kh) rows as element offsets relative to the voxel (combo c + 5 khalf)
-  int roff[6];
+  // the lane's six (kd, kh) rows as BYTE offsets of their centre tap relative to the segment's first voxel (combo c + 5 khalf;
+  // spare rows repeat the centre row: their k-slots meet zero weights)
+  int rowb[6];
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
     const int cb = c + 5 * khalf;
-    roff[c] = cb < 9 ? ((cb / 3 - 1) * H + (cb % 3 - 1)) * W : 0;
+    rowb[c] = ((cb < 9 ? ((cb / 3 - 1) * H + (cb % 3 - 1)) * W : 0) + r) * 4;
   }
   const int64_t xbytes = (int64_t)N * CIN * D * H * W * 4;
   // (the launcher keeps the input below 2 GiB; raw buffer, no stride: out-of-range offsets read as zeros)
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)xbytes, 0x00020000);
-  constexpr int NS = (FSTATS || MODE == STEM_BWD_REDUCE) ? 16 : 1;
-  float ssum[NS], qsum[NS], sds = 0.f;               // forward: sum, sum of squares; backward reduction: sum dz, sum dz x-hat, slope term
+  float ssum[16], qsum[16];
 #pragma unroll
-  for (int i = 0; i < NS; ++i) { ssum[i] = 0.f; qsum[i] = 0.f; }
+  for (int i = 0; i < 16; ++i) { ssum[i] = 0.f; qsum[i] = 0.f; }
 
+  // Round 6: the segment walk in SCALAR registers.  The round-3 form derived (n, d, h, w0) of every segment from a lane-indexed
+  // wave id - three 32-bit divisions and every `segment exists` test as per-lane code, an exec-mask branch around each of the 16
+  // loads - and formed 16 load addresses with three VALU operations each: about 330 VALU instructions per 32-voxel segment
+  // against two MFMAs, which - not the 262-MB write - set this kernel's time (profiles/r06_kernel_ab.txt section 1: the
+  // store-free build still took 62 of 93 us).  Now: coordinates advance by a precomputed mixed-radix step with carries
+  // (no division in the loop), a segment's loads are six vector adds (row offset + scalar segment base; kw = 0 one more each,
+  // kw = 2 the instruction's immediate offset), and segments whose 3 x 3 x 3 neighbourhoods lie inside the volume for every
+  // lane skip the sixteen padding selects.
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
-  struct Seg { int n, d, h, w0; };
-  auto seg_of = [&](int64_t tt) {
-    unsigned t = (unsigned)tt * 4u + (unsigned)wave;
-    Seg g;
-    g.w0 = (int)(t % (unsigned)tilesW) * 32; t /= (unsigned)tilesW;
-    g.h = (int)(t % (unsigned)H); t /= (unsigned)H;
-    g.d = (int)(t % (unsigned)D);
-    g.n = (int)(t / (unsigned)D);                    // >= N: a segment past the end of the list (the last tile may be ragged)
-    return g;
-  };
-  // row-contiguous register sets (see the header): set 0 = voxel lane & 15, set 1 = voxel 16 + (lane & 15), 16-byte run
-  // (lane >> 5) + 2 ((lane >> 4) & 1) of the voxel's 64-byte row
-  const int rv = lane & 15, rrun = (lane >> 5) + 2 * ((lane >> 4) & 1);
-  // the segment's 16 loads per lane.  Byte offset of (row c, kw): a VECTOR offset that is negative (= huge, out of range -> 0)
-  // exactly when the element lies before the tensor.  (A scalar offset must not carry the kw shift: the range check sees the
-  // vector offset alone, and a row that starts one element before the tensor would lose its two valid taps.)
-  auto issue = [&](const Seg& g, float (&xv)[CIN][16], u32x4e (&dv)[2]) {
+  auto sread = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  const unsigned uW = (unsigned)tilesW, uH = (unsigned)H, uD = (unsigned)D;
+  unsigned sw_, sh_, sd_, sn_, cw, ch, cd, cn;      // the step and the current segment as (w tile, h, d, n) digits
+  {
+    unsigned t = sread((unsigned)tr.step * 4u);
+    sw_ = sread(t % uW); t = sread(t / uW);
+    sh_ = sread(t % uH); t = sread(t / uH);
+    sd_ = sread(t % uD); sn_ = sread(t / uD);
+    t = sread((unsigned)tr.first * 4u + (unsigned)wave);
+    cw = sread(t % uW); t = sread(t / uW);
+    ch = sread(t % uH); t = sread(t / uH);
+    cd = sread(t % uD); cn = sread(t / uD);          // >= N: a segment past the end of the list (the last tile may be ragged)
+  }
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    if (cn < (unsigned)N) {
+      const int n = (int)cn, d = (int)cd, h = (int)ch, w0 = (int)cw * 32;
+      // ---- the segment's 16 loads per lane and input channel.  A row that starts before the tensor has a negative = huge
+      // vector offset: out of range -> 0.  (The kw = 0 tap is a vector offset of its own, not a negative immediate: the range
+      // check sees vector offset + immediate, and element -1 of the tensor must not turn into a valid address.)
+      float xv[CIN][16];
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-      const int vidx = (((g.n * CIN + ci) * D + g.d) * H + g.h) * W + g.w0 + r;
+      for (int ci = 0; ci < CIN; ++ci) {
+        const int sbase = ((((n * CIN + ci) * D + d) * H + h) * W + w0) * 4;          // scalar byte offset of the segment's first voxel
 #pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int c = p / 3, kw = p % 3;
-        // a row before the tensor: a negative = huge offset, out of range -> 0.  For ci > 0 such an offset lands in the previous
-        // channel's plane instead - inside the tensor - and is cleared by the padding selects below like any other halo value
-        const unsigned off = g.n < N ? (unsigned)(vidx + roff[c < 6 ? c : 5] + kw - 1) * 4u : 0x80000000u;
-        xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        for (int c = 0; c < 6; ++c) {
+          const unsigned oc = (unsigned)(rowb[c] + sbase), ol = oc - 4u;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int p = 3 * c + kw;
+            if (p < 16)
+              xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, kw == 0 ? ol : (kw == 1 ? oc : oc + 4u), 0, 0));
+          }
+        }
       }
-    }
-    if constexpr (BWD) {
-      const bf16_t* drow = bn.dout + ((int64_t)((g.n * D + g.d) * H + g.h) * W + g.w0) * bn.ldd + co0 + 8 * rrun;
+      // ---- padding.  interior: every tap of every lane lies inside the volume (scalar test) - no selects at all
+      const bool interior = d >= 1 && d + 1 < D && h >= 1 && h + 1 < H && w0 >= 1 && w0 + 32 < W;
+      const int wv = w0 + r;
+      const bool wc = wv < W;
+      f32x16 acc = cinit;
+      if (interior) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const bool ok = g.n < N && g.w0 + rv + 16 * q < W;
-        dv[q] = ok ? *reinterpret_cast<const u32x4e*>(drow + (int64_t)(rv + 16 * q) * bn.ldd) : u32x4e{0u, 0u, 0u, 0u};
+        for (int ci = 0; ci < CIN; ++ci) {
+          bf16x8 bfr[2];
+#pragma unroll
+          for (int p = 0; p < 16; ++p) bfr[p >> 3][p & 7] = (bf16_t)xv[ci][p];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
+        }
+      } else {
+        // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
+        unsigned dh = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          const int dd = d + c / 3 - 1, hh = h + c % 3 - 1;
+          if (dd >= 0 && dd < D && hh >= 0 && hh < H) dh |= 1u << c;
+        }
+        const unsigned dhl = dh >> (5 * khalf);
+        const bool wl = wv - 1 >= 0 && wv - 1 < W, wr = wv + 1 < W;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          bf16x8 bfr[2];
+#pragma unroll
+          for (int p = 0; p < 16; ++p) {
+            const int c = p / 3, kw = p % 3;
+            const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
+            bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[ci][p] : 0.f);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
+        }
       }
-    }
-  };
-  auto consume = [&](const Seg& g, const float (&xv)[CIN][16], const u32x4e (&dv)[2]) {
-    if (g.n >= N) return;                            // wave-uniform
-    const int n = g.n, d = g.d, h = g.h;
-    // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
-    unsigned dh = 0;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      const int dd = d + c / 3 - 1, hh = h + c % 3 - 1;
-      if (dd >= 0 && dd < D && hh >= 0 && hh < H) dh |= 1u << c;
-    }
-    const unsigned dhl = dh >> (5 * khalf);
-    const int wv = g.w0 + r;
-    const bool wl = wv - 1 >= 0 && wv - 1 < W, wc = wv < W, wr = wv + 1 < W;
-    f32x16 acc = cinit;
-#pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-      bf16x8 bfr[2];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const int c = p / 3, kw = p % 3;
-        const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
-        bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[ci][p] : 0.f);
-      }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
-    }
-    if constexpr (FSTATS) {
       if (wc) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
       }
-    }
-    if constexpr (MODE == STEM_STATS) return;
-    // d(a) of the lane's voxel in accumulator order: the two exchanges of the store path, backwards (both are involutions)
-    float dd_[BWD ? 16 : 1];
-    if constexpr (BWD) {
-      unsigned pk[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const u32x2e sw = __builtin_amdgcn_permlane16_swap(dv[0][e], dv[1][e], false, false);
-        pk[e] = sw[0];
-        pk[4 + e] = sw[1];
-      }
-#pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
-          pk[4 * g2 + e] = sw[0];
-          pk[4 * g2 + 2 + e] = sw[1];
-        }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        dd_[2 * q] = __builtin_bit_cast(float, pk[q] << 16);
-        dd_[2 * q + 1] = __builtin_bit_cast(float, pk[q] & 0xffff0000u);
-      }
-    }
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if constexpr (MODE == STEM_CONV) v[i] = acc[i];
-      else {
-        const float yq = (float)(bf16_t)acc[i];                      // y as the separate passes read it back
-        const float z = fmaf(yq, sc[i], sh[i]);
-        if constexpr (MODE == STEM_ACT) v[i] = z > 0.f ? z : z * slope;
-        else {
-          const float da = dd_[i];
-          const float dz = z > 0.f ? da : da * slope;
-          const float xh = (yq - bm[i]) * brs[i];
-          if constexpr (MODE == STEM_BWD_REDUCE) {
-            if (wc) {
-              sds += z > 0.f ? 0.f : da * z;
-              ssum[i] += dz;
-              qsum[i] = fmaf(dz, xh, qsum[i]);
-            }
-          } else v[i] = sc[i] * (dz - k0[i] - xh * k1[i]);
-        }
-      }
-    }
-    if constexpr (WRITES) {
-      // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the 32-lane swaps the low half holds 0-7 and 16-23, the
-      // high half 8-15 and 24-31 of its voxel; after the 16-lane swaps a register set holds whole 64-byte rows of 16 voxels
+      // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the swaps the low half holds 0-7 and 16-23, the high
+      // half 8-15 and 24-31 of its voxel
       unsigned pk[8];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const bf16_t e0 = (bf16_t)v[4 * q], e1 = (bf16_t)v[4 * q + 1], e2 = (bf16_t)v[4 * q + 2], e3 = (bf16_t)v[4 * q + 3];
+        const bf16_t e0 = (bf16_t)acc[4 * q], e1 = (bf16_t)acc[4 * q + 1], e2 = (bf16_t)acc[4 * q + 2], e3 = (bf16_t)acc[4 * q + 3];
         pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
         pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
       }
@@ -420,62 +345,44 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
           pk[4 * g2 + e] = sw[0];
           pk[4 * g2 + 2 + e] = sw[1];
         }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {                     // run 8 khalf (pk[0..3]) <-> run 16 + 8 khalf (pk[4..7]) across 16-lane rows
-        const u32x2e sw = __builtin_amdgcn_permlane16_swap(pk[e], pk[4 + e], false, false);
-        pk[e] = sw[0];
-        pk[4 + e] = sw[1];
+      if (wc) {
+        bf16_t* dst = y + ((int64_t)(((n * D + d) * H + h)) * W + wv) * ldy + co0 + 8 * khalf;
+        *reinterpret_cast<u32x4e*>(dst) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
       }
-      bf16_t* drow = y + ((int64_t)((n * D + d) * H + h) * W + g.w0) * ldy + co0 + 8 * rrun;
-      if (g.w0 + rv < W) *reinterpret_cast<u32x4e*>(drow + (int64_t)rv * ldy) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
-      if (g.w0 + rv + 16 < W) *reinterpret_cast<u32x4e*>(drow + (int64_t)(rv + 16) * ldy) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
     }
-  };
-  // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured: 134 us
-  // against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
-  float xa[CIN][16];
-  u32x4e da[2];
-  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
-    const Seg ga = seg_of(tt);
-    issue(ga, xa, da);
-    consume(ga, xa, da);
+    // ---- next segment of this wave: += 4 step in (w tile, h, d, n) digits, carries as scalar selects
+    cw += sw_;
+    unsigned carry = cw >= uW ? 1u : 0u;
+    cw -= carry ? uW : 0u;
+    ch += sh_ + carry;
+    carry = ch >= uH ? 1u : 0u;
+    ch -= carry ? uH : 0u;
+    cd += sd_ + carry;
+    carry = cd >= uD ? 1u : 0u;
+    cd -= carry ? uD : 0u;
+    cn += sn_ + carry;
   }
-  if constexpr (FSTATS || MODE == STEM_BWD_REDUCE) {
-    if (!FSTATS || stats) {
-      // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
+  // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured in round 3:
+  // 134 us against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
+  if (stats) {
+    // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < 16; ++i)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); qsum[i] += __shfl_xor(qsum[i], o, 64); }
-      if constexpr (MODE == STEM_BWD_REDUCE) {
+      for (int o = 16; o > 0; o >>= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); qsum[i] += __shfl_xor(qsum[i], o, 64); }
+    if (r == 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sds += __shfl_xor(sds, o, 64);
-        if (lane == 0) red[wave][2][0] = sds;
+      for (int i = 0; i < 16; ++i) {
+        const int ch = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+        red[wave][0][ch] = ssum[i];
+        red[wave][1][ch] = qsum[i];
       }
-      if (r == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ch = (i & 3) + 8 * (i >> 2) + 4 * khalf;
-          red[wave][0][ch] = ssum[i];
-          red[wave][1][ch] = qsum[i];
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < 64) {
-        const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
-        const float t = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
-        if constexpr (FSTATS) stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = t;
-        else bn.part[(int64_t)blockIdx.x * (2 * Cout + 1) + which * Cout + co0 + c] = t;
-      }
-      if constexpr (MODE == STEM_BWD_REDUCE) {
-        // the slope term is ONE number per layer: the launch of channel block co0 ADDS its share (launches are stream-ordered,
-        // block co0 = 0 starts the row's sum)
-        if (threadIdx.x == 64) {
-          const float t = red[0][2][0] + red[1][2][0] + red[2][2][0] + red[3][2][0];
-          float* p = bn.part + (int64_t)blockIdx.x * (2 * Cout + 1) + 2 * Cout;
-          *p = co0 == 0 ? t : *p + t;
-        }
-      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      stats[((int64_t)blockIdx.x * 2 + which) * Cout + co0 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     }
   }
 }
@@ -731,7 +638,14 @@ outconv_fwd_t(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict
   f32x4e cinit;                                       // D rows 4 kg + i = classes
 #pragma unroll
   for (int i = 0; i < 4; ++i) cinit[i] = (bias && 4 * kg + i < ncls) ? bias[4 * kg + i] : 0.f;
-  auto swz = [](int vox) { return (vox / (16 / CH)) % CH; };
+  // 16-byte chunk c of voxel v sits at slot c ^ swz(v) of the voxel's row.  ds_read_b128 is serviced in four groups of 16 lanes
+  // that are NOT contiguous ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: MI355X_MICROARCH.md, LDS): a B-fragment read
+  // (lane = voxel r16, chunk kg) puts voxels 0-3, 12-15 with chunk kg and voxels 4-11 with chunk kg + 1 into one group.  The
+  // round-3 swizzle (v / 4) % 4 was chosen for contiguous groups and is 2-way conflicted for these (36 % of this kernel's LDS
+  // cycles, profiles/r05_pmc_sq_counters.txt); (v >> 1) & 2 - for 128-byte rows 2 ((v >> 1) & 3) - is conflict-free for
+  // every tap shift (exhaustive check over all bases: profiles/r06_kernel_ab.txt section 3).  The staging stores (8 contiguous
+  // lanes = 128 contiguous bytes, permuted inside 64-byte rows) are conflict-free under any such swizzle.
+  auto swz = [](int vox) { return CH == 4 ? ((vox >> 1) & 2) : (((vox >> 1) & 3) * 2); };
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);
   constexpr int NLD = (SH * SW * CH + 255) / 256;
   uint4 xreg[NLD];
@@ -1071,6 +985,274 @@ outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 }
 
 // ------------------------------------------------------------------------------------------
+// outconv_dgrad_rows<MODE> (round 6): the fused out_conv backward (MODE 1 | 2 of outconv_dgrad_mfma above: out_conv's data
+// gradient is recomputed and meets the BatchNorm + PReLU backward of the site in front of it in registers) as a STREAM of
+// 32-voxel row segments, one per wave, in the form of stem_fwd_rows - no LDS tile, no block barrier.  The tile kernel moves its
+// 295 | 557 MB at 2.2 | 3.9 TB/s (profiles/r05_kernel_trace_by_shape.csv: 134 | 143 us alone): every tile is a chain fill ->
+// barrier -> commit -> barrier -> MFMA -> LDS transpose -> store with two blocks per CU, i.e. 43 KB in flight per CU against a
+// memory latency of microseconds.  Here:
+//   * the product is TRANSPOSED, D[ci][voxel] = Wb[ci][k] G^T[k][voxel], with the k-slots of outconv_dgrad_mfma (pair p = 8 s + 4
+//     khalf + e = (tap, class), slots 2 e / 2 e + 1 = the hi / lo bf16 terms of the fp32 dlogit against the same weight): the same
+//     products in the same slots, so d is the value the tile kernel forms;
+//   * B operand: the lane's <= 10 dlogits come straight from the fp32 planes through a buffer descriptor (27-fold reuse in L1 / L2;
+//     a row before the tensor = negative = huge offset -> 0); segments whose 3 x 3 neighbourhoods lie inside the plane for every
+//     lane skip the padding selects;
+//   * a lane ends up with 16 channels of ONE voxel (accumulator rows (i & 3) + 8 (i >> 2) + 4 khalf): y arrives as two fully
+//     coalesced 16-byte loads per lane (whole 64-byte voxel rows per instruction) and is brought into that order by
+//     v_permlane16_swap + v_permlane32_swap - the store path of stem_fwd_rows backwards - so the BatchNorm arithmetic runs on the
+//     accumulator registers with the lane's 16 channels' constants resident;
+//   * MODE 1: sum dz, sum dz x-hat, the slope term as 16 + 16 + 1 running sums per lane, folded once per kernel -> one partial
+//     row per block; MODE 2: dy = fma(dz, scale, fma(y, A, B)) leaves through the two lane exchanges of stem_fwd_rows.
+// The segment walk is scalar (mixed-radix step with carries, see stem_fwd_rows).
+template <int MODE, int NCLS>
+__global__ void __launch_bounds__(256, 3)
+outconv_dgrad_rows(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx, int N, int D,
+                   int H, int W, int tilesW, int64_t ntiles, int xcd, const bf16_t* __restrict__ yv, int64_t ldy,
+                   const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd, const float* __restrict__ bn_scale,
+                   const float* __restrict__ bn_shift, const float* __restrict__ slope_p, const float* __restrict__ coef,
+                   float* __restrict__ part) {
+  static_assert(MODE == 1 || MODE == 2, "reduction or apply");
+  static_assert(NCLS == 2, "k-slot tables below are written for two classes (every shipped configuration); others keep the tile kernel");
+  constexpr int C0 = 32, NPAIR = 9 * NCLS, KS = (NPAIR + 7) / 8;      // 18 pairs, 3 k-steps of 16
+  __shared__ float red[4][3][32];
+  __shared__ __attribute__((aligned(16))) float cst[4][32];          // BatchNorm constants per channel: z scale, z shift, A, B
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  const int64_t Vs = (int64_t)D * H * W;
+  // k-slots as in outconv_dgrad_mfma: pair p = 8 s + 4 khalf + e = (tap, class) = (p / 2, p % 2), slots 2 e / 2 e + 1 of the
+  // lane's 8 = its hi / lo terms.  With two classes e >> 1 picks the tap (4 s + 2 khalf + (e >> 1)) and e & 1 the class: the
+  // class plane is the load's SCALAR offset (non-negative: the range check, which sees the vector offset alone, is not weakened),
+  // so a lane keeps one vector offset per (s, e >> 1).
+  bf16x8 afr[KS];                                      // A: row = channel r
+  int toff[KS][2];                                     // byte offset of tap (s, e >> 1) relative to the segment's first voxel, + 4 r
+  unsigned tapsel = 0;                                 // 4 bits per (s, e >> 1): the tap index (9 = spare)
+#pragma unroll
+  for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pr = 8 * sx + 4 * khalf + e;
+      const bool ok = pr < NPAIR;
+      const int tap = ok ? pr / NCLS : 4, cls = pr % NCLS;
+      const bf16_t wv = ok ? wb[((int64_t)tap * C0 + r) * NCLS + cls] : (bf16_t)0.f;
+      afr[sx][2 * e] = wv;
+      afr[sx][2 * e + 1] = wv;
+      if ((e & 1) == 0) {
+        toff[sx][e >> 1] = ((tap / 3 - 1) * W + (tap % 3 - 1) + r) * 4;
+        tapsel |= (unsigned)(ok ? tap : 9) << (4 * (2 * sx + (e >> 1)));
+      }
+    }
+  const int cls_bytes = (int)(Vs * 4);
+  const int64_t gbytes = (int64_t)N * NCLS * Vs * 4;
+  // (the launcher keeps the dlogits below 2 GiB; raw buffer, no stride: out-of-range offsets read as zeros)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dl, 0, (int)gbytes, 0x00020000);
+  // BatchNorm constants.  z = fma(y, c0, c1); MODE 1: x-hat = fma(y, c2, c3) (= (y - mean) rstd); MODE 2: dy = scale (dz - k0 -
+  // x-hat k1) = fma(dz, c0, fma(y, c2, c3)) with the finalize's coefficients folded into c2 / c3 (outconv_dgrad_mfma's constants).
+  // They live in LDS: a lane's 16 channels are four runs of four (8 q + 4 khalf ..), one 16-byte broadcast read per run and array.
+  if (threadIdx.x < 32) {
+    const int c = threadIdx.x;
+    const float m_ = bn_mean[c], rs_ = bn_rstd[c], sc_ = bn_scale[c];
+    cst[0][c] = sc_;
+    cst[1][c] = bn_shift[c];
+    if (MODE == 1) { cst[2][c] = rs_; cst[3][c] = -m_ * rs_; }
+    else { const float k0 = coef[c], k1 = coef[C0 + c]; cst[2][c] = -sc_ * k1 * rs_; cst[3][c] = -sc_ * (k0 - k1 * m_ * rs_); }
+  }
+  __syncthreads();
+  const float bslope = *slope_p;
+  float sdz[MODE == 1 ? 16 : 1], sdx[MODE == 1 ? 16 : 1], sds = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MODE == 1 ? 16 : 1); ++i) { sdz[i] = 0.f; sdx[i] = 0.f; }
+  // row-contiguous register sets of the y loads: set 0 = voxel lane & 15, set 1 = voxel 16 + (lane & 15), 16-byte run
+  // (lane >> 5) + 2 ((lane >> 4) & 1) of the voxel's 64-byte row
+  const int rv = lane & 15, rrun = (lane >> 5) + 2 * ((lane >> 4) & 1);
+
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
+  auto sread = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  const unsigned uW = (unsigned)tilesW, uH = (unsigned)H, uD = (unsigned)D;
+  unsigned sw_, sh_, sd_, sn_;                         // 4 step as (w tile, h, d, n) digits
+  struct Seg { unsigned cw, ch, cd, cn; };
+  Seg nx;                                              // the segment whose loads are issued next
+  {
+    unsigned t = sread((unsigned)tr.step * 4u);
+    sw_ = sread(t % uW); t = sread(t / uW);
+    sh_ = sread(t % uH); t = sread(t / uH);
+    sd_ = sread(t % uD); sn_ = sread(t / uD);
+    t = sread((unsigned)tr.first * 4u + (unsigned)wave);
+    nx.cw = sread(t % uW); t = sread(t / uW);
+    nx.ch = sread(t % uH); t = sread(t / uH);
+    nx.cd = sread(t % uD); nx.cn = sread(t / uD);     // >= N: a segment past the end of the list (the last tile may be ragged)
+  }
+  auto advance = [&](Seg& g) {                         // += 4 step, carries as scalar selects
+    g.cw += sw_;
+    unsigned carry = g.cw >= uW ? 1u : 0u;
+    g.cw -= carry ? uW : 0u;
+    g.ch += sh_ + carry;
+    carry = g.ch >= uH ? 1u : 0u;
+    g.ch -= carry ? uH : 0u;
+    g.cd += sd_ + carry;
+    carry = g.cd >= uD ? 1u : 0u;
+    g.cd -= carry ? uD : 0u;
+    g.cn += sn_ + carry;
+  };
+  // one segment's loads: the lane's dlogits (2 classes x 2 taps per k-step) and y of the segment's 32 voxels.  They are issued a
+  // whole segment ahead of their use: with three waves per SIMD that keeps about 50 KB of y in flight per CU
+  auto issue = [&](const Seg& g, float (&gv)[KS][4], u32x4e (&yq)[2]) {
+    if (g.cn >= (unsigned)N) return;
+    const int n = (int)g.cn, d = (int)g.cd, h = (int)g.ch, w0 = (int)g.cw * 32;
+    const int sbase = (((n * NCLS * D + d) * H + h) * W + w0) * 4;                     // scalar byte offset in the class-0 plane
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        gv[sx][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (unsigned)(toff[sx][e >> 1] + sbase),
+                                                                                    (e & 1) ? cls_bytes : 0, 0));
+    const int64_t vrow = (((int64_t)n * D + d) * H + h) * W + w0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const bool ok = w0 + rv + 16 * q < W;
+      yq[q] = ok ? *reinterpret_cast<const u32x4e*>(yv + (vrow + rv + 16 * q) * ldy + 8 * rrun) : u32x4e{0u, 0u, 0u, 0u};
+    }
+  };
+  auto consume = [&](const Seg& g, const float (&gv)[KS][4], const u32x4e (&yq)[2]) {
+    if (g.cn >= (unsigned)N) return;
+    const int n = (int)g.cn, d = (int)g.cd, h = (int)g.ch, w0 = (int)g.cw * 32;
+    // ---- out_conv's data gradient of the lane's voxel: 16 channels.  Padding: bit t of `tapok` = tap t lies inside the plane
+    // for this lane (bit 9 = the spare slots: never); interior segments (scalar test) have every tap valid
+    const bool interior = h >= 1 && h + 1 < H && w0 >= 1 && w0 + 32 < W;
+    const int wv = w0 + r;
+    const bool wc = wv < W;
+    unsigned tapok = 0x1ffu;
+    if (!interior) {
+      const unsigned colm = (wv - 1 >= 0 && wv - 1 < W ? 1u : 0u) | (wc ? 2u : 0u) | (wv + 1 < W ? 4u : 0u);     // kw = 0, 1, 2
+      tapok = (h >= 1 ? colm : 0u) | (colm << 3) | (h + 1 < H ? colm << 6 : 0u);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) {
+      bf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned tap = (tapsel >> (4 * (2 * sx + (e >> 1)))) & 15u;
+        const float gq = ((tapok >> tap) & 1u) ? gv[sx][e] : 0.f;
+        const bf16_t hi = (bf16_t)gq;
+        b[2 * e] = hi;
+        b[2 * e + 1] = (bf16_t)(gq - (float)hi);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[sx], b, acc, 0, 0, 0);
+    }
+    // ---- y of the lane's voxel in accumulator order: the two exchanges of the store path, backwards (both are involutions)
+    unsigned pk[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32x2e sw = __builtin_amdgcn_permlane16_swap(yq[0][e], yq[1][e], false, false);
+      pk[e] = sw[0];
+      pk[4 + e] = sw[1];
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+        pk[4 * g2 + e] = sw[0];
+        pk[4 * g2 + 2 + e] = sw[1];
+      }
+    // ---- the BatchNorm + PReLU backward of fplx_bn_act_bwd_reduce / _apply (elementwise.hip: dz_of, dropout-free) on the bf16
+    // values that would have been stored; quad q = channels 8 q + 4 khalf + (0..3)
+    unsigned ok8[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4e c0 = *reinterpret_cast<const f32x4e*>(&cst[0][8 * q + 4 * khalf]);
+      const f32x4e c1 = *reinterpret_cast<const f32x4e*>(&cst[1][8 * q + 4 * khalf]);
+      const f32x4e c2 = *reinterpret_cast<const f32x4e*>(&cst[2][8 * q + 4 * khalf]);
+      const f32x4e c3 = *reinterpret_cast<const f32x4e*>(&cst[3][8 * q + 4 * khalf]);
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * q + j;
+        const unsigned word = pk[2 * q + (j >> 1)];
+        const float a = __builtin_bit_cast(float, (j & 1) ? (word & 0xffff0000u) : (word << 16));
+        const float dd = (float)(bf16_t)acc[i];
+        const float z = fmaf(a, c0[j], c1[j]);
+        const float dz = z > 0.f ? dd : dd * bslope;
+        const float t_ = fmaf(a, c2[j], c3[j]);
+        if (MODE == 1) {
+          if (wc) {
+            sds += z > 0.f ? 0.f : dd * z;
+            sdz[i] += dz;
+            sdx[i] = fmaf(dz, t_, sdx[i]);
+          }
+        } else o[j] = fmaf(dz, c0[j], t_);
+      }
+      if (MODE == 2) {
+        const bf16_t e0 = (bf16_t)o[0], e1 = (bf16_t)o[1], e2 = (bf16_t)o[2], e3 = (bf16_t)o[3];
+        ok8[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+        ok8[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+      }
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const u32x2e sw = __builtin_amdgcn_permlane32_swap(ok8[4 * g2 + e], ok8[4 * g2 + 2 + e], false, false);
+          ok8[4 * g2 + e] = sw[0];
+          ok8[4 * g2 + 2 + e] = sw[1];
+        }
+      if (wc) {
+        bf16_t* dst = dx + ((((int64_t)n * D + d) * H + h) * W + wv) * ldx + 8 * khalf;
+        *reinterpret_cast<u32x4e*>(dst) = u32x4e{ok8[0], ok8[1], ok8[2], ok8[3]};
+        *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{ok8[4], ok8[5], ok8[6], ok8[7]};
+      }
+    }
+  };
+  float gA[KS][4], gB[KS][4];
+  u32x4e yA[2], yB[2];
+  Seg cur = nx;
+  issue(cur, gA, yA);
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    nx = cur;
+    advance(nx);
+    if (tt + tr.step < tr.end) issue(nx, gB, yB);
+    consume(cur, gA, yA);
+    cur = nx;
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gA[sx][e] = gB[sx][e];
+    yA[0] = yB[0];
+    yA[1] = yB[1];
+  }
+  if (MODE == 1) {
+    // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves -
+    // every addition in a fixed order
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) { sdz[i] += __shfl_xor(sdz[i], o, 64); sdx[i] += __shfl_xor(sdx[i], o, 64); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sds += __shfl_xor(sds, o, 64);
+    if (lane == 0) red[wave][2][0] = sds;
+    if (r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+        red[wave][0][c] = sdz[i];
+        red[wave][1][c] = sdx[i];
+      }
+    }
+    __syncthreads();
+    float* row = part + (int64_t)blockIdx.x * (2 * C0 + 1);
+    if (threadIdx.x < 64) {
+      const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+      row[which * C0 + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+    if (threadIdx.x == 64) row[2 * C0] = red[0][2][0] + red[1][2][0] + red[2][2][0] + red[3][2][0];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // out_conv weight gradient: rows = ci (32 per block column), cols = classes (padded to 32), K = voxels.
 // x tile [voxel][32 ch] with an in-plane halo in LDS (transposed reads), dlogits straight from the
 // fp32 planes; the 9 taps are dealt to the 4 waves (3/2/2/2).
@@ -1242,26 +1424,6 @@ extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout
   return edge_blocks(tiles_of(n, d, h, w, &th, &tw));
 }
 
-// the LDS-free row kernel's launch: the same number of blocks (= statistics rows) as the tile kernel
-template <int MODE>
-static int stem_rows_launch(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d, int h, int w,
-                            int cin, int cout, float* stats, const StemBn& bn, hipStream_t st, const char* what) {
-  int th, tw;
-  const int nb = edge_blocks(tiles_of(n, d, h, w, &th, &tw));
-  const int tilesW = (w + 31) / 32;
-  const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
-  for (int co0 = 0; co0 < cout; co0 += 32) {
-    if (cin == 1) stem_fwd_rows<1, MODE><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on(), bn);
-    else stem_fwd_rows<4, MODE><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on(), bn);
-  }
-  const int rc = fplx_check_launch(what);
-  return rc < 0 ? rc : 1;
-}
-static bool stem_rows_shape_ok(int n, int d, int h, int w, int cin, int cout) {
-  return (cin == 1 || cin == 4) && cout % 32 == 0 && fplx_knob(FPLX_K_STEM_ROWS) && (cin == 1 || fplx_knob(FPLX_K_STEM_ROWS) != 2) &&
-         (int64_t)n * cin * d * h * w < ((int64_t)1 << 29) && (int64_t)n * d * h * w < ((int64_t)1 << 31);
-}
-
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                                   int h, int w, int cin, int cout, float* stats, hipStream_t st) {
   if (!(cin == 1 || cin == 4) || cout % 32 != 0) return 0;
@@ -1269,8 +1431,18 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt);
-  if (vec_ok && stem_rows_shape_ok(n, d, h, w, cin, cout))         // the LDS-free row kernel (knob stem_rows = 2: in_chns = 1 only)
-    return stem_rows_launch<STEM_CONV>(x, wf, bias, y, ldy, n, d, h, w, cin, cout, stats, StemBn{}, st, "edge_stem_fwd_rows");
+  if (vec_ok && fplx_knob(FPLX_K_STEM_ROWS) && (cin == 1 || fplx_knob(FPLX_K_STEM_ROWS) != 2) &&
+      (int64_t)n * cin * d * h * w < ((int64_t)1 << 29)) {
+    // the LDS-free row kernel; the same number of blocks (= statistics rows) as the tile kernel  (knob 2: in_chns = 1 only)
+    const int tilesW = (w + 31) / 32;
+    const int64_t segs = (int64_t)n * d * h * tilesW, nt4 = (segs + 3) / 4;
+    for (int co0 = 0; co0 < cout; co0 += 32) {
+      if (cin == 1) stem_fwd_rows<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+      else stem_fwd_rows<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, tilesW, nt4, fplx_xcd_on());
+    }
+    int rc0 = fplx_check_launch("edge_stem_fwd_rows");
+    return rc0 < 0 ? rc0 : 1;
+  }
   for (int co0 = 0; co0 < cout; co0 += 32) {
     if (cin == 1)
       stem_fwd_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)wf, bias, (bf16_t*)y, ldy, n, d, h, w, co0, cout, stats, nt, th, tw, vec_ok, fplx_xcd_on());
@@ -1279,31 +1451,6 @@ extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* b
   }
   int rc = fplx_check_launch("edge_stem_fwd");
   return rc < 0 ? rc : 1;
-}
-
-// ---- the stem site without its pre-BatchNorm tensor (round 6; see stem_fwd_rows): rows > 0 = the statistics rows of the forward
-// passes = the partial rows (2 cout + 1 floats each) of the backward reduction; 0 = not available for this shape
-extern "C" int fplx_edge_stem_site_rows(int n, int d, int h, int w, int cin, int cout) {
-  if (!fplx_knob(FPLX_K_STEM_SITE) || !stem_rows_shape_ok(n, d, h, w, cin, cout)) return 0;
-  int th, tw;
-  return edge_blocks(tiles_of(n, d, h, w, &th, &tw));
-}
-// mode: 1 statistics, 2 activation, 3 backward reduction, 4 backward apply (STEM_*); out: a (mode 2) or dy (mode 4: may alias dout)
-extern "C" int fplx_edge_stem_site(int mode, const float* x, const void* wf, const float* bias, void* out, int64_t ldo, int n, int d,
-                                   int h, int w, int cin, int cout, float* stats, const float* mean, const float* rstd,
-                                   const float* scale, const float* shift, const float* slope, const float* coef,
-                                   const void* dout, int64_t ldd, float* part, hipStream_t st) {
-  if (!fplx_edge_stem_site_rows(n, d, h, w, cin, cout)) return 0;
-  if ((mode == STEM_ACT || mode == STEM_BWD_APPLY) && (ldo % 8 != 0 || ((uintptr_t)out % 16) != 0)) return 0;
-  if ((mode == STEM_BWD_REDUCE || mode == STEM_BWD_APPLY) && (ldd % 8 != 0 || ((uintptr_t)dout % 16) != 0)) return 0;
-  const StemBn bn{mean, rstd, scale, shift, slope, coef, (const bf16_t*)dout, ldd, part};
-  switch (mode) {
-    case STEM_STATS: return stem_rows_launch<STEM_STATS>(x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, stats, bn, st, "edge_stem_site_stats");
-    case STEM_ACT: return stem_rows_launch<STEM_ACT>(x, wf, bias, out, ldo, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_act");
-    case STEM_BWD_REDUCE: return stem_rows_launch<STEM_BWD_REDUCE>(x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_bwd_reduce");
-    case STEM_BWD_APPLY: return stem_rows_launch<STEM_BWD_APPLY>(x, wf, bias, out, ldo, n, d, h, w, cin, cout, nullptr, bn, st, "edge_stem_site_bwd_apply");
-  }
-  return 0;
 }
 
 extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout) {
@@ -1378,7 +1525,18 @@ extern "C" int fplx_edge_outconv_bn_ok(int n, int d, int h, int w, int c0, int n
   return c0 == 32 && ncls >= 1 && ncls <= 4 && (int64_t)n * d * h * w < ((int64_t)1 << 31);
 }
 // blocks of the fused data-gradient kernels = partial rows the reduction form writes
-extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w) {
+// the fused backward as a stream of row segments (outconv_dgrad_rows, knob outconv_dgrad_rows): tiles of four 32-voxel segments
+static bool outconv_rows_on(int n, int d, int h, int w, int ncls) {
+  return fplx_knob(FPLX_K_OUTCONV_DGRAD_ROWS) != 0 && ncls == 2 && (int64_t)n * ncls * d * h * w < ((int64_t)1 << 29) &&
+         (int64_t)n * d * h * w < ((int64_t)1 << 31);
+}
+static int64_t outconv_rows_tiles(int n, int d, int h, int w) { return ((int64_t)n * d * h * ((w + 31) / 32) + 3) / 4; }
+// partial rows of the fused backward's reduction = its blocks
+extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w, int ncls) {
+  if (outconv_rows_on(n, d, h, w, ncls)) {
+    const int64_t nt4 = outconv_rows_tiles(n, d, h, w);
+    return (int)(nt4 < 1024 ? nt4 : 1024);
+  }
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   return (int)(nt < 2048 ? nt : 2048);
@@ -1403,6 +1561,18 @@ extern "C" int fplx_edge_outconv_dgrad_bn(int mode, const float* dl, const void*
                                           int d, int h, int w, int c0, int ncls, hipStream_t st) {
   if (!fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls) || ldy % 8 != 0 || ((uintptr_t)y % 16)) return 0;
   if (mode == 2 && (lddy % 8 != 0 || ((uintptr_t)dy % 16))) return 0;
+  if (outconv_rows_on(n, d, h, w, ncls)) {
+    const int64_t nt4 = outconv_rows_tiles(n, d, h, w);
+    const int nbr = fplx_edge_outconv_bn_rows(n, d, h, w, ncls), tilesW = (w + 31) / 32;
+    if (mode == 1)
+      outconv_dgrad_rows<1, 2><<<nbr, 256, 0, st>>>(dl, (const bf16_t*)wb, nullptr, 0, n, d, h, w, tilesW, nt4, fplx_xcd_on(),
+                                                    (const bf16_t*)y, ldy, mean, rstd, scale, shift, slope, nullptr, part);
+    else
+      outconv_dgrad_rows<2, 2><<<nbr, 256, 0, st>>>(dl, (const bf16_t*)wb, (bf16_t*)dy, lddy, n, d, h, w, tilesW, nt4,
+                                                    fplx_xcd_on(), (const bf16_t*)y, ldy, mean, rstd, scale, shift, slope, coef, nullptr);
+    const int rcr = fplx_check_launch("edge_outconv_dgrad_rows");
+    return rcr < 0 ? rcr : 1;
+  }
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = (int)(nt < 2048 ? nt : 2048);

@@ -571,11 +571,6 @@ extern "C" int fplx_march_conv3d_fwd_act(const void* x, int64_t ldx, const void*
 extern "C" int fplx_mfma_conv3d_plan(int n, int d, int h, int w, int cin, int cout, int mid, int* kernel, int* geo, int* ksplit);
 extern "C" int fplx_mfma_conv3d_stats_rows(int n, int d, int h, int w, int cin, int cout);
 extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout);
-extern "C" int fplx_edge_stem_site_rows(int n, int d, int h, int w, int cin, int cout);
-extern "C" int fplx_edge_stem_site(int mode, const float* x, const void* wf, const float* bias, void* out, int64_t ldo, int n, int d,
-                                   int h, int w, int cin, int cout, float* stats, const float* mean, const float* rstd,
-                                   const float* scale, const float* shift, const float* slope, const float* coef,
-                                   const void* dout, int64_t ldd, float* part, hipStream_t st);
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                                   int h, int w, int cin, int cout, float* stats, hipStream_t st);
 extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
@@ -584,7 +579,7 @@ extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy,
 extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
                                      int d, int h, int w, int cin, int ncls, hipStream_t st);
 extern "C" int fplx_edge_outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls);
-extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w);
+extern "C" int fplx_edge_outconv_bn_rows(int n, int d, int h, int w, int ncls);
 extern "C" int fplx_edge_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* slope,
                                         void* a, int64_t lda, const float* wf, const float* bias, float* out, int n, int d,
                                         int h, int w, int c0, int ncls, hipStream_t st);
@@ -888,57 +883,6 @@ int fplx_conv3d_plan_query(int n, int d, int h, int w, int cin, int cout, int kd
   return FPLX_OK;
 }
 
-/* ---- the stem site without its pre-BatchNorm tensor (round 6, csrc/conv_edge.hip: stem_fwd_rows) ---- */
-int fplx_stem_site_rows(int n, int d, int h, int w, int cin, int cout) {
-  if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
-  return fplx_edge_stem_site_rows(n, d, h, w, cin, cout);
-}
-
-int fplx_stem_site_fwd(const float* x, const void* wf, const float* bias, int n, int d, int h, int w, int cin, int cout,
-                       float* stats, const float* scale, const float* shift, const float* slope, void* a, int64_t lda,
-                       fplx_stream_t stream) {
-  FPLX_REQUIRE(x && wf, FPLX_E_NULL, "stem_site_fwd: null pointer");
-  FPLX_REQUIRE(fplx_stem_site_rows(n, d, h, w, cin, cout) > 0, FPLX_E_BADSHAPE,
-               "stem_site_fwd: %dx%dx%dx%d, %d -> %d channels is not a stem site of the row kernel (fplx_stem_site_rows)", n, d, h, w, cin, cout);
-  FPLX_REQUIRE((a != nullptr) != (stats != nullptr), FPLX_E_NULL, "stem_site_fwd: give EITHER stats (pass 1) OR a (pass 2)");
-  int rc;
-  if (stats)
-    rc = fplx_edge_stem_site(1, x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, stats, nullptr, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, 0, nullptr, (hipStream_t)stream);
-  else {
-    FPLX_REQUIRE(scale && shift && slope, FPLX_E_NULL, "stem_site_fwd: the activation pass needs scale, shift and the PReLU slope");
-    FPLX_REQUIRE(lda >= cout && lda % 8 == 0 && (uintptr_t)a % 16 == 0, FPLX_E_BADSHAPE, "stem_site_fwd: a must be 16-byte aligned, lda %% 8 == 0");
-    rc = fplx_edge_stem_site(2, x, wf, bias, a, lda, n, d, h, w, cin, cout, nullptr, nullptr, nullptr, scale, shift, slope, nullptr,
-                             nullptr, 0, nullptr, (hipStream_t)stream);
-  }
-  if (rc < 0) return rc;
-  FPLX_REQUIRE(rc == 1, FPLX_E_BADSHAPE, "stem_site_fwd: operands refused by the row kernel");
-  return FPLX_OK;
-}
-
-int fplx_stem_site_bwd(const float* x, const void* wf, const float* bias, int n, int d, int h, int w, int cin, int cout,
-                       const void* dout, int64_t ldd, const float* mean, const float* rstd, const float* scale, const float* shift,
-                       const float* slope, float* part, const float* coef, void* dy, int64_t ldo, fplx_stream_t stream) {
-  FPLX_REQUIRE(x && wf && dout && mean && rstd && scale && shift && slope, FPLX_E_NULL, "stem_site_bwd: null pointer");
-  FPLX_REQUIRE(fplx_stem_site_rows(n, d, h, w, cin, cout) > 0, FPLX_E_BADSHAPE,
-               "stem_site_bwd: %dx%dx%dx%d, %d -> %d channels is not a stem site of the row kernel (fplx_stem_site_rows)", n, d, h, w, cin, cout);
-  FPLX_REQUIRE((part != nullptr) != (dy != nullptr), FPLX_E_NULL, "stem_site_bwd: give EITHER part (reduction) OR coef + dy (apply)");
-  FPLX_REQUIRE(ldd >= cout && ldd % 8 == 0 && (uintptr_t)dout % 16 == 0, FPLX_E_BADSHAPE, "stem_site_bwd: dout must be 16-byte aligned, ldd %% 8 == 0");
-  int rc;
-  if (part)
-    rc = fplx_edge_stem_site(3, x, wf, bias, nullptr, 0, n, d, h, w, cin, cout, nullptr, mean, rstd, scale, shift, slope, nullptr, dout,
-                             ldd, part, (hipStream_t)stream);
-  else {
-    FPLX_REQUIRE(coef, FPLX_E_NULL, "stem_site_bwd: the apply pass needs the finalize's coef");
-    FPLX_REQUIRE(ldo >= cout && ldo % 8 == 0 && (uintptr_t)dy % 16 == 0, FPLX_E_BADSHAPE, "stem_site_bwd: dy must be 16-byte aligned, ldo %% 8 == 0");
-    rc = fplx_edge_stem_site(4, x, wf, bias, dy, ldo, n, d, h, w, cin, cout, nullptr, mean, rstd, scale, shift, slope, coef, dout, ldd,
-                             nullptr, (hipStream_t)stream);
-  }
-  if (rc < 0) return rc;
-  FPLX_REQUIRE(rc == 1, FPLX_E_BADSHAPE, "stem_site_bwd: operands refused by the row kernel");
-  return FPLX_OK;
-}
-
 int fplx_conv3d_fwd(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,
                     const void* wp, const float* bias, void* y, int y_dt, int64_t yn, int64_t yd, int64_t yh,
                     int64_t yw, int64_t yc, int n, int d, int h, int w, int cin, int cout, int kd, int kh, int kw,
@@ -1149,7 +1093,7 @@ static bool outconv_bn_ok(int n, int d, int h, int w, int c0, int ncls) {
   return n > 0 && d > 0 && h > 0 && w > 0 && fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls);
 }
 int fplx_outconv_bn_rows(int n, int d, int h, int w, int c0, int ncls) {
-  return outconv_bn_ok(n, d, h, w, c0, ncls) ? fplx_edge_outconv_bn_rows(n, d, h, w) : 0;
+  return outconv_bn_ok(n, d, h, w, c0, ncls) ? fplx_edge_outconv_bn_rows(n, d, h, w, ncls) : 0;
 }
 int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
                         int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,

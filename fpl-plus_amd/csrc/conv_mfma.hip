@@ -1985,8 +1985,8 @@ splitk_finish_k(const float* __restrict__ partial, int ks, int64_t V, int Cout, 
 // per lane at a 128-byte stride: every wave instruction touches 32 cache lines for 1 KiB (96 us = 3.4 TB/s alone, 195 us
 // beside the weight-gradient stream).  Here a block takes MB parents of one row at a time; their children are four
 // CONTIGUOUS child-row pieces (128 Cout/32 bytes per parent and (i, j)), fetched with fully coalesced 16-byte loads into
-// registers one segment ahead and committed to LDS with the 16-byte chunk index XOR-ed by (parent & 7) (the fragment
-// reads of 16 lanes then hit 8 different slots: 2-way instead of 8-way conflicts).  The product is TRANSPOSED,
+// registers one segment ahead and committed to LDS with the 16-byte chunk index XOR-ed by a swizzle of the parent index that
+// follows ds_read_b128's lane groups (pswz below: conflict-free fragment reads since round 6).  The product is TRANSPOSED,
 // D[ci][parent] = Wb[ci][k] dy^T[k][parent]: the weights are the A operand and stay in registers for the whole kernel, a lane
 // ends up with 16 input channels of ONE parent, two v_permlane32_swap exchanges make them two 16-byte stores.
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2d;
@@ -2018,6 +2018,14 @@ deconv_dgrad_rows(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __re
     o.n = (int)(t / (unsigned)D);
     return o;
   };
+  // chunk q of parent p sits at slot q ^ pswz(p) of the parent's U slots.  A fragment read is one chunk index for 32 parents
+  // (lane = parent r), and ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): the
+  // swizzle must separate the 16 parents of a GROUP, not 16 consecutive ones.  Round 3's p & 7 left parents {0, 24}, {12, 20}, ...
+  // of a group on one slot - 2-way conflicts on every read, a third of the kernel's LDS cycles (profiles/r05_pmc_sq_counters.txt:
+  // 33 %).  U = 8 (128-byte rows: slot mod 16 = 8 (p & 1) + (q ^ swz)): bits 1, 3, 4 of p take all eight values over the even and
+  // over the odd parents of either group; U = 16 (256-byte rows): p & 15 is distinct over both groups.  The staging stores (8
+  // contiguous lanes = 8 consecutive q of one parent) stay one contiguous 128-byte run under both.
+  auto pswz = [](int p) { return U == 8 ? (((p >> 1) & 1) | (((p >> 3) & 3) << 1)) : (p & 15); };
   uint4 reg[NIT];
   auto fetch = [&](const Seg& g) {
 #pragma unroll
@@ -2041,7 +2049,7 @@ deconv_dgrad_rows(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __re
     for (int k = 0; k < NIT; ++k) {
       const int e = tid + 256 * k;
       const int q = e % U, p = (e / U) % MB, ij = e / (U * MB);
-      *reinterpret_cast<uint4*>(sm + (((ij * MB + p) * U) + (q ^ (p & 7))) * 16) = reg[k];
+      *reinterpret_cast<uint4*>(sm + (((ij * MB + p) * U) + (q ^ pswz(p))) * 16) = reg[k];
     }
     __syncthreads();
     if (tt + tr.step < tr.end) {
@@ -2057,7 +2065,7 @@ deconv_dgrad_rows(const bf16_t* __restrict__ dy, int64_t ldy, const bf16_t* __re
 #pragma unroll
       for (int s_ = 0; s_ < KS; ++s_) {
         const int q = kk * (4 * CO32) + 2 * s_ + kq;
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sm + (((ij * MB + mt * 32 + r) * U) + (q ^ (r & 7))) * 16);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sm + (((ij * MB + mt * 32 + r) * U) + (q ^ pswz(r))) * 16);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[tap][s_], b, acc, 0, 0, 0);
       }
     }

@@ -63,10 +63,6 @@ class Engine(object):
         # out_conv fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn / _dgrad_bn_*):
         # one pass over that site's tensor forward, two instead of three (+ the data gradient's write) backward
         self.use_outconv_fusion = _lib.host_knob("outconv_fuse") != 0
-        # the stem site (first convolution -> DSBN -> PReLU, training, bf16, no dropout there) without its pre-BatchNorm tensor:
-        # every pass recomputes the 27-tap convolution from the fp32 input (fplx_stem_site_fwd / _bwd) - four passes over a
-        # [V, C0] tensor less per step
-        self.use_stem_site = _lib.host_knob("stem_site") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
         # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
@@ -393,22 +389,9 @@ class Engine(object):
                 return None, None, pp
             if n_x0:
                 raise RuntimeError("fplx: the shared skip tensor of level %d was planned for the fused kernel" % l)
+            y = empty(vox[l], cout)
             bnbuf = torch.empty((4, cout), dtype=torch.float32, device=dev)
             bnm = bn.bns[domain]
-            if (train and keep and self.use_stem_site and x_dt == F32 and not cat2 and not mid and pp == 0.0 and pool is None and
-                    not defer_act and adt == torch.bfloat16 and xin is x and ops.ld_of(out_view) % 8 == 0 and
-                    out_view.data_ptr() % 16 == 0):
-                rows = ops.stem_site_rows(dims[l], cin, cout)
-                if rows > 0:
-                    # the stem site: statistics from a first pass that stores nothing, the activation from a second one - the
-                    # convolution's own output is never written (y = None tells backward to recompute it as well)
-                    stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
-                    ops.stem_site_fwd_stats(xin, packs[key][0], conv.bias, dims[l], cin, cout, stats)
-                    ops.bn_train_finalize(stats, rows, cout, vox[l], bnm.weight, bnm.bias, bnm.running_mean,
-                                          bnm.running_var, bnm.num_batches_tracked, bnbuf, bnm.momentum, bnm.eps)
-                    ops.stem_site_fwd_act(xin, packs[key][0], conv.bias, dims[l], cin, cout, bnbuf, prelu.weight, out_view)
-                    return None, bnbuf, pp
-            y = empty(vox[l], cout)
             if train:
                 rows = ops.conv3d_stats_rows(dims[l], cin, cout, (3, 3, 3), x_dt, a_dt, mid)
                 stats = torch.empty((rows, 2, cout), dtype=torch.float32, device=dev)
@@ -586,9 +569,7 @@ class Engine(object):
         maxc = max(ft) * 2
         part_floats = ops.num_partials(vox[0]) * (2 * maxc + 1)
         if sv.oc_fused:        # the fused out_conv backward writes one partial row per tile block: up to 2048 rows of 2 ft[0] + 1
-            part_floats = max(part_floats, ops.outconv_bn_rows(dims[0]) * (2 * ft[0] + 1))
-        if sv.blocks[0]["y1"] is None:      # the stem site's backward reduction: one partial row per block of the row kernel
-            part_floats = max(part_floats, ops.stem_site_rows(dims[0], sv.blocks[0]["cin"], ft[0]) * (2 * ft[0] + 1))
+            part_floats = max(part_floats, ops.outconv_bn_rows(dims[0], ft[0], ncls) * (2 * ft[0] + 1))
         part = torch.empty(part_floats, dtype=torch.float32, device=dev)
         coef = torch.empty((2, maxc), dtype=torch.float32, device=dev)
 
@@ -642,12 +623,7 @@ class Engine(object):
             reduced: the producer of d_out already wrote the BatchNorm reduction's partial rows (pool_bwd_bn_reduce)"""
             c = ft[l]
             gkey = "%s.bns.%d" % (bnkey, domain)
-            if y is None:         # the stem site: its pre-BatchNorm tensor was never stored - both passes recompute it from the input
-                conv_b = net.get_param(key + ".bias")
-                ops.stem_site_bwd(xin, packs[key][0], conv_b, dims[l], cin, c, d_out, d_out, bnbuf,
-                                  net.get_param(relukey + ".weight"), sv.train, gv[gkey + ".weight"], gv[gkey + ".bias"],
-                                  gv[relukey + ".weight"], part, coef)
-            elif from_logits:     # d_out is not given: it is out_conv's data gradient, recomputed inside the two BatchNorm passes
+            if from_logits:     # d_out is not given: it is out_conv's data gradient, recomputed inside the two BatchNorm passes
                 ops.outconv_dgrad_bn_bwd(dlogits, packs["out_conv"][1], y, bnbuf, net.get_param(relukey + ".weight"), sv.train,
                                          gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, d_out,
                                          dims[l], c, ncls)

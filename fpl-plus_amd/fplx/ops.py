@@ -319,9 +319,9 @@ def outconv_fwd_bn(y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls):
 
 def outconv_dgrad_bn_bwd(dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls):
     """backward of [BN + PReLU -> out_conv] without ever storing out_conv's data gradient: reduction (recomputing it from
-    dlogits), the usual finalize, apply (recomputing it again) -> dy.  part must hold outconv_bn_rows(dims) x (2 c0 + 1) floats."""
+    dlogits), the usual finalize, apply (recomputing it again) -> dy.  part must hold outconv_bn_rows(dims, c0, ncls) x (2 c0 + 1) floats."""
     n, d, h, w = dims
-    rows = outconv_bn_rows(dims)
+    rows = outconv_bn_rows(dims, c0, ncls)
     if part.numel() < rows * (2 * c0 + 1):
         raise ValueError("fplx: partial-row buffer too small for the fused out_conv backward (%d < %d floats)" % (part.numel(), rows * (2 * c0 + 1)))
     bn = [ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3])]
@@ -331,46 +331,6 @@ def outconv_dgrad_bn_bwd(dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dsl
          ptr(coef), stream())
     call("fplx_outconv_dgrad_bn_apply", ptr(dlogits), ptr(wb), ptr(y), ld_of(y), bn[0], bn[1], bn[2], bn[3], ptr(slope), ptr(coef),
          ptr(dy), ld_of(dy), n, d, h, w, int(c0), int(ncls), stream())
-
-
-# ---- the stem site without its pre-BatchNorm tensor (fplx.h: fplx_stem_site_rows / _fwd / _bwd)
-def stem_site_rows(dims, cin, cout):
-    """> 0: Conv3d(in_chns -> C0) -> DSBN -> PReLU of the network's first site can run without storing the convolution's output
-    (each pass recomputes it from the fp32 input); the value = statistics rows = partial rows of the backward reduction"""
-    n, d, h, w = dims
-    return _lib.lib().fplx_stem_site_rows(n, d, h, w, int(cin), int(cout))
-
-
-def stem_site_fwd_stats(x, wf, bias, dims, cin, cout, stats):
-    """pass 1: the convolution's BatchNorm statistics rows [rows][2][cout]; nothing else is stored"""
-    n, d, h, w = dims
-    call("fplx_stem_site_fwd", ptr(x), ptr(wf), ptr(bias), n, d, h, w, int(cin), int(cout), ptr(stats), None, None, None, None, 0,
-         stream())
-
-
-def stem_site_fwd_act(x, wf, bias, dims, cin, cout, bnbuf, slope, a):
-    """pass 2: a = PReLU(scale * conv(x) + shift) -> bf16"""
-    n, d, h, w = dims
-    call("fplx_stem_site_fwd", ptr(x), ptr(wf), ptr(bias), n, d, h, w, int(cin), int(cout), None, ptr(bnbuf[2]), ptr(bnbuf[3]),
-         ptr(slope), ptr(a), ld_of(a), stream())
-
-
-def stem_site_bwd(x, wf, bias, dims, cin, cout, dout, dy, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef):
-    """backward of the stem site's DSBN + PReLU on a recomputed convolution output: reduction, the usual finalize, apply -> dy
-    (gradient w.r.t. the convolution's output; may alias dout).  part: stem_site_rows x (2 cout + 1) floats."""
-    n, d, h, w = dims
-    rows = stem_site_rows(dims, cin, cout)
-    if rows <= 0:
-        raise ValueError("fplx: not a stem site of the row kernel (stem_site_rows)")
-    if part.numel() < rows * (2 * cout + 1):
-        raise ValueError("fplx: partial-row buffer too small for the stem site's backward (%d < %d floats)" % (part.numel(), rows * (2 * cout + 1)))
-    bn = [ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3])]
-    call("fplx_stem_site_bwd", ptr(x), ptr(wf), ptr(bias), n, d, h, w, int(cin), int(cout), ptr(dout), ld_of(dout), bn[0], bn[1], bn[2],
-         bn[3], ptr(slope), ptr(part), None, None, 0, stream())
-    call("fplx_bn_act_bwd_finalize", ptr(part), rows, int(cout), n * d * h * w, 1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope),
-         ptr(coef), stream())
-    call("fplx_stem_site_bwd", ptr(x), ptr(wf), ptr(bias), n, d, h, w, int(cin), int(cout), ptr(dout), ld_of(dout), bn[0], bn[1], bn[2],
-         bn[3], ptr(slope), None, ptr(coef), ptr(dy), ld_of(dy), stream())
 
 
 def bn_pool_fused_ok(c, dtype):

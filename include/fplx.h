@@ -270,28 +270,6 @@ int fplx_bn_act_bwd_apply(const void* y, int64_t ldy, const void* dout, int64_t 
                           const float* slope, const float* coef, float p, uint64_t seed, uint32_t stream_id,
                           int64_t voxels, int c, int dt, fplx_stream_t stream);
 
-/* ---- the stem site without its pre-BatchNorm tensor (round 6).  The first site of the network, Conv3d(in_chns -> C0, 3x3x3) ->
- * DomainSpecificBatchNorm3d -> PReLU (unet2d5_dsbn.py:54, 74-77; in_chns = 1 or 4, C0 % 32 == 0, bf16 activations, no dropout
- * at this site), is 27 taps of one or four fp32 input channels: its output y costs 2 C0 bytes per voxel to store and to re-read
- * but two MFMAs per input channel to recompute.  These calls replace fplx_conv3d_fwd (stem) + fplx_bn_act_fwd and
- * fplx_bn_act_bwd_reduce / _apply of that site: y is never stored, each pass recomputes it from x (fp32 NCDHW, contiguous) and
- * rounds it to bf16 where the stored tensor was rounded, so the arithmetic per element is that of the separate passes.
- *   fplx_stem_site_rows   > 0: the site can run this way; the value = statistics rows of pass 1 = partial rows of the backward
- *                         reduction (rows x (2 C0 + 1) floats); 0: keep the separate passes
- *   fplx_stem_site_fwd    stats != NULL (a == NULL): pass 1, the statistics rows [rows][2][C0] for fplx_bn_train_finalize;
- *                         a != NULL (stats == NULL): pass 2, a = PReLU(scale * y + shift) -> bf16 [V, lda]
- *   fplx_stem_site_bwd    dout = gradient w.r.t. a (bf16 [V, ldd]); part != NULL (dy == NULL): the reduction's partial rows for
- *                         fplx_bn_act_bwd_finalize(part, rows, C0, ...); dy != NULL (part == NULL): dy = gradient w.r.t. y from
- *                         the finalize's coef (dy may alias dout), the operand of the stem's weight gradient
- * wf: fplx_pack_conv_weight's forward pack of the stem weight in bf16. */
-int fplx_stem_site_rows(int n, int d, int h, int w, int cin, int cout);
-int fplx_stem_site_fwd(const float* x, const void* wf, const float* bias, int n, int d, int h, int w, int cin, int cout,
-                       float* stats, const float* scale, const float* shift, const float* slope, void* a, int64_t lda,
-                       fplx_stream_t stream);
-int fplx_stem_site_bwd(const float* x, const void* wf, const float* bias, int n, int d, int h, int w, int cin, int cout,
-                       const void* dout, int64_t ldd, const float* mean, const float* rstd, const float* scale, const float* shift,
-                       const float* slope, float* part, const float* coef, void* dy, int64_t ldo, fplx_stream_t stream);
-
 /* ------------------------------------------------------------------ pooling
  * nn.MaxPool3d(2,2) (unet2d5_dsbn.py:106,117).  x [N,D,H,W,C] ld ldx -> y [N,D/2,H/2,W/2,C] ld ldy */
 int fplx_maxpool2_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int n, int d, int h, int w, int c,

@@ -602,121 +602,6 @@ def test_stem_kernels_bf16(shape):
     assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
 
 
-# ---- the stem site without its pre-BatchNorm tensor (round 6: fplx_stem_site_rows / _fwd / _bwd)
-@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 1, 32, 5, 16, 64), (1, 4, 32, 2, 16, 64), (3, 1, 32, 5, 7, 161),
-                                   (1, 1, 32, 1, 1, 1), (1, 1, 32, 1, 1, 40), (2, 1, 64, 6, 20, 96), (2, 4, 32, 3, 10, 48)])
-def test_stem_site_passes_equal_the_separate_passes(shape):
-    """Conv3d(in_chns -> C0) -> DSBN -> PReLU of the first site with the convolution RECOMPUTED in every pass instead of stored:
-    pass 1 writes the statistics rows of the plain stem forward (bit for bit), pass 2 the activation fplx_bn_act_fwd forms from
-    the stored tensor (bit for bit); the backward reduction and apply against fplx_bn_act_bwd on the stored tensor (the sums in
-    another fixed order: gradients of the affine parameters to 1e-5, dy equal up to rare single bf16 steps) and against float64
-    autograd through the same chain.  Ragged widths, single rows, several samples, 4 input channels, 64 output channels."""
-    from fplx import ops
-    n, cin, cout, d, h, w = shape
-    dims, v = (n, d, h, w), n * d * h * w
-    rows = ops.stem_site_rows(dims, cin, cout)
-    assert rows > 0 and rows == ops.conv3d_stats_rows(dims, cin, cout, (3, 3, 3), ops.F32, ops.BF16)
-    assert ops.stem_site_rows(dims, 2, cout) == 0 and ops.stem_site_rows(dims, cin, 48) == 0
-    x = torch.from_numpy(detdata.normal("ss.x%s" % (shape,), (n, cin, d, h, w))).cuda()
-    wt = torch.from_numpy(detdata.normal("ss.w%s" % (shape,), (cout, cin, 3, 3, 3), 0.3)).bfloat16().float()
-    b = torch.from_numpy(detdata.normal("ss.b%s" % (shape,), (cout,))).cuda()
-    gamma = torch.from_numpy(detdata.normal("ss.g%s" % (shape,), (cout,)) * 0.3 + 1.0).float().cuda()
-    beta = torch.from_numpy(detdata.normal("ss.be%s" % (shape,), (cout,)) * 0.3).float().cuda()
-    slope = torch.full((1,), 0.25, device="cuda")
-    dout = torch.from_numpy(detdata.normal("ss.d%s" % (shape,), (v, cout))).bfloat16().cuda()
-    wf, _ = ops.pack_conv_weight(wt.cuda(), torch.bfloat16, False)
-    # ---- the separate passes (the path the engine takes with the knob off)
-    stats0 = torch.zeros((rows, 2, cout), device="cuda")
-    y = torch.zeros((v, cout), dtype=torch.bfloat16, device="cuda")
-    ops.conv3d_fwd(x, ops.planar_strides(cin, d, h, w), ops.F32, wf, b, y, ops.cl_strides(d, h, w, cout), ops.BF16, dims, cin, cout,
-                   (3, 3, 3), stats0)
-    rm, rv, nbt = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda")
-    bnbuf = torch.empty((4, cout), device="cuda")
-    ops.bn_train_finalize(stats0, rows, cout, v, gamma, beta, rm, rv, nbt, bnbuf)
-    a0 = torch.empty_like(y)
-    ops.bn_act_fwd(y, a0, bnbuf, slope, 0.0, 0, 0, cout)
-    part = torch.zeros(max(ops.num_partials(v), rows) * (2 * cout + 1), device="cuda")
-    coef = torch.empty((2, cout), device="cuda")
-    g0, b0, s0 = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
-    dy0 = torch.empty_like(y)
-    ops.bn_act_bwd(y, dout, dy0, bnbuf, slope, 0.0, 0, 0, cout, True, g0, b0, s0, part, coef)
-    # ---- the site passes
-    stats1 = torch.full((rows, 2, cout), 7.0, device="cuda")
-    ops.stem_site_fwd_stats(x, wf, b, dims, cin, cout, stats1)
-    assert torch.equal(stats1, stats0)
-    a1 = torch.full_like(y, 3.0)
-    ops.stem_site_fwd_act(x, wf, b, dims, cin, cout, bnbuf, slope, a1)
-    assert torch.equal(a1, a0)
-    g1, b1, s1 = torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")
-    part.fill_(float("nan"))
-    dy1 = torch.full_like(y, 3.0)
-    ops.stem_site_bwd(x, wf, b, dims, cin, cout, dout, dy1, bnbuf, slope, True, g1, b1, s1, part, coef)
-    for got, ref in ((g1, g0), (b1, b0), (s1, s0)):
-        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6 * v ** 0.5, (got, ref)
-    dd = (dy1.float() - dy0.float()).abs()
-    assert float(dd.max()) <= 2.0 ** -6 * float(dy0.float().abs().max()) + 1e-30 and float((dd > 0).float().mean()) <= 2e-3
-    # in place (dy aliases dout), as the engine calls it
-    d2 = dout.clone()
-    ops.stem_site_bwd(x, wf, b, dims, cin, cout, d2, d2, bnbuf, slope, True, torch.zeros_like(g1), torch.zeros_like(b1),
-                      torch.zeros_like(s1), part, coef)
-    assert torch.equal(d2, dy1)
-    # ---- float64 autograd through conv -> batch statistics -> affine -> PReLU on the bf16-rounded operands
-    if v > 1:
-        xq = x.cpu().bfloat16().double()
-        yq = y.cpu().double().requires_grad_(True)              # the stored convolution output IS the chain's input here
-        ga, be, sl = gamma.cpu().double().requires_grad_(True), beta.cpu().double().requires_grad_(True), slope.cpu().double().requires_grad_(True)
-        mu, var = yq.mean(0), yq.var(0, unbiased=False)
-        z = (yq - mu) / torch.sqrt(var + 1e-5) * ga + be
-        act = torch.where(z > 0, z, z * sl)
-        act.backward(dout.cpu().double())
-        sc = float(yq.grad.abs().max())
-        assert float((dy1.cpu().double() - yq.grad).abs().max()) <= 2e-2 * sc + 1e-6
-        assert float((g1.cpu().double() - ga.grad).abs().max()) <= 1e-2 * float(ga.grad.abs().max()) + 1e-4
-        assert float((b1.cpu().double() - be.grad).abs().max()) <= 1e-2 * float(be.grad.abs().max()) + 1e-4
-        assert abs(float(s1.cpu()) - float(sl.grad)) <= 1e-2 * abs(float(sl.grad)) + 1e-3
-
-
-def test_network_step_with_and_without_the_stem_site():
-    """the engine with the stem site recomputed in every pass (Engine.use_stem_site, the default: the first convolution's output
-    is never stored) against the separate passes: same logits bit for bit (the forward arithmetic is identical), the loss equal,
-    the parameters after one Adam step within the noise of another order of additions in three BatchNorm sums; the 2.5D stem
-    (a Conv2d) and a dropout at the stem site keep the separate passes"""
-    import fplx
-    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
-             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
-    lab = torch.zeros(2, 2, 16, 32, 64)
-    lab[:, 0] = 1.0
-    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
-    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
-    lab = lab.cuda()
-    res = []
-    for fuse in (True, False):
-        torch.manual_seed(3)
-        net = fplx.UNet2D5_dsbn(dict(p)).cuda()
-        net.engine.use_stem_site = fuse
-        net.train()
-        with torch.no_grad():
-            net.dropout_seed, net._fwd_counter = 9, 0
-        ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
-        logits, sv = net.engine.forward(x, 1, True, net.dropout_active(), 9, 0, keep=True)
-        assert (sv.blocks[0]["y1"] is None) == fuse
-        out = ts.step(x, lab, 1)
-        res.append((logits.clone(), net.flat_params.detach().clone(), float(out[0])))
-    assert torch.equal(res[0][0], res[1][0])
-    assert abs(res[0][2] - res[1][2]) < 1e-6
-    rel = float((res[0][1] - res[1][1]).abs().max()) / float(res[1][1].abs().max())
-    assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr
-    for extra in (dict(conv_dims=[2, 2, 3, 3, 3]), dict(dropout=[0.2, 0, 0.3, 0.4, 0.5])):
-        net = fplx.UNet2D5_dsbn(dict(p, **extra)).cuda().train()
-        _, sv = net.engine.forward(x, 0, True, net.dropout_active(), 9, 0, keep=True)
-        assert sv.blocks[0]["y1"] is not None
-    net = fplx.UNet2D5_dsbn(dict(p)).cuda().eval()           # eval-mode BatchNorm with a backward: the stored tensor
-    _, sv = net.engine.forward(x, 0, False, net.dropout_active(), 9, 0, keep=True)
-    assert sv.blocks[0]["y1"] is not None
-
-
 @pytest.mark.parametrize("shape", [(2, 32, 2, 3, 9, 35), (1, 32, 3, 2, 16, 64), (1, 64, 2, 2, 8, 40)])
 def test_outconv_kernels_bf16(shape):
     """bf16 NDHWC features <-> fp32 NCDHW logits, kernel (1,3,3): forward, data gradient, weight gradient"""
@@ -1053,8 +938,19 @@ def test_conv3d_fwd_act_two_tensor_form(shape):
                 assert float((y1.float() - y2[:, :cout].float()).abs().max()) < 2e-2 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (1, 2, 16, 64, 2), (1, 4, 24, 40, 3)])
-def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape):
+@pytest.fixture(params=[1, 0], ids=["rows", "tiles"])
+def outconv_dgrad_rows_knob(request):
+    """the fused out_conv backward has two kernels for two classes: the stream of row segments (outconv_dgrad_rows, round 6, the
+    default) and the tile kernel (outconv_dgrad_mfma<1, MODE>: knob outconv_dgrad_rows = 0; what 3 and 4 classes always take)"""
+    from fplx import _lib
+    _lib.set_tuning("outconv_dgrad_rows", request.param)
+    yield request.param
+    _lib.set_tuning("outconv_dgrad_rows", 1)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (1, 2, 16, 64, 2), (1, 4, 24, 40, 3), (2, 5, 40, 96, 2), (1, 1, 1, 1, 2),
+                                   (3, 2, 7, 161, 2)])
+def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape, outconv_dgrad_rows_knob):
     """fplx_outconv_fwd_bn / fplx_outconv_dgrad_bn_reduce / _apply (out_conv fused with the BatchNorm + PReLU passes of the
     convolution site in front of it; reference unet2d5_dsbn.py:79-81 + 293-294, 307) against the calls they replace: forward -
     fplx_bn_act_fwd then fplx_conv3d_fwd (1,3,3): the activation and the logits bit for bit; backward - fplx_conv3d_fwd with the
@@ -1091,7 +987,7 @@ def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape):
     d_ref = torch.empty(v, c0, dtype=bf, device="cuda")
     ops.conv3d_fwd(dl, pl(ncls, d, h, w), ops.F32, wob, None, d_ref, cl(d, h, w, c0), ops.BF16, dims, ncls, c0, (1, 3, 3), None)
     maxc = 64
-    part = torch.empty((max(ops.num_partials(v), ops.outconv_bn_rows(dims)), 2 * maxc + 1), device="cuda")
+    part = torch.empty((max(ops.num_partials(v), ops.outconv_bn_rows(dims, c0, ncls)), 2 * maxc + 1), device="cuda")
     coef = torch.empty((2, maxc), device="cuda")
     gr = [torch.zeros(c0, device="cuda"), torch.zeros(c0, device="cuda"), torch.zeros(1, device="cuda")]
     ops.bn_act_bwd(y, d_ref, d_ref, bnbuf, slope, 0.0, 0, 0, c0, True, gr[0], gr[1], gr[2], part, coef)
@@ -1107,8 +1003,8 @@ def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape):
         ops.outconv_dgrad_bn_bwd(dl, wob, y, bnbuf, slope, True, gf[0], gf[1], gf[2], part.view(-1)[:8], coef, dy, dims, c0, ncls)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (2, 2, 17, 40, 3), (2, 4, 24, 33, 4), (1, 2, 16, 64, 2)])
-def test_outconv_fused_kernels_against_float64_autograd(shape):
+@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (2, 2, 17, 40, 3), (2, 4, 24, 33, 4), (1, 2, 16, 64, 2), (2, 3, 20, 96, 2)])
+def test_outconv_fused_kernels_against_float64_autograd(shape, outconv_dgrad_rows_knob):
     """VERDICT r04 parity hole (a): fplx_outconv_fwd_bn / fplx_outconv_dgrad_bn_reduce / _apply per kernel against float64
     torch autograd of BatchNorm3d(train) -> PReLU -> Conv3d(C0 -> classes, (1,3,3)) (reference unet2d5_dsbn.py:79-81, 293-294,
     307), for 2, 3 and 4 classes, ragged tiles, n = 2 - not against other HIP kernels.  The oracle sees the bf16 values of y and
@@ -1142,7 +1038,7 @@ def test_outconv_fused_kernels_against_float64_autograd(shape):
     lg_b = F.conv3d(a5, wo_b, None, padding=(0, 1, 1))
     a_ref.retain_grad()
     (lg_b * dl.double()).sum().backward()
-    part = torch.empty(max(ops.num_partials(v) * (2 * c0 + 1), ops.outconv_bn_rows(dims) * (2 * c0 + 1)), device="cuda")
+    part = torch.empty(max(ops.num_partials(v) * (2 * c0 + 1), ops.outconv_bn_rows(dims, c0, ncls) * (2 * c0 + 1)), device="cuda")
     coef = torch.empty((2, c0), device="cuda")
     gf = [torch.zeros(c0, device="cuda"), torch.zeros(c0, device="cuda"), torch.zeros(1, device="cuda")]
     dy = torch.full((v, c0), 7.0, dtype=bf, device="cuda")
@@ -1169,7 +1065,18 @@ def test_fused_out_conv_backward_on_a_narrow_network_with_many_level0_tiles():
     shape = (1, 1, 16, 192, 224)
     dims = (shape[0],) + shape[2:]
     vox = dims[0] * dims[1] * dims[2] * dims[3]
-    assert ops.outconv_bn_rows(dims) * 65 > ops.num_partials(vox) * (4 * 64 + 1)          # the case the old sizing missed
+    from fplx import _lib
+    _lib.set_tuning("outconv_dgrad_rows", 0)          # the tile kernel: one partial row per tile block, up to 2048
+    try:
+        assert ops.outconv_bn_rows(dims) * 65 > ops.num_partials(vox) * (4 * 64 + 1)          # the case the old sizing missed
+        _fused_out_conv_narrow_network_case(p, shape)
+    finally:
+        _lib.set_tuning("outconv_dgrad_rows", 1)
+    _fused_out_conv_narrow_network_case(p, shape)         # and with the row kernel (at most 1024 rows)
+
+
+def _fused_out_conv_narrow_network_case(p, shape):
+    import fplx
     g = torch.Generator().manual_seed(5)
     x = torch.randn(shape, generator=g).cuda()
     lab = torch.zeros((1, 2) + shape[2:])

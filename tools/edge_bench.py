@@ -60,7 +60,7 @@ def main():
     dwo, dbo = torch.empty_like(wo), torch.empty(ncls, device=dev)
     res.append(("out_conv wgrad", timeit(lambda: ops.conv3d_wgrad(feat, cl(d, h, w, c0), ops.BF16, dl, pl(ncls, d, h, w), ops.F32,
                                                                   dwo, None, dims, c0, ncls, (1, 3, 3), wsb2)), tb + v * ncls * 4))
-    # ---- the stem site: the separate passes on the stored tensor against the passes that recompute the convolution (round 6)
+    # ---- the level-0 BatchNorm passes of a 32-channel site beside them (what a fused edge kernel would have to beat)
     gamma, beta = torch.ones(c0, device=dev), torch.zeros(c0, device=dev)
     rm, rv, nbt = torch.zeros(c0, device=dev), torch.ones(c0, device=dev), torch.zeros(1, dtype=torch.long, device=dev)
     bnbuf = torch.empty((4, c0), device=dev)
@@ -69,18 +69,25 @@ def main():
     act = torch.empty_like(feat)
     dout = torch.randn(v, c0, device=dev, generator=g).to(bf)
     dyb = torch.empty_like(feat)
-    srows = ops.stem_site_rows(dims, 1, c0)
-    part = torch.empty(max(ops.num_partials(v), srows) * (2 * c0 + 1), device=dev)
+    part = torch.empty(ops.num_partials(v) * (2 * c0 + 1), device=dev)
     coef = torch.empty((2, c0), device=dev)
     gg, gb, gs = torch.zeros(c0, device=dev), torch.zeros(c0, device=dev), torch.zeros(1, device=dev)
     res.append(("bn_act_fwd 32ch", timeit(lambda: ops.bn_act_fwd(feat, act, bnbuf, slope, 0.0, 0, 0, c0)), 2 * tb))
     res.append(("bn_act_bwd 32ch", timeit(lambda: ops.bn_act_bwd(feat, dout, dyb, bnbuf, slope, 0.0, 0, 0, c0, True, gg, gb, gs, part,
                                                                   coef)), 5 * tb))
-    if srows > 0:
-        res.append(("stem site stats", timeit(lambda: ops.stem_site_fwd_stats(img, wsf, bs, dims, 1, c0, stats)), v * 4))
-        res.append(("stem site act", timeit(lambda: ops.stem_site_fwd_act(img, wsf, bs, dims, 1, c0, bnbuf, slope, act)), tb + v * 4))
-        res.append(("stem site bwd", timeit(lambda: ops.stem_site_bwd(img, wsf, bs, dims, 1, c0, dout, dyb, bnbuf, slope, True, gg, gb,
-                                                                      gs, part, coef)), 3 * tb + 2 * v * 4))
+    # ---- out_conv fused with the last site's BatchNorm passes: forward, and the backward pair (reduce + finalize + apply) with
+    # the row-segment kernel (default) and the tile kernel
+    from fplx import _lib
+    lg2 = torch.empty(n, ncls, d, h, w, device=dev)
+    res.append(("outconv_fwd_bn", timeit(lambda: ops.outconv_fwd_bn(feat, bnbuf, slope, act, wof, bo, lg2, dims, c0, ncls)),
+                2 * tb + v * ncls * 4))
+    for knob in (1, 0):
+        _lib.set_tuning("outconv_dgrad_rows", knob)
+        prt = torch.empty(max(ops.num_partials(v), ops.outconv_bn_rows(dims, c0, ncls)) * (2 * c0 + 1), device=dev)
+        res.append(("outconv bwd fused %s" % ("rows" if knob else "tiles"),
+                    timeit(lambda: ops.outconv_dgrad_bn_bwd(dl, wob, feat, bnbuf, slope, True, gg, gb, gs, prt, coef, dyb, dims, c0, ncls)),
+                    3 * tb + 2 * v * ncls * 4))
+    _lib.set_tuning("outconv_dgrad_rows", 1)
     env = {k: v_ for k, v_ in os.environ.items() if k.startswith("FPLX_")}
     for name, us, nbytes in res:
         print("%-16s %8.1f us  %6.0f GB/s  %s" % (name, us, nbytes / us / 1e3, env))
