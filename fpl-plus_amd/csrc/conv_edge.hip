@@ -255,116 +255,127 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
   const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
   auto sread = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
   const unsigned uW = (unsigned)tilesW, uH = (unsigned)H, uD = (unsigned)D;
-  unsigned sw_, sh_, sd_, sn_, cw, ch, cd, cn;      // the step and the current segment as (w tile, h, d, n) digits
+  unsigned sw_, sh_, sd_, sn_;                      // 4 step as (w tile, h, d, n) digits
+  struct Seg { unsigned cw, ch, cd, cn; };
+  Seg cur;
   {
     unsigned t = sread((unsigned)tr.step * 4u);
     sw_ = sread(t % uW); t = sread(t / uW);
     sh_ = sread(t % uH); t = sread(t / uH);
     sd_ = sread(t % uD); sn_ = sread(t / uD);
     t = sread((unsigned)tr.first * 4u + (unsigned)wave);
-    cw = sread(t % uW); t = sread(t / uW);
-    ch = sread(t % uH); t = sread(t / uH);
-    cd = sread(t % uD); cn = sread(t / uD);          // >= N: a segment past the end of the list (the last tile may be ragged)
+    cur.cw = sread(t % uW); t = sread(t / uW);
+    cur.ch = sread(t % uH); t = sread(t / uH);
+    cur.cd = sread(t % uD); cur.cn = sread(t / uD);  // >= N: a segment past the end of the list (the last tile may be ragged)
   }
-  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
-    if (cn < (unsigned)N) {
-      const int n = (int)cn, d = (int)cd, h = (int)ch, w0 = (int)cw * 32;
-      // ---- the segment's 16 loads per lane and input channel.  A row that starts before the tensor has a negative = huge
-      // vector offset: out of range -> 0.  (The kw = 0 tap is a vector offset of its own, not a negative immediate: the range
-      // check sees vector offset + immediate, and element -1 of the tensor must not turn into a valid address.)
-      float xv[CIN][16];
+  auto advance = [&](Seg& g) {                        // += 4 step in (w tile, h, d, n) digits, carries as scalar selects
+    g.cw += sw_;
+    unsigned carry = g.cw >= uW ? 1u : 0u;
+    g.cw -= carry ? uW : 0u;
+    g.ch += sh_ + carry;
+    carry = g.ch >= uH ? 1u : 0u;
+    g.ch -= carry ? uH : 0u;
+    g.cd += sd_ + carry;
+    carry = g.cd >= uD ? 1u : 0u;
+    g.cd -= carry ? uD : 0u;
+    g.cn += sn_ + carry;
+  };
+  // ---- the segment's 16 loads per lane and input channel.  A row that starts before the tensor has a negative = huge
+  // vector offset: out of range -> 0.  (The kw = 0 tap is a vector offset of its own, not a negative immediate: the range
+  // check sees vector offset + immediate, and element -1 of the tensor must not turn into a valid address.)
+  auto issue = [&](const Seg& g, float (&xv)[CIN][16]) {
+    if (g.cn >= (unsigned)N) return;
+    const int n = (int)g.cn, d = (int)g.cd, h = (int)g.ch, w0 = (int)g.cw * 32;
 #pragma unroll
-      for (int ci = 0; ci < CIN; ++ci) {
-        const int sbase = ((((n * CIN + ci) * D + d) * H + h) * W + w0) * 4;          // scalar byte offset of the segment's first voxel
+    for (int ci = 0; ci < CIN; ++ci) {
+      const int sbase = ((((n * CIN + ci) * D + d) * H + h) * W + w0) * 4;          // scalar byte offset of the segment's first voxel
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const unsigned oc = (unsigned)(rowb[c] + sbase), ol = oc - 4u;
+      for (int c = 0; c < 6; ++c) {
+        const unsigned oc = (unsigned)(rowb[c] + sbase), ol = oc - 4u;
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int p = 3 * c + kw;
-            if (p < 16)
-              xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, kw == 0 ? ol : (kw == 1 ? oc : oc + 4u), 0, 0));
-          }
+        for (int kw = 0; kw < 3; ++kw) {
+          const int p = 3 * c + kw;
+          if (p < 16)
+            xv[ci][p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, kw == 0 ? ol : (kw == 1 ? oc : oc + 4u), 0, 0));
         }
-      }
-      // ---- padding.  interior: every tap of every lane lies inside the volume (scalar test) - no selects at all
-      const bool interior = d >= 1 && d + 1 < D && h >= 1 && h + 1 < H && w0 >= 1 && w0 + 32 < W;
-      const int wv = w0 + r;
-      const bool wc = wv < W;
-      f32x16 acc = cinit;
-      if (interior) {
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          bf16x8 bfr[2];
-#pragma unroll
-          for (int p = 0; p < 16; ++p) bfr[p >> 3][p & 7] = (bf16_t)xv[ci][p];
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
-        }
-      } else {
-        // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
-        unsigned dh = 0;
-#pragma unroll
-        for (int c = 0; c < 9; ++c) {
-          const int dd = d + c / 3 - 1, hh = h + c % 3 - 1;
-          if (dd >= 0 && dd < D && hh >= 0 && hh < H) dh |= 1u << c;
-        }
-        const unsigned dhl = dh >> (5 * khalf);
-        const bool wl = wv - 1 >= 0 && wv - 1 < W, wr = wv + 1 < W;
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          bf16x8 bfr[2];
-#pragma unroll
-          for (int p = 0; p < 16; ++p) {
-            const int c = p / 3, kw = p % 3;
-            const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
-            bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[ci][p] : 0.f);
-          }
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
-        }
-      }
-      if (wc) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
-      }
-      // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the swaps the low half holds 0-7 and 16-23, the high
-      // half 8-15 and 24-31 of its voxel
-      unsigned pk[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bf16_t e0 = (bf16_t)acc[4 * q], e1 = (bf16_t)acc[4 * q + 1], e2 = (bf16_t)acc[4 * q + 2], e3 = (bf16_t)acc[4 * q + 3];
-        pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
-        pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
-      }
-#pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2)                    // (q0, q1) and (q2, q3): high half of the first <-> low half of the second
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
-          pk[4 * g2 + e] = sw[0];
-          pk[4 * g2 + 2 + e] = sw[1];
-        }
-      if (wc) {
-        bf16_t* dst = y + ((int64_t)(((n * D + d) * H + h)) * W + wv) * ldy + co0 + 8 * khalf;
-        *reinterpret_cast<u32x4e*>(dst) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
-        *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
       }
     }
-    // ---- next segment of this wave: += 4 step in (w tile, h, d, n) digits, carries as scalar selects
-    cw += sw_;
-    unsigned carry = cw >= uW ? 1u : 0u;
-    cw -= carry ? uW : 0u;
-    ch += sh_ + carry;
-    carry = ch >= uH ? 1u : 0u;
-    ch -= carry ? uH : 0u;
-    cd += sd_ + carry;
-    carry = cd >= uD ? 1u : 0u;
-    cd -= carry ? uD : 0u;
-    cn += sn_ + carry;
+  };
+  auto consume = [&](const Seg& g, const float (&xv)[CIN][16]) {
+    if (g.cn >= (unsigned)N) return;
+    const int n = (int)g.cn, d = (int)g.cd, h = (int)g.ch, w0 = (int)g.cw * 32;
+    // ---- padding.  interior: every tap of every lane lies inside the volume (scalar test) - no selects at all
+    const bool interior = d >= 1 && d + 1 < D && h >= 1 && h + 1 < H && w0 >= 1 && w0 + 32 < W;
+    const int wv = w0 + r;
+    const bool wc = wv < W;
+    f32x16 acc = cinit;
+    if (interior) {
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        bf16x8 bfr[2];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) bfr[p >> 3][p & 7] = (bf16_t)xv[ci][p];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
+      }
+    } else {
+      // rows of the zero padding: bit c of `dh` = combo c lies inside the volume (scalar); the lane's view starts at 5 khalf
+      unsigned dh = 0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const int dd = d + c / 3 - 1, hh = h + c % 3 - 1;
+        if (dd >= 0 && dd < D && hh >= 0 && hh < H) dh |= 1u << c;
+      }
+      const unsigned dhl = dh >> (5 * khalf);
+      const bool wl = wv - 1 >= 0 && wv - 1 < W, wr = wv + 1 < W;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        bf16x8 bfr[2];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+          const int c = p / 3, kw = p % 3;
+          const bool ok = ((dhl >> c) & 1u) && (kw == 0 ? wl : (kw == 1 ? wc : wr)) && p < (khalf ? 12 : 15);
+          bfr[p >> 3][p & 7] = (bf16_t)(ok ? xv[ci][p] : 0.f);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][0], bfr[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[ci][1], bfr[1], acc, 0, 0, 0);
+      }
+    }
+    if (wc) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ssum[i] += acc[i]; qsum[i] = fmaf(acc[i], acc[i], qsum[i]); }
+    }
+    // quads q = i >> 2 hold channels 8 q + 4 khalf + (0..3); after the swaps the low half holds 0-7 and 16-23, the high
+    // half 8-15 and 24-31 of its voxel
+    unsigned pk[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bf16_t e0 = (bf16_t)acc[4 * q], e1 = (bf16_t)acc[4 * q + 1], e2 = (bf16_t)acc[4 * q + 2], e3 = (bf16_t)acc[4 * q + 3];
+      pk[2 * q] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+      pk[2 * q + 1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+    }
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)                    // (q0, q1) and (q2, q3): high half of the first <-> low half of the second
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const u32x2e sw = __builtin_amdgcn_permlane32_swap(pk[4 * g2 + e], pk[4 * g2 + 2 + e], false, false);
+        pk[4 * g2 + e] = sw[0];
+        pk[4 * g2 + 2 + e] = sw[1];
+      }
+    if (wc) {
+      bf16_t* dst = y + ((int64_t)(((n * D + d) * H + h)) * W + wv) * ldy + co0 + 8 * khalf;
+      *reinterpret_cast<u32x4e*>(dst) = u32x4e{pk[0], pk[1], pk[2], pk[3]};
+      *reinterpret_cast<u32x4e*>(dst + 16) = u32x4e{pk[4], pk[5], pk[6], pk[7]};
+    }
+  };
+  // (The loads of segment t + 1 issued before segment t is computed - 128 registers, still four waves per SIMD - were measured
+  // again in round 6: 88.5 / 91.0 us against 90.5 / 89.7 us, no change; profiles/r06_kernel_ab.txt section 4.)
+  float xa[CIN][16];
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    issue(cur, xa);
+    consume(cur, xa);
+    advance(cur);
   }
-  // (two segments in flight per wave - the loads of segment t + 1 issued before segment t is computed - were measured in round 3:
-  // 134 us against 91 us, the second register set costs a wave per SIMD and the occupancy hides more latency than the prefetch)
   if (stats) {
     // a lane's sums belong to channels (i & 3) + 8 (i >> 2) + 4 khalf: fold the 32 voxel lanes of each half, then the waves
 #pragma unroll
