@@ -400,11 +400,33 @@ stem_fwd_rows(const float* __restrict__ x, const bf16_t* __restrict__ wf, const 
 
 // ------------------------------------------------------------------------------------------
 // stem weight gradient: rows = (ci, tap) padded to 32*RT, cols = 32 output channels, K = voxels
-template <int CIN>
+// BN (round 6): the stem site's dy - the gradient w.r.t. the convolution's output - has ONE consumer, this kernel (the network
+// input needs no data gradient), so the apply pass of the site's BatchNorm + PReLU backward (fplx_bn_act_bwd_apply: read y, read
+// d(a), write dy - 786 MB at the benchmark shape) only feeds the 262 MB this kernel reads back.  With BN the kernel takes y and
+// d(a) instead and forms dy = scale (dz - k0 - x-hat k1) -> bf16 on the 16-byte pieces it stages (a thread always stages channel
+// chunk threadIdx.x & 3: its eight channels' constants sit in registers): the arithmetic of bn_act_bwd_apply_g_k on the same
+// values, rounded where the stored tensor was, so dw is bit for bit the two-pass result - and dy is never written or re-read.
+struct StemBnBwd {
+  const bf16_t* y;                                     // the site's convolution output (pre-BatchNorm), [V][ldy]
+  int64_t ldy;
+  const float *mean, *rstd, *scale, *shift, *slope, *coef;      // coef: fplx_bn_act_bwd_finalize's [2][Cout]
+  int cout;
+};
+template <int CIN, bool BN = false>
 __global__ void __launch_bounds__(256)
 stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int64_t ldy, float* __restrict__ part,
-                int N, int D, int H, int W, int co0, int64_t ntiles, int tilesH, int tilesW, int xcd) {
+                int N, int D, int H, int W, int co0, int64_t ntiles, int tilesH, int tilesW, int xcd, const StemBnBwd bn = StemBnBwd{}) {
   constexpr int KTOT = 27 * CIN, RT = (KTOT + 31) / 32;
+  float bsc[BN ? 8 : 1], bsh[BN ? 8 : 1], bm[BN ? 8 : 1], brs[BN ? 8 : 1], bk0[BN ? 8 : 1], bk1[BN ? 8 : 1], bslope = 0.f;
+  if constexpr (BN) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = co0 + (threadIdx.x & 3) * 8 + j;
+      bsc[j] = bn.scale[c]; bsh[j] = bn.shift[c]; bm[j] = bn.mean[c]; brs[j] = bn.rstd[c];
+      bk0[j] = bn.coef[c]; bk1[j] = bn.coef[bn.cout + c];
+    }
+    bslope = *bn.slope;
+  }
   __shared__ bf16_t xs[CIN * 3 * SH * SW + 16];
   __shared__ __attribute__((aligned(16))) char dys[TH * TW * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -433,8 +455,24 @@ stem_wgrad_mfma(const float* __restrict__ x, const bf16_t* __restrict__ dy, int6
       const int vox = i >> 2, ch = i & 3;
       const int h = t.h0 + vox / TW, w = t.w0 + vox % TW;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (h < H && w < W)
-        v = *reinterpret_cast<const uint4*>(dy + ((((int64_t)t.n * D + t.d) * H + h) * W + w) * ldy + co0 + ch * 8);
+      if (h < H && w < W) {
+        const int64_t vx = (((int64_t)t.n * D + t.d) * H + h) * W + w;
+        v = *reinterpret_cast<const uint4*>(dy + vx * ldy + co0 + ch * 8);
+        if constexpr (BN) {                            // v = d(a): the apply pass of the site's BatchNorm + PReLU backward, in place
+          const uint4 yv4 = *reinterpret_cast<const uint4*>(bn.y + vx * bn.ldy + co0 + ch * 8);
+          bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&v);
+          const bf16x8 y8 = *reinterpret_cast<const bf16x8*>(&yv4);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float a = (float)y8[j], dd = (float)d8[j];
+            const float z = fmaf(a, bsc[j], bsh[j]);
+            const float dz = z > 0.f ? dd : dd * bslope;
+            const float xh = (a - bm[j]) * brs[j];
+            d8[j] = (bf16_t)(bsc[j] * (dz - bk0[j] - xh * bk1[j]));
+          }
+          v = *reinterpret_cast<uint4*>(&d8);
+        }
+      }
       *reinterpret_cast<uint4*>(dys + vox * 64 + ch * 16) = v;
     }
     __syncthreads();
@@ -1471,20 +1509,35 @@ extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int 
   return (size_t)nb * ((27 * cin + 31) / 32) * 1024 * sizeof(float);
 }
 
-extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
-                                    int cin, int cout, void* ws, hipStream_t st) {
+// y != NULL: dy is d(a), the gradient w.r.t. the site's OUTPUT, and the BatchNorm + PReLU backward apply runs inside the kernel
+// (stem_wgrad_mfma<CIN, true>; coef from fplx_bn_act_bwd_finalize)
+extern "C" int fplx_edge_stem_wgrad_bn(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
+                                       int cin, int cout, void* ws, hipStream_t st, const void* y, int64_t ldyy, const float* mean,
+                                       const float* rstd, const float* scale, const float* shift, const float* slope,
+                                       const float* coef) {
   if (!(cin == 1 || cin == 4) || cout % 32 != 0 || ldy % 8 != 0 || ((uintptr_t)dy % 16)) return 0;
+  if (y && (ldyy % 8 != 0 || ((uintptr_t)y % 16))) return 0;
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = edge_blocks(nt, STEM_WGRAD_MULT);
   const int rt = (27 * cin + 31) / 32;
+  const StemBnBwd bn{(const bf16_t*)y, ldyy, mean, rstd, scale, shift, slope, coef, cout};
   for (int co0 = 0; co0 < cout; co0 += 32) {
-    if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on());
+    if (y) {
+      if (cin == 1) stem_wgrad_mfma<1, true><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on(), bn);
+      else stem_wgrad_mfma<4, true><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on(), bn);
+    }
+    else if (cin == 1) stem_wgrad_mfma<1><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on());
     else stem_wgrad_mfma<4><<<nb, 256, 0, st>>>(x, (const bf16_t*)dy, ldy, (float*)ws, n, d, h, w, co0, nt, th, tw, fplx_xcd_on());
     stem_wgrad_reduce<<<(rt * 1024 + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nb, rt, cin, co0, dw);
   }
   int rc = fplx_check_launch("edge_stem_wgrad");
   return rc < 0 ? rc : 1;
+}
+extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
+                                    int cin, int cout, void* ws, hipStream_t st) {
+  return fplx_edge_stem_wgrad_bn(x, dy, ldy, dw, n, d, h, w, cin, cout, ws, st, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                                 nullptr, nullptr);
 }
 
 extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,

@@ -574,6 +574,10 @@ extern "C" int fplx_edge_stem_rows(int n, int d, int h, int w, int cin, int cout
 extern "C" int fplx_edge_stem_fwd(const float* x, const void* wf, const float* bias, void* y, int64_t ldy, int n, int d,
                                   int h, int w, int cin, int cout, float* stats, hipStream_t st);
 extern "C" size_t fplx_edge_stem_wgrad_ws_bytes(int n, int d, int h, int w, int cin, int cout);
+extern "C" int fplx_edge_stem_wgrad_bn(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
+                                       int cin, int cout, void* ws, hipStream_t st, const void* y, int64_t ldyy, const float* mean,
+                                       const float* rstd, const float* scale, const float* shift, const float* slope,
+                                       const float* coef);
 extern "C" int fplx_edge_stem_wgrad(const float* x, const void* dy, int64_t ldy, float* dw, int n, int d, int h, int w,
                                     int cin, int cout, void* ws, hipStream_t st);
 extern "C" int fplx_edge_outconv_fwd(const void* x, int64_t ldx, const float* wf, const float* bias, float* out, int n,
@@ -1124,6 +1128,24 @@ int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void
                                            n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: pointers / leading dimensions not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
+}
+
+/* the stem's weight gradient with the site's BatchNorm + PReLU backward apply formed on the way in (include/fplx.h) */
+int fplx_stem_wgrad_bn(const float* x, const void* y, int64_t ldy, const void* dout, int64_t ldd, const float* mean,
+                       const float* rstd, const float* scale, const float* shift, const float* slope, const float* coef,
+                       float* dw, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(x && y && dout && mean && rstd && scale && shift && slope && coef && dw && ws, FPLX_E_NULL, "stem_wgrad_bn: null pointer");
+  FPLX_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0, FPLX_E_BADSHAPE, "stem_wgrad_bn: bad shape");
+  const size_t need = fplx_edge_stem_wgrad_ws_bytes(n, d, h, w, cin, cout);
+  FPLX_REQUIRE(need > 0, FPLX_E_BADSHAPE, "stem_wgrad_bn: %d -> %d channels is not a stem the MFMA kernel takes (in_chns 1 | 4, C0 %% 32 == 0)", cin, cout);
+  FPLX_REQUIRE(ws_bytes >= need, FPLX_E_WORKSPACE, "stem_wgrad_bn: workspace %zu < %zu (fplx_conv3d_wgrad_ws_bytes)", ws_bytes, need);
+  FPLX_REQUIRE(ldy >= cout && ldd >= cout && ldy % 8 == 0 && ldd % 8 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)dout % 16 == 0,
+               FPLX_E_BADSHAPE, "stem_wgrad_bn: y and dout must be 16-byte aligned with leading dimensions %% 8 == 0");
+  const int r = fplx_edge_stem_wgrad_bn(x, dout, ldd, dw, n, d, h, w, cin, cout, ws, (hipStream_t)stream, y, ldy, mean, rstd, scale,
+                                        shift, slope, coef);
+  if (r < 0) return r;
+  FPLX_REQUIRE(r == 1, FPLX_E_BADSHAPE, "stem_wgrad_bn: operands refused");
+  return FPLX_OK;
 }
 
 int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t sh, int64_t sw, int64_t sc,

@@ -63,6 +63,9 @@ class Engine(object):
         # out_conv fused with the BatchNorm + PReLU passes of the site in front of it (fplx_outconv_fwd_bn / _dgrad_bn_*):
         # one pass over that site's tensor forward, two instead of three (+ the data gradient's write) backward
         self.use_outconv_fusion = _lib.host_knob("outconv_fuse") != 0
+        # the stem site's backward: its dy has one consumer, the stem's weight gradient, which forms it from y and d(a) itself
+        # (fplx_stem_wgrad_bn) - the apply pass of that site's BatchNorm backward (write dy, read it back) disappears
+        self.use_stem_wgrad_bn = _lib.host_knob("stem_wgrad_bn") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
         # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
@@ -628,8 +631,21 @@ class Engine(object):
                                          gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, d_out,
                                          dims[l], c, ncls)
             else:
+                # (the stem site: no data gradient, so dy's only consumer is the weight gradient - which forms it itself)
+                stem_fused = (self.use_stem_wgrad_bn and not want_dx and tap is None and sv.train and x_dt == F32 and p == 0.0 and
+                              gv[key + ".weight"].dim() == 5 and adt == torch.bfloat16 and not isinstance(xin, tuple) and
+                              ops.ld_of(d_out) % 8 == 0 and d_out.data_ptr() % 16 == 0 and ops.stem_wgrad_bn_ok(dims[l], cin, c))
                 ops.bn_act_bwd(y, d_out, d_out, bnbuf, net.get_param(relukey + ".weight"), p, sv.seed, sid, c, sv.train,
-                               gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced)
+                               gv[gkey + ".weight"], gv[gkey + ".bias"], gv[relukey + ".weight"], part, coef, reduced,
+                               apply=not stem_fused)
+                if stem_fused:
+                    fn = lambda: ops.stem_wgrad_bn(xin, y, d_out, bnbuf, net.get_param(relukey + ".weight"), coef,
+                                                   gv[key + ".weight"], dims[l], cin, c, ws if wgrad_here else ws_w)
+                    if wgrad_here:
+                        fn()
+                    else:
+                        on_side(fn, d_out, xin, y, coef)
+                    return
             if tap is not None:
                 tap(key + ".dy", d_out)
             # conv bias followed by train-mode BatchNorm: d/d bias == sum of dy == 0 exactly

@@ -352,9 +352,10 @@ def pool_bwd_bn_reduce(y, dy, dskip, dx, bnbuf, slope, dims, c, part, pd=2):
          stream())
 
 
-def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope, part, coef, reduced=False):
+def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta, dslope, part, coef, reduced=False, apply=True):
     """three-stage backward of the fused BN-apply + PReLU + dropout pass; dy may alias dout.
-    reduced: `part` already holds the partial rows (pool_bwd_bn_reduce wrote them while it formed dout)"""
+    reduced: `part` already holds the partial rows (pool_bwd_bn_reduce wrote them while it formed dout)
+    apply=False: reduction + finalize only - `coef` is left for a consumer that forms dy itself (stem_wgrad_bn)"""
     v = y.shape[0]
     rows = num_partials(v)
     if not reduced:
@@ -362,9 +363,31 @@ def bn_act_bwd(y, dout, dy, bnbuf, slope, p, seed, sid, c, train, dgamma, dbeta,
              ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), float(p), int(seed), int(sid), v, c, dt_of(y), ptr(part), stream())
     call("fplx_bn_act_bwd_finalize", ptr(part), rows, c, v, 1 if train else 0, ptr(dgamma), ptr(dbeta), ptr(dslope),
          ptr(coef), stream())
+    if not apply:
+        return
     call("fplx_bn_act_bwd_apply", ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(dy), ld_of(dy), ptr(bnbuf[0]),
          ptr(bnbuf[1]), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(coef), float(p), int(seed), int(sid), v, c,
          dt_of(y), stream())
+
+
+def stem_wgrad_bn_ok(dims, cin, cout):
+    """True if the stem site's weight gradient can take y and d(a) and form dy itself (fplx_stem_wgrad_bn): the layers
+    fplx_conv3d_plan_query gives to the MFMA stem kernels (fp32 NCDHW input of 1 | 4 channels, C0 % 32 == 0)"""
+    import ctypes
+    n, d, h, w = dims
+    kern, g, ks, r = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(_lib.lib().fplx_conv3d_plan_query(n, d, h, w, int(cin), int(cout), 3, 3, 3, F32, BF16, ctypes.byref(kern),
+                                                 ctypes.byref(g), ctypes.byref(ks), ctypes.byref(r)))
+    return kern.value == 6                               # FPLX_KERNEL_STEM
+
+
+def stem_wgrad_bn(x, y, dout, bnbuf, slope, coef, dw, dims, cin, cout, ws):
+    """weight gradient of the stem convolution from y (its stored output) and dout = gradient w.r.t. the site's OUTPUT: the apply
+    pass of the site's BatchNorm + PReLU backward runs on the pieces the kernel stages; dy is never stored"""
+    n, d, h, w = dims
+    call("fplx_stem_wgrad_bn", ptr(x), ptr(y), ld_of(y), ptr(dout), ld_of(dout), ptr(bnbuf[0]), ptr(bnbuf[1]), ptr(bnbuf[2]),
+         ptr(bnbuf[3]), ptr(slope), ptr(coef), ptr(dw), n, d, h, w, int(cin), int(cout), ptr(ws), ws.numel() * ws.element_size(),
+         stream())
 
 
 def maxpool2_fwd(x, y, dims, c, pd=2):

@@ -138,6 +138,19 @@ int fplx_conv3d_wgrad(const void* x, int x_dt, int64_t sn, int64_t sd, int64_t s
                       float* dw, float* db, int n, int d, int h, int w, int cin, int cout,
                       int kd, int kh, int kw, void* ws, size_t ws_bytes, fplx_stream_t stream);
 
+/* The stem site's weight gradient fused with the apply pass of its BatchNorm + PReLU backward (round 6).  The gradient w.r.t.
+ * the output of the network's first convolution (Conv3d(in_chns -> C0), unet2d5_dsbn.py:54, 74-77) has one consumer - this
+ * weight gradient; the network input needs no data gradient - so fplx_bn_act_bwd_apply + fplx_conv3d_wgrad of that site (write dy,
+ * read it back) become one call: y = the convolution's stored output (bf16 [V, ldy]), dout = gradient w.r.t. the site's output a
+ * (bf16 [V, ldd]), mean .. slope = the site's BatchNorm constants, coef = fplx_bn_act_bwd_finalize's; the kernel forms
+ * dy = scale (dz - k0 - x-hat k1) -> bf16 on the pieces it stages (fplx_bn_act_bwd_apply's arithmetic, dropout-free) and dy is
+ * never stored.  x: fp32 NCDHW contiguous, in_chns 1 | 4, C0 % 32 == 0 (fplx_conv3d_plan_query answers FPLX_KERNEL_STEM for the
+ * forward); dw, ws as fplx_conv3d_wgrad with ws of fplx_conv3d_wgrad_ws_bytes(.., 3, 3, 3) bytes.  dw is bit for bit the
+ * two-call result. */
+int fplx_stem_wgrad_bn(const float* x, const void* y, int64_t ldy, const void* dout, int64_t ldd, const float* mean,
+                       const float* rstd, const float* scale, const float* shift, const float* slope, const float* coef,
+                       float* dw, int n, int d, int h, int w, int cin, int cout, void* ws, size_t ws_bytes, fplx_stream_t stream);
+
 /* The first convolution of an UpBlock reads torch.cat([skip, up], dim=1) (unet2d5_dsbn.py:182-183).  Where the two
  * halves are 32 channels wide (level 0) a concat BUFFER would be addressed in half 128-byte lines by every other
  * kernel that touches one half (pooling, transposed convolution), so there the concatenation is never built: these

@@ -602,6 +602,95 @@ def test_stem_kernels_bf16(shape):
     assert float((dw.cpu() - wr.grad).abs().max()) < 1e-2 * float(wr.grad.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 32, 3, 9, 35), (1, 1, 32, 5, 16, 64), (1, 4, 32, 2, 16, 64), (3, 1, 32, 5, 7, 161),
+                                   (1, 1, 32, 1, 1, 1), (2, 1, 64, 6, 20, 96), (2, 4, 32, 3, 10, 48)])
+def test_stem_weight_gradient_with_the_batchnorm_apply_inside(shape):
+    """fplx_stem_wgrad_bn (round 6): the stem site's dy has one consumer - the stem's weight gradient - which forms it from the
+    stored convolution output y and the gradient w.r.t. the site's output while it stages them, so the apply pass of the site's
+    BatchNorm + PReLU backward is never run and dy never stored.  Same arithmetic on the same values, rounded where the stored
+    tensor was: dw bit for bit the result of fplx_bn_act_bwd (all three stages) + fplx_conv3d_wgrad; ragged tiles, single voxels,
+    several samples, 4 input channels, 64 output channels (two 32-channel launches)."""
+    from fplx import ops
+    n, cin, cout, d, h, w = shape
+    dims, v = (n, d, h, w), n * d * h * w
+    assert ops.stem_wgrad_bn_ok(dims, cin, cout) and not ops.stem_wgrad_bn_ok(dims, 2, cout) and not ops.stem_wgrad_bn_ok(dims, cin, 48)
+    x = torch.from_numpy(detdata.normal("sw.x%s" % (shape,), (n, cin, d, h, w))).cuda()
+    y = torch.from_numpy(detdata.normal("sw.y%s" % (shape,), (v, cout))).bfloat16().cuda()
+    dout = torch.from_numpy(detdata.normal("sw.d%s" % (shape,), (v, cout))).bfloat16().cuda()
+    g = torch.Generator().manual_seed(7)
+    mean, var = torch.randn(cout, generator=g) * 0.3, torch.rand(cout, generator=g) + 0.5
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    rstd = torch.rsqrt(var + 1e-5)
+    bnbuf = torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd]).cuda()
+    slope = torch.tensor([0.25]).cuda()
+    part = torch.empty(ops.num_partials(v) * (2 * cout + 1), device="cuda")
+    coef = torch.empty((2, 2 * cout), device="cuda")           # (the engine's buffer is wider than the site: the finalize writes it flat)
+    ws = torch.empty(ops.conv3d_wgrad_ws_bytes(dims, cin, cout, (3, 3, 3)), dtype=torch.uint8, device="cuda")
+    # ---- the separate passes
+    gr = [torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")]
+    dy = torch.empty_like(dout)
+    ops.bn_act_bwd(y, dout, dy, bnbuf, slope, 0.0, 0, 0, cout, True, gr[0], gr[1], gr[2], part, coef)
+    dw_ref = torch.zeros((cout, cin, 3, 3, 3), device="cuda")
+    ops.conv3d_wgrad(x, ops.planar_strides(cin, d, h, w), ops.F32, dy, ops.cl_strides(d, h, w, cout), ops.BF16, dw_ref, None, dims,
+                     cin, cout, (3, 3, 3), ws)
+    # ---- reduction + finalize only, then the fused weight gradient
+    gf = [torch.zeros(cout, device="cuda"), torch.zeros(cout, device="cuda"), torch.zeros(1, device="cuda")]
+    coef2 = torch.full_like(coef, float("nan"))
+    d2 = dout.clone()
+    ops.bn_act_bwd(y, d2, d2, bnbuf, slope, 0.0, 0, 0, cout, True, gf[0], gf[1], gf[2], part, coef2, apply=False)
+    assert torch.equal(d2, dout)                                  # no apply pass ran
+    for a_, b_ in zip(gf, gr):
+        assert torch.equal(a_, b_)
+    dw = torch.full((cout, cin, 3, 3, 3), 7.0, device="cuda")
+    ops.stem_wgrad_bn(x, y, d2, bnbuf, slope, coef2, dw, dims, cin, cout, ws)
+    assert torch.equal(dw, dw_ref)
+    assert float(dw_ref.abs().max()) > 0 or v == 1
+    from fplx._lib import FplxError
+    with pytest.raises(FplxError):
+        ops.stem_wgrad_bn(x, y, d2, bnbuf, slope, coef2, dw, dims, cin, cout, ws[:16])
+
+
+def test_network_step_with_and_without_the_fused_stem_weight_gradient():
+    """the engine with the stem's weight gradient forming dy itself (Engine.use_stem_wgrad_bn, the default) against the separate
+    apply pass: the same arithmetic on the same values - parameters, losses and the Adam moments bit for bit after three steps; a
+    dropout at the stem site and a 2.5D stem (Conv2d) keep the separate pass"""
+    import fplx
+    from fplx import ops
+    p = dict(in_chns=1, feature_chns=[32, 64, 128, 256, 512], dropout=[0, 0, 0.3, 0.4, 0.5], conv_dims=[3] * 5, class_num=2,
+             bilinear=False, num_domains=2, net_type="UNet2D5_dsbn", precision="bf16")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 16, 32, 64, generator=g).cuda()
+    lab = torch.zeros(2, 2, 16, 32, 64)
+    lab[:, 0] = 1.0
+    lab[:, 0, 4:10, 8:20, 16:40] = 0.0
+    lab[:, 1, 4:10, 8:20, 16:40] = 1.0
+    lab = lab.cuda()
+    res, calls = [], []
+    inner = ops.stem_wgrad_bn
+
+    def counting(*a, **kw):
+        calls.append(1)
+        return inner(*a, **kw)
+    ops.stem_wgrad_bn = counting
+    try:
+        for fuse, extra in ((True, {}), (False, {}), (True, dict(dropout=[0.2, 0, 0.3, 0.4, 0.5])), (True, dict(conv_dims=[2, 2, 3, 3, 3]))):
+            torch.manual_seed(3)
+            net = fplx.UNet2D5_dsbn(dict(p, **extra)).cuda()
+            net.engine.use_stem_wgrad_bn = fuse
+            with torch.no_grad():
+                net.dropout_seed, net._fwd_counter = 9, 0
+            ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
+            n0 = len(calls)
+            outs = [ts.step(x, lab, it % 2).clone() for it in range(3)]
+            torch.cuda.synchronize()
+            res.append((net.flat_params.detach().clone(), torch.stack(outs), ts.opt.exp_avg.clone(), len(calls) - n0))
+    finally:
+        ops.stem_wgrad_bn = inner
+    assert res[0][3] == 3 and res[1][3] == 0 and res[2][3] == 0 and res[3][3] == 0
+    for k in range(3):
+        assert torch.equal(res[0][k], res[1][k]), k
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 2, 3, 9, 35), (1, 32, 3, 2, 16, 64), (1, 64, 2, 2, 8, 40)])
 def test_outconv_kernels_bf16(shape):
     """bf16 NDHWC features <-> fp32 NCDHW logits, kernel (1,3,3): forward, data gradient, weight gradient"""

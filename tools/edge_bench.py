@@ -75,6 +75,12 @@ def main():
     res.append(("bn_act_fwd 32ch", timeit(lambda: ops.bn_act_fwd(feat, act, bnbuf, slope, 0.0, 0, 0, c0)), 2 * tb))
     res.append(("bn_act_bwd 32ch", timeit(lambda: ops.bn_act_bwd(feat, dout, dyb, bnbuf, slope, 0.0, 0, 0, c0, True, gg, gb, gs, part,
                                                                   coef)), 5 * tb))
+    # ---- the stem site's backward tail: apply pass + weight gradient against the weight gradient that forms dy itself
+    ops.bn_act_bwd(feat, dout, dyb, bnbuf, slope, 0.0, 0, 0, c0, True, gg, gb, gs, part, coef)
+    res.append(("bn bwd reduce+fin", timeit(lambda: ops.bn_act_bwd(feat, dout, dyb, bnbuf, slope, 0.0, 0, 0, c0, True, gg, gb, gs, part,
+                                                                    coef, apply=False)), 2 * tb))
+    res.append(("stem wgrad + bn", timeit(lambda: ops.stem_wgrad_bn(img, feat, dout, bnbuf, slope, coef, dws, dims, 1, c0, wsb)),
+                2 * tb + v * 4))
     # ---- out_conv fused with the last site's BatchNorm passes: forward, and the backward pair (reduce + finalize + apply) with
     # the row-segment kernel (default) and the tile kernel
     from fplx import _lib
