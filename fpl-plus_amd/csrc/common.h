@@ -128,6 +128,7 @@ __device__ __forceinline__ FplxTileRange fplx_xcd_tiles(int64_t ntiles, int on) 
   X(STEM_ROWS, "stem_rows", 1)             /* 0: the tile kernel for in_chns = 1 too */                                 \
   X(OUTCONV_T, "outconv_t", 1)             /* 0: the 32 x 32 out_conv forward (classes as columns) */                    \
   X(OUTCONV_DGRAD_MFMA, "outconv_dgrad_mfma", 1)                                                                       \
+  X(OUTCONV_FWD_ROWS, "outconv_fwd_rows", 1) /* fused out_conv forward as a march of row segments (outconv_fwd_rows); 0: the tile kernel outconv_fwd_t<1, true> (A/B, tested both ways) */ \
   X(OUTCONV_DGRAD_ROWS, "outconv_dgrad_rows", 1) /* fused out_conv backward as a stream of row segments (outconv_dgrad_rows); 0: the tile kernel (A/B, tested both ways) */ \
   X(PACK_TILED, "pack_tiled", 1)                                                                                       \
   X(PACK_MULTI, "pack_multi", 1)                                                                                       \

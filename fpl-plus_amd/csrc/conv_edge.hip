@@ -776,6 +776,160 @@ outconv_fwd_t(const bf16_t* __restrict__ x, int64_t ldx, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// outconv_fwd_rows (round 6, Cin = 32, the BatchNorm-fused form): outconv_fwd_t<1, true> as a march of row segments, one strip
+// per WAVE - no block barrier, a wave-private LDS ring.  The tile kernel moves its 557 MB at 3.5 TB/s (157 us alone): a tile is
+// a chain fill -> barrier -> BatchNorm + commit -> barrier -> MFMA with two blocks per CU.  Here a wave owns a strip of 32 voxels
+// (w) x S rows (h) of one depth slice and marches down h:
+//   * row h + 1 of the pre-BatchNorm tensor y (34 voxels with the w halo, 136 pieces of 16 bytes: lane -> pieces lane, lane + 64,
+//     and for lanes 0-7 lane + 128; a lane always meets channel chunk lane & 3, its constants sit in registers) is requested TWO
+//     rows ahead, gets a = PReLU(scale y + shift) -> bf16 applied ONCE, is written out as the activation for the strip's own
+//     voxels and committed to slot (h + 1) mod 3 of the wave's ring (voxel rows of 64 bytes, chunk ^ ((v >> 1) & 2): conflict-free
+//     for ds_read_b128's lane groups under every tap shift, see outconv_fwd_t);
+//   * output row h = 18 MFMAs (16 x 16 x 32, two 16-voxel column groups x 9 taps) on the three ring slots, B fragments by
+//     ds_read_b128, weights resident as the A operand; the logits leave as 64-byte stores per class and column group.
+// Rows outside the volume and the w halo outside it are zeros (the convolution's padding applies to a, not to y).
+// Same arithmetic per element as the tile kernel; a and the logits are its bits.
+__global__ void __launch_bounds__(256, 4)
+outconv_fwd_rows(const bf16_t* __restrict__ y, int64_t ldy, const float* __restrict__ wf, const float* __restrict__ bias,
+                 float* __restrict__ out, int N, int D, int H, int W, int ncls, int tilesW, int hsegs, int S, int64_t ntask, int xcd,
+                 const float* __restrict__ bn_scale, const float* __restrict__ bn_shift, const float* __restrict__ slope_p,
+                 bf16_t* __restrict__ aout, int64_t lda) {
+  constexpr int RW = 34, SLOT = RW * 64;               // a ring slot: 34 voxel rows of 64 bytes
+  __shared__ __attribute__((aligned(16))) char ring_all[4][3 * SLOT];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r16 = lane & 15, kg = lane >> 4;
+  char* ring = ring_all[wave];
+  const int64_t Vs = (int64_t)D * H * W;
+  // A fragments: row = class r16 (zero rows beyond ncls), the lane's 8 channels 8 kg .. 8 kg + 7.  They live in LDS ([tap][lane],
+  // one conflict-free 16-byte read per MFMA pair): as 36 registers they cost the kernel its fourth wave per SIMD, and with one
+  // strip per wave the number of resident waves is what decides whether the benchmark's 4000 strips run in one round or two
+  __shared__ __attribute__((aligned(16))) bf16x8 afr_l[9][64];
+  if (wave == 0) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      bf16x8 a;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = r16 < ncls ? (bf16_t)wf[((int64_t)tap * ncls + r16) * 32 + 8 * kg + j] : (bf16_t)0.f;
+      afr_l[tap][lane] = a;
+    }
+  }
+  __syncthreads();
+  f32x4e cinit;                                       // D rows 4 kg + i = classes
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cinit[i] = (bias && 4 * kg + i < ncls) ? bias[4 * kg + i] : 0.f;
+  float bsc[8], bsh[8];                                // the lane's channel chunk is lane & 3 for all three of its pieces
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bsc[j] = bn_scale[(lane & 3) * 8 + j]; bsh[j] = bn_shift[(lane & 3) * 8 + j]; }
+  const float bslope = *slope_p;
+  auto swz = [](int v) { return (v >> 1) & 2; };
+  // the lane's three pieces of a row: voxel (0..33) of piece t, LDS byte offset inside a slot
+  int pvox[3], poff[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    pvox[t] = (lane >> 2) + 16 * t;
+    poff[t] = pvox[t] * 64 + (((lane & 3) ^ swz(pvox[t])) * 16);
+  }
+  const bool p2 = lane < 8;                            // piece 2 exists for voxels 32, 33 only
+  // B fragment offsets: column group cg, tap column kw -> voxel cg * 16 + r16 + kw, chunk kg
+  int boff[2][3];
+#pragma unroll
+  for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int v = cg * 16 + r16 + kw;
+      boff[cg][kw] = v * 64 + ((kg ^ swz(v)) * 16);
+    }
+  const FplxTileRange tr = fplx_xcd_tiles((ntask + 3) / 4, xcd);      // a block takes 4 consecutive tasks, one per wave
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    const int64_t task = tt * 4 + wave;
+    if (task >= ntask) continue;                       // wave-uniform
+    unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)task);
+    const int hs = (int)(t % (unsigned)hsegs); t /= (unsigned)hsegs;
+    const int w0 = (int)(t % (unsigned)tilesW) * 32; t /= (unsigned)tilesW;
+    const int d = (int)(t % (unsigned)D);
+    const int n = (int)(t / (unsigned)D);
+    const int hA = hs * S, hB = hA + S < H ? hA + S : H;          // the strip's output rows [hA, hB)
+    const int64_t plane = ((int64_t)n * D + d) * H;                // voxel index of (n, d, 0, 0) / W
+    // ---- loads of input row hh (hA - 1 .. hB): three 16-byte pieces per lane, zeros outside the volume
+    auto issue = [&](int hh, u32x4e (&v)[3]) {
+      const bool rowin = hh >= 0 && hh < H;
+#pragma unroll
+      for (int t_ = 0; t_ < 3; ++t_) {
+        const int wv = w0 - 1 + pvox[t_];
+        const bool ok = rowin && wv >= 0 && wv < W && (t_ < 2 || p2);
+        v[t_] = ok ? *reinterpret_cast<const u32x4e*>(y + ((plane + hh) * W + wv) * ldy + (lane & 3) * 8) : u32x4e{0u, 0u, 0u, 0u};
+      }
+    };
+    // ---- BatchNorm apply + PReLU on a loaded row, activation out for the strip's own voxels, commit to ring slot (hh + 1) mod 3
+    auto commit = [&](int hh, const u32x4e (&v)[3]) {
+      const bool rowin = hh >= 0 && hh < H, rowown = hh >= hA && hh < hB;
+      char* slot = ring + ((hh + 1) % 3) * SLOT;       // hh >= -1
+#pragma unroll
+      for (int t_ = 0; t_ < 3; ++t_) {
+        if (t_ == 2 && !p2) continue;
+        const int wv = w0 - 1 + pvox[t_];
+        u32x4e o = u32x4e{0u, 0u, 0u, 0u};
+        if (rowin && wv >= 0 && wv < W) {
+          bf16x8 v8 = __builtin_bit_cast(bf16x8, v[t_]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float z = fmaf((float)v8[j], bsc[j], bsh[j]);
+            z = z > 0.f ? z : z * bslope;
+            v8[j] = (bf16_t)z;
+          }
+          o = __builtin_bit_cast(u32x4e, v8);
+          if (rowown && pvox[t_] >= 1 && pvox[t_] <= 32)          // the strip's own voxel: its activation goes to memory
+            *reinterpret_cast<u32x4e*>(aout + ((plane + hh) * W + wv) * lda + (lane & 3) * 8) = o;
+        }
+        *reinterpret_cast<u32x4e*>(slot + poff[t_]) = o;
+      }
+    };
+    u32x4e ra[3], rb[3], rc[3];
+    issue(hA - 1, ra);
+    issue(hA, rb);
+    commit(hA - 1, ra);
+    issue(hA + 1, rc);
+    commit(hA, rb);
+    // rows: at step ho the ring holds rows ho - 1, ho (committed) and ho + 1 arrives from `rc`; row ho + 2 is requested
+    for (int ho = hA; ho < hB; ++ho) {
+#pragma unroll
+      for (int t_ = 0; t_ < 3; ++t_) ra[t_] = rc[t_];
+      if (ho + 1 < hB) issue(ho + 2, rc);
+      commit(ho + 1, ra);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      f32x4e acc[2] = {cinit, cinit};
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const char* slot = ring + ((ho + kh) % 3) * SLOT;          // input row ho - 1 + kh sits in slot (ho + kh) mod 3
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const bf16x8 a = afr_l[kh * 3 + kw][lane];
+#pragma unroll
+          for (int cg = 0; cg < 2; ++cg) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(slot + boff[cg][kw]);
+            acc[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[cg], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();                 // the slot of row ho - 1 is overwritten by the next commit
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const int wv = w0 + cg * 16 + r16;
+        if (wv < W) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cls = 4 * kg + i;
+            if (cls < ncls) out[((int64_t)n * ncls + cls) * Vs + ((int64_t)d * H + ho) * W + wv] = acc[cg][i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // out_conv data gradient (class_num -> C0): thread = one voxel x all C0 channels; the fp32 planar dlogits
 // are read once (9 taps x classes, coalesced along w), the mirrored pack wb[tap'][ci][co] sits in LDS as
 // fp32 [tap][co][ci] and is read by broadcast; one 16-byte store per 8 channels.
@@ -1610,6 +1764,16 @@ extern "C" int fplx_edge_outconv_fwd_bn(const void* y, int64_t ldy, const float*
                                         int h, int w, int c0, int ncls, hipStream_t st) {
   if (!fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls) || ldy % 8 != 0 || lda % 8 != 0 || ((uintptr_t)y % 16) || ((uintptr_t)a % 16))
     return 0;
+  if (fplx_knob(FPLX_K_OUTCONV_FWD_ROWS) != 0) {
+    // the march of row segments (outconv_fwd_rows): strips of 32 voxels x S rows, one per wave
+    const int tilesW = (w + 31) / 32, S = 32, hsegs = (h + S - 1) / S;
+    const int64_t ntask = (int64_t)n * d * tilesW * hsegs, nblk = (ntask + 3) / 4;
+    const int nbr = (int)(nblk < 4096 ? nblk : 4096);
+    outconv_fwd_rows<<<nbr, 256, 0, st>>>((const bf16_t*)y, ldy, wf, bias, out, n, d, h, w, ncls, tilesW, hsegs, S, ntask, fplx_xcd_on(),
+                                          scale, shift, slope, (bf16_t*)a, lda);
+    const int rcr = fplx_check_launch("edge_outconv_fwd_rows");
+    return rcr < 0 ? rcr : 1;
+  }
   int th, tw;
   const int64_t nt = tiles_of(n, d, h, w, &th, &tw);
   const int nb = (int)(nt < 2048 ? nt : 2048);

@@ -1033,12 +1033,14 @@ def outconv_dgrad_rows_knob(request):
     default) and the tile kernel (outconv_dgrad_mfma<1, MODE>: knob outconv_dgrad_rows = 0; what 3 and 4 classes always take)"""
     from fplx import _lib
     _lib.set_tuning("outconv_dgrad_rows", request.param)
+    _lib.set_tuning("outconv_fwd_rows", request.param)          # (and the fused forward: outconv_fwd_rows | outconv_fwd_t<1, true>)
     yield request.param
     _lib.set_tuning("outconv_dgrad_rows", 1)
+    _lib.set_tuning("outconv_fwd_rows", 1)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (1, 2, 16, 64, 2), (1, 4, 24, 40, 3), (2, 5, 40, 96, 2), (1, 1, 1, 1, 2),
-                                   (3, 2, 7, 161, 2)])
+                                   (3, 2, 7, 161, 2), (1, 2, 70, 33, 4), (2, 1, 32, 32, 2), (1, 1, 33, 64, 1)])
 def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape, outconv_dgrad_rows_knob):
     """fplx_outconv_fwd_bn / fplx_outconv_dgrad_bn_reduce / _apply (out_conv fused with the BatchNorm + PReLU passes of the
     convolution site in front of it; reference unet2d5_dsbn.py:79-81 + 293-294, 307) against the calls they replace: forward -

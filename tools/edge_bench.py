@@ -85,8 +85,11 @@ def main():
     # the row-segment kernel (default) and the tile kernel
     from fplx import _lib
     lg2 = torch.empty(n, ncls, d, h, w, device=dev)
-    res.append(("outconv_fwd_bn", timeit(lambda: ops.outconv_fwd_bn(feat, bnbuf, slope, act, wof, bo, lg2, dims, c0, ncls)),
-                2 * tb + v * ncls * 4))
+    for knob in (1, 0):
+        _lib.set_tuning("outconv_fwd_rows", knob)
+        res.append(("outconv_fwd_bn %s" % ("rows" if knob else "tiles"),
+                    timeit(lambda: ops.outconv_fwd_bn(feat, bnbuf, slope, act, wof, bo, lg2, dims, c0, ncls)), 2 * tb + v * ncls * 4))
+    _lib.set_tuning("outconv_fwd_rows", 1)
     for knob in (1, 0):
         _lib.set_tuning("outconv_dgrad_rows", knob)
         prt = torch.empty(max(ops.num_partials(v), ops.outconv_bn_rows(dims, c0, ncls)) * (2 * c0 + 1), device=dev)
