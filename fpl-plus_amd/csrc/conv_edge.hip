@@ -1208,7 +1208,7 @@ outconv_dgrad_mfma(const float* __restrict__ dl, const bf16_t* __restrict__ wb, 
 //     row per block; MODE 2: dy = fma(dz, scale, fma(y, A, B)) leaves through the two lane exchanges of stem_fwd_rows.
 // The segment walk is scalar (mixed-radix step with carries, see stem_fwd_rows).
 template <int MODE, int NCLS>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 4)
 outconv_dgrad_rows(const float* __restrict__ dl, const bf16_t* __restrict__ wb, bf16_t* __restrict__ dx, int64_t ldx, int N, int D,
                    int H, int W, int tilesW, int64_t ntiles, int xcd, const bf16_t* __restrict__ yv, int64_t ldy,
                    const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd, const float* __restrict__ bn_scale,
