@@ -67,7 +67,7 @@ class KernelTimer(object):
         for name in ("conv3d_fwd", "conv3d_wgrad", "conv3d_fwd_cat2", "conv3d_dgrad_split2", "conv3d_wgrad_cat2",
                      "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad", "maxpool2_fwd",
                      "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "adam_pack_step", "pack_weights_multi",
-                     "pack_conv_weights_batched", "outconv_fwd_bn", "outconv_dgrad_bn_bwd"):
+                     "pack_conv_weights_batched", "outconv_fwd_bn", "outconv_dgrad_bn_bwd", "stem_wgrad_bn"):
             self._wrap(name)
 
     def _key(self, name, a, kw={}):
@@ -86,7 +86,8 @@ class KernelTimer(object):
             return ("conv3d_wgrad", a[4], a[5], a[6], (3, 3, 3))
         if name == "bn_act_bwd":                # (y, dout, dy, bnbuf, slope, p, seed, sid, c, ...): voxels x channels of the site
             red = bool(kw.get("reduced", a[15] if len(a) > 15 else False))      # the DownBlock tails: the reduction was fused elsewhere
-            return (name + "(apply only)" if red else name, int(a[0].shape[0]), int(a[8]))
+            app = bool(kw.get("apply", a[16] if len(a) > 16 else True))         # the stem site: the weight gradient forms dy itself
+            return (name + ("(apply only)" if red else "") + ("" if app else "(reduce only)"), int(a[0].shape[0]), int(a[8]))
         if name == "bn_act_fwd":                # (y, out, bnbuf, slope, p, seed, sid, c)
             return (name, int(a[0].shape[0]), int(a[7]))
         # the remaining ops carry what their byte model needs (row_model below)
@@ -100,6 +101,8 @@ class KernelTimer(object):
             return (name, tuple(a[7]), int(a[8]), int(a[9]))
         if name == "outconv_dgrad_bn_bwd":      # (dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls)
             return (name, tuple(a[12]), int(a[13]), int(a[14]))
+        if name == "stem_wgrad_bn":             # (x, y, dout, bnbuf, slope, coef, dw, dims, cin, cout, ws)
+            return (name, tuple(a[7]), int(a[8]), int(a[9]))
         if name in ("maxpool2_fwd",):           # (x, pooled, dims, c, pd)
             return (name, tuple(a[2]), int(a[3]), int(a[4]) if len(a) > 4 else 2)
         if name in ("maxpool2_bwd",):           # (skip, d_pool, d_skip, d_x, dims, c, pd)
@@ -183,9 +186,14 @@ def row_model(key):
             nbytes = vox * (cin + cout) * 2.0
         if name == "conv3d_wgrad":
             nbytes += taps * cin * cout * 4.0
-    elif name in ("bn_act_bwd", "bn_act_bwd(apply only)", "bn_act_fwd"):
-        tensors = {"bn_act_bwd": 5.0, "bn_act_bwd(apply only)": 3.0, "bn_act_fwd": 2.0}[name]
+    elif name in ("bn_act_bwd", "bn_act_bwd(apply only)", "bn_act_bwd(reduce only)", "bn_act_fwd"):
+        tensors = {"bn_act_bwd": 5.0, "bn_act_bwd(apply only)": 3.0, "bn_act_bwd(reduce only)": 2.0, "bn_act_fwd": 2.0}[name]
         nbytes = tensors * key[1] * key[2] * 2.0
+    elif name == "stem_wgrad_bn":                # fp32 input + y + d(a) read, dw written: the apply pass's dy never exists
+        _, dims, cin, cout = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        flops = 2.0 * vox * cin * cout * 27
+        nbytes = vox * (cin * 4.0 + 2 * cout * 2.0) + 27 * cin * cout * 4.0
     elif name in ("deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad"):
         _, dims, cin, cout, pd = key
         vox = dims[0] * dims[1] * dims[2] * dims[3]
@@ -232,11 +240,11 @@ def row_model(key):
     return ("mfma" if flops / nbytes >= ridge else "hbm"), nbytes, flops
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_hbm_traffic.json")
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r05_pmc_hbm_traffic.json,
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/r06_pmc_hbm_traffic.json,
     made by tools/pmc_summary.py from separate --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of THIS command with the gfx950
     x2 FETCH correction).  The summary records the sha256 of the kernel sources it was measured on: if conv_march.hip or
     common.h have changed since, the figure is stale and None is reported.  None also if there is no matching entry."""
@@ -704,7 +712,7 @@ def main():
         # the largest HBM-bound consumer beside the dominant convolution (the BatchNorm backward passes are the
         # biggest group of the table): bn_act_bwd = reduce (reads d(out), y) + finalize + apply (reads both, writes dy) =
         # 5 tensors of voxels x C bf16; bn_act_fwd = 2
-        bns = {k: v for k, v in summ.items() if k[0] in ("bn_act_bwd", "bn_act_fwd")}       # (not the apply-only form)
+        bns = {k: v for k, v in summ.items() if k[0] in ("bn_act_bwd", "bn_act_fwd")}       # (not the apply-only / reduce-only forms)
         if bns:
             kb = max(bns, key=lambda kk: bns[kk][2])
             nb = (5.0 if kb[0] == "bn_act_bwd" else 2.0) * kb[1] * kb[2] * 2.0
