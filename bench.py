@@ -67,7 +67,7 @@ class KernelTimer(object):
         for name in ("conv3d_fwd", "conv3d_wgrad", "conv3d_fwd_cat2", "conv3d_dgrad_split2", "conv3d_wgrad_cat2",
                      "bn_act_fwd", "bn_act_bwd", "deconv2_fwd", "deconv2_dgrad", "deconv2_wgrad", "maxpool2_fwd",
                      "maxpool2_bwd", "seg_loss_fwd", "seg_loss_bwd", "adam_step", "adam_pack_step", "pack_weights_multi",
-                     "pack_conv_weights_batched", "outconv_fwd_bn", "outconv_dgrad_bn_bwd", "stem_wgrad_bn"):
+                     "pack_conv_weights_batched", "outconv_fwd_bn", "outconv_dgrad_bn_bwd", "stem_wgrad_bn", "outconv_wgrad_bn"):
             self._wrap(name)
 
     def _key(self, name, a, kw={}):
@@ -98,7 +98,9 @@ class KernelTimer(object):
         if name == "deconv2_wgrad":             # (x, d_up, gw, gb, dims_in, cin, cout, ws, pd)
             return (name, tuple(a[4]), int(a[5]), int(a[6]), int(a[8]) if len(a) > 8 else 2)
         if name == "outconv_fwd_bn":            # (y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls)
-            return (name, tuple(a[7]), int(a[8]), int(a[9]))
+            return (name + ("(logits only)" if a[3] is None else ""), tuple(a[7]), int(a[8]), int(a[9]))
+        if name == "outconv_wgrad_bn":          # (y, bnbuf, slope, dlogits, dw, db, dims, c0, ncls, ws)
+            return (name, tuple(a[6]), int(a[7]), int(a[8]))
         if name == "outconv_dgrad_bn_bwd":      # (dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls)
             return (name, tuple(a[12]), int(a[13]), int(a[14]))
         if name == "stem_wgrad_bn":             # (x, y, dout, bnbuf, slope, coef, dw, dims, cin, cout, ws)
@@ -204,6 +206,14 @@ def row_model(key):
         _, dims, c0, ncls = key
         vox = dims[0] * dims[1] * dims[2] * dims[3]
         flops, nbytes = 2.0 * vox * 9 * c0 * ncls, vox * (4.0 * c0 + 4.0 * ncls)
+    elif name == "outconv_fwd_bn(logits only)":  # y read, logits written: the activation is not stored
+        _, dims, c0, ncls = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        flops, nbytes = 2.0 * vox * 9 * c0 * ncls, vox * (2.0 * c0 + 4.0 * ncls)
+    elif name == "outconv_wgrad_bn":             # y + dlogits read
+        _, dims, c0, ncls = key
+        vox = dims[0] * dims[1] * dims[2] * dims[3]
+        flops, nbytes = 2.0 * vox * 9 * c0 * ncls, vox * (2.0 * c0 + 4.0 * ncls) + 9 * c0 * ncls * 4.0
     elif name == "outconv_dgrad_bn_bwd":
         _, dims, c0, ncls = key
         vox = dims[0] * dims[1] * dims[2] * dims[3]

@@ -879,7 +879,7 @@ outconv_fwd_rows(const bf16_t* __restrict__ y, int64_t ldy, const float* __restr
             v8[j] = (bf16_t)z;
           }
           o = __builtin_bit_cast(u32x4e, v8);
-          if (rowown && pvox[t_] >= 1 && pvox[t_] <= 32)          // the strip's own voxel: its activation goes to memory
+          if (aout && rowown && pvox[t_] >= 1 && pvox[t_] <= 32)  // the strip's own voxel: its activation goes to memory (if wanted)
             *reinterpret_cast<u32x4e*>(aout + ((plane + hh) * W + wv) * lda + (lane & 3) * 8) = o;
         }
         *reinterpret_cast<u32x4e*>(slot + poff[t_]) = o;
@@ -1603,6 +1603,221 @@ outconv_wgrad_reduce(const float* __restrict__ part, int nblk, int ncit, int C0,
   dw[((int64_t)co * C0 + cit * 32 + ci_l) * 9 + tap] = t;
 }
 
+// ------------------------------------------------------------------------------------------
+// outconv_wgrad_rows (round 6): out_conv's weight and bias gradients from the PRE-BatchNorm tensor y of the site in front of
+// it, as a stream of 32-voxel row segments (one per wave, no block barrier; the form of outconv_dgrad_rows).  With it the
+// activation a = PReLU(BN(y)) of that site has no reader left in the training step - the fused forward (outconv_fwd_rows)
+// and backward (outconv_dgrad_rows) form it from y on their own - so it is never stored: one 262-MB write and the kernel
+// that re-read it (outconv_wgrad_mfma, 135 us) leave the step.
+//   D[ci][pair] += sum over the segment's 32 voxels u of a[ci][u] g[pair][u],  pair = (tap, class),  g = dlogit[class][u - off(tap)]
+//   * A (rows = channels, K = voxels): y arrives as two coalesced 16-byte pieces per lane (voxel (lane >> 2) + 16 t, channel
+//     chunk lane & 3 - the lane's 8 channels' constants stay in registers), gets BatchNorm + PReLU -> bf16 exactly as the
+//     stored activation did, goes to the wave's 2-KB LDS tile [voxel][32 ch] (lane-linear 16-byte writes) and comes back
+//     transposed through ds_read_b64_tr_b16;
+//   * B (cols = pairs, K = voxels): the lane's 8 consecutive voxels of its pair are 8 consecutive floats of a dlogit row -
+//     two 16-byte buffer loads per k-step straight from the fp32 planes (27-fold reuse in L1 / L2), rounded to bf16 (the
+//     tile kernel's operand); rows above / below the plane and the two columns beside it are zeros; lanes beyond the
+//     last pair read out of range (zeros);
+//   * the bias gradient is the plain fp32 sum of the centre tap's lanes.
+// One partial row of 9 ncls 32 + ncls floats per block, summed in a fixed order by outconv_wgrad_rows_reduce.
+__global__ void __launch_bounds__(256, 4)
+outconv_wgrad_rows(const bf16_t* __restrict__ yv, int64_t ldy, const float* __restrict__ dl, float* __restrict__ part, int N, int D,
+                   int H, int W, int ncls, int tilesW, int64_t ntiles, int xcd, const float* __restrict__ bn_scale,
+                   const float* __restrict__ bn_shift, const float* __restrict__ slope_p) {
+  constexpr int C0 = 32;
+  __shared__ __attribute__((aligned(16))) char smem[4][4096];        // per wave: the a tile (2 KB); at the end its 32 x 32 sums
+  __shared__ float sbf[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, khalf = lane >> 5;
+  char* atile = smem[wave];
+  const int64_t Vs = (int64_t)D * H * W;
+  const int npair = 9 * ncls;
+  // ---- A side: pieces and constants
+  const int pv = lane >> 2, chunk = lane & 3;
+  float bsc[8], bsh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bsc[j] = bn_scale[chunk * 8 + j]; bsh[j] = bn_shift[chunk * 8 + j]; }
+  const float bslope = *slope_p;
+  const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int lane_off = (8 * (g4 >> 1) + q4) * 64 + (16 * (g4 & 1) + 4 * p4) * 2;      // tr_frag64: row = channel lane & 31
+  // ---- B side: the lane's pair
+  const bool pok = r < npair;
+  const int tap = pok ? r / ncls : 4, cls = pok ? r % ncls : 0;
+  const int kh = tap / 3, kw = tap % 3;
+  // source voxel of element j of k-step s: row h - (kh - 1), column w0 + 16 s + 8 khalf + j - (kw - 1)
+  const int goff = pok ? ((-(kh - 1)) * W - (kw - 1) + 8 * khalf) * 4 + cls * (int)(Vs * 4) : (int)0x80000000;
+  const int64_t gbytes = (int64_t)N * ncls * Vs * 4;          // (the launcher keeps the dlogits below 2 GiB)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dl, 0, (int)gbytes, 0x00020000);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float sb = 0.f;
+
+  const FplxTileRange tr = fplx_xcd_tiles(ntiles, xcd);   // tiles = 4 consecutive 32-voxel segments (one per wave)
+  auto sread = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+  const unsigned uW = (unsigned)tilesW, uH = (unsigned)H, uD = (unsigned)D;
+  unsigned sw_, sh_, sd_, sn_;
+  struct Seg { unsigned cw, ch, cd, cn; };
+  Seg nx;
+  {
+    unsigned t = sread((unsigned)tr.step * 4u);
+    sw_ = sread(t % uW); t = sread(t / uW);
+    sh_ = sread(t % uH); t = sread(t / uH);
+    sd_ = sread(t % uD); sn_ = sread(t / uD);
+    t = sread((unsigned)tr.first * 4u + (unsigned)wave);
+    nx.cw = sread(t % uW); t = sread(t / uW);
+    nx.ch = sread(t % uH); t = sread(t / uH);
+    nx.cd = sread(t % uD); nx.cn = sread(t / uD);
+  }
+  auto advance = [&](Seg& g) {
+    g.cw += sw_;
+    unsigned carry = g.cw >= uW ? 1u : 0u;
+    g.cw -= carry ? uW : 0u;
+    g.ch += sh_ + carry;
+    carry = g.ch >= uH ? 1u : 0u;
+    g.ch -= carry ? uH : 0u;
+    g.cd += sd_ + carry;
+    carry = g.cd >= uD ? 1u : 0u;
+    g.cd -= carry ? uD : 0u;
+    g.cn += sn_ + carry;
+  };
+  auto issue = [&](const Seg& g, u32x4e (&gq)[4], u32x4e (&yq)[2]) {
+    if (g.cn >= (unsigned)N) return;
+    const int n = (int)g.cn, d = (int)g.cd, h = (int)g.ch, w0 = (int)g.cw * 32;
+    const int sbase = (((n * ncls * D + d) * H + h) * W + w0) * 4;         // byte offset of the segment in the class-0 plane
+    const bool rowok = (unsigned)(h - (kh - 1)) < (unsigned)H;
+    const int o = goff + sbase;                          // >= 0, except: -4 where the window starts one column left of the tensor's first row
+    if (n == 0 && d == 0 && h <= 1 && w0 == 0) {
+      // (the hardware adds offsets without wrapping: a window that starts below the tensor is out of range as a whole.  Such
+      // a lane loads from the tensor's first byte and moves the components up; the column mask zeroes component 0 anyway)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ok = o + (k >> 1) * 64 + (k & 1) * 16;
+        const bool neg = ok < 0;
+        int ol = neg ? 0 : ok;
+        asm volatile("" : "+v"(ol));                     // (one opaque offset: no base + immediate split of a negative base)
+        const u32x4e q = __builtin_bit_cast(u32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rowok ? (unsigned)ol : 0x80000000u, 0, 0));
+        gq[k] = neg ? u32x4e{0u, q.x, q.y, q.z} : q;
+      }
+    } else {
+      const unsigned vo = rowok ? (unsigned)o : 0x80000000u;
+      // (a window that reaches beyond the tensor's last byte returns zeros there: raw buffers are range-checked per dword)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        gq[k] = __builtin_bit_cast(u32x4e, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + (unsigned)((k >> 1) * 64 + (k & 1) * 16), 0, 0));
+    }
+    const int64_t vrow = (((int64_t)n * D + d) * H + h) * W + w0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const bool ok = w0 + pv + 16 * t < W;
+      yq[t] = ok ? *reinterpret_cast<const u32x4e*>(yv + (vrow + pv + 16 * t) * ldy + 8 * chunk) : u32x4e{0u, 0u, 0u, 0u};
+    }
+  };
+  auto consume = [&](const Seg& g, const u32x4e (&gq)[4], const u32x4e (&yq)[2]) {
+    if (g.cn >= (unsigned)N) return;
+    const int w0 = (int)g.cw * 32;
+    // ---- a = PReLU(scale y + shift) -> bf16 into the tile (zeros beyond W: such voxels then add nothing to any sum)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      u32x4e o = u32x4e{0u, 0u, 0u, 0u};
+      if (w0 + pv + 16 * t < W) {
+        bf16x8 v8 = __builtin_bit_cast(bf16x8, yq[t]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float z = fmaf((float)v8[j], bsc[j], bsh[j]);
+          z = z > 0.f ? z : z * bslope;
+          v8[j] = (bf16_t)z;
+        }
+        o = __builtin_bit_cast(u32x4e, v8);
+      }
+      *reinterpret_cast<u32x4e*>(atile + (lane + 64 * t) * 16) = o;
+    }
+    // ---- g: columns outside the plane are zeros (only the segments that touch a row end have any)
+    float gf[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // (whole-vector cast: __builtin_bit_cast(float, gq[k][e]) on a vector ELEMENT reads element 0 with this compiler)
+      const f32x4e q = __builtin_bit_cast(f32x4e, gq[k]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gf[4 * k + e] = q[e];
+    }
+    if (!(w0 >= 1 && w0 + 33 <= W)) {
+      const int wsrc = w0 + 8 * khalf - (kw - 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if ((unsigned)(wsrc + 16 * s + j) >= (unsigned)W) gf[8 * s + j] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sb += gf[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 fa = tr_frag64(atile + 16 * s * 64 + lane_off);
+      bf16x8 fb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fb[j] = (bf16_t)gf[8 * s + j];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();                   // the tile is rewritten by the next segment
+  };
+  u32x4e gA[4], gB[4], yA[2], yB[2];
+  Seg cur = nx;
+  issue(cur, gA, yA);
+  for (int64_t tt = tr.first; tt < tr.end; tt += tr.step) {
+    nx = cur;
+    advance(nx);
+    if (tt + tr.step < tr.end) issue(nx, gB, yB);
+    consume(cur, gA, yA);
+    cur = nx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gA[k] = gB[k];
+    yA[0] = yB[0];
+    yA[1] = yB[1];
+  }
+  // ---- fold the four waves in a fixed order: sums[pair r][channel]
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* fold = reinterpret_cast<float*>(smem[wave]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) fold[r * 32 + (i & 3) + 8 * (i >> 2) + 4 * khalf] = acc[i];
+  sbf[wave][lane] = sb;
+  __syncthreads();
+  const int rowf = npair * C0 + ncls;
+  float* row = part + (int64_t)blockIdx.x * rowf;
+  for (int i = threadIdx.x; i < npair * C0; i += 256) {
+    const float* f0 = reinterpret_cast<const float*>(smem[0]);
+    row[i] = ((f0[i] + f0[1024 + i]) + f0[2048 + i]) + f0[3072 + i];
+  }
+  if ((int)threadIdx.x < ncls) {
+    const int pl = 4 * ncls + threadIdx.x;              // the centre tap's pair of this class
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) t += sbf[wv][pl] + sbf[wv][32 + pl];
+    row[npair * C0 + threadIdx.x] = t;
+  }
+}
+
+// dw[class][ci][tap], db[class] = sums over the block rows of outconv_wgrad_rows
+__global__ void __launch_bounds__(256)
+outconv_wgrad_rows_reduce(const float* __restrict__ part, int nblk, int ncls, float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[256];
+  constexpr int C0 = 32;
+  const int total = 9 * ncls * C0 + ncls;
+  const int i = blockIdx.x * SP_OUT + (threadIdx.x & (SP_OUT - 1));
+  const float t = sum_partials(part, nblk, total, i, red);
+  if (threadIdx.x >= SP_OUT || i >= total) return;
+  if (i >= 9 * ncls * C0) {
+    if (db) db[i - 9 * ncls * C0] = t;
+    return;
+  }
+  const int pair = i >> 5, ci = i & 31, tap = pair / ncls, cls = pair % ncls;
+  dw[((int64_t)cls * C0 + ci) * 9 + tap] = t;
+}
+
 inline int64_t tiles_of(int n, int d, int h, int w, int* th, int* tw) {
   *th = (h + TH - 1) / TH;
   *tw = (w + TW - 1) / TW;
@@ -1764,6 +1979,7 @@ extern "C" int fplx_edge_outconv_fwd_bn(const void* y, int64_t ldy, const float*
                                         int h, int w, int c0, int ncls, hipStream_t st) {
   if (!fplx_edge_outconv_bn_ok(n, d, h, w, c0, ncls) || ldy % 8 != 0 || lda % 8 != 0 || ((uintptr_t)y % 16) || ((uintptr_t)a % 16))
     return 0;
+  if (!a && fplx_knob(FPLX_K_OUTCONV_FWD_ROWS) == 0) return 0;      // only the march of row segments can leave the activation out
   if (fplx_knob(FPLX_K_OUTCONV_FWD_ROWS) != 0) {
     // the march of row segments (outconv_fwd_rows): strips of 32 voxels x S rows, one per wave
     const int tilesW = (w + 31) / 32, S = 32, hsegs = (h + S - 1) / S;
@@ -1812,6 +2028,28 @@ extern "C" int fplx_edge_outconv_dgrad_bn(int mode, const float* dl, const void*
                                                  fplx_xcd_on(), (const bf16_t*)y, ldy, mean, rstd, scale, shift, slope, coef,
                                                  nullptr);
   const int rc = fplx_check_launch("edge_outconv_dgrad_bn");
+  return rc < 0 ? rc : 1;
+}
+
+// out_conv's weight + bias gradients from the pre-BatchNorm tensor (outconv_wgrad_rows): 0 = not available for this shape
+extern "C" size_t fplx_edge_outconv_wgrad_bn_ws_bytes(int n, int d, int h, int w, int c0, int ncls) {
+  if (c0 != 32 || ncls < 1 || ncls > 3 || fplx_knob(FPLX_K_OUTCONV_FWD_ROWS) == 0 ||
+      (int64_t)n * ncls * d * h * w >= ((int64_t)1 << 29))
+    return 0;
+  const int64_t nt4 = outconv_rows_tiles(n, d, h, w);
+  return (size_t)(nt4 < 1024 ? nt4 : 1024) * (9 * ncls * 32 + ncls) * sizeof(float);
+}
+extern "C" int fplx_edge_outconv_wgrad_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* slope,
+                                          const float* dl, float* dw, float* db, int n, int d, int h, int w, int c0, int ncls,
+                                          void* ws, hipStream_t st) {
+  if (fplx_edge_outconv_wgrad_bn_ws_bytes(n, d, h, w, c0, ncls) == 0 || ldy % 8 != 0 || ((uintptr_t)y % 16)) return 0;
+  const int64_t nt4 = outconv_rows_tiles(n, d, h, w);
+  const int nbr = (int)(nt4 < 1024 ? nt4 : 1024), tilesW = (w + 31) / 32;
+  outconv_wgrad_rows<<<nbr, 256, 0, st>>>((const bf16_t*)y, ldy, dl, (float*)ws, n, d, h, w, ncls, tilesW, nt4, fplx_xcd_on(), scale,
+                                          shift, slope);
+  const int total = 9 * ncls * 32 + ncls;
+  outconv_wgrad_rows_reduce<<<(total + SP_OUT - 1) / SP_OUT, 256, 0, st>>>((const float*)ws, nbr, ncls, dw, db);
+  const int rc = fplx_check_launch("edge_outconv_wgrad_bn");
   return rc < 0 ? rc : 1;
 }
 

@@ -594,6 +594,10 @@ extern "C" int fplx_edge_outconv_dgrad_bn(int mode, const float* dl, const void*
 extern "C" int fplx_edge_outconv_dgrad(const float* dl, const void* wb, void* dx, int64_t ldx, int n, int d, int h, int w,
                                        int c0, int ncls, hipStream_t st);
 extern "C" size_t fplx_edge_outconv_wgrad_ws_bytes(int n, int d, int h, int w, int c0, int ncls);
+extern "C" size_t fplx_edge_outconv_wgrad_bn_ws_bytes(int n, int d, int h, int w, int c0, int ncls);
+extern "C" int fplx_edge_outconv_wgrad_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* slope,
+                                          const float* dl, float* dw, float* db, int n, int d, int h, int w, int c0, int ncls,
+                                          void* ws, hipStream_t st);
 extern "C" int fplx_edge_outconv_wgrad(const void* x, int64_t ldx, const float* dl, float* dw, int n, int d, int h, int w,
                                        int c0, int ncls, void* ws, hipStream_t st);
 extern "C" int fplx_mfma_deconv2_fwd(const void* x, int64_t ldx, const void* wf, const float* bias, void* y, int64_t ldy,
@@ -1102,7 +1106,9 @@ int fplx_outconv_bn_rows(int n, int d, int h, int w, int c0, int ncls) {
 int fplx_outconv_fwd_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope, void* a,
                         int64_t lda, const float* wf, const float* bias, float* logits, int n, int d, int h, int w, int c0,
                         int ncls, fplx_stream_t stream) {
-  FPLX_REQUIRE(y && scale && shift && prelu_slope && a && wf && logits, FPLX_E_NULL, "outconv_fwd_bn: null pointer");
+  FPLX_REQUIRE(y && scale && shift && prelu_slope && wf && logits, FPLX_E_NULL, "outconv_fwd_bn: null pointer");
+  FPLX_REQUIRE(a || fplx_edge_outconv_wgrad_bn_ws_bytes(n, d, h, w, c0, ncls) > 0, FPLX_E_NULL,
+               "outconv_fwd_bn: a = NULL only where fplx_outconv_wgrad_bn_ws_bytes(...) > 0 (the weight gradient then needs no stored activation)");
   FPLX_REQUIRE(outconv_bn_ok(n, d, h, w, c0, ncls), FPLX_E_BADSHAPE, "outconv_fwd_bn: c0 = %d, classes = %d not supported (fplx_outconv_bn_rows == 0)", c0, ncls);
   const int r = fplx_edge_outconv_fwd_bn(y, ldy, scale, shift, prelu_slope, a, lda, wf, bias, logits, n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_fwd_bn: pointers / leading dimensions not 16-byte aligned");
@@ -1127,6 +1133,21 @@ int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void
   const int r = fplx_edge_outconv_dgrad_bn(2, dlogits, wb, y, ldy, mean, rstd, scale, shift, prelu_slope, coef, nullptr, dy, lddy,
                                            n, d, h, w, c0, ncls, (hipStream_t)stream);
   if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_dgrad_bn_apply: pointers / leading dimensions not 16-byte aligned");
+  return r < 0 ? r : FPLX_OK;
+}
+
+size_t fplx_outconv_wgrad_bn_ws_bytes(int n, int d, int h, int w, int c0, int ncls) {
+  return outconv_bn_ok(n, d, h, w, c0, ncls) ? fplx_edge_outconv_wgrad_bn_ws_bytes(n, d, h, w, c0, ncls) : 0;
+}
+int fplx_outconv_wgrad_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope,
+                          const float* dlogits, float* dw, float* db, int n, int d, int h, int w, int c0, int ncls, void* ws,
+                          size_t ws_bytes, fplx_stream_t stream) {
+  FPLX_REQUIRE(y && scale && shift && prelu_slope && dlogits && dw && ws, FPLX_E_NULL, "outconv_wgrad_bn: null pointer");
+  const size_t need = fplx_outconv_wgrad_bn_ws_bytes(n, d, h, w, c0, ncls);
+  FPLX_REQUIRE(need > 0, FPLX_E_BADSHAPE, "outconv_wgrad_bn: c0 = %d, classes = %d not supported (fplx_outconv_wgrad_bn_ws_bytes == 0)", c0, ncls);
+  FPLX_REQUIRE(ws_bytes >= need, FPLX_E_WORKSPACE, "outconv_wgrad_bn: workspace %zu < %zu bytes", ws_bytes, need);
+  const int r = fplx_edge_outconv_wgrad_bn(y, ldy, scale, shift, prelu_slope, dlogits, dw, db, n, d, h, w, c0, ncls, ws, (hipStream_t)stream);
+  if (r == 0) return fplx_fail(FPLX_E_BADSHAPE, "outconv_wgrad_bn: y / its leading dimension not 16-byte aligned");
   return r < 0 ? r : FPLX_OK;
 }
 

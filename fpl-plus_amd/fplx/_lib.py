@@ -186,6 +186,7 @@ _HOST_KNOBS = {
     "stem_wg_main": 1,      # Engine.stem_wgrad_on_main
     "outconv_fuse": 1,      # Engine.use_outconv_fusion: out_conv fused with the last site's BatchNorm + PReLU passes
     "stem_wgrad_bn": 1,     # Engine.use_stem_wgrad_bn: the stem's weight gradient forms dy from y and d(a) itself (no apply pass)
+    "outconv_wgrad_bn": 1,  # Engine.use_outconv_wgrad_bn: out_conv's weight gradient from y (fplx_outconv_wgrad_bn); the last site's activation is never stored
     "bucket_elems": 1 << 21,    # TrainStep: gradient all-reduce bucket size (elements)
     "pack_small_multi": 1,  # Engine._pack: the transposed-convolution and out_conv packs of a step in one launch (fplx_pack_weights_multi)
     "adam_pack": 1,         # FusedAdam.step_flat: the shared segment's Adam and the 3x3x3 weight packs in one launch (fplx_adam_pack_step)

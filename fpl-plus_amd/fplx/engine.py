@@ -25,7 +25,7 @@ LEVEL_OF_BLOCK = [0, 1, 2, 3, 4, 3, 2, 1, 0]      # block0..4, up1..up4
 class Saved(object):
     """what one forward leaves behind for its backward"""
     __slots__ = ("x", "dims", "domain", "train", "seed", "step", "blocks", "cats", "pooled", "packs",
-                 "drop_on", "deconv_in", "skips", "split", "oc_fused", "pack_gen")
+                 "drop_on", "deconv_in", "skips", "split", "oc_fused", "oc_wg", "pack_gen")
 
 
 class Engine(object):
@@ -66,6 +66,9 @@ class Engine(object):
         # the stem site's backward: its dy has one consumer, the stem's weight gradient, which forms it from y and d(a) itself
         # (fplx_stem_wgrad_bn) - the apply pass of that site's BatchNorm backward (write dy, read it back) disappears
         self.use_stem_wgrad_bn = _lib.host_knob("stem_wgrad_bn") != 0
+        # out_conv's weight gradient takes the last site's PRE-BatchNorm tensor too (fplx_outconv_wgrad_bn): with the fused
+        # forward / backward above that site's activation has no reader left and is neither allocated nor written
+        self.use_outconv_wgrad_bn = _lib.host_knob("outconv_wgrad_bn") != 0
         self._fold_cache = {}              # (act dtype, domain) -> {site key: (folded forward pack, folded bias)}
         # TIMING PROBE ONLY (tools/step_ab.py "@defer_probe=1"): the decoder's weight gradients of a step are
         # not launched in backward but beside the NEXT step's forward - their results are discarded by that step's gradient
@@ -301,6 +304,8 @@ class Engine(object):
         # the last site's BatchNorm + PReLU inside the out_conv kernel (not where that site runs the folded inference form)
         oc_fuse = (self.use_outconv_fusion and not fuse and mc == 1 and adt == torch.bfloat16 and
                    ops.outconv_bn_ok((N, D, H, W), net.ft_chns[0], net.n_class))
+        oc_wg = (oc_fuse and self.use_outconv_wgrad_bn and
+                 ops.outconv_wgrad_bn_ws_bytes((N, D, H, W), net.ft_chns[0], net.n_class) > 0)
         if mc > 1 and (train or keep):
             raise ValueError("fplx: Monte-Carlo replication (mc > 1) is an inference mode: eval-mode BatchNorm, keep=False")
         # first encoder level whose input differs between Monte-Carlo passes (the level after the first active dropout)
@@ -466,7 +471,7 @@ class Engine(object):
             else:
                 ops.deconv2_fwd(cur, packs["up%d.%s" % (j + 1, up.tname())][0], tr.bias, ups[l], dims[l + 1], ft[l + 1],
                                 ft[l], pds[l])
-            out = empty(vox[l], ft[l])
+            out = None if (j == 3 and oc_wg) else empty(vox[l], ft[l])     # oc_wg: nothing reads the last activation
             xin = ((eskips[l] if skip_mod[l] else skips[l]), ups[l]) if split[l] else cats[l]
             conv_block(5 + j, xin, ops.cl_strides(*dims[l][1:], 2 * ft[l]), a_dt, 2 * ft[l], l, out, n_x0=skip_mod[l])
             cur = out
@@ -486,6 +491,7 @@ class Engine(object):
             ops.conv3d_fwd(cur, ops.cl_strides(D, H, W, ft[0]), a_dt, packs["out_conv"][0], net.out_conv.bias, logits,
                            ops.planar_strides(ncls, D, H, W), F32, dims[0], ft[0], ncls, (1, 3, 3), None)
         sv.oc_fused = oc_fuse
+        sv.oc_wg = oc_wg
         if deferred_join is not None:
             torch.cuda.current_stream().wait_event(deferred_join)
             self._deferred_keep = None
@@ -517,7 +523,7 @@ class Engine(object):
             return torch.empty((v, c), dtype=adt, device=dev)
 
         # workspace: max over layers
-        need = ops.conv3d_wgrad_ws_bytes(dims[0], ft[0], ncls, (1, 3, 3))
+        need = max(ops.conv3d_wgrad_ws_bytes(dims[0], ft[0], ncls, (1, 3, 3)), ops.outconv_wgrad_bn_ws_bytes(dims[0], ft[0], ncls))
         for b in range(9):
             l = LEVEL_OF_BLOCK[b]
             cin1 = sv.blocks[b]["cin"]
@@ -580,6 +586,12 @@ class Engine(object):
         last = sv.blocks[8]["out"]
 
         def outconv_wgrad():
+            if getattr(sv, "oc_wg", False):            # (the forward stored no activation: it is formed again from y)
+                b8 = sv.blocks[8]
+                on_side(lambda: ops.outconv_wgrad_bn(b8["y2"], b8["bn2"], net.get_param(net.block_keys[8] + ".relu_2.weight"),
+                                                     dlogits, gv["out_conv.weight"], gv["out_conv.bias"], dims[0], ft[0], ncls,
+                                                     ws_w), dlogits)
+                return
             on_side(lambda: ops.conv3d_wgrad(last, ops.cl_strides(D, H, W, ft[0]), a_dt, dlogits,
                                              ops.planar_strides(ncls, D, H, W), F32, gv["out_conv.weight"],
                                              gv["out_conv.bias"], dims[0], ft[0], ncls, (1, 3, 3), ws_w), dlogits)

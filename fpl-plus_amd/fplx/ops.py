@@ -311,10 +311,25 @@ def outconv_bn_ok(dims, c0, ncls):
 
 
 def outconv_fwd_bn(y, bnbuf, slope, a, wf, bias, logits, dims, c0, ncls):
-    """a = PReLU(BN(y)) (bnbuf rows 2 / 3 = scale / shift) and logits = out_conv(a) in one pass over y"""
+    """a = PReLU(BN(y)) (bnbuf rows 2 / 3 = scale / shift) and logits = out_conv(a) in one pass over y.  a = None: the
+    activation is not written (allowed where outconv_wgrad_bn_ws_bytes(...) > 0: backward then takes everything from y)"""
     n, d, h, w = dims
-    call("fplx_outconv_fwd_bn", ptr(y), ld_of(y), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(a), ld_of(a), ptr(wf), ptr(bias),
-         ptr(logits), n, d, h, w, int(c0), int(ncls), stream())
+    call("fplx_outconv_fwd_bn", ptr(y), ld_of(y), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(a), int(c0) if a is None else ld_of(a),
+         ptr(wf), ptr(bias), ptr(logits), n, d, h, w, int(c0), int(ncls), stream())
+
+
+def outconv_wgrad_bn_ws_bytes(dims, c0, ncls):
+    """workspace of outconv_wgrad_bn; 0 where that form is not available (the stored activation + conv3d_wgrad are needed)"""
+    n, d, h, w = dims
+    return int(_lib.lib().fplx_outconv_wgrad_bn_ws_bytes(n, d, h, w, int(c0), int(ncls)))
+
+
+def outconv_wgrad_bn(y, bnbuf, slope, dlogits, dw, db, dims, c0, ncls, ws):
+    """out_conv's weight (and bias, db may be None) gradient from the PRE-BatchNorm tensor y of the site in front of it: the
+    activation is formed on the way in (fplx_outconv_wgrad_bn), so the forward never has to store it"""
+    n, d, h, w = dims
+    call("fplx_outconv_wgrad_bn", ptr(y), ld_of(y), ptr(bnbuf[2]), ptr(bnbuf[3]), ptr(slope), ptr(dlogits), ptr(dw), ptr(db),
+         n, d, h, w, int(c0), int(ncls), ptr(ws), ws.numel() * ws.element_size(), stream())
 
 
 def outconv_dgrad_bn_bwd(dlogits, wb, y, bnbuf, slope, train, dgamma, dbeta, dslope, part, coef, dy, dims, c0, ncls):

@@ -310,12 +310,19 @@ int fplx_pool_bwd_bn_reduce(const void* y, int64_t ldy, const void* dy, int64_t 
  * convolution site in front of it (ConvBlockND's second site of the last UpBlock, unet2d5_dsbn.py:79-81; dropout-free, bf16
  * NDHWC, C0 = 32, classes <= 4: fplx_outconv_bn_rows > 0).  The out_conv operands are 1 / 8 the size of that site's tensors, so
  *   fplx_outconv_fwd_bn          reads the site's PRE-BatchNorm output y, applies a = PReLU(scale y + shift) on the way into its
- *                                tiles, writes a (what backward keeps) and the fp32 planar logits: fplx_bn_act_fwd + fplx_conv3d_fwd
+ *                                tiles, writes a (unless NULL, see below) and the fp32 planar logits: fplx_bn_act_fwd + fplx_conv3d_fwd
  *                                in one pass over y; a and the logits are the bits of the two-call path;
  *   fplx_outconv_dgrad_bn_reduce / _apply   never store out_conv's data gradient: both RECOMPUTE it from dlogits (fp32 planar)
  *                                and the mirrored pack wb and run fplx_bn_act_bwd_reduce / _apply on it - _reduce writes
  *                                fplx_outconv_bn_rows(...) partial rows of 2 C0 + 1 floats for fplx_bn_act_bwd_finalize,
- *                                _apply takes the finalize's coef and writes dy (gradient w.r.t. y).
+ *                                _apply takes the finalize's coef and writes dy (gradient w.r.t. y);
+ *   fplx_outconv_wgrad_bn        out_conv's weight gradient dw [classes][C0][1][3][3] and bias gradient db [classes] (NULL: not
+ *                                wanted) from y as well: a is formed on the way in, exactly as fplx_outconv_fwd_bn forms it.
+ *                                With the three of them a has no reader left in a training step, and fplx_outconv_fwd_bn takes
+ *                                a = NULL (no activation written) wherever fplx_outconv_wgrad_bn_ws_bytes(...) > 0 - classes <= 3;
+ *                                0 = this form is not available, a is required and fplx_conv3d_wgrad takes the gradient from it.
+ *                                ws: fplx_outconv_wgrad_bn_ws_bytes(...) bytes.  dw agrees with fplx_conv3d_wgrad on the stored a
+ *                                to fp32 summation order (same bf16 operands).
  * mean / rstd / scale / shift: the site's BatchNorm constants (fplx_bn_train_finalize / fplx_bn_eval_prepare). */
 /* partial rows the fused backward writes, or 0 where the fused forms do not apply (the caller then runs the separate passes) */
 int fplx_outconv_bn_rows(int n, int d, int h, int w, int c0, int ncls);
@@ -329,6 +336,10 @@ int fplx_outconv_dgrad_bn_apply(const float* dlogits, const void* wb, const void
                                 const float* rstd, const float* scale, const float* shift, const float* prelu_slope,
                                 const float* coef, void* dy, int64_t lddy, int n, int d, int h, int w, int c0, int ncls,
                                 fplx_stream_t stream);
+size_t fplx_outconv_wgrad_bn_ws_bytes(int n, int d, int h, int w, int c0, int ncls);
+int fplx_outconv_wgrad_bn(const void* y, int64_t ldy, const float* scale, const float* shift, const float* prelu_slope,
+                          const float* dlogits, float* dw, float* db, int n, int d, int h, int w, int c0, int ncls, void* ws,
+                          size_t ws_bytes, fplx_stream_t stream);
 
 /* (Tri / bi)linear x2 upsampling, align_corners = True - UpBlock with bilinear = True (unet2d5_dsbn.py:148-150, 172-176:
  * nn.Upsample(scale_factor=2, mode='trilinear' | 'bilinear', align_corners=True) behind a kernel-1 convolution, which runs

@@ -1094,6 +1094,70 @@ def test_outconv_fused_with_the_last_sites_batchnorm_passes(shape, outconv_dgrad
         ops.outconv_dgrad_bn_bwd(dl, wob, y, bnbuf, slope, True, gf[0], gf[1], gf[2], part.view(-1)[:8], coef, dy, dims, c0, ncls)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (1, 2, 16, 64, 2), (1, 4, 24, 40, 3), (2, 5, 40, 96, 2), (1, 1, 1, 1, 2),
+                                   (3, 2, 7, 161, 2), (2, 1, 32, 32, 2), (1, 1, 33, 64, 1), (1, 3, 5, 31, 3), (2, 2, 3, 97, 2)])
+def test_outconv_wgrad_from_the_pre_batchnorm_tensor(shape):
+    """fplx_outconv_wgrad_bn (round 6: out_conv's weight + bias gradient from the PRE-BatchNorm tensor y of the site in front
+    of it, so that site's activation is never stored; reference unet2d5_dsbn.py:79-81 + 293-294, 307) and fplx_outconv_fwd_bn
+    with a = NULL: (a) the logits without the activation store are the bits of the call that stores it; (b) dw / db against
+    fplx_conv3d_wgrad on the stored activation - the same bf16 operands, another order of fp32 additions: 1e-4 of the largest
+    entry; (c) dw / db against float64 torch (bf16 activation, fp32 dlogits): 1e-2.  1-3 classes, ragged rows, W < 32, n > 1;
+    where the form is not available (4 classes, the tile kernels) the query says 0 and a = NULL is refused."""
+    from fplx import ops, _lib
+    n, d, h, w, ncls = shape
+    c0, v, bf, dims = 32, n * d * h * w, torch.bfloat16, (n, d, h, w)
+    assert ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls) > 0
+    assert ops.outconv_wgrad_bn_ws_bytes(dims, c0, 4) == 0 and ops.outconv_wgrad_bn_ws_bytes(dims, 64, ncls) == 0
+    g = torch.Generator().manual_seed(23 + w)
+    y = (torch.randn(v, c0, generator=g) * (0.5 + torch.rand(c0, generator=g)) + torch.randn(c0, generator=g) * 0.3).to(bf).cuda()
+    gamma, beta = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    mean, var = torch.randn(c0, generator=g) * 0.3, torch.rand(c0, generator=g) + 0.5
+    rstd = torch.rsqrt(var + 1e-5)
+    bnbuf = torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd]).cuda()
+    slope = torch.tensor([0.25]).cuda()
+    wo = torch.randn(ncls, c0, 1, 3, 3, generator=g) * 0.1
+    wof, _ = ops.pack_conv_weight(wo.cuda(), torch.float32, False)
+    bias = torch.randn(ncls, generator=g).cuda()
+    cl, pl = ops.cl_strides, ops.planar_strides
+    # (a) forward without the activation store
+    a_ref = torch.empty(v, c0, dtype=bf, device="cuda")
+    lg_ref = torch.empty(n, ncls, d, h, w, device="cuda")
+    ops.outconv_fwd_bn(y, bnbuf, slope, a_ref, wof, bias, lg_ref, dims, c0, ncls)
+    lg = torch.full((n, ncls, d, h, w), 7.0, device="cuda")
+    ops.outconv_fwd_bn(y, bnbuf, slope, None, wof, bias, lg, dims, c0, ncls)
+    assert torch.equal(lg, lg_ref)
+    # (b) against the weight gradient on the stored activation
+    dl = (torch.randn(n, ncls, d, h, w, generator=g) * 0.05).cuda()
+    ws = torch.empty(max(ops.conv3d_wgrad_ws_bytes(dims, c0, ncls, (1, 3, 3)), ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls)),
+                     dtype=torch.uint8, device="cuda")
+    dw_ref, db_ref = torch.zeros(ncls, c0, 1, 3, 3, device="cuda"), torch.zeros(ncls, device="cuda")
+    ops.conv3d_wgrad(a_ref, cl(d, h, w, c0), ops.BF16, dl, pl(ncls, d, h, w), ops.F32, dw_ref, db_ref, dims, c0, ncls, (1, 3, 3), ws)
+    dw, db = torch.full((ncls, c0, 1, 3, 3), 7.0, device="cuda"), torch.full((ncls,), 7.0, device="cuda")
+    ops.outconv_wgrad_bn(y, bnbuf, slope, dl, dw, db, dims, c0, ncls, ws)
+    assert float((dw - dw_ref).abs().max()) <= 1e-4 * float(dw_ref.abs().max()) + 1e-7
+    assert float((db - db_ref).abs().max()) <= 1e-4 * float(db_ref.abs().max()) + 1e-6
+    dw2 = torch.full((ncls, c0, 1, 3, 3), 7.0, device="cuda")
+    ops.outconv_wgrad_bn(y, bnbuf, slope, dl, dw2, None, dims, c0, ncls, ws)          # no bias gradient wanted; same bits again
+    assert torch.equal(dw2, dw)
+    # (c) against float64 torch
+    a5 = a_ref.double().cpu().view(n, d, h, w, c0).permute(0, 4, 1, 2, 3)
+    w64 = wo.double().requires_grad_(True)
+    b64 = bias.double().cpu().requires_grad_(True)
+    (F.conv3d(a5, w64, b64, padding=(0, 1, 1)) * dl.double().cpu()).sum().backward()
+    assert float((dw.cpu().double() - w64.grad).abs().max()) <= 1e-2 * float(w64.grad.abs().max())
+    assert float((db.cpu().double() - b64.grad).abs().max()) <= 1e-2 * float(b64.grad.abs().max()) + 1e-6
+    # errors: workspace, unavailable form
+    with pytest.raises(RuntimeError):
+        ops.outconv_wgrad_bn(y, bnbuf, slope, dl, dw, db, dims, c0, ncls, ws[:16])
+    _lib.set_tuning("outconv_fwd_rows", 0)
+    try:
+        assert ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls) == 0
+        with pytest.raises(ValueError):
+            ops.outconv_fwd_bn(y, bnbuf, slope, None, wof, bias, lg, dims, c0, ncls)
+    finally:
+        _lib.set_tuning("outconv_fwd_rows", 1)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 9, 35, 2), (2, 2, 17, 40, 3), (2, 4, 24, 33, 4), (1, 2, 16, 64, 2), (2, 3, 20, 96, 2)])
 def test_outconv_fused_kernels_against_float64_autograd(shape, outconv_dgrad_rows_knob):
     """VERDICT r04 parity hole (a): fplx_outconv_fwd_bn / fplx_outconv_dgrad_bn_reduce / _apply per kernel against float64
@@ -1208,19 +1272,23 @@ def test_network_step_with_and_without_the_out_conv_fusion():
     lab[:, 1, 4:10, 8:20, 16:40] = 1.0
     lab = lab.cuda()
     res = []
-    for fuse in (True, False):
+    # (fused, out_conv's weight gradient from the pre-BatchNorm tensor = the last activation never stored - the default) |
+    # (fused, activation stored) | separate passes
+    for fuse, wg in ((True, True), (True, False), (False, False)):
         torch.manual_seed(3)
         net = fplx.UNet2D5_dsbn(dict(p)).cuda()
         net.engine.use_outconv_fusion = fuse
+        net.engine.use_outconv_wgrad_bn = wg
         net.train()
         with torch.no_grad():
             net.dropout_seed, net._fwd_counter = 9, 0
         ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-3, weight_decay=1e-5)
         logits, sv = net.engine.forward(x, 1, True, net.dropout_active(), 9, 0, keep=True)
-        assert bool(sv.oc_fused) == fuse
+        assert bool(sv.oc_fused) == fuse and bool(sv.oc_wg) == wg and (sv.blocks[8]["out"] is None) == wg
         out = ts.step(x, lab, 1)
         res.append((logits.clone(), net.flat_params.detach().clone(), float(out[0])))
-    assert torch.equal(res[0][0], res[1][0])
-    assert abs(res[0][2] - res[1][2]) < 1e-6
-    rel = float((res[0][1] - res[1][1]).abs().max()) / float(res[1][1].abs().max())
-    assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr
+    for k in (1, 2):
+        assert torch.equal(res[0][0], res[k][0])
+        assert abs(res[0][2] - res[k][2]) < 1e-6
+        rel = float((res[0][1] - res[k][1]).abs().max()) / float(res[k][1].abs().max())
+        assert rel < 2e-3, rel           # one Adam step of lr 1e-3: a sign flip of a near-zero gradient moves a parameter by 2 lr

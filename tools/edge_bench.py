@@ -90,6 +90,12 @@ def main():
         res.append(("outconv_fwd_bn %s" % ("rows" if knob else "tiles"),
                     timeit(lambda: ops.outconv_fwd_bn(feat, bnbuf, slope, act, wof, bo, lg2, dims, c0, ncls)), 2 * tb + v * ncls * 4))
     _lib.set_tuning("outconv_fwd_rows", 1)
+    # the forward without the activation store, and out_conv's weight + bias gradient from the pre-BatchNorm tensor
+    res.append(("outconv_fwd_bn rows, logits only",
+                timeit(lambda: ops.outconv_fwd_bn(feat, bnbuf, slope, None, wof, bo, lg2, dims, c0, ncls)), tb + v * ncls * 4))
+    wsb3 = torch.empty(max(1, ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls)), dtype=torch.uint8, device=dev)
+    res.append(("out_conv wgrad from y", timeit(lambda: ops.outconv_wgrad_bn(feat, bnbuf, slope, dl, dwo, dbo, dims, c0, ncls, wsb3)),
+                tb + v * ncls * 4))
     for knob in (1, 0):
         _lib.set_tuning("outconv_dgrad_rows", knob)
         prt = torch.empty(max(ops.num_partials(v), ops.outconv_bn_rows(dims, c0, ncls)) * (2 * c0 + 1), device=dev)
@@ -99,7 +105,7 @@ def main():
     _lib.set_tuning("outconv_dgrad_rows", 1)
     env = {k: v_ for k, v_ in os.environ.items() if k.startswith("FPLX_")}
     for name, us, nbytes in res:
-        print("%-16s %8.1f us  %6.0f GB/s  %s" % (name, us, nbytes / us / 1e3, env))
+        print("%-34s %8.1f us  %6.0f GB/s  %s" % (name, us, nbytes / us / 1e3, env))
 
 
 if __name__ == "__main__":
