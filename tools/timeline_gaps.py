@@ -95,3 +95,14 @@ for q, v in sorted(alone.items(), key=lambda kv: -kv[1]):
     for (qq, nn), vv in sorted(alone_k.items(), key=lambda kv: -kv[1]):
         if qq == q and qq != mainq and vv / 1e3 / nsteps > 5:
             print("      %8.1f us  %s" % (vv / 1e3 / nsteps, nn))
+
+# the last step in full detail around its ends: offset from the step's first kernel, duration, queue
+if len(stem) > 1:
+    s0, s1 = stem[-2], stem[-1]
+    last = [(s_, e_, q, n) for s_, e_, q, n in rows if s0 <= s_ < s1]
+    if last:
+        tend = max(e_ for s_, e_, q, n in last)
+        print("last step, its final 1.3 ms (start offset us, duration us, queue, kernel):")
+        for s_, e_, q, n in last:
+            if e_ >= tend - 1300000:
+                print("  %9.1f %8.1f  q%s  %s" % ((s_ - s0) / 1e3, (e_ - s_) / 1e3, "1" if q == mainq else "2", n))
