@@ -5,6 +5,8 @@ per setting with min / max.
 
     python tools/step_ab.py "wg_roll=0" "wg_roll=1" ["wg_roll=1,wg_roll_geo=1" ...] [--steps 20] [--rounds 5]
     engine attributes are set with a leading '@':  "@use_side_stream=0";  TrainStep attributes with '%':  "%adam_overlap=0"
+    "!fplx_name=1" SKIPS every call of that C entry point (an upper bound for what removing a launch could return: the step's
+    results are then garbage - timing probes only)
 """
 import os
 import sys
@@ -30,7 +32,7 @@ def parse(arg):
         if not item or item == "default":
             continue
         k, v = item.split("=")
-        if k.startswith("@") or k.startswith("%"):
+        if k.startswith("@") or k.startswith("%") or k.startswith("!"):
             attrs[k] = int(v)
         else:
             knobs[k] = int(v)
@@ -59,7 +61,12 @@ def main():
     net = fplx.UNet2D5_dsbn(dict(bench.NET)).to(dev)
     net._ensure_flat()
     ts = fplx.TrainStep(net, (1.0, 0.0, 0.0, 0.0), True, lr=1e-4, weight_decay=1e-5, milestones=[10000, 20000], gamma=0.5)
-    attr_keys = sorted({k for _, _, at in settings for k in at})
+    skipped = set()
+    from fplx import ops
+    real_call = ops.call
+    ops.call = lambda name, *a: None if name in skipped else real_call(name, *a)
+    skip_keys = sorted({k for _, _, at in settings for k in at if k[0] == "!"})
+    attr_keys = sorted({k for _, _, at in settings for k in at if k[0] != "!"})
     owner = lambda k: net.engine if k[0] == "@" else ts
     attr_def = {k: getattr(owner(k), k[1:]) for k in attr_keys}
     runs = [(name, kn, at, []) for name, kn, at in settings]
@@ -72,6 +79,8 @@ def main():
               net.engine.invalidate()                     # packs / plans cached under the previous knobs
               for k in attr_keys:
                   setattr(owner(k), k[1:], type(attr_def[k])(at[k]) if k in at else attr_def[k])
+              skipped.clear()
+              skipped.update(k[1:] for k in skip_keys if at.get(k, 0))
               for i in range(3 if r else 6):
                   ts.step(batches[i % 2][0], batches[i % 2][1], i % 2)
               torch.cuda.synchronize()
