@@ -49,6 +49,57 @@ def test_full_size_train_steps_are_bitwise_reproducible_and_learn():
     assert int(sd["block0.conv.bn3d1.bns.1.num_batches_tracked"]) == 3
 
 
+def test_full_size_out_conv_gradients_without_the_stored_activation():
+    """the out_conv weight / bias gradient from the pre-BatchNorm tensor (fplx_outconv_wgrad_bn, reference unet2d5_dsbn.py:
+    79-81 + 293-294, 307) at the benchmark's level-0 size 2 x 80 x 160 x 160, through size-independent properties: (a) it equals
+    fplx_conv3d_wgrad on the activation fplx_outconv_fwd_bn would have stored (same bf16 operands: 1e-4 of the largest entry);
+    (b) linearity in the dlogits: dw(g1 + g2) = dw(g1) + dw(g2) for dlogits that are exact in bf16 (the sums of bf16-exact
+    integers stay exact in the operand rounding); (c) bitwise run-to-run reproducibility; (d) the logits of the forward that
+    stores no activation are the bits of the one that does."""
+    from fplx import ops
+    n, d, h, w, ncls, c0 = 2, 80, 160, 160, 2, 32
+    dims, v, bf = (n, d, h, w), n * d * h * w, torch.bfloat16
+    assert ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls) > 0
+    g = torch.Generator(device="cuda").manual_seed(3)
+    y = (torch.randn(v, c0, generator=g, device="cuda") * 0.8 + 0.1).to(bf)
+    gamma, beta = torch.rand(c0, generator=g, device="cuda") + 0.5, torch.randn(c0, generator=g, device="cuda") * 0.2
+    mean, rstd = torch.randn(c0, generator=g, device="cuda") * 0.1, torch.rand(c0, generator=g, device="cuda") + 0.7
+    bnbuf = torch.stack([mean, rstd, gamma * rstd, beta - mean * gamma * rstd])
+    slope = torch.tensor([0.25], device="cuda")
+    wo = torch.randn(ncls, c0, 1, 3, 3, generator=g, device="cuda") * 0.1
+    wof, _ = ops.pack_conv_weight(wo, torch.float32, False)
+    bias = torch.randn(ncls, generator=g, device="cuda")
+    a = torch.empty(v, c0, dtype=bf, device="cuda")
+    lg_a = torch.empty(n, ncls, d, h, w, device="cuda")
+    lg = torch.empty(n, ncls, d, h, w, device="cuda")
+    ops.outconv_fwd_bn(y, bnbuf, slope, a, wof, bias, lg_a, dims, c0, ncls)
+    ops.outconv_fwd_bn(y, bnbuf, slope, None, wof, bias, lg, dims, c0, ncls)
+    assert torch.equal(lg, lg_a)                                                       # (d)
+    g1 = torch.randint(-8, 9, (n, ncls, d, h, w), generator=g, device="cuda").float() / 64.0
+    g2 = torch.randint(-8, 9, (n, ncls, d, h, w), generator=g, device="cuda").float() / 64.0
+    ws = torch.empty(max(ops.conv3d_wgrad_ws_bytes(dims, c0, ncls, (1, 3, 3)), ops.outconv_wgrad_bn_ws_bytes(dims, c0, ncls)),
+                     dtype=torch.uint8, device="cuda")
+
+    def wg(dl):
+        dw, db = torch.empty(ncls, c0, 1, 3, 3, device="cuda"), torch.empty(ncls, device="cuda")
+        ops.outconv_wgrad_bn(y, bnbuf, slope, dl, dw, db, dims, c0, ncls, ws)
+        return dw, db
+
+    dw1, db1 = wg(g1)
+    dw2, db2 = wg(g2)
+    dw12, db12 = wg(g1 + g2)
+    dw1b, db1b = wg(g1)
+    assert torch.equal(dw1, dw1b) and torch.equal(db1, db1b)                           # (c)
+    scale = float(dw12.abs().max()) + float(dw1.abs().max())
+    assert float((dw12 - (dw1 + dw2)).abs().max()) <= 2e-5 * scale                     # (b): fp32 summation order only
+    assert float((db12 - (db1 + db2)).abs().max()) <= 2e-5 * (float(db1.abs().max()) + float(db2.abs().max()) + 1.0)
+    dw_ref, db_ref = torch.empty(ncls, c0, 1, 3, 3, device="cuda"), torch.empty(ncls, device="cuda")
+    ops.conv3d_wgrad(a, ops.cl_strides(d, h, w, c0), ops.BF16, g1, ops.planar_strides(ncls, d, h, w), ops.F32, dw_ref, db_ref, dims, c0,
+                     ncls, (1, 3, 3), ws)
+    assert float((dw1 - dw_ref).abs().max()) <= 1e-4 * float(dw_ref.abs().max())      # (a)
+    assert float((db1 - db_ref).abs().max()) <= 1e-4 * float(db_ref.abs().max()) + 1e-3
+
+
 def test_full_size_forward_is_deterministic_under_dropout_seed():
     import fplx
     torch.manual_seed(3)
